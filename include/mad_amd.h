@@ -1,0 +1,233 @@
+/*
+ * mad_amd.h -- C-ABI of libmad_amd.so, the MI355X (gfx950) implementation of the
+ * MaD anchor-matching hot path.
+ *
+ * The reference (LBM-EPFL/MaD) has no FFI: its boundary is a set of Python
+ * methods.  Each entry point below replaces the *body* of one of them; the
+ * Python mirror in mad_amd/ keeps the reference's names and signatures and calls
+ * these through ctypes.  See INTEGRATION.md for the binding a reference
+ * maintainer would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative MAD_E* code; nothing
+ *     throws across the ABI; mad_last_error(ctx) gives the message;
+ *   - unless a parameter says "device", buffers are caller-owned HOST memory
+ *     (numpy arrays) and the call is synchronous on return;
+ *   - the library owns only what lives inside a mad_ctx / mad_set;
+ *   - one ctx per GPU; a ctx is not thread-safe, distinct ctxs may be driven
+ *     from distinct threads;
+ *   - 3x3 matrices are row-major double[9]; volumes are [nx][ny][nz], z fastest;
+ *   - variable-length outputs take a capacity; on overflow the call returns
+ *     MAD_ENOSPC and stores the needed size in the count argument.
+ *
+ * File:line references are into the reference checkout (mad/...).
+ */
+#ifndef MAD_AMD_H
+#define MAD_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MAD_OK        0
+#define MAD_EINVAL   -22   /* bad argument */
+#define MAD_ENOMEM   -12   /* device allocation failed */
+#define MAD_ENOSPC   -28   /* output capacity too small */
+#define MAD_ENODEV   -19   /* no usable gfx950 device */
+#define MAD_EDOM     -33   /* input outside the supported range */
+#define MAD_EHIP     -5    /* HIP runtime error */
+
+#define MAD_MAX_Z      128 /* zones per EQSP table */
+#define MAD_MAX_FIELDS 64  /* gradient-field slots per ctx */
+#define MAD_RESULT_COLS 23 /* row width of MaD._match_dsc results, MaD.py:451 */
+
+typedef struct mad_ctx mad_ctx;
+typedef struct mad_set mad_set;   /* device-resident oriented-anchor rows of one structure */
+
+/* ---- context ----------------------------------------------------------- */
+
+int mad_init(int device, mad_ctx **out);
+void mad_destroy(mad_ctx *ctx);
+const char *mad_last_error(const mad_ctx *ctx);   /* ctx may be NULL: last init error */
+int mad_synchronize(mad_ctx *ctx);
+/* HIP stream (hipStream_t) every kernel of this ctx is launched on, for callers that time with events. */
+void *mad_stream(mad_ctx *ctx);
+/*
+ * Per-kernel-group timing with HIP events recorded on the ctx stream around each launch.
+ * Groups: "orient", "describe", "correlate", "pairs", "pose", "topk", "refine", "density", "ccc".
+ * Off by default; mad_timing_get drains pending events (a sync) and returns the accumulated
+ * device time and launch count since the last reset; mad_last_ms = total / launches (<0 if none).
+ */
+int mad_timing_enable(mad_ctx *ctx, int on);
+int mad_timing_reset(mad_ctx *ctx);
+int mad_timing_get(mad_ctx *ctx, const char *what, double *total_ms, int64_t *launches);
+double mad_last_ms(mad_ctx *ctx, const char *what);
+
+/*
+ * EQSP zone tables.  which = 0: orientation sphere (Orientator.py:16, 112 zones);
+ * which = 1: descriptor sphere (Descriptor.py:17, 16 zones).  bounds = Z x
+ * [theta_min, phi_min, theta_max, phi_max] (eqsp.py:16-20).  For which = 0 also
+ * pass the 3x3 matrices the reference derives from the zone centres:
+ * to_dom[a] = rotation bringing the centre of zone a onto +z (Orientator.py:198-205,
+ * identity for a = 0) and adj_sec[a] = z-rotation of Orientator.py:259-263.
+ */
+int mad_set_eqsp(mad_ctx *ctx, int which, int Z, const double *bounds,
+                 const double *to_dom, const double *adj_sec);
+
+/* ---- gradient fields (input of the path; produced by MapSpace.py:178-189) ---- */
+
+/*
+ * Upload one octave's gradient field into slot (0..MAD_MAX_FIELDS-1): three planar
+ * float32 volumes, the layout of the reference's grad_list view (MapSpace.py:187).
+ * On the device the field is repacked to one 16-byte texel per voxel
+ * {gx, gy, gz, |g|}.
+ */
+int mad_upload_field(mad_ctx *ctx, int slot, const float *gx, const float *gy, const float *gz,
+                     int nx, int ny, int nz);
+/* Same, from a DEVICE buffer holding the three planes back to back ([3][nx][ny][nz]). */
+int mad_upload_field_device(mad_ctx *ctx, int slot, const float *g3_device, int nx, int ny, int nz);
+int mad_free_field(mad_ctx *ctx, int slot);
+
+/* ---- a1-a8: Orientator.assign_orientations (Orientator.py:68-110) ------------ */
+
+/*
+ * coords: n x 3 integer voxel positions in the octave of `slot` (DensityFeature.coords).
+ * octave: 1 = base grid (unit stride), 0 = upsampled grid (stride 2), Orientator.py:128-158.
+ * r = box_side (8 for the default patch of 16).  Rows are emitted in anchor order
+ * x main bin ascending x secondary bin ascending (Orientator.py:90-106).
+ * row_count (nullable): Z quantised zone counts per row (DensityFeature.ar_count).
+ * n_reject (nullable): anchors refused by the border test (Orientator.py:131-135).
+ */
+int mad_orient(mad_ctx *ctx, int slot, int octave, const int32_t *coords, int n, int r,
+               int lim_main, int lim_sec,
+               int32_t *row_anchor, int32_t *row_main, int32_t *row_sec, double *row_R,
+               int32_t *row_count, int64_t *n_rows, int64_t cap, int32_t *n_reject);
+
+/* ---- a9-a10: Descriptor.generate_descriptors (Descriptor.py:106-202) --------- */
+
+/*
+ * coords: n_rows x 3 anchor voxel positions, R: n_rows x 9 Rfinal.  dsc: n_rows x
+ * (64 * Zd) int16, sub-cube major (id j*16+i*4+k, Descriptor.py:44-64), zone minor.
+ * A row whose sample cube leaves the grid is all zero (Descriptor.py:140-149).
+ */
+int mad_describe(mad_ctx *ctx, int slot, int octave, const int32_t *coords, const double *R,
+                 int64_t n_rows, int r, int16_t *dsc);
+
+/* ---- a11: MaD._match_dsc part 1 (MaD.py:416-424) ----------------------------- */
+
+/*
+ * hi: n_hi x D, lo: n_lo x D int16 descriptor counts (D = 1024; every |count| <= 127,
+ * else MAD_EDOM).  Emits every (hi, lo) with normalised correlation > cc, row-major,
+ * with its score.
+ */
+int mad_correlate(mad_ctx *ctx, const int16_t *hi, int64_t n_hi, const int16_t *lo, int64_t n_lo,
+                  int D, double cc, int32_t *pair_hi, int32_t *pair_lo, double *pair_score,
+                  int64_t *n_pairs, int64_t cap);
+
+/* ---- a12: MaD._match_dsc part 2 (MaD.py:426-451) ----------------------------- */
+
+/*
+ * Per-row inputs: p = subv_map_coords (n x 3), R = Rfinal (n x 9), meta = {index,
+ * oct_scale, main_bin} (n x 3 int32).  hi_cloud / lo_cloud: the unique sub-voxel
+ * coordinates of rows present in at least one pair (MaD.py:427-428).
+ * results (nullable): n_pairs x 23 as MaD.py:451.  counts (nullable): number of
+ * hi cloud points brought within `dist` of a lo cloud point (repeatability =
+ * 100 * count / l_hi).
+ */
+int mad_pose_score(mad_ctx *ctx, const int32_t *pair_hi, const int32_t *pair_lo, const double *pair_score,
+                   int64_t n_pairs,
+                   const double *hi_p, const double *hi_R, const int32_t *hi_meta, int64_t n_hi,
+                   const double *lo_p, const double *lo_R, const int32_t *lo_meta, int64_t n_lo,
+                   const double *hi_cloud, int64_t l_hi, const double *lo_cloud, int64_t l_lo,
+                   double dist, double *results, int32_t *counts);
+
+/*
+ * Indices of the first k pairs in the order of MaD._filter_dsc_pairs' stable sort
+ * (MaD.py:480): count descending, ties in input order.
+ */
+int mad_topk(mad_ctx *ctx, const int32_t *counts, int64_t n, int64_t k, int64_t *order);
+
+/* ---- device-resident pipeline (same kernels, no host round trips) -------------- */
+
+/*
+ * A mad_set holds the oriented-anchor rows of one structure (map or subunit) on
+ * the device: descriptors, Rfinal, anchor ids and the anchors' sub-voxel
+ * coordinates.  mad_set_build runs a1-a10 for the anchors of both octaves:
+ *   slot_of_octave[o] = field slot of octave o (or -1),
+ *   anc_coords n x 3 int32, anc_octave n int32, anc_subv n x 3 double (Angstrom),
+ *   anc_index n int32 (DensityFeature.index).
+ * Row order = anchor order (as given) x main x sec, exactly the reference's list.
+ */
+int mad_set_create(mad_ctx *ctx, mad_set **out);
+void mad_set_destroy(mad_ctx *ctx, mad_set *set);
+int mad_set_build(mad_ctx *ctx, mad_set *set, const int *slot_of_octave,
+                  const int32_t *anc_coords, const int32_t *anc_octave, const double *anc_subv,
+                  const int32_t *anc_index, int n_anchors, int r, int lim_main, int lim_sec);
+/* Load rows computed earlier (descriptor cache, MaD.py:861-875): anchor = row -> anchor id. */
+int mad_set_load(mad_ctx *ctx, mad_set *set, int64_t n_rows, const int32_t *row_anchor,
+                 const int32_t *row_main, const double *row_R, const int16_t *dsc, int D,
+                 const double *anc_subv, const int32_t *anc_index, const int32_t *anc_octave, int n_anchors);
+int mad_set_size(mad_ctx *ctx, const mad_set *set, int64_t *n_rows, int32_t *n_anchors);
+/* Any of the output pointers may be NULL. */
+int mad_set_download(mad_ctx *ctx, const mad_set *set, int32_t *row_anchor, int32_t *row_main,
+                     int32_t *row_sec, double *row_R, int16_t *dsc);
+
+/*
+ * a11 + a12 + top-k for one (subunit = hi, map = lo) pair of sets, entirely on the
+ * device.  results: k x 23 rows of MaD.py:451 in the order of MaD.py:480 (fewer if
+ * n_pairs < k: *n_out).  pair_index (nullable): k row-major pair ranks.
+ * stats (nullable) int64[4] = {n_pairs, l_hi, l_lo, n_correlations}.
+ */
+int mad_match_topk(mad_ctx *ctx, const mad_set *hi, const mad_set *lo, double cc, double dist,
+                   int64_t k, double *results, int64_t *pair_index, int64_t *n_out, int64_t *stats);
+/* After mad_match_topk: all pairs of that call (for MaD._match_dsc's full return value). */
+int mad_match_fetch(mad_ctx *ctx, int32_t *pair_hi, int32_t *pair_lo, double *pair_score,
+                    int32_t *counts, int64_t cap);
+/* After mad_match_topk: which anchors of each set appear in a pair (uint8 flags). */
+int mad_match_used(mad_ctx *ctx, uint8_t *hi_anchor_used, int32_t n_hi_anchors,
+                   uint8_t *lo_anchor_used, int32_t n_lo_anchors);
+
+/* ---- a13: structure_utils.refine_pdb (structure_utils.py:58-161) --------------- */
+
+/*
+ * Upload the density map the candidates are refined in (Dmap.grid3d, float32
+ * [nx][ny][nz], origin and voxel spacing in Angstrom).  The library derives the
+ * np.gradient field (structure_utils.py:80) once and keeps both.
+ */
+int mad_upload_density(mad_ctx *ctx, const float *grid, int nx, int ny, int nz,
+                       double ox, double oy, double oz, double voxsp);
+/*
+ * Refine n_cand rigid placements of the same n_atoms-atom structure at once
+ * (one persistent workgroup per candidate).  coords: n_cand x n_atoms x 3, updated
+ * in place.  converged / last_step: per candidate, the reference's return values.
+ */
+int mad_refine(mad_ctx *ctx, double *coords, int n_cand, int64_t n_atoms, int n_steps,
+               double max_step, double min_step, int32_t *converged, int32_t *last_step);
+
+/* ---- a14-a15: PDB.structure_to_density (PDB.py:131-292) ------------------------ */
+
+/*
+ * atoms n x 3 (Angstrom), mass n.  Call with grid = NULL to get dims (output grid
+ * shape) and origin; then with grid = float32[dims0*dims1*dims2] ([x][y][z]).
+ */
+int mad_structure_to_density(mad_ctx *ctx, const double *atoms, const double *mass, int64_t n,
+                             double resolution, double voxsp, double isovalue, int pad,
+                             int32_t dims[3], double origin[3], float *grid);
+
+/* ---- a16: Dmap.get_CCC_with_grid (Dmap.py:153-258) ----------------------------- */
+
+/*
+ * Both grids float32 [x][y][z]; voxels below isovalue are zeroed IN PLACE in both,
+ * as the reference does (Dmap.py:160-161).  *ccc = <a,b>/sqrt(<a,a><b,b>) over the
+ * overlap box, 0 if the boxes do not overlap.
+ */
+int mad_ccc(mad_ctx *ctx, float *grid1, const int32_t dims1[3], const double origin1[3],
+            float *grid2, const int32_t dims2[3], const double origin2[3],
+            double voxsp, double isovalue, double *ccc);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MAD_AMD_H */

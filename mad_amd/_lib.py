@@ -1,0 +1,363 @@
+"""ctypes binding of libmad_amd.so (the C-ABI in include/mad_amd.h).
+
+This is the ONLY compute back-end of the package: there is no CPU fallback.  If the
+shared library is missing, or no gfx950 device can be opened, the first call raises
+`MadBackendError` -- loudly, as a drop-in for a hot path must.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmad_amd.so")
+RESULT_COLS = 23
+
+ERRORS = {-22: "EINVAL", -12: "ENOMEM", -28: "ENOSPC", -19: "ENODEV", -33: "EDOM", -5: "EHIP"}
+
+# every symbol include/mad_amd.h declares (tests check the library exports all of them)
+SYMBOLS = [
+    "mad_init", "mad_destroy", "mad_last_error", "mad_synchronize", "mad_stream",
+    "mad_timing_enable", "mad_timing_reset", "mad_timing_get", "mad_last_ms",
+    "mad_set_eqsp", "mad_upload_field", "mad_upload_field_device", "mad_free_field",
+    "mad_orient", "mad_describe", "mad_correlate", "mad_pose_score", "mad_topk",
+    "mad_set_create", "mad_set_destroy", "mad_set_build", "mad_set_load", "mad_set_size", "mad_set_download",
+    "mad_match_topk", "mad_match_fetch", "mad_match_used",
+    "mad_upload_density", "mad_refine", "mad_structure_to_density", "mad_ccc",
+]
+
+
+class MadBackendError(RuntimeError):
+    pass
+
+
+_dll = None
+
+
+def load_library():
+    """dlopen the HIP library (works without a GPU; opening a device does not)."""
+    global _dll
+    if _dll is None:
+        if not os.path.exists(LIB_PATH):
+            raise MadBackendError(
+                "MaD> %s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C mad_amd/csrc` (there is no CPU fallback)" % LIB_PATH)
+        try:
+            _dll = C.CDLL(LIB_PATH)
+        except OSError as e:
+            raise MadBackendError("MaD> cannot load %s: %s" % (LIB_PATH, e))
+        _dll.mad_last_error.restype = C.c_char_p
+        _dll.mad_last_error.argtypes = [C.c_void_p]
+        _dll.mad_stream.restype = C.c_void_p
+        _dll.mad_stream.argtypes = [C.c_void_p]
+        _dll.mad_last_ms.restype = C.c_double
+        _dll.mad_last_ms.argtypes = [C.c_void_p, C.c_char_p]
+        _dll.mad_destroy.restype = None
+        _dll.mad_set_destroy.restype = None
+    return _dll
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _c(a, dt):
+    return np.ascontiguousarray(a, dtype=dt)
+
+
+class DeviceSet(object):
+    """Device-resident oriented-anchor rows of one structure (mad_set)."""
+
+    def __init__(self, lib):
+        self.lib = lib
+        self.h = C.c_void_p()
+        lib._chk(lib.dll.mad_set_create(lib.ctx, C.byref(self.h)))
+        self.n_anchors = 0
+
+    def size(self):
+        n = C.c_int64(0)
+        a = C.c_int32(0)
+        self.lib._chk(self.lib.dll.mad_set_size(self.lib.ctx, self.h, C.byref(n), C.byref(a)))
+        return n.value, a.value
+
+    def download(self, want_dsc=True, D=1024):
+        n, _ = self.size()
+        out = dict(anchor=np.zeros(n, np.int32), main=np.zeros(n, np.int32), sec=np.zeros(n, np.int32),
+                   R=np.zeros((n, 3, 3)), dsc=np.zeros((n, D), np.int16) if want_dsc else None)
+        self.lib._chk(self.lib.dll.mad_set_download(self.lib.ctx, self.h, _p(out["anchor"]), _p(out["main"]), _p(out["sec"]),
+                                                    _p(out["R"]), _p(out["dsc"])))
+        return out
+
+    def close(self):
+        if self.h and self.lib.ctx:
+            self.lib.dll.mad_set_destroy(self.lib.ctx, self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Lib(object):
+    """One mad_ctx on one GPU."""
+
+    def __init__(self, device=0):
+        self.dll = load_library()
+        self.ctx = C.c_void_p()
+        rc = self.dll.mad_init(C.c_int(device), C.byref(self.ctx))
+        if rc != 0:
+            msg = self.dll.mad_last_error(None)
+            self.ctx = None
+            raise MadBackendError("MaD> mad_init(device=%d) failed (%s): %s -- the hot path runs on an MI355X only"
+                                  % (device, ERRORS.get(rc, rc), msg.decode() if msg else ""))
+        self.device = device
+        self._fields = {}      # id(array) -> slot bookkeeping is done by the callers
+        self._next_slot = 0
+        self._eq_loaded = {}
+
+    # -- plumbing -----------------------------------------------------------------
+    def _chk(self, rc):
+        if rc != 0:
+            msg = self.dll.mad_last_error(self.ctx)
+            raise MadBackendError("MaD> %s: %s" % (ERRORS.get(rc, rc), msg.decode() if msg else ""))
+
+    def close(self):
+        if self.ctx:
+            self.dll.mad_destroy(self.ctx)
+        self.ctx = None
+
+    def synchronize(self):
+        self._chk(self.dll.mad_synchronize(self.ctx))
+
+    def stream(self):
+        return self.dll.mad_stream(self.ctx)
+
+    def timing_enable(self, on=True):
+        self._chk(self.dll.mad_timing_enable(self.ctx, C.c_int(1 if on else 0)))
+
+    def timing_reset(self):
+        self._chk(self.dll.mad_timing_reset(self.ctx))
+
+    def timing_get(self, what):
+        t = C.c_double(0)
+        n = C.c_int64(0)
+        self._chk(self.dll.mad_timing_get(self.ctx, what.encode(), C.byref(t), C.byref(n)))
+        return t.value, n.value
+
+    # -- tables and fields ----------------------------------------------------------
+    def set_eqsp(self, which, bounds, to_dom=None, adj_sec=None):
+        bounds = _c(bounds, np.float64)
+        to_dom = None if to_dom is None else _c(to_dom, np.float64)
+        adj_sec = None if adj_sec is None else _c(adj_sec, np.float64)
+        self._chk(self.dll.mad_set_eqsp(self.ctx, C.c_int(which), C.c_int(len(bounds)), _p(bounds), _p(to_dom), _p(adj_sec)))
+
+    def new_slot(self):
+        s = self._next_slot
+        self._next_slot += 1
+        if s >= 64:
+            raise MadBackendError("MaD> out of gradient-field slots; free some with free_field()")
+        return s
+
+    def upload_field(self, slot, grad):
+        """grad: the reference's grad_list entry, shape (X, Y, Z, 3), any strides; or a (3, X, Y, Z) array."""
+        g = np.asarray(grad)
+        if g.ndim != 4:
+            raise ValueError("gradient field must be 4-D")
+        if g.shape[-1] == 3:
+            g = np.moveaxis(g, -1, 0)
+        elif g.shape[0] != 3:
+            raise ValueError("gradient field must be (X, Y, Z, 3) or (3, X, Y, Z)")
+        planes = [_c(g[i], np.float32) for i in range(3)]
+        nx, ny, nz = planes[0].shape
+        self._chk(self.dll.mad_upload_field(self.ctx, C.c_int(slot), _p(planes[0]), _p(planes[1]), _p(planes[2]),
+                                            C.c_int(nx), C.c_int(ny), C.c_int(nz)))
+
+    def upload_field_device(self, slot, dev_ptr, nx, ny, nz):
+        self._chk(self.dll.mad_upload_field_device(self.ctx, C.c_int(slot), C.c_void_p(dev_ptr), C.c_int(nx), C.c_int(ny), C.c_int(nz)))
+
+    def free_field(self, slot):
+        self._chk(self.dll.mad_free_field(self.ctx, C.c_int(slot)))
+
+    # -- stage API --------------------------------------------------------------------
+    def orient(self, slot, octave, coords, r=8, lim_main=6, lim_sec=6, want_counts=True, Z=112):
+        coords = _c(coords, np.int32).reshape(-1, 3)
+        n = len(coords)
+        cap = max(1, n * lim_main * lim_sec)
+        ra, rm, rs = (np.zeros(cap, np.int32) for _ in range(3))
+        R = np.zeros((cap, 9))
+        cnt = np.zeros((cap, Z), np.int32) if want_counts else None
+        nrows = C.c_int64(0)
+        nrej = C.c_int32(0)
+        self._chk(self.dll.mad_orient(self.ctx, C.c_int(slot), C.c_int(octave), _p(coords), C.c_int(n), C.c_int(r),
+                                      C.c_int(lim_main), C.c_int(lim_sec), _p(ra), _p(rm), _p(rs), _p(R), _p(cnt),
+                                      C.byref(nrows), C.c_int64(cap), C.byref(nrej)))
+        k = nrows.value
+        return dict(anchor=ra[:k].copy(), main=rm[:k].copy(), sec=rs[:k].copy(), R=R[:k].reshape(k, 3, 3).copy(),
+                    counts=None if cnt is None else cnt[:k].copy(), n_reject=nrej.value)
+
+    def describe(self, slot, octave, coords, R, r=8, Zd=16):
+        coords = _c(coords, np.int32).reshape(-1, 3)
+        R = _c(R, np.float64).reshape(-1, 9)
+        n = len(coords)
+        out = np.zeros((n, 64 * Zd), np.int16)
+        self._chk(self.dll.mad_describe(self.ctx, C.c_int(slot), C.c_int(octave), _p(coords), _p(R), C.c_int64(n), C.c_int(r), _p(out)))
+        return out
+
+    def correlate(self, hi, lo, cc):
+        hi, lo = _c(hi, np.int16), _c(lo, np.int16)
+        n_hi, D = hi.shape
+        n_lo = lo.shape[0]
+        npairs = C.c_int64(0)
+        cap = 1 << 16
+        while True:
+            ph, pl, ps = np.zeros(cap, np.int32), np.zeros(cap, np.int32), np.zeros(cap)
+            rc = self.dll.mad_correlate(self.ctx, _p(hi), C.c_int64(n_hi), _p(lo), C.c_int64(n_lo), C.c_int(D), C.c_double(cc),
+                                        _p(ph), _p(pl), _p(ps), C.byref(npairs), C.c_int64(cap))
+            if rc == -28:      # ENOSPC: the needed size came back in npairs
+                cap = npairs.value
+                continue
+            self._chk(rc)
+            break
+        k = npairs.value
+        return ph[:k].copy(), pl[:k].copy(), ps[:k].copy()
+
+    def pose_score(self, pair_hi, pair_lo, pair_score, hi_p, hi_R, hi_meta, lo_p, lo_R, lo_meta, hi_cloud, lo_cloud,
+                   dist=4.0, want_results=True):
+        pair_hi, pair_lo = _c(pair_hi, np.int32), _c(pair_lo, np.int32)
+        pair_score = _c(pair_score, np.float64)
+        hi_p, lo_p = _c(hi_p, np.float64), _c(lo_p, np.float64)
+        hi_R, lo_R = _c(hi_R, np.float64).reshape(-1, 9), _c(lo_R, np.float64).reshape(-1, 9)
+        hi_meta, lo_meta = _c(hi_meta, np.int32), _c(lo_meta, np.int32)
+        hi_cloud, lo_cloud = _c(hi_cloud, np.float64), _c(lo_cloud, np.float64)
+        n = len(pair_hi)
+        res = np.zeros((n, RESULT_COLS)) if want_results else None
+        cnt = np.zeros(n, np.int32)
+        self._chk(self.dll.mad_pose_score(self.ctx, _p(pair_hi), _p(pair_lo), _p(pair_score), C.c_int64(n),
+                                          _p(hi_p), _p(hi_R), _p(hi_meta), C.c_int64(len(hi_p)),
+                                          _p(lo_p), _p(lo_R), _p(lo_meta), C.c_int64(len(lo_p)),
+                                          _p(hi_cloud), C.c_int64(len(hi_cloud)), _p(lo_cloud), C.c_int64(len(lo_cloud)),
+                                          C.c_double(dist), _p(res), _p(cnt)))
+        return res, cnt
+
+    def topk(self, counts, k):
+        counts = _c(counts, np.int32)
+        k = min(int(k), len(counts))
+        order = np.zeros(max(k, 1), np.int64)
+        self._chk(self.dll.mad_topk(self.ctx, _p(counts), C.c_int64(len(counts)), C.c_int64(k), _p(order)))
+        return order[:k]
+
+    # -- device-resident pipeline -------------------------------------------------------
+    def set_build(self, slots, anc_coords, anc_octave, anc_subv, anc_index, r=8, lim_main=6, lim_sec=6):
+        s = DeviceSet(self)
+        slots = (C.c_int * 2)(int(slots[0]), int(slots[1]))
+        anc_coords = _c(anc_coords, np.int32).reshape(-1, 3)
+        anc_octave = _c(anc_octave, np.int32)
+        anc_subv = _c(anc_subv, np.float64).reshape(-1, 3)
+        anc_index = _c(anc_index, np.int32)
+        s.n_anchors = len(anc_octave)
+        self._chk(self.dll.mad_set_build(self.ctx, s.h, slots, _p(anc_coords), _p(anc_octave), _p(anc_subv), _p(anc_index),
+                                         C.c_int(len(anc_octave)), C.c_int(r), C.c_int(lim_main), C.c_int(lim_sec)))
+        return s
+
+    def set_load(self, row_anchor, row_main, row_R, dsc, anc_subv, anc_index, anc_octave):
+        s = DeviceSet(self)
+        row_anchor, row_main = _c(row_anchor, np.int32), _c(row_main, np.int32)
+        row_R = _c(row_R, np.float64).reshape(-1, 9)
+        dsc = _c(dsc, np.int16)
+        if dsc.ndim != 2:
+            dsc = dsc.reshape(len(row_anchor), -1)
+        anc_subv = _c(anc_subv, np.float64).reshape(-1, 3)
+        anc_index, anc_octave = _c(anc_index, np.int32), _c(anc_octave, np.int32)
+        s.n_anchors = len(anc_index)
+        self._chk(self.dll.mad_set_load(self.ctx, s.h, C.c_int64(len(row_anchor)), _p(row_anchor), _p(row_main), _p(row_R),
+                                        _p(dsc), C.c_int(dsc.shape[1] if len(dsc) else 1024), _p(anc_subv), _p(anc_index),
+                                        _p(anc_octave), C.c_int(len(anc_index))))
+        return s
+
+    def match_topk(self, hi, lo, cc, dist, k):
+        k = int(k)
+        res = np.zeros((max(k, 1), RESULT_COLS))
+        idx = np.zeros(max(k, 1), np.int64)
+        n_out = C.c_int64(0)
+        stats = np.zeros(4, np.int64)
+        self._chk(self.dll.mad_match_topk(self.ctx, hi.h, lo.h, C.c_double(cc), C.c_double(dist), C.c_int64(k), _p(res), _p(idx),
+                                          C.byref(n_out), _p(stats)))
+        g = n_out.value
+        return res[:g], idx[:g], dict(n_pairs=int(stats[0]), l_hi=int(stats[1]), l_lo=int(stats[2]), n_corr=int(stats[3]))
+
+    def match_fetch(self, n_pairs):
+        ph, pl = np.zeros(n_pairs, np.int32), np.zeros(n_pairs, np.int32)
+        ps, cn = np.zeros(n_pairs), np.zeros(n_pairs, np.int32)
+        self._chk(self.dll.mad_match_fetch(self.ctx, _p(ph), _p(pl), _p(ps), _p(cn), C.c_int64(n_pairs)))
+        return ph, pl, ps, cn
+
+    def match_used(self, n_hi_anchors, n_lo_anchors):
+        uh, ul = np.zeros(max(n_hi_anchors, 1), np.uint8), np.zeros(max(n_lo_anchors, 1), np.uint8)
+        self._chk(self.dll.mad_match_used(self.ctx, _p(uh), C.c_int32(n_hi_anchors), _p(ul), C.c_int32(n_lo_anchors)))
+        return uh[:n_hi_anchors].astype(bool), ul[:n_lo_anchors].astype(bool)
+
+    # -- refinement / density / ccc --------------------------------------------------------
+    def upload_density(self, grid, origin, voxsp):
+        grid = _c(grid, np.float32)
+        nx, ny, nz = grid.shape
+        self._chk(self.dll.mad_upload_density(self.ctx, _p(grid), C.c_int(nx), C.c_int(ny), C.c_int(nz),
+                                              C.c_double(origin[0]), C.c_double(origin[1]), C.c_double(origin[2]), C.c_double(voxsp)))
+
+    def refine(self, coords, n_steps=500, max_step=0.5, min_step=0.01):
+        """coords: (n_cand, n_atoms, 3) or (n_atoms, 3).  Returns (coords, converged[], last_step[])."""
+        c = _c(coords, np.float64).copy()
+        single = c.ndim == 2
+        if single:
+            c = c[None]
+        n_cand, n_atoms, _ = c.shape
+        conv, last = np.zeros(n_cand, np.int32), np.zeros(n_cand, np.int32)
+        self._chk(self.dll.mad_refine(self.ctx, _p(c), C.c_int(n_cand), C.c_int64(n_atoms), C.c_int(n_steps),
+                                      C.c_double(max_step), C.c_double(min_step), _p(conv), _p(last)))
+        if single:
+            return c[0], bool(conv[0]), int(last[0])
+        return c, conv.astype(bool), last
+
+    def structure_to_density(self, atoms, mass, resolution, voxsp, isovalue=0.0, pad=0):
+        atoms, mass = _c(atoms, np.float64), _c(mass, np.float64)
+        dims = np.zeros(3, np.int32)
+        org = np.zeros(3)
+        args = (self.ctx, _p(atoms), _p(mass), C.c_int64(len(atoms)), C.c_double(resolution), C.c_double(voxsp),
+                C.c_double(isovalue), C.c_int(pad), _p(dims), _p(org))
+        self._chk(self.dll.mad_structure_to_density(*args, None))
+        grid = np.zeros(tuple(int(d) for d in dims), np.float32)
+        self._chk(self.dll.mad_structure_to_density(*args, _p(grid)))
+        return grid, float(org[0]), float(org[1]), float(org[2])
+
+    def ccc(self, g1, o1, g2, o2, voxsp, isovalue=0.0):
+        """Both grids must be C-contiguous float32; they are clamped in place like the reference."""
+        for g in (g1, g2):
+            if g.dtype != np.float32 or not g.flags.c_contiguous or not g.flags.writeable:
+                raise ValueError("ccc needs writable C-contiguous float32 grids")
+        d1, d2 = np.array(g1.shape, np.int32), np.array(g2.shape, np.int32)
+        o1, o2 = _c(o1, np.float64), _c(o2, np.float64)
+        out = C.c_double(0)
+        self._chk(self.dll.mad_ccc(self.ctx, _p(g1), _p(d1), _p(o1), _p(g2), _p(d2), _p(o2), C.c_double(voxsp),
+                                   C.c_double(isovalue), C.byref(out)))
+        return out.value
+
+
+_default = None
+
+
+def get_lib(device=None):
+    """Process-wide default context (device from MAD_DEVICE / LOCAL_RANK / 0)."""
+    global _default
+    if _default is None:
+        if device is None:
+            device = int(os.environ.get("MAD_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+        _default = Lib(device)
+    return _default
+
+
+def reset_lib():
+    global _default
+    if _default is not None:
+        _default.close()
+    _default = None

@@ -1,0 +1,245 @@
+// mad_common.h -- internal declarations shared by the translation units of libmad_amd.so.
+// gfx950 only: 64-lane wavefronts are assumed throughout.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "../../include/mad_amd.h"
+
+#define MAD_WAVE 64
+
+// ---------------------------------------------------------------------------
+// device-side tables
+// ---------------------------------------------------------------------------
+
+// One EQSP partition as the kernels use it.  Zones of one belt share their phi
+// bounds (mad/eqsp/eqsp.py:37-46), so a direction is classified by finding its
+// belt first and then testing only that belt's azimuth sectors -- the same
+// strict comparisons against the same table values as the reference's scan of
+// all zones (Orientator.py:324-334).
+struct EqspDev {
+    int Z;
+    int nbelt;
+    double th_lo[MAD_MAX_Z];
+    double th_hi[MAD_MAX_Z];
+    double ph_lo[MAD_MAX_Z];     // per belt
+    double ph_hi[MAD_MAX_Z];     // per belt
+    int belt_first[MAD_MAX_Z];   // per belt: first zone
+    int belt_count[MAD_MAX_Z];   // per belt: number of zones
+    double to_dom[MAD_MAX_Z][9];
+    double adj_sec[MAD_MAX_Z][9];
+};
+
+// One octave's gradient field: a texel is {gx, gy, gz, |g|} (|g| in float32 exactly
+// as numpy forms it: sqrt((gx*gx + gy*gy) + gz*gz), Orientator.py:139).
+struct FieldDev {
+    const float4 *tex;
+    int nx, ny, nz;
+};
+
+// ---------------------------------------------------------------------------
+// host-side context
+// ---------------------------------------------------------------------------
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+enum { MAD_T_ORIENT = 0, MAD_T_DESCRIBE, MAD_T_CORRELATE, MAD_T_PAIRS, MAD_T_POSE, MAD_T_TOPK, MAD_T_REFINE,
+       MAD_T_DENSITY, MAD_T_CCC, MAD_T_COUNT };
+
+#define MAD_T_RING 32
+
+struct TimerGroup {
+    hipEvent_t start[MAD_T_RING];
+    hipEvent_t stop[MAD_T_RING];
+    int pending = 0;
+    double total_ms = 0.0;
+    int64_t launches = 0;
+};
+
+struct DensityDev {
+    float *grid = nullptr;       // [nx][ny][nz]
+    float4 *grad = nullptr;      // np.gradient texels {d/dx, d/dy, d/dz, 0}
+    int nx = 0, ny = 0, nz = 0;
+    double o[3] = {0, 0, 0};
+    double vs = 0;
+};
+
+struct MatchState {            // buffers of the most recent mad_match_topk call
+    int64_t n_pairs = 0;
+    int32_t l_hi = 0, l_lo = 0;
+    int32_t n_hi_anchors = 0, n_lo_anchors = 0;
+};
+
+struct mad_ctx {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    char err[512] = {0};
+    FieldDev fields[MAD_MAX_FIELDS];
+    void *field_mem[MAD_MAX_FIELDS];
+    EqspDev *eq[2] = {nullptr, nullptr};     // device copies
+    EqspDev eq_host[2];
+    bool eq_set[2] = {false, false};
+    int8_t *mask_off = nullptr;              // sphere-mask offsets for the current r
+    int mask_r = -1;
+    int mask_n = 0;
+    // named grow-only scratch buffers
+    DevBuf scratch[64];
+    // host pinned staging for small read-backs
+    int64_t *pinned = nullptr;
+    DensityDev dens;
+    MatchState match;
+    bool timing = false;
+    TimerGroup timers[MAD_T_COUNT];
+    int n_cu = 256;
+};
+
+struct mad_set {
+    int32_t n_anchors = 0;
+    int64_t n_rows = 0;
+    int64_t n_rows_pad = 0;      // rows rounded up to the GEMM tile
+    int D = 0;
+    // per anchor
+    DevBuf anc_coords, anc_octave, anc_subv, anc_index;
+    // per row
+    DevBuf row_anchor, row_main, row_sec, row_R, dsc, dsc8, norm;
+    // cell list over ALL anchors of the set (used when the set is the map side)
+    DevBuf cell_start, cell_pts, cell_ids;
+    double cell_min[3] = {0, 0, 0};
+    double cell_size = 0;
+    int cell_dim[3] = {0, 0, 0};
+    bool cells_ready = false;
+};
+
+// scratch slots
+enum {
+    S_COORDS = 0, S_OCT, S_SLOT_CNT, S_SLOT_MAIN, S_SLOT_SEC, S_SLOT_HIST, S_ROW_OFF, S_SCAN_TMP,
+    S_ROW_ANCHOR, S_ROW_MAIN, S_ROW_SEC, S_ROW_R, S_ROW_COUNT, S_DSC, S_ROW_COORDS,
+    S_HI16, S_LO16, S_HI8, S_LO8, S_HNORM, S_LNORM, S_CMAT, S_ROWCNT, S_ROWOFF,
+    S_PAIR_HI, S_PAIR_LO, S_PAIR_SCORE, S_COUNTS, S_USED_HI, S_USED_LO, S_HI_CLOUD, S_MISC,
+    S_HIST, S_SEL, S_RESULTS, S_TMP_A, S_TMP_B, S_TMP_C, S_TMP_D, S_TMP_E, S_TMP_F, S_TMP_G,
+    S_TIE_FLAG, S_TIE_OFF, S_SEL_OUT, S_TMP_H, S_TMP_I, S_TMP_J,
+    S_CELL_START, S_CELL_PTS, S_CELL_IDS, S_N_SLOTS
+};
+static_assert(S_N_SLOTS <= 64, "grow mad_ctx::scratch");
+
+int mad_fail(mad_ctx *ctx, int code, const char *fmt, ...);
+int mad_reserve(mad_ctx *ctx, DevBuf &b, size_t bytes);            // grow-only device buffer
+void mad_release(DevBuf &b);
+template <class T> static inline T *scratch(mad_ctx *ctx, int slot) { return (T *)ctx->scratch[slot].p; }
+
+void mad_timer_begin(mad_ctx *ctx, int group);
+void mad_timer_end(mad_ctx *ctx, int group);
+
+// exclusive prefix sum of n int32 on the ctx stream; out[n] receives the total (out has n+1 entries)
+int mad_scan_i32(mad_ctx *ctx, const int32_t *in, int32_t *out, int64_t n);
+
+// implemented in mad_orient.hip; used by the set API in mad_match.hip
+int mad_orient_device(mad_ctx *ctx, FieldDev f0, FieldDev f1, const int32_t *d_coords, const int32_t *d_octave,
+                      int uniform_octave, int n, int r, int lim_main, int lim_sec, bool want_hist,
+                      int64_t *n_rows_out, int32_t *n_reject_out);
+int mad_describe_device(mad_ctx *ctx, FieldDev f0, FieldDev f1, const int32_t *d_anc_coords, const int32_t *d_anc_octave,
+                        int uniform_octave, const int32_t *d_row_anchor, const double *d_row_R, int64_t n_rows,
+                        int r, int16_t *d_dsc);
+int mad_build_cells(mad_ctx *ctx, mad_set *set, const double *h_subv, double cell);
+
+#define MAD_HIP(call)                                                                            \
+    do {                                                                                         \
+        hipError_t e__ = (call);                                                                 \
+        if (e__ != hipSuccess)                                                                   \
+            return mad_fail(ctx, MAD_EHIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, __LINE__); \
+    } while (0)
+
+#define MAD_TRY(call)            \
+    do {                         \
+        int rc__ = (call);       \
+        if (rc__ != MAD_OK) return rc__; \
+    } while (0)
+
+static inline int64_t mad_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---------------------------------------------------------------------------
+// device helpers
+// ---------------------------------------------------------------------------
+#ifdef __HIPCC__
+
+__device__ __forceinline__ int wave_sum_i32(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, MAD_WAVE);
+    return v;
+}
+__device__ __forceinline__ int wave_max_i32(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, MAD_WAVE));
+    return v;
+}
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, MAD_WAVE);
+    return v;
+}
+__device__ __forceinline__ double wave_max_f64(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, MAD_WAVE));
+    return v;
+}
+__device__ __forceinline__ unsigned lane_id() { return threadIdx.x & (MAD_WAVE - 1); }
+__device__ __forceinline__ unsigned long long lanemask_lt() { return (1ull << lane_id()) - 1ull; }
+
+// Block-wide exclusive scan of one int per thread (blockDim.x multiple of 64, <= 1024).
+// `warp_tot` must hold blockDim.x/64 + 1 ints of LDS.  Returns the exclusive prefix;
+// *total gets the block sum.
+__device__ __forceinline__ int block_excl_scan(int v, int *warp_tot, int *total) {
+    const int lane = lane_id(), w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int o = 1; o < MAD_WAVE; o <<= 1) {
+        int t = __shfl_up(inc, o, MAD_WAVE);
+        if (lane >= o) inc += t;
+    }
+    if (lane == MAD_WAVE - 1) warp_tot[w] = inc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int i = 0; i < nw; i++) { int t = warp_tot[i]; warp_tot[i] = run; run += t; }
+        warp_tot[nw] = run;
+    }
+    __syncthreads();
+    int res = inc - v + warp_tot[w];
+    *total = warp_tot[nw];
+    __syncthreads();
+    return res;
+}
+
+// Classify a direction given as (theta, theta + 2pi, phi) and call f(zone) for every
+// zone whose strict bounds contain it (Orientator.py:328-331).  Zones can overlap by
+// a sliver next to a sector that wraps past 2pi (the tables are rounded to 4
+// decimals), so more than one call is possible; callers that need "last match wins"
+// (Descriptor.py:187) keep the last.
+template <class F>
+__device__ __forceinline__ void eqsp_classify(const EqspDev *t, double th, double sth, double ph, F &&f) {
+    const int nb = t->nbelt;
+    for (int b = 0; b < nb; b++) {
+        if (ph < t->ph_hi[b] && ph > t->ph_lo[b]) {
+            const int a0 = t->belt_first[b], a1 = a0 + t->belt_count[b];
+            for (int a = a0; a < a1; a++) {
+                const double lo = t->th_lo[a], hi = t->th_hi[a];
+                if ((th < hi && th > lo) || (sth < hi && sth > lo)) f(a);
+            }
+            break;
+        }
+    }
+}
+
+#define MAD_TWO_PI 6.283185307179586476925286766559
+
+#endif  // __HIPCC__

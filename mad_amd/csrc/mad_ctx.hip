@@ -1,0 +1,376 @@
+// mad_ctx.hip -- context, error reporting, device memory, EQSP tables, gradient-field
+// upload, timing and the prefix-sum utility of libmad_amd.so (gfx950).
+#include "mad_common.h"
+
+static char g_init_err[512] = "";
+
+int mad_fail(mad_ctx *ctx, int code, const char *fmt, ...) {
+    char *dst = ctx ? ctx->err : g_init_err;
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(dst, 512, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+extern "C" const char *mad_last_error(const mad_ctx *ctx) { return ctx ? ctx->err : g_init_err; }
+
+int mad_reserve(mad_ctx *ctx, DevBuf &b, size_t bytes) {
+    if (bytes == 0) bytes = 16;
+    if (b.cap >= bytes) return MAD_OK;
+    if (b.p) {
+        MAD_HIP(hipStreamSynchronize(ctx->stream));
+        (void)hipFree(b.p);
+        b.p = nullptr;
+        b.cap = 0;
+    }
+    size_t want = bytes + bytes / 4 + 256;    // 25 % slack: the buffers only grow
+    want = (want + 255) & ~size_t(255);
+    hipError_t e = hipMalloc(&b.p, want);
+    if (e != hipSuccess) {
+        b.p = nullptr;
+        return mad_fail(ctx, MAD_ENOMEM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+    }
+    b.cap = want;
+    return MAD_OK;
+}
+
+void mad_release(DevBuf &b) {
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+}
+
+extern "C" int mad_init(int device, mad_ctx **out) {
+    if (!out) return mad_fail(nullptr, MAD_EINVAL, "mad_init: out is NULL");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0)
+        return mad_fail(nullptr, MAD_ENODEV, "mad_init: no HIP device (%s)", hipGetErrorString(e));
+    if (device < 0 || device >= ndev) return mad_fail(nullptr, MAD_EINVAL, "mad_init: device %d of %d", device, ndev);
+    e = hipSetDevice(device);
+    if (e != hipSuccess) return mad_fail(nullptr, MAD_ENODEV, "hipSetDevice(%d): %s", device, hipGetErrorString(e));
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) return mad_fail(nullptr, MAD_ENODEV, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return mad_fail(nullptr, MAD_ENODEV, "mad_init: device %d is %s; this library is built for gfx950 only", device,
+                        prop.gcnArchName);
+    mad_ctx *ctx = new mad_ctx();
+    ctx->device = device;
+    ctx->n_cu = prop.multiProcessorCount;
+    for (int i = 0; i < MAD_MAX_FIELDS; i++) {
+        ctx->fields[i] = FieldDev{nullptr, 0, 0, 0};
+        ctx->field_mem[i] = nullptr;
+    }
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipMalloc((void **)&ctx->eq[0], sizeof(EqspDev)) != hipSuccess ||
+        hipMalloc((void **)&ctx->eq[1], sizeof(EqspDev)) != hipSuccess ||
+        hipHostMalloc((void **)&ctx->pinned, 4096) != hipSuccess) {
+        mad_fail(nullptr, MAD_EHIP, "mad_init: stream / table allocation failed");
+        delete ctx;
+        return MAD_EHIP;
+    }
+    for (int g = 0; g < MAD_T_COUNT; g++)
+        for (int i = 0; i < MAD_T_RING; i++) {
+            (void)hipEventCreate(&ctx->timers[g].start[i]);
+            (void)hipEventCreate(&ctx->timers[g].stop[i]);
+        }
+    *out = ctx;
+    return MAD_OK;
+}
+
+extern "C" void mad_destroy(mad_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (int i = 0; i < MAD_MAX_FIELDS; i++)
+        if (ctx->field_mem[i]) (void)hipFree(ctx->field_mem[i]);
+    for (auto &b : ctx->scratch) mad_release(b);
+    if (ctx->eq[0]) (void)hipFree(ctx->eq[0]);
+    if (ctx->eq[1]) (void)hipFree(ctx->eq[1]);
+    if (ctx->mask_off) (void)hipFree(ctx->mask_off);
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->dens.grid) (void)hipFree(ctx->dens.grid);
+    if (ctx->dens.grad) (void)hipFree(ctx->dens.grad);
+    for (int g = 0; g < MAD_T_COUNT; g++)
+        for (int i = 0; i < MAD_T_RING; i++) {
+            (void)hipEventDestroy(ctx->timers[g].start[i]);
+            (void)hipEventDestroy(ctx->timers[g].stop[i]);
+        }
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" int mad_synchronize(mad_ctx *ctx) {
+    if (!ctx) return MAD_EINVAL;
+    MAD_HIP(hipStreamSynchronize(ctx->stream));
+    return MAD_OK;
+}
+
+extern "C" void *mad_stream(mad_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+// ---------------------------------------------------------------------------
+// timing: HIP events on the ctx stream around each kernel group
+// ---------------------------------------------------------------------------
+
+static void timer_drain(mad_ctx *ctx, TimerGroup &t) {
+    for (int i = 0; i < t.pending; i++) {
+        float ms = 0;
+        if (hipEventSynchronize(t.stop[i]) == hipSuccess && hipEventElapsedTime(&ms, t.start[i], t.stop[i]) == hipSuccess)
+            t.total_ms += ms;
+        t.launches++;
+    }
+    t.pending = 0;
+}
+
+void mad_timer_begin(mad_ctx *ctx, int group) {
+    if (!ctx->timing) return;
+    TimerGroup &t = ctx->timers[group];
+    if (t.pending == MAD_T_RING) timer_drain(ctx, t);
+    (void)hipEventRecord(t.start[t.pending], ctx->stream);
+}
+
+void mad_timer_end(mad_ctx *ctx, int group) {
+    if (!ctx->timing) return;
+    TimerGroup &t = ctx->timers[group];
+    (void)hipEventRecord(t.stop[t.pending], ctx->stream);
+    t.pending++;
+}
+
+static const char *k_timer_names[MAD_T_COUNT] = {"orient", "describe", "correlate", "pairs", "pose",
+                                                 "topk",   "refine",   "density",   "ccc"};
+
+extern "C" int mad_timing_enable(mad_ctx *ctx, int on) {
+    if (!ctx) return MAD_EINVAL;
+    ctx->timing = on != 0;
+    return MAD_OK;
+}
+
+extern "C" int mad_timing_reset(mad_ctx *ctx) {
+    if (!ctx) return MAD_EINVAL;
+    for (int g = 0; g < MAD_T_COUNT; g++) {
+        timer_drain(ctx, ctx->timers[g]);
+        ctx->timers[g].total_ms = 0;
+        ctx->timers[g].launches = 0;
+    }
+    return MAD_OK;
+}
+
+extern "C" int mad_timing_get(mad_ctx *ctx, const char *what, double *total_ms, int64_t *launches) {
+    if (!ctx || !what) return MAD_EINVAL;
+    for (int g = 0; g < MAD_T_COUNT; g++)
+        if (strcmp(what, k_timer_names[g]) == 0) {
+            timer_drain(ctx, ctx->timers[g]);
+            if (total_ms) *total_ms = ctx->timers[g].total_ms;
+            if (launches) *launches = ctx->timers[g].launches;
+            return MAD_OK;
+        }
+    return mad_fail(ctx, MAD_EINVAL, "mad_timing_get: unknown group '%s'", what);
+}
+
+extern "C" double mad_last_ms(mad_ctx *ctx, const char *what) {
+    double t = -1;
+    int64_t n = 0;
+    if (mad_timing_get(ctx, what, &t, &n) != MAD_OK || n == 0) return -1.0;
+    return t / (double)n;
+}
+
+// ---------------------------------------------------------------------------
+// EQSP tables
+// ---------------------------------------------------------------------------
+
+extern "C" int mad_set_eqsp(mad_ctx *ctx, int which, int Z, const double *bounds, const double *to_dom,
+                            const double *adj_sec) {
+    if (!ctx) return MAD_EINVAL;
+    if (which < 0 || which > 1 || Z < 2 || Z > MAD_MAX_Z || !bounds)
+        return mad_fail(ctx, MAD_EINVAL, "mad_set_eqsp: which=%d Z=%d", which, Z);
+    if (which == 0 && (!to_dom || !adj_sec)) return mad_fail(ctx, MAD_EINVAL, "mad_set_eqsp: orientation table needs matrices");
+    EqspDev &h = ctx->eq_host[which];
+    memset(&h, 0, sizeof(h));
+    h.Z = Z;
+    double prev = -1.0;
+    int nb = -1;
+    for (int a = 0; a < Z; a++) {
+        h.th_lo[a] = bounds[4 * a];
+        h.th_hi[a] = bounds[4 * a + 2];
+        if (nb < 0 || bounds[4 * a + 1] != prev) {      // a new belt starts when phi_min changes (eqsp.py:40)
+            nb++;
+            h.ph_lo[nb] = bounds[4 * a + 1];
+            h.ph_hi[nb] = bounds[4 * a + 3];
+            h.belt_first[nb] = a;
+            h.belt_count[nb] = 0;
+            prev = bounds[4 * a + 1];
+        } else if (bounds[4 * a + 3] != h.ph_hi[nb]) {
+            return mad_fail(ctx, MAD_EINVAL, "mad_set_eqsp: zone %d does not share its belt's phi_max", a);
+        }
+        h.belt_count[nb]++;
+    }
+    h.nbelt = nb + 1;
+    if (to_dom) memcpy(h.to_dom, to_dom, sizeof(double) * 9 * Z);
+    if (adj_sec) memcpy(h.adj_sec, adj_sec, sizeof(double) * 9 * Z);
+    MAD_HIP(hipMemcpyAsync(ctx->eq[which], &h, sizeof(EqspDev), hipMemcpyHostToDevice, ctx->stream));
+    MAD_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->eq_set[which] = true;
+    return MAD_OK;
+}
+
+// ---------------------------------------------------------------------------
+// gradient fields
+// ---------------------------------------------------------------------------
+
+// planar {gx,gy,gz} -> texel {gx,gy,gz,|g|}; |g| with one float32 rounding per operation
+__global__ __launch_bounds__(256) void k_pack_field(const float *__restrict__ gx, const float *__restrict__ gy,
+                                                    const float *__restrict__ gz, float4 *__restrict__ tex, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += step) {
+        const float x = gx[i], y = gy[i], z = gz[i];
+        const float s = __fadd_rn(__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)), __fmul_rn(z, z));
+        tex[i] = make_float4(x, y, z, __fsqrt_rn(s));
+    }
+}
+
+static int field_alloc(mad_ctx *ctx, int slot, int nx, int ny, int nz, size_t *n_out) {
+    if (slot < 0 || slot >= MAD_MAX_FIELDS) return mad_fail(ctx, MAD_EINVAL, "field slot %d out of range", slot);
+    if (nx < 2 || ny < 2 || nz < 2) return mad_fail(ctx, MAD_EINVAL, "field dims %dx%dx%d", nx, ny, nz);
+    const size_t n = (size_t)nx * ny * nz;
+    if (ctx->field_mem[slot]) {
+        MAD_HIP(hipStreamSynchronize(ctx->stream));
+        (void)hipFree(ctx->field_mem[slot]);
+        ctx->field_mem[slot] = nullptr;
+        ctx->fields[slot] = FieldDev{nullptr, 0, 0, 0};
+    }
+    hipError_t e = hipMalloc(&ctx->field_mem[slot], n * sizeof(float4));
+    if (e != hipSuccess) {
+        ctx->field_mem[slot] = nullptr;
+        return mad_fail(ctx, MAD_ENOMEM, "field of %zu texels: %s", n, hipGetErrorString(e));
+    }
+    ctx->fields[slot] = FieldDev{(const float4 *)ctx->field_mem[slot], nx, ny, nz};
+    *n_out = n;
+    return MAD_OK;
+}
+
+extern "C" int mad_upload_field_device(mad_ctx *ctx, int slot, const float *g3, int nx, int ny, int nz) {
+    if (!ctx || !g3) return MAD_EINVAL;
+    size_t n = 0;
+    MAD_TRY(field_alloc(ctx, slot, nx, ny, nz, &n));
+    const int blocks = (int)std::min<size_t>(mad_ceil_div((int64_t)n, 256), (size_t)ctx->n_cu * 16);
+    hipLaunchKernelGGL(k_pack_field, dim3(blocks), dim3(256), 0, ctx->stream, g3, g3 + n, g3 + 2 * n,
+                       (float4 *)ctx->field_mem[slot], n);
+    MAD_HIP(hipGetLastError());
+    MAD_HIP(hipStreamSynchronize(ctx->stream));
+    return MAD_OK;
+}
+
+extern "C" int mad_upload_field(mad_ctx *ctx, int slot, const float *gx, const float *gy, const float *gz, int nx,
+                                int ny, int nz) {
+    if (!ctx || !gx || !gy || !gz) return MAD_EINVAL;
+    const size_t n = (size_t)nx * ny * nz;
+    float *stage = nullptr;
+    hipError_t e = hipMalloc((void **)&stage, 3 * n * sizeof(float));
+    if (e != hipSuccess) return mad_fail(ctx, MAD_ENOMEM, "field staging: %s", hipGetErrorString(e));
+    int rc = MAD_OK;
+    if (hipMemcpyAsync(stage, gx, n * sizeof(float), hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+        hipMemcpyAsync(stage + n, gy, n * sizeof(float), hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+        hipMemcpyAsync(stage + 2 * n, gz, n * sizeof(float), hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+        rc = mad_fail(ctx, MAD_EHIP, "field upload failed");
+    if (rc == MAD_OK) rc = mad_upload_field_device(ctx, slot, stage, nx, ny, nz);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(stage);
+    return rc;
+}
+
+extern "C" int mad_free_field(mad_ctx *ctx, int slot) {
+    if (!ctx || slot < 0 || slot >= MAD_MAX_FIELDS) return MAD_EINVAL;
+    if (ctx->field_mem[slot]) {
+        MAD_HIP(hipStreamSynchronize(ctx->stream));
+        (void)hipFree(ctx->field_mem[slot]);
+    }
+    ctx->field_mem[slot] = nullptr;
+    ctx->fields[slot] = FieldDev{nullptr, 0, 0, 0};
+    return MAD_OK;
+}
+
+// ---------------------------------------------------------------------------
+// exclusive prefix sum (three launches: chunk sums, scan of sums, apply)
+// ---------------------------------------------------------------------------
+
+#define SCAN_THREADS 256
+#define SCAN_ITEMS 8
+#define SCAN_CHUNK (SCAN_THREADS * SCAN_ITEMS)
+
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_sums(const int32_t *__restrict__ in, int64_t n,
+                                                            int32_t *__restrict__ sums) {
+    __shared__ int wt[SCAN_THREADS / MAD_WAVE];
+    const int64_t base = (int64_t)blockIdx.x * SCAN_CHUNK;
+    int s = 0;
+    for (int i = 0; i < SCAN_ITEMS; i++) {
+        const int64_t idx = base + (int64_t)i * SCAN_THREADS + threadIdx.x;
+        if (idx < n) s += in[idx];
+    }
+    s = wave_sum_i32(s);
+    if (lane_id() == 0) wt[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int t = 0;
+        for (int i = 0; i < SCAN_THREADS / MAD_WAVE; i++) t += wt[i];
+        sums[blockIdx.x] = t;
+    }
+}
+
+// one block: exclusive scan of nb chunk sums in place; sums[nb] = total
+__global__ __launch_bounds__(1024) void k_scan_top(int32_t *__restrict__ sums, int64_t nb) {
+    __shared__ int wt[1024 / MAD_WAVE + 1];
+    __shared__ int carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < nb; base += 1024) {
+        const int64_t i = base + threadIdx.x;
+        const int v = (i < nb) ? sums[i] : 0;
+        int tot;
+        const int ex = block_excl_scan(v, wt, &tot);
+        if (i < nb) sums[i] = carry + ex;
+        __syncthreads();
+        if (threadIdx.x == 0) carry += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) sums[nb] = carry;
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(const int32_t *__restrict__ in, int32_t *__restrict__ out,
+                                                             int64_t n, const int32_t *__restrict__ sums, int64_t nb) {
+    __shared__ int wt[SCAN_THREADS / MAD_WAVE + 1];
+    const int64_t base = (int64_t)blockIdx.x * SCAN_CHUNK + (int64_t)threadIdx.x * SCAN_ITEMS;
+    int v[SCAN_ITEMS];
+    int s = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) {
+        v[i] = (base + i < n) ? in[base + i] : 0;
+        s += v[i];
+    }
+    int tot;
+    int run = block_excl_scan(s, wt, &tot) + sums[blockIdx.x];
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) {
+        if (base + i < n) out[base + i] = run;
+        run += v[i];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = sums[nb];
+}
+
+int mad_scan_i32(mad_ctx *ctx, const int32_t *in, int32_t *out, int64_t n) {
+    if (n <= 0) {
+        MAD_HIP(hipMemsetAsync(out, 0, sizeof(int32_t), ctx->stream));
+        return MAD_OK;
+    }
+    const int64_t nb = mad_ceil_div(n, SCAN_CHUNK);
+    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_SCAN_TMP], (size_t)(nb + 1) * sizeof(int32_t)));
+    int32_t *sums = scratch<int32_t>(ctx, S_SCAN_TMP);
+    hipLaunchKernelGGL(k_scan_sums, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, ctx->stream, in, n, sums);
+    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, ctx->stream, sums, nb);
+    hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, ctx->stream, in, out, n, sums, nb);
+    MAD_HIP(hipGetLastError());
+    return MAD_OK;
+}

@@ -1,0 +1,535 @@
+// mad_orient.hip -- orientation assignment (a1-a8) and descriptor generation (a9-a10)
+// for gfx950.  Reference: mad/Orientator.py:68-343, mad/Descriptor.py:106-202.
+//
+// Orientation: one 256-thread workgroup per anchor.  Only the voxels of the 17^3 box
+// that carry weight (inside the 1.05 r sphere, |g| >= 1e-5: 2517 at most for r = 8)
+// are fetched; their unit gradients are kept in LDS as float32 and every re-binning
+// pass (one in float32 semantics, one per main-bin candidate in float64 after the
+// rotation) runs out of LDS.
+//
+// Description: one 256-thread workgroup per oriented row; each thread owns a (j, k)
+// column of the 16^3 sample lattice and gathers its 16 nearest-neighbour texels with
+// 16 independent 16-byte loads; the 64 x 16 histogram lives in LDS.
+#include "mad_common.h"
+
+#define ORI_THREADS 256
+#define ORI_MAX_FAN 64          // lim_main * lim_sec must not exceed this
+#define ORI_MAX_MAIN 8
+
+// ---------------------------------------------------------------------------
+// sphere mask (Orientator.py:38-47)
+// ---------------------------------------------------------------------------
+
+static int ensure_mask(mad_ctx *ctx, int r) {
+    if (ctx->mask_r == r) return MAD_OK;
+    const int B = 2 * r + 1;
+    int8_t *h = (int8_t *)malloc((size_t)B * B * B * 4);
+    int n = 0;
+    for (int i = -r; i <= r; i++)
+        for (int j = -r; j <= r; j++)
+            for (int k = -r; k <= r; k++)
+                if (sqrt((double)(i * i + j * j + k * k)) <= r * 1.05) {
+                    h[4 * n] = (int8_t)i; h[4 * n + 1] = (int8_t)j; h[4 * n + 2] = (int8_t)k; h[4 * n + 3] = 0;
+                    n++;
+                }
+    if (ctx->mask_off) {
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipFree(ctx->mask_off);
+        ctx->mask_off = nullptr;
+    }
+    hipError_t e = hipMalloc((void **)&ctx->mask_off, (size_t)n * 4);
+    if (e == hipSuccess) e = hipMemcpy(ctx->mask_off, h, (size_t)n * 4, hipMemcpyHostToDevice);
+    free(h);
+    if (e != hipSuccess) return mad_fail(ctx, MAD_EHIP, "sphere mask upload: %s", hipGetErrorString(e));
+    ctx->mask_r = r;
+    ctx->mask_n = n;
+    return MAD_OK;
+}
+
+// ---------------------------------------------------------------------------
+// orientation kernel
+// ---------------------------------------------------------------------------
+
+struct OrientArgs {
+    FieldDev f[2];                 // octave 0 (upsampled, stride 2) and 1 (base, stride 1)
+    const int32_t *coords;         // n x 3
+    const int32_t *octave;         // n, or nullptr -> uniform_octave
+    int uniform_octave;
+    int n;
+    int r;
+    int nmask;
+    const int8_t *mask_off;        // nmask x {dx,dy,dz,0}
+    const EqspDev *eq;
+    int lim_main, lim_sec;
+    int fan;                       // lim_main * lim_sec
+    int32_t *slot_cnt;             // n: rows produced, -1 = rejected at the border
+    int32_t *slot_main;            // n x fan
+    int32_t *slot_sec;             // n x fan
+    int32_t *slot_hist;            // n x lim_main x Z quantised counts per accepted main bin (or nullptr)
+    int32_t *slot_hidx;            // n x fan: which of the anchor's hist rows a slot uses
+};
+
+// Quantise `hist` (Z counts in LDS) to 0..50 of its max (Orientator.py:336-340) into q.
+// Executed by wave 0 only; returns the max (0 = nothing counted, q left = hist).
+__device__ __forceinline__ int quantise_wave0(const int *hist, int *q, int Z) {
+    const int lane = lane_id();
+    const int c0 = lane < Z ? hist[lane] : 0;
+    const int c1 = lane + 64 < Z ? hist[lane + 64] : 0;
+    const int mx = wave_max_i32(max(c0, c1));
+    if (lane < Z) q[lane] = mx ? (int)((double)c0 / (double)mx * 50.0) : c0;
+    if (lane + 64 < Z) q[lane + 64] = mx ? (int)((double)c1 / (double)mx * 50.0) : c1;
+    return mx;
+}
+
+__global__ __launch_bounds__(ORI_THREADS) void k_orient(OrientArgs A) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    float *vx = (float *)smem;
+    float *vy = vx + A.nmask;
+    float *vz = vy + A.nmask;
+    __shared__ int hist[MAD_MAX_Z];
+    __shared__ int q0[MAD_MAX_Z];
+    __shared__ int q1[MAD_MAX_Z];
+    __shared__ int main_list[MAD_MAX_Z];
+    __shared__ int sec_list[MAD_MAX_Z];
+    __shared__ int s_nvox, s_nmain, s_mx, s_nsec, s_ok;
+    __shared__ double s_dom[9];
+
+    const int a = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int oct = A.octave ? A.octave[a] : A.uniform_octave;
+    const FieldDev F = A.f[oct == 1 ? 1 : 0];
+    const int stride = (oct == 1) ? 1 : 2;
+    const int r = A.r;
+    const int Z = A.eq->Z;
+    const int x = A.coords[3 * a], y = A.coords[3 * a + 1], z = A.coords[3 * a + 2];
+
+    // step01 border test (Orientator.py:128-135 / 149-155)
+    {
+        const int xm = x - r * stride, ym = y - r * stride, zm = z - r * stride;
+        const int xp = x + r * stride + 1, yp = y + r * stride + 1, zp = z + r * stride + 1;
+        if (xm < 0 || ym < 0 || zm < 0 || xp > F.nx - 1 || yp > F.ny - 1 || zp > F.nz - 1) {
+            if (tid == 0) A.slot_cnt[a] = -1;
+            return;
+        }
+    }
+    if (tid == 0) s_nvox = 0;
+    for (int i = tid; i < MAD_MAX_Z; i += ORI_THREADS) hist[i] = 0;
+    __syncthreads();
+
+    // step01: fetch, normalise (float32, Orientator.py:139-147), keep weighted voxels only
+    const float cutoff = 1e-5f;
+    for (int m = tid; m < A.nmask; m += ORI_THREADS) {
+        const int dx = A.mask_off[4 * m], dy = A.mask_off[4 * m + 1], dz = A.mask_off[4 * m + 2];
+        const size_t src = ((size_t)(x + dx * stride) * F.ny + (size_t)(y + dy * stride)) * F.nz + (size_t)(z + dz * stride);
+        const float4 t = F.tex[src];
+        if (!(t.w < cutoff)) {
+            float gx = t.x, gy = t.y, gz = t.z;
+            if (t.w > cutoff) { gx = __fdiv_rn(gx, t.w); gy = __fdiv_rn(gy, t.w); gz = __fdiv_rn(gz, t.w); }
+            const int slot = atomicAdd(&s_nvox, 1);
+            vx[slot] = gx; vy[slot] = gy; vz[slot] = gz;
+        }
+    }
+    __syncthreads();
+    const int nvox = s_nvox;
+
+    // step02: first binning on the float32 box (Orientator.py:307-334)
+    {
+        const float two_pi_f = (float)MAD_TWO_PI;
+        for (int v = tid; v < nvox; v += ORI_THREADS) {
+            float th = (float)atan2((double)vy[v], (double)vx[v]);
+            if (th < 0.0f) th = __fadd_rn(th, two_pi_f);
+            const float sth = __fadd_rn(th, two_pi_f);
+            double cz = (double)vz[v];
+            cz = cz > 1.0 ? 1.0 : (cz < -1.0 ? -1.0 : cz);
+            const float ph = (float)acos(cz);
+            eqsp_classify(A.eq, (double)th, (double)sth, (double)ph, [&](int zn) { atomicAdd(&hist[zn], 1); });
+        }
+    }
+    __syncthreads();
+    if (tid < MAD_WAVE) {
+        const int mx = quantise_wave0(hist, q0, Z);
+        // main bins: quantised count > 0.8 * max (Orientator.py:181)
+        const int lane = lane_id();
+        const bool p0 = lane < Z && (double)q0[lane] > 50 * 0.8;
+        const bool p1 = lane + 64 < Z && (double)q0[lane + 64] > 50 * 0.8;
+        const unsigned long long m0 = __ballot(p0), m1 = __ballot(p1);
+        const int n0 = __popcll(m0);
+        if (p0) main_list[__popcll(m0 & lanemask_lt())] = lane;
+        if (p1) main_list[n0 + __popcll(m1 & lanemask_lt())] = lane + 64;
+        if (lane == 0) { s_mx = mx; s_nmain = n0 + __popcll(m1); }
+    }
+    __syncthreads();
+    const int nmain = s_nmain;
+    if (s_mx == 0 || nmain == 0 || nmain > A.lim_main) {      // Orientator.py:182-184
+        if (tid == 0) A.slot_cnt[a] = 0;
+        return;
+    }
+
+    int produced = 0;      // rows emitted so far (uniform across the block)
+    int hist_rows = 0;
+    for (int mi = 0; mi < nmain; mi++) {
+        const int mb = main_list[mi];
+        __syncthreads();
+        if (mb != 0) {
+            // step03: rotate by to_dom (float64) and re-bin (Orientator.py:204-206, 303)
+            if (tid < 9) s_dom[tid] = A.eq->to_dom[mb][tid];
+            for (int i = tid; i < MAD_MAX_Z; i += ORI_THREADS) hist[i] = 0;
+            __syncthreads();
+            const double d0 = s_dom[0], d1 = s_dom[1], d2 = s_dom[2], d3 = s_dom[3], d4 = s_dom[4], d5 = s_dom[5],
+                         d6 = s_dom[6], d7 = s_dom[7], d8 = s_dom[8];
+            for (int v = tid; v < nvox; v += ORI_THREADS) {
+                const double g0 = vx[v], g1 = vy[v], g2 = vz[v];
+                const double rx = g0 * d0 + g1 * d1 + g2 * d2;
+                const double ry = g0 * d3 + g1 * d4 + g2 * d5;
+                double rz = g0 * d6 + g1 * d7 + g2 * d8;
+                double th = atan2(ry, rx);
+                if (th < 0) th += MAD_TWO_PI;
+                const double sth = th + MAD_TWO_PI;
+                rz = rz > 1.0 ? 1.0 : (rz < -1.0 ? -1.0 : rz);
+                const double ph = acos(rz);
+                eqsp_classify(A.eq, th, sth, ph, [&](int zn) { atomicAdd(&hist[zn], 1); });
+            }
+            __syncthreads();
+            if (tid < MAD_WAVE) quantise_wave0(hist, q1, Z);
+        } else {
+            for (int i = tid; i < Z; i += ORI_THREADS) q1[i] = q0[i];      // Orientator.py:211: no re-binning
+        }
+        __syncthreads();
+        // step04: secondary bins among the non-pole zones (Orientator.py:228-239)
+        if (tid < MAD_WAVE) {
+            const int lane = lane_id();
+            const int i0 = lane, i1 = lane + 64;
+            const bool in0 = i0 >= 1 && i0 < Z - 1, in1 = i1 >= 1 && i1 < Z - 1;
+            const int c0 = in0 ? q1[i0] : 0, c1 = in1 ? q1[i1] : 0;
+            const int mx = wave_max_i32(max(c0, c1));
+            bool p0 = false, p1 = false;
+            if (mx > 0) {
+                p0 = in0 && (double)((int)((double)c0 / (double)mx * 50.0)) > 50 * 0.8;
+                p1 = in1 && (double)((int)((double)c1 / (double)mx * 50.0)) > 50 * 0.8;
+            }
+            const unsigned long long m0 = __ballot(p0), m1 = __ballot(p1);
+            const int n0 = __popcll(m0), ns = n0 + __popcll(m1);
+            if (p0) sec_list[__popcll(m0 & lanemask_lt())] = i0;
+            if (p1) sec_list[n0 + __popcll(m1 & lanemask_lt())] = i1;
+            if (lane == 0) { s_nsec = ns; s_ok = (mx > 0 && ns <= A.lim_sec) ? 1 : 0; }
+        }
+        __syncthreads();
+        if (s_ok) {
+            const int ns = s_nsec;
+            if (tid < ns) {
+                const size_t o = (size_t)a * A.fan + produced + tid;
+                A.slot_main[o] = mb;
+                A.slot_sec[o] = sec_list[tid];
+                A.slot_hidx[o] = hist_rows;
+            }
+            if (A.slot_hist)
+                for (int i = tid; i < Z; i += ORI_THREADS) A.slot_hist[((size_t)a * A.lim_main + hist_rows) * Z + i] = q1[i];
+            produced += ns;
+            hist_rows++;
+        }
+    }
+    if (tid == 0) A.slot_cnt[a] = produced;
+}
+
+// clamp the "rejected" marker to 0 rows, count rejects
+__global__ void k_slot_counts(const int32_t *slot_cnt, int32_t *cnt, int n, int32_t *n_reject) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int c = slot_cnt[i];
+    cnt[i] = c < 0 ? 0 : c;
+    if (c < 0) atomicAdd(n_reject, 1);
+}
+
+// expand the per-anchor slots into the compact row list; Rfinal = adj_sec @ to_dom (Orientator.py:105)
+__global__ void k_orient_rows(const int32_t *slot_cnt, const int32_t *slot_main, const int32_t *slot_sec,
+                              const int32_t *slot_hist, const int32_t *slot_hidx, const int32_t *row_off, int n, int fan,
+                              int lim_main, const EqspDev *eq, int32_t *row_anchor, int32_t *row_main, int32_t *row_sec,
+                              double *row_R, int32_t *row_count) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int a = (int)(gid / fan), s = (int)(gid % fan);
+    if (a >= n) return;
+    const int c = slot_cnt[a];
+    if (s >= c) return;
+    const int64_t row = (int64_t)row_off[a] + s;
+    const int mb = slot_main[(size_t)a * fan + s], sb = slot_sec[(size_t)a * fan + s];
+    row_anchor[row] = a;
+    row_main[row] = mb;
+    row_sec[row] = sb;
+    const double *A = eq->adj_sec[sb], *B = eq->to_dom[mb];
+    double *o = row_R + 9 * row;
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) o[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+    if (row_count) {
+        const int Z = eq->Z;
+        const int32_t *h = slot_hist + ((size_t)a * lim_main + slot_hidx[(size_t)a * fan + s]) * Z;
+        for (int i = 0; i < Z; i++) row_count[row * Z + i] = h[i];
+    }
+}
+
+// Runs a1-a8 for n anchors whose coordinates (and octaves) are already on the device.
+// Leaves the rows in scratch S_ROW_ANCHOR / S_ROW_MAIN / S_ROW_SEC / S_ROW_R (/ S_ROW_COUNT).
+int mad_orient_device(mad_ctx *ctx, FieldDev f0, FieldDev f1, const int32_t *d_coords, const int32_t *d_octave,
+                      int uniform_octave, int n, int r, int lim_main, int lim_sec, bool want_hist,
+                      int64_t *n_rows_out, int32_t *n_reject_out) {
+    if (!ctx->eq_set[0]) return mad_fail(ctx, MAD_EINVAL, "mad_orient: orientation EQSP table not set");
+    if (r < 1 || r > 10) return mad_fail(ctx, MAD_EINVAL, "mad_orient: box_side %d outside 1..10", r);
+    if (lim_main < 1 || lim_main > ORI_MAX_MAIN || lim_sec < 1 || lim_main * lim_sec > ORI_MAX_FAN)
+        return mad_fail(ctx, MAD_EINVAL, "mad_orient: lim_main=%d lim_sec=%d unsupported", lim_main, lim_sec);
+    *n_rows_out = 0;
+    if (n_reject_out) *n_reject_out = 0;
+    if (n <= 0) return MAD_OK;
+    MAD_TRY(ensure_mask(ctx, r));
+    const int Z = ctx->eq_host[0].Z;
+    const int fan = lim_main * lim_sec;
+    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_SLOT_CNT], (size_t)n * 4));
+    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_SLOT_MAIN], (size_t)n * fan * 4));
+    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_SLOT_SEC], (size_t)n * fan * 4));
+    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_TMP_A], (size_t)n * fan * 4));
+    if (want_hist) MAD_TRY(mad_reserve(ctx, ctx->scratch[S_SLOT_HIST], (size_t)n * lim_main * Z * 4));
+    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_ROW_OFF], (size_t)(n + 1) * 4 + 16));
+    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_TMP_B], (size_t)n * 4 + 16));
+
+    OrientArgs A;
+    A.f[0] = f0; A.f[1] = f1;
+    A.coords = d_coords; A.octave = d_octave; A.uniform_octave = uniform_octave;
+    A.n = n; A.r = r; A.nmask = ctx->mask_n; A.mask_off = ctx->mask_off; A.eq = ctx->eq[0];
+    A.lim_main = lim_main; A.lim_sec = lim_sec; A.fan = fan;
+    A.slot_cnt = scratch<int32_t>(ctx, S_SLOT_CNT);
+    A.slot_main = scratch<int32_t>(ctx, S_SLOT_MAIN);
+    A.slot_sec = scratch<int32_t>(ctx, S_SLOT_SEC);
+    A.slot_hist = want_hist ? scratch<int32_t>(ctx, S_SLOT_HIST) : nullptr;
+    A.slot_hidx = scratch<int32_t>(ctx, S_TMP_A);
+
+    int32_t *d_cnt = scratch<int32_t>(ctx, S_TMP_B);
+    int32_t *d_nrej = d_cnt + n;      // one spare int behind the counts
+    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_TMP_B], (size_t)(n + 4) * 4));
+    d_cnt = scratch<int32_t>(ctx, S_TMP_B);
+    d_nrej = d_cnt + n;
+    MAD_HIP(hipMemsetAsync(d_nrej, 0, 4, ctx->stream));
+
+    mad_timer_begin(ctx, MAD_T_ORIENT);
+    const size_t lds = (size_t)ctx->mask_n * 3 * sizeof(float);
+    hipLaunchKernelGGL(k_orient, dim3(n), dim3(ORI_THREADS), lds, ctx->stream, A);
+    mad_timer_end(ctx, MAD_T_ORIENT);
+    hipLaunchKernelGGL(k_slot_counts, dim3((unsigned)mad_ceil_div(n, 256)), dim3(256), 0, ctx->stream, A.slot_cnt, d_cnt,
+                       n, d_nrej);
+    MAD_HIP(hipGetLastError());
+    int32_t *row_off = scratch<int32_t>(ctx, S_ROW_OFF);
+    MAD_TRY(mad_scan_i32(ctx, d_cnt, row_off, n));
+    MAD_HIP(hipMemcpyAsync(&ctx->pinned[0], row_off + n, 4, hipMemcpyDeviceToHost, ctx->stream));
+    MAD_HIP(hipMemcpyAsync(&ctx->pinned[1], d_nrej, 4, hipMemcpyDeviceToHost, ctx->stream));
+    MAD_HIP(hipStreamSynchronize(ctx->stream));
+    const int64_t rows = *(int32_t *)&ctx->pinned[0];
+    if (n_reject_out) *n_reject_out = *(int32_t *)&ctx->pinned[1];
+    *n_rows_out = rows;
+    if (rows == 0) return MAD_OK;
+    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_ROW_ANCHOR], (size_t)rows * 4));
+    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_ROW_MAIN], (size_t)rows * 4));
+    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_ROW_SEC], (size_t)rows * 4));
+    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_ROW_R], (size_t)rows * 9 * 8));
+    if (want_hist) MAD_TRY(mad_reserve(ctx, ctx->scratch[S_ROW_COUNT], (size_t)rows * Z * 4));
+    const int64_t total = (int64_t)n * fan;
+    hipLaunchKernelGGL(k_orient_rows, dim3((unsigned)mad_ceil_div(total, 256)), dim3(256), 0, ctx->stream, A.slot_cnt,
+                       A.slot_main, A.slot_sec, A.slot_hist, A.slot_hidx, row_off, n, fan, lim_main, ctx->eq[0],
+                       scratch<int32_t>(ctx, S_ROW_ANCHOR), scratch<int32_t>(ctx, S_ROW_MAIN),
+                       scratch<int32_t>(ctx, S_ROW_SEC), scratch<double>(ctx, S_ROW_R),
+                       want_hist ? scratch<int32_t>(ctx, S_ROW_COUNT) : nullptr);
+    MAD_HIP(hipGetLastError());
+    return MAD_OK;
+}
+
+extern "C" int mad_orient(mad_ctx *ctx, int slot, int octave, const int32_t *coords, int n, int r, int lim_main,
+                          int lim_sec, int32_t *row_anchor, int32_t *row_main, int32_t *row_sec, double *row_R,
+                          int32_t *row_count, int64_t *n_rows, int64_t cap, int32_t *n_reject) {
+    if (!ctx || !n_rows) return MAD_EINVAL;
+    if (slot < 0 || slot >= MAD_MAX_FIELDS || !ctx->fields[slot].tex)
+        return mad_fail(ctx, MAD_EINVAL, "mad_orient: field slot %d is empty", slot);
+    if (octave != 0 && octave != 1) return mad_fail(ctx, MAD_EINVAL, "mad_orient: octave %d", octave);
+    if (n > 0 && !coords) return mad_fail(ctx, MAD_EINVAL, "mad_orient: coords is NULL");
+    *n_rows = 0;
+    if (n <= 0) { if (n_reject) *n_reject = 0; return MAD_OK; }
+    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_COORDS], (size_t)n * 12));
+    MAD_HIP(hipMemcpyAsync(ctx->scratch[S_COORDS].p, coords, (size_t)n * 12, hipMemcpyHostToDevice, ctx->stream));
+    int64_t rows = 0;
+    FieldDev f = ctx->fields[slot];
+    MAD_TRY(mad_orient_device(ctx, f, f, scratch<int32_t>(ctx, S_COORDS), nullptr, octave, n, r, lim_main, lim_sec,
+                              row_count != nullptr, &rows, n_reject));
+    *n_rows = rows;
+    if (rows > cap) return mad_fail(ctx, MAD_ENOSPC, "mad_orient: %lld rows, capacity %lld", (long long)rows, (long long)cap);
+    if (rows == 0) return MAD_OK;
+    const int Z = ctx->eq_host[0].Z;
+    if (row_anchor) MAD_HIP(hipMemcpyAsync(row_anchor, ctx->scratch[S_ROW_ANCHOR].p, rows * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (row_main) MAD_HIP(hipMemcpyAsync(row_main, ctx->scratch[S_ROW_MAIN].p, rows * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (row_sec) MAD_HIP(hipMemcpyAsync(row_sec, ctx->scratch[S_ROW_SEC].p, rows * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (row_R) MAD_HIP(hipMemcpyAsync(row_R, ctx->scratch[S_ROW_R].p, rows * 72, hipMemcpyDeviceToHost, ctx->stream));
+    if (row_count) MAD_HIP(hipMemcpyAsync(row_count, ctx->scratch[S_ROW_COUNT].p, rows * Z * 4, hipMemcpyDeviceToHost, ctx->stream));
+    MAD_HIP(hipStreamSynchronize(ctx->stream));
+    return MAD_OK;
+}
+
+// ---------------------------------------------------------------------------
+// descriptor kernel
+// ---------------------------------------------------------------------------
+
+#define DSC_THREADS 256
+
+struct DescribeArgs {
+    FieldDev f[2];
+    const int32_t *anc_coords;     // per anchor (or per row when row_anchor == nullptr)
+    const int32_t *anc_octave;     // per anchor, or nullptr -> uniform_octave
+    int uniform_octave;
+    const int32_t *row_anchor;     // row -> anchor, or nullptr (identity)
+    const double *row_R;           // n_rows x 9
+    int64_t n_rows;
+    int r;
+    const EqspDev *eq;
+    int16_t *dsc;                  // n_rows x 64*Z
+};
+
+template <int S>
+__global__ __launch_bounds__(DSC_THREADS) void k_describe(DescribeArgs A) {
+    __shared__ int hist[64 * 16];
+    __shared__ double sR[9], sInv[9];
+    __shared__ int s_oob;
+    const int64_t row = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int a = A.row_anchor ? A.row_anchor[row] : (int)row;
+    const int oct = A.anc_octave ? A.anc_octave[a] : A.uniform_octave;
+    const FieldDev F = A.f[oct == 1 ? 1 : 0];
+    const int Z = A.eq->Z;
+    constexpr int q4 = S / 4;          // S = 2 r samples per axis (16)
+    const int D = 64 * Z;
+
+    if (tid == 0) {
+        // inverse of Rfinal by cofactors (np.linalg.inv, Descriptor.py:132)
+        const double *m = A.row_R + 9 * row;
+        const double c00 = m[4] * m[8] - m[5] * m[7];
+        const double c01 = m[5] * m[6] - m[3] * m[8];
+        const double c02 = m[3] * m[7] - m[4] * m[6];
+        const double det = m[0] * c00 + m[1] * c01 + m[2] * c02;
+        const double id = 1.0 / det;
+        sInv[0] = c00 * id; sInv[1] = (m[2] * m[7] - m[1] * m[8]) * id; sInv[2] = (m[1] * m[5] - m[2] * m[4]) * id;
+        sInv[3] = c01 * id; sInv[4] = (m[0] * m[8] - m[2] * m[6]) * id; sInv[5] = (m[2] * m[3] - m[0] * m[5]) * id;
+        sInv[6] = c02 * id; sInv[7] = (m[1] * m[6] - m[0] * m[7]) * id; sInv[8] = (m[0] * m[4] - m[1] * m[3]) * id;
+        for (int i = 0; i < 9; i++) sR[i] = m[i];
+        s_oob = 0;
+    }
+    for (int i = tid; i < D; i += DSC_THREADS) hist[i] = 0;
+    __syncthreads();
+
+    const double c0 = (double)A.anc_coords[3 * a], c1 = (double)A.anc_coords[3 * a + 1], c2 = (double)A.anc_coords[3 * a + 2];
+    const double i0 = sInv[0], i1 = sInv[1], i2 = sInv[2], i3 = sInv[3], i4 = sInv[4], i5 = sInv[5], i6 = sInv[6],
+                 i7 = sInv[7], i8 = sInv[8];
+    // this thread's (j, k) column of the S^3 lattice; threads beyond S*S idle (S <= 16)
+    const int j = tid / S, k = tid % S;
+    const bool active = tid < S * S;
+    unsigned idx[S];
+    bool oob = false;
+    if (active) {
+#pragma unroll
+        for (int i = 0; i < S; i++) {
+            double l0, l1, l2;      // Descriptor.py:34-35
+            if (oct == 0) { l0 = -2 * A.r + 1 + 2 * i; l1 = -2 * A.r + 1 + 2 * j; l2 = -2 * A.r + 1 + 2 * k; }
+            else { l0 = -A.r + 0.5 + i; l1 = -A.r + 0.5 + j; l2 = -A.r + 0.5 + k; }
+            const double p0 = (l0 * i0 + l1 * i1 + l2 * i2) + c0;      // Descriptor.py:132-133
+            const double p1 = (l0 * i3 + l1 * i4 + l2 * i5) + c1;
+            const double p2 = (l0 * i6 + l1 * i7 + l2 * i8) + c2;
+            // nearest neighbour of scipy's RegularGridInterpolator, bounds_error=True (MapSpace.py:189)
+            if (!(p0 >= 0.0) || !(p0 <= (double)(F.nx - 1)) || !(p1 >= 0.0) || !(p1 <= (double)(F.ny - 1)) ||
+                !(p2 >= 0.0) || !(p2 <= (double)(F.nz - 1))) {
+                oob = true;
+                idx[i] = 0;
+                continue;
+            }
+            int a0 = min((int)floor(p0), F.nx - 2), a1 = min((int)floor(p1), F.ny - 2), a2 = min((int)floor(p2), F.nz - 2);
+            a0 = (p0 - (double)a0 <= 0.5) ? a0 : a0 + 1;
+            a1 = (p1 - (double)a1 <= 0.5) ? a1 : a1 + 1;
+            a2 = (p2 - (double)a2 <= 0.5) ? a2 : a2 + 1;
+            idx[i] = (unsigned)(((size_t)a0 * F.ny + a1) * F.nz + a2);
+        }
+    }
+    if (oob) s_oob = 1;
+    __syncthreads();
+    if (s_oob) {      // Descriptor.py:142-149: the whole descriptor is zero
+        for (int i = tid; i < D; i += DSC_THREADS) A.dsc[row * D + i] = 0;
+        return;
+    }
+    if (active) {
+        float4 t[S];
+#pragma unroll
+        for (int i = 0; i < S; i++) t[i] = F.tex[idx[i]];
+        const double r0 = sR[0], r1 = sR[1], r2 = sR[2], r3 = sR[3], r4 = sR[4], r5 = sR[5], r6 = sR[6], r7 = sR[7], r8 = sR[8];
+#pragma unroll
+        for (int i = 0; i < S; i++) {
+            const float magn = t[i].w;
+            if (magn < 1e-5f) continue;                                   // Descriptor.py:190 (zone -1)
+            float gx = t[i].x, gy = t[i].y, gz = t[i].z;
+            if (magn > 1e-12f) { gx = __fdiv_rn(gx, magn); gy = __fdiv_rn(gy, magn); gz = __fdiv_rn(gz, magn); }
+            const double g0 = gx, g1 = gy, g2 = gz;                       // Descriptor.py:155 g @ R.T
+            const double rx = g0 * r0 + g1 * r1 + g2 * r2;
+            const double ry = g0 * r3 + g1 * r4 + g2 * r5;
+            double rz = g0 * r6 + g1 * r7 + g2 * r8;
+            double th = atan2(ry, rx);
+            if (th < 0) th += MAD_TWO_PI;
+            const double sth = th + MAD_TWO_PI;
+            rz = rz > 1.0 ? 1.0 : (rz < -1.0 ? -1.0 : rz);
+            const double ph = acos(rz);
+            int zone = 0;                                                 // Descriptor.py:173 default, :187 last wins
+            eqsp_classify(A.eq, th, sth, ph, [&](int zn) { zone = zn; });
+            const int sub = (j / q4) * 16 + (i / q4) * 4 + (k / q4);      // Descriptor.py:44-64
+            atomicAdd(&hist[sub * Z + zone], 1);
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < D; i += DSC_THREADS) A.dsc[row * D + i] = (int16_t)hist[i];
+}
+
+int mad_describe_device(mad_ctx *ctx, FieldDev f0, FieldDev f1, const int32_t *d_anc_coords, const int32_t *d_anc_octave,
+                        int uniform_octave, const int32_t *d_row_anchor, const double *d_row_R, int64_t n_rows, int r,
+                        int16_t *d_dsc) {
+    if (!ctx->eq_set[1]) return mad_fail(ctx, MAD_EINVAL, "mad_describe: descriptor EQSP table not set");
+    if (ctx->eq_host[1].Z != 16) return mad_fail(ctx, MAD_EINVAL, "mad_describe: kernel is built for 16 descriptor zones");
+    if (r < 2 || r > 8 || (r % 2)) return mad_fail(ctx, MAD_EINVAL, "mad_describe: dsc radius %d must be 2, 4, 6 or 8", r);
+    if (n_rows <= 0) return MAD_OK;
+    for (int o = 0; o < 2; o++) {
+        const FieldDev &f = o ? f1 : f0;
+        if (f.tex && (size_t)f.nx * f.ny * f.nz >= (size_t)1 << 32)
+            return mad_fail(ctx, MAD_EINVAL, "mad_describe: field of %dx%dx%d texels exceeds 2^32", f.nx, f.ny, f.nz);
+    }
+    DescribeArgs A;
+    A.f[0] = f0; A.f[1] = f1;
+    A.anc_coords = d_anc_coords; A.anc_octave = d_anc_octave; A.uniform_octave = uniform_octave;
+    A.row_anchor = d_row_anchor; A.row_R = d_row_R; A.n_rows = n_rows; A.r = r; A.eq = ctx->eq[1]; A.dsc = d_dsc;
+    mad_timer_begin(ctx, MAD_T_DESCRIBE);
+    switch (2 * r) {
+        case 4: hipLaunchKernelGGL(k_describe<4>, dim3((unsigned)n_rows), dim3(DSC_THREADS), 0, ctx->stream, A); break;
+        case 8: hipLaunchKernelGGL(k_describe<8>, dim3((unsigned)n_rows), dim3(DSC_THREADS), 0, ctx->stream, A); break;
+        case 12: hipLaunchKernelGGL(k_describe<12>, dim3((unsigned)n_rows), dim3(DSC_THREADS), 0, ctx->stream, A); break;
+        default: hipLaunchKernelGGL(k_describe<16>, dim3((unsigned)n_rows), dim3(DSC_THREADS), 0, ctx->stream, A); break;
+    }
+    mad_timer_end(ctx, MAD_T_DESCRIBE);
+    MAD_HIP(hipGetLastError());
+    return MAD_OK;
+}
+
+extern "C" int mad_describe(mad_ctx *ctx, int slot, int octave, const int32_t *coords, const double *R, int64_t n_rows,
+                            int r, int16_t *dsc) {
+    if (!ctx) return MAD_EINVAL;
+    if (slot < 0 || slot >= MAD_MAX_FIELDS || !ctx->fields[slot].tex)
+        return mad_fail(ctx, MAD_EINVAL, "mad_describe: field slot %d is empty", slot);
+    if (octave != 0 && octave != 1) return mad_fail(ctx, MAD_EINVAL, "mad_describe: octave %d", octave);
+    if (n_rows <= 0) return MAD_OK;
+    if (!coords || !R || !dsc) return mad_fail(ctx, MAD_EINVAL, "mad_describe: NULL argument");
+    const int D = 64 * ctx->eq_host[1].Z;
+    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_ROW_COORDS], (size_t)n_rows * 12));
+    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_ROW_R], (size_t)n_rows * 72));
+    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_DSC], (size_t)n_rows * D * 2));
+    MAD_HIP(hipMemcpyAsync(ctx->scratch[S_ROW_COORDS].p, coords, (size_t)n_rows * 12, hipMemcpyHostToDevice, ctx->stream));
+    MAD_HIP(hipMemcpyAsync(ctx->scratch[S_ROW_R].p, R, (size_t)n_rows * 72, hipMemcpyHostToDevice, ctx->stream));
+    FieldDev f = ctx->fields[slot];
+    MAD_TRY(mad_describe_device(ctx, f, f, scratch<int32_t>(ctx, S_ROW_COORDS), nullptr, octave, nullptr,
+                                scratch<double>(ctx, S_ROW_R), n_rows, r, scratch<int16_t>(ctx, S_DSC)));
+    MAD_HIP(hipMemcpyAsync(dsc, ctx->scratch[S_DSC].p, (size_t)n_rows * D * 2, hipMemcpyDeviceToHost, ctx->stream));
+    MAD_HIP(hipStreamSynchronize(ctx->stream));
+    return MAD_OK;
+}

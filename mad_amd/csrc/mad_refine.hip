@@ -1,0 +1,559 @@
+// mad_refine.hip -- rigid-body refinement (a13), density simulation (a14-a15) and
+// cross-correlation (a16) for gfx950.  Reference: mad/structure_utils.py:58-161,
+// mad/PDB.py:131-292, mad/Dmap.py:153-258.
+//
+//  refine  : the <= 500 steps are sequentially dependent, so each candidate runs in ONE
+//            persistent 1024-thread workgroup that keeps the rigid transform in LDS and
+//            walks the steps without returning to the host; parallelism is over atoms
+//            (trilinear gather of the np.gradient texels) and over candidates (one
+//            workgroup each).  Reductions use a fixed tree, so results are reproducible.
+//  density : float64 atomic splat, three separable float64 blur passes (the reference's
+//            Gaussian is a product of 1-D Gaussians), float32 normalise + threshold.
+//  ccc     : three float64 dot products over the overlap box.
+#include "mad_common.h"
+
+#define RF_THREADS 1024
+#define RF_WAVES (RF_THREADS / MAD_WAVE)
+
+// ---------------------------------------------------------------------------
+// np.gradient texels of the density map (structure_utils.py:80)
+// ---------------------------------------------------------------------------
+
+__device__ __forceinline__ float grad1(const float *g, int n, int i, size_t c, size_t st) {
+    if (i == 0) return __fdiv_rn(__fsub_rn(g[c + st], g[c]), 1.0f);
+    if (i == n - 1) return __fdiv_rn(__fsub_rn(g[c], g[c - st]), 1.0f);
+    return __fdiv_rn(__fsub_rn(g[c + st], g[c - st]), 2.0f);
+}
+
+__global__ __launch_bounds__(256) void k_density_grad(const float *__restrict__ g, int nx, int ny, int nz,
+                                                      float4 *__restrict__ out) {
+    const size_t n = (size_t)nx * ny * nz;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += step) {
+        const int z = (int)(i % nz), y = (int)((i / nz) % ny), x = (int)(i / ((size_t)nz * ny));
+        out[i] = make_float4(grad1(g, nx, x, i, (size_t)ny * nz), grad1(g, ny, y, i, (size_t)nz), grad1(g, nz, z, i, 1), 0.f);
+    }
+}
+
+extern "C" int mad_upload_density(mad_ctx *ctx, const float *grid, int nx, int ny, int nz, double ox, double oy, double oz,
+                                  double voxsp) {
+    if (!ctx || !grid) return MAD_EINVAL;
+    if (nx < 2 || ny < 2 || nz < 2 || !(voxsp > 0)) return mad_fail(ctx, MAD_EINVAL, "mad_upload_density: dims %dx%dx%d vs %g", nx, ny, nz, voxsp);
+    DensityDev &d = ctx->dens;
+    const size_t n = (size_t)nx * ny * nz;
+    MAD_HIP(hipStreamSynchronize(ctx->stream));
+    if (d.grid) (void)hipFree(d.grid);
+    if (d.grad) (void)hipFree(d.grad);
+    d.grid = nullptr; d.grad = nullptr;
+    if (hipMalloc((void **)&d.grid, n * sizeof(float)) != hipSuccess || hipMalloc((void **)&d.grad, n * sizeof(float4)) != hipSuccess)
+        return mad_fail(ctx, MAD_ENOMEM, "mad_upload_density: %zu voxels", n);
+    d.nx = nx; d.ny = ny; d.nz = nz; d.o[0] = ox; d.o[1] = oy; d.o[2] = oz; d.vs = voxsp;
+    MAD_HIP(hipMemcpyAsync(d.grid, grid, n * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    const int blocks = (int)std::min<size_t>(mad_ceil_div((int64_t)n, 256), (size_t)ctx->n_cu * 16);
+    hipLaunchKernelGGL(k_density_grad, dim3(blocks), dim3(256), 0, ctx->stream, d.grid, nx, ny, nz, d.grad);
+    MAD_HIP(hipGetLastError());
+    MAD_HIP(hipStreamSynchronize(ctx->stream));
+    return MAD_OK;
+}
+
+// ---------------------------------------------------------------------------
+// refinement
+// ---------------------------------------------------------------------------
+
+struct RefineArgs {
+    const float4 *grad;
+    int nx, ny, nz;
+    double o[3], del[3], vs;
+    double *coords;      // n_cand x n_atoms x 3, in/out (current coordinates)
+    double *init;        // n_cand x n_atoms x 3 scratch: start coordinates
+    double *prev;        // n_cand x n_atoms x 3 scratch: coordinates at the last batch boundary
+    int64_t n_atoms;
+    int n_steps;
+    double max_step, min_step;
+    int32_t *converged, *last_step;
+};
+
+// fixed-order block reduction of NV doubles per thread (sum or max); result valid in all threads
+template <int NV, bool IS_MAX>
+__device__ __forceinline__ void block_reduce(double *v, double *lds /* RF_WAVES * NV + NV */) {
+    const int lane = lane_id(), w = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NV; i++) v[i] = IS_MAX ? wave_max_f64(v[i]) : wave_sum_f64(v[i]);
+    __syncthreads();
+    if (lane == 0)
+#pragma unroll
+        for (int i = 0; i < NV; i++) lds[w * NV + i] = v[i];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 0; i < NV; i++) {
+            double a = lds[i];
+            for (int k = 1; k < RF_WAVES; k++) a = IS_MAX ? fmax(a, lds[k * NV + i]) : a + lds[k * NV + i];
+            lds[RF_WAVES * NV + i] = a;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NV; i++) v[i] = lds[RF_WAVES * NV + i];
+}
+
+// math_utils.py:15-27
+__device__ __forceinline__ void rod_mat(const double ax[3], double angle, double *m) {
+    const double a = cos(angle / 2.0), s = sin(angle / 2.0);
+    const double b = -ax[0] * s, c = -ax[1] * s, d = -ax[2] * s;
+    const double aa = a * a, bb = b * b, cc = c * c, dd = d * d;
+    const double bc = b * c, ad = a * d, ac = a * c, ab = a * b, bd = b * d, cd = c * d;
+    m[0] = aa + bb - cc - dd; m[1] = 2 * (bc + ad); m[2] = 2 * (bd - ac);
+    m[3] = 2 * (bc - ad); m[4] = aa + cc - bb - dd; m[5] = 2 * (cd + ab);
+    m[6] = 2 * (bd + ac); m[7] = 2 * (cd - ab); m[8] = aa + dd - bb - cc;
+}
+
+// math_utils.py:5-13: a vector that cannot be normalised is returned as is
+__device__ __forceinline__ void unit_vec(const double v[3], double o[3]) {
+    const double n = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    if (n == 0.0 || n != n) { o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; return; }
+    o[0] = v[0] / n; o[1] = v[1] / n; o[2] = v[2] / n;
+}
+
+__global__ __launch_bounds__(RF_THREADS) void k_refine(RefineArgs A) {
+    __shared__ double red[RF_WAVES * 7 + 7];
+    __shared__ double s_rot[9], s_trans[3], s_upd[12];      // s_upd: step translation (3) or step rotation (9) + centre
+    __shared__ double s_step;
+    __shared__ int s_flag;      // 1 = NaN abort, 2 = converged
+    const int cand = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int64_t n = A.n_atoms;
+    double *cur = A.coords + (size_t)cand * n * 3;
+    double *ini = A.init + (size_t)cand * n * 3;
+    double *prv = A.prev + (size_t)cand * n * 3;
+
+    // structure_utils.py:65-67: start copy, centroid, farthest atom
+    double v[7];
+    v[0] = v[1] = v[2] = 0;
+    for (int64_t i = tid; i < n; i += RF_THREADS) {
+        const double x = cur[3 * i], y = cur[3 * i + 1], z = cur[3 * i + 2];
+        ini[3 * i] = x; ini[3 * i + 1] = y; ini[3 * i + 2] = z;
+        prv[3 * i] = x; prv[3 * i + 1] = y; prv[3 * i + 2] = z;
+        v[0] += x; v[1] += y; v[2] += z;
+    }
+    block_reduce<3, false>(v, red);
+    const double cen0 = v[0] / (double)n, cen1 = v[1] / (double)n, cen2 = v[2] / (double)n;
+    v[0] = 0;
+    for (int64_t i = tid; i < n; i += RF_THREADS) {
+        const double a = ini[3 * i] - cen0, b = ini[3 * i + 1] - cen1, c = ini[3 * i + 2] - cen2;
+        v[0] = fmax(v[0], sqrt(a * a + b * b + c * c));
+    }
+    block_reduce<1, true>(v, red);
+    const double maxd = v[0];
+    if (tid == 0) {
+        for (int i = 0; i < 9; i++) s_rot[i] = (i % 4 == 0) ? 1.0 : 0.0;
+        s_trans[0] = s_trans[1] = s_trans[2] = 0;
+        s_step = A.max_step;
+        s_flag = 0;
+    }
+    __syncthreads();
+
+    int batch = 0, step = 0, conv = 0;
+    for (step = 0; step < A.n_steps; step++) {
+        const double r0 = s_rot[0], r1 = s_rot[1], r2 = s_rot[2], r3 = s_rot[3], r4 = s_rot[4], r5 = s_rot[5], r6 = s_rot[6],
+                     r7 = s_rot[7], r8 = s_rot[8];
+        const double ct0 = cen0 + s_trans[0], ct1 = cen1 + s_trans[1], ct2 = cen2 + s_trans[2];
+        const double step_size = s_step;
+        for (int i = 0; i < 7; i++) v[i] = 0;
+        for (int64_t i = tid; i < n; i += RF_THREADS) {
+            // :91-96 re-apply the accumulated transform to the start coordinates
+            const double a = ini[3 * i] - cen0, b = ini[3 * i + 1] - cen1, c = ini[3 * i + 2] - cen2;
+            const double p0 = (a * r0 + b * r3 + c * r6) + ct0;
+            const double p1 = (a * r1 + b * r4 + c * r7) + ct1;
+            const double p2 = (a * r2 + b * r5 + c * r8) + ct2;
+            cur[3 * i] = p0; cur[3 * i + 1] = p1; cur[3 * i + 2] = p2;
+            if (p0 != p0 || p1 != p1 || p2 != p2) v[6] = 1.0;
+            // :101-103 atoms strictly inside the map
+            const bool inside = (p0 > A.o[0]) && (p0 < A.o[0] + A.nx * A.vs - A.vs) && (p1 > A.o[1]) &&
+                                (p1 < A.o[1] + A.ny * A.vs - A.vs) && (p2 > A.o[2]) && (p2 < A.o[2] + A.nz * A.vs - A.vs);
+            if (!inside) continue;
+            // :106 trilinear interpolation of the gradient (scipy RegularGridInterpolator, linear)
+            const double p[3] = {p0, p1, p2};
+            const int dims[3] = {A.nx, A.ny, A.nz};
+            int i0[3];
+            double y[3];
+#pragma unroll
+            for (int d = 0; d < 3; d++) {
+                int ii = (int)floor((p[d] - A.o[d]) / A.vs);
+                ii = max(0, min(ii, dims[d] - 2));
+                while (ii > 0 && p[d] < A.o[d] + ii * A.del[d]) ii--;
+                while (ii < dims[d] - 2 && p[d] >= A.o[d] + (ii + 1) * A.del[d]) ii++;
+                const double g0 = A.o[d] + ii * A.del[d], g1 = A.o[d] + (ii + 1) * A.del[d];
+                i0[d] = ii;
+                y[d] = (p[d] - g0) / (g1 - g0);
+            }
+            double g[3] = {0, 0, 0};
+#pragma unroll
+            for (int cx = 0; cx < 2; cx++)
+#pragma unroll
+                for (int cy = 0; cy < 2; cy++)
+#pragma unroll
+                    for (int cz = 0; cz < 2; cz++) {
+                        double wgt = 1.0;
+                        wgt = wgt * (cx ? y[0] : 1 - y[0]);
+                        wgt = wgt * (cy ? y[1] : 1 - y[1]);
+                        wgt = wgt * (cz ? y[2] : 1 - y[2]);
+                        const float4 t = A.grad[((size_t)(i0[0] + cx) * A.ny + (i0[1] + cy)) * A.nz + (i0[2] + cz)];
+                        g[0] = g[0] + (double)t.x * wgt;
+                        g[1] = g[1] + (double)t.y * wgt;
+                        g[2] = g[2] + (double)t.z * wgt;
+                    }
+            v[0] += g[0]; v[1] += g[1]; v[2] += g[2];
+            // :121-122 torque about the START centroid
+            const double c0 = p0 - cen0, c1 = p1 - cen1, c2 = p2 - cen2;
+            v[3] += g[1] * c2 - g[2] * c1;
+            v[4] += g[2] * c0 - g[0] * c2;
+            v[5] += g[0] * c1 - g[1] * c0;
+        }
+        block_reduce<7, false>(v, red);
+        if (v[6] != 0.0) {      // :97-98
+            if (tid == 0) { A.converged[cand] = 0; A.last_step[cand] = step; }
+            return;
+        }
+        const bool is_trans = (step % 2) == 0;
+        if (tid == 0) {
+            if (is_trans) {      // :111-116
+                double u[3];
+                unit_vec(v, u);
+                for (int d = 0; d < 3; d++) { u[d] *= step_size; s_upd[d] = u[d]; s_trans[d] += u[d]; }
+            } else {             // :123-138
+                double ax[3], sm[9], nr[9];
+                unit_vec(v + 3, ax);
+                rod_mat(ax, step_size / maxd, sm);
+                for (int i = 0; i < 9; i++) s_upd[i] = sm[i];
+                for (int i = 0; i < 3; i++)
+                    for (int j = 0; j < 3; j++) nr[3 * i + j] = s_rot[3 * i] * sm[j] + s_rot[3 * i + 1] * sm[3 + j] + s_rot[3 * i + 2] * sm[6 + j];
+                for (int i = 0; i < 9; i++) s_rot[i] = nr[i];
+            }
+        }
+        __syncthreads();
+        batch++;
+        const bool batch_end = batch == 4;
+        double mn = 0;
+        if (is_trans) {
+            const double u0 = s_upd[0], u1 = s_upd[1], u2 = s_upd[2];
+            for (int64_t i = tid; i < n; i += RF_THREADS) {
+                const double x = cur[3 * i] + u0, yv = cur[3 * i + 1] + u1, z = cur[3 * i + 2] + u2;
+                cur[3 * i] = x; cur[3 * i + 1] = yv; cur[3 * i + 2] = z;
+                if (batch_end) {
+                    const double a = prv[3 * i] - x, b = prv[3 * i + 1] - yv, c = prv[3 * i + 2] - z;
+                    mn = fmax(mn, sqrt(a * a + b * b + c * c));
+                    prv[3 * i] = x; prv[3 * i + 1] = yv; prv[3 * i + 2] = z;
+                }
+            }
+        } else {
+            const double m0 = s_upd[0], m1 = s_upd[1], m2 = s_upd[2], m3 = s_upd[3], m4 = s_upd[4], m5 = s_upd[5],
+                         m6 = s_upd[6], m7 = s_upd[7], m8 = s_upd[8];
+            const double n0 = -1 * cen0 - s_trans[0], n1 = -1 * cen1 - s_trans[1], n2 = -1 * cen2 - s_trans[2];
+            for (int64_t i = tid; i < n; i += RF_THREADS) {
+                const double a = cur[3 * i] + n0, b = cur[3 * i + 1] + n1, c = cur[3 * i + 2] + n2;
+                const double x = (a * m0 + b * m3 + c * m6) + ct0;
+                const double yv = (a * m1 + b * m4 + c * m7) + ct1;
+                const double z = (a * m2 + b * m5 + c * m8) + ct2;
+                cur[3 * i] = x; cur[3 * i + 1] = yv; cur[3 * i + 2] = z;
+                if (batch_end) {
+                    const double pa = prv[3 * i] - x, pb = prv[3 * i + 1] - yv, pc = prv[3 * i + 2] - z;
+                    mn = fmax(mn, sqrt(pa * pa + pb * pb + pc * pc));
+                    prv[3 * i] = x; prv[3 * i + 1] = yv; prv[3 * i + 2] = z;
+                }
+            }
+        }
+        if (batch_end) {      // :141-147
+            double mv[1] = {mn};
+            block_reduce<1, true>(mv, red);
+            if (tid == 0 && mv[0] < s_step) s_step *= 0.5;
+            batch = 0;
+        }
+        __syncthreads();
+        if (s_step < A.min_step) { conv = 1; break; }      // :150-152
+    }
+    if (step == A.n_steps) step = A.n_steps - 1;
+    if (tid == 0) { A.converged[cand] = conv; A.last_step[cand] = step; }
+}
+
+extern "C" int mad_refine(mad_ctx *ctx, double *coords, int n_cand, int64_t n_atoms, int n_steps, double max_step,
+                          double min_step, int32_t *converged, int32_t *last_step) {
+    if (!ctx) return MAD_EINVAL;
+    if (!ctx->dens.grad) return mad_fail(ctx, MAD_EINVAL, "mad_refine: call mad_upload_density first");
+    if (n_cand <= 0) return MAD_OK;
+    if (!coords || !converged || !last_step || n_atoms <= 0 || n_steps < 0)
+        return mad_fail(ctx, MAD_EINVAL, "mad_refine: bad argument");
+    const size_t bytes = (size_t)n_cand * n_atoms * 24;
+    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_TMP_E], bytes));
+    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_TMP_F], bytes));
+    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_TMP_H], bytes));
+    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_MISC], 256 + (size_t)n_cand * 8));
+    MAD_HIP(hipMemcpyAsync(ctx->scratch[S_TMP_E].p, coords, bytes, hipMemcpyHostToDevice, ctx->stream));
+    const DensityDev &d = ctx->dens;
+    RefineArgs A;
+    A.grad = d.grad; A.nx = d.nx; A.ny = d.ny; A.nz = d.nz; A.vs = d.vs;
+    for (int i = 0; i < 3; i++) {
+        A.o[i] = d.o[i];
+        volatile double t = d.o[i] + d.vs;      // np.arange's element step: (start + step) - start
+        A.del[i] = t - d.o[i];
+    }
+    A.coords = scratch<double>(ctx, S_TMP_E); A.init = scratch<double>(ctx, S_TMP_F); A.prev = scratch<double>(ctx, S_TMP_H);
+    A.n_atoms = n_atoms; A.n_steps = n_steps; A.max_step = max_step; A.min_step = min_step;
+    A.converged = scratch<int32_t>(ctx, S_MISC) + 64;
+    A.last_step = A.converged + n_cand;
+    mad_timer_begin(ctx, MAD_T_REFINE);
+    hipLaunchKernelGGL(k_refine, dim3(n_cand), dim3(RF_THREADS), 0, ctx->stream, A);
+    mad_timer_end(ctx, MAD_T_REFINE);
+    MAD_HIP(hipGetLastError());
+    MAD_HIP(hipMemcpyAsync(coords, A.coords, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    MAD_HIP(hipMemcpyAsync(converged, A.converged, (size_t)n_cand * 4, hipMemcpyDeviceToHost, ctx->stream));
+    MAD_HIP(hipMemcpyAsync(last_step, A.last_step, (size_t)n_cand * 4, hipMemcpyDeviceToHost, ctx->stream));
+    MAD_HIP(hipStreamSynchronize(ctx->stream));
+    return MAD_OK;
+}
+
+// ---------------------------------------------------------------------------
+// density simulation
+// ---------------------------------------------------------------------------
+
+// PDB.py:263-288: trilinear splat of the atomic masses; grid [px][py][pz], z fastest
+__global__ void k_splat(const double *__restrict__ atoms, const double *__restrict__ mass, int64_t n, double mn0, double mn1,
+                        double mn2, double vs, int margin, int px, int py, int pz, double *__restrict__ grid) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double gx = margin + (atoms[3 * i] - mn0) / vs;
+    const double gy = margin + (atoms[3 * i + 1] - mn1) / vs;
+    const double gz = margin + (atoms[3 * i + 2] - mn2) / vs;
+    const int x0 = (int)floor(gx), y0 = (int)floor(gy), z0 = (int)floor(gz);
+    const double a = (x0 + 1) - gx, b = (y0 + 1) - gy, c = (z0 + 1) - gz, m = mass[i];
+    const double wx[2] = {a, 1 - a}, wy[2] = {b, 1 - b}, wz[2] = {c, 1 - c};
+#pragma unroll
+    for (int dx = 0; dx < 2; dx++)
+#pragma unroll
+        for (int dy = 0; dy < 2; dy++)
+#pragma unroll
+            for (int dz = 0; dz < 2; dz++) {
+                const int x = x0 + dx, y = y0 + dy, z = z0 + dz;
+                if (x < 0 || y < 0 || z < 0 || x >= px || y >= py || z >= pz) continue;
+                unsafeAtomicAdd(&grid[((size_t)x * py + y) * pz + z], m * wx[dx] * wy[dy] * wz[dz]);
+            }
+}
+
+__global__ __launch_bounds__(256) void k_max_f64(const double *__restrict__ v, size_t n, double *__restrict__ out) {
+    __shared__ double wt[4];
+    double m = -INFINITY;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) m = fmax(m, v[i]);
+    m = wave_max_f64(m);
+    if (lane_id() == 0) wt[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmax(fmax(wt[0], wt[1]), fmax(wt[2], wt[3]));
+        // atomic max on the bit pattern: valid for non-negative doubles, which splat and blur outputs are
+        atomicMax((unsigned long long *)out, (unsigned long long)__double_as_longlong(fmax(m, 0.0)));
+    }
+}
+
+// one separable full-mode pass along `axis`; in dims d[3] -> out dims with d[axis] + 2r.
+// scale_ptr (nullable): divide inputs by *scale_ptr first (PDB.py:290 grid / max)
+__global__ __launch_bounds__(256) void k_blur_axis(const double *__restrict__ in, int d0, int d1, int d2, int axis, int r,
+                                                   const double *__restrict__ taps, const double *__restrict__ scale_ptr,
+                                                   double *__restrict__ out) {
+    const int o0 = d0 + (axis == 0 ? 2 * r : 0), o1 = d1 + (axis == 1 ? 2 * r : 0), o2 = d2 + (axis == 2 ? 2 * r : 0);
+    const size_t n = (size_t)o0 * o1 * o2;
+    const double inv = scale_ptr ? *scale_ptr : 1.0;
+    const int dn = axis == 0 ? d0 : (axis == 1 ? d1 : d2);
+    const size_t st = axis == 0 ? (size_t)d1 * d2 : (axis == 1 ? (size_t)d2 : 1);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int z = (int)(i % o2), y = (int)((i / o2) % o1), x = (int)(i / ((size_t)o2 * o1));
+        const int pos = axis == 0 ? x : (axis == 1 ? y : z);
+        // out[pos] = sum_t in[pos - t] * g[t], t = 0..2r  (full convolution)
+        const int xi = axis == 0 ? 0 : x, yi = axis == 1 ? 0 : y, zi = axis == 2 ? 0 : z;
+        const size_t base = ((size_t)xi * d1 + yi) * d2 + zi;
+        double acc = 0;
+        for (int t = 0; t <= 2 * r; t++) {
+            const int s = pos - t;
+            if (s < 0 || s >= dn) continue;
+            const double val = in[base + (size_t)s * st];
+            acc += (scale_ptr ? val / inv : val) * taps[t];
+        }
+        out[i] = acc;
+    }
+}
+
+__global__ void k_to_f32(const double *__restrict__ in, size_t n, float *__restrict__ out, unsigned *__restrict__ maxbits) {
+    float m = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float f = (float)in[i];
+        out[i] = f;
+        m = fmaxf(m, f);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, MAD_WAVE));
+    if (lane_id() == 0) atomicMax(maxbits, __float_as_uint(m));
+}
+
+// PDB.py:162-163: / max (float32), then zero below the isovalue
+__global__ void k_norm_f32(float *__restrict__ g, size_t n, const unsigned *__restrict__ maxbits, float iso) {
+    const float mx = __uint_as_float(*maxbits);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float v = __fdiv_rn(g[i], mx);
+        if (v < iso) v = 0.f;
+        g[i] = v;
+    }
+}
+
+extern "C" int mad_structure_to_density(mad_ctx *ctx, const double *atoms, const double *mass, int64_t n, double resolution,
+                                        double voxsp, double isovalue, int pad, int32_t dims[3], double origin[3], float *grid) {
+    if (!ctx || !atoms || !mass || !dims || !origin || n <= 0) return ctx ? mad_fail(ctx, MAD_EINVAL, "mad_structure_to_density: bad argument") : MAD_EINVAL;
+    if (!(voxsp > 0) || !(resolution > 0) || pad < 0) return mad_fail(ctx, MAD_EINVAL, "mad_structure_to_density: resolution %g voxsp %g pad %d", resolution, voxsp, pad);
+    // PDB.py:237-257 lattice-aligned bounding box
+    double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int64_t i = 0; i < n; i++)
+        for (int d = 0; d < 3; d++) {
+            const double v = atoms[3 * i + d];
+            if (!(v == v)) return mad_fail(ctx, MAD_EDOM, "mad_structure_to_density: NaN coordinate");
+            mn[d] = v < mn[d] ? v : mn[d];
+            mx[d] = v > mx[d] ? v : mx[d];
+        }
+    const int margin = 2 + pad;
+    int p[3];
+    for (int d = 0; d < 3; d++) {
+        mn[d] = voxsp * floor(mn[d] / voxsp);
+        mx[d] = voxsp * ceil(mx[d] / voxsp);
+        p[d] = (int)ceil((mx[d] - mn[d]) / voxsp) + 2 * margin + 1;
+    }
+    // PDB.py:144-145 kernel size
+    const double sig = resolution / (M_PI * sqrt(2.0)) / voxsp;
+    const int r = (int)ceil(3.0 * sig);
+    for (int d = 0; d < 3; d++) {
+        dims[d] = p[d] + 2 * r;
+        origin[d] = mn[d] - (r + margin) * voxsp;      // PDB.py:157-159
+    }
+    if (!grid) return MAD_OK;
+    if (r > 64) return mad_fail(ctx, MAD_EINVAL, "mad_structure_to_density: kernel radius %d", r);
+    const size_t np_ = (size_t)p[0] * p[1] * p[2], no = (size_t)dims[0] * dims[1] * dims[2];
+    // 1-D taps; the 3-D kernel of PDB.py:148-150 is their outer product over the cube of their sum
+    double taps[129], ts = 0;
+    for (int t = -r; t <= r; t++) { taps[t + r] = exp(-(double)(t * t) / (2.0 * sig * sig)); ts += taps[t + r]; }
+    for (int t = 0; t <= 2 * r; t++) taps[t] /= ts;
+    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_TMP_E], (size_t)n * 24));
+    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_TMP_F], (size_t)n * 8));
+    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_TMP_H], no * 8));
+    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_TMP_I], no * 8));
+    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_TMP_J], no * 4));
+    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_MISC], 4096));
+    double *d_atoms = scratch<double>(ctx, S_TMP_E), *d_mass = scratch<double>(ctx, S_TMP_F);
+    double *bufA = scratch<double>(ctx, S_TMP_H), *bufB = scratch<double>(ctx, S_TMP_I);
+    float *d_out = scratch<float>(ctx, S_TMP_J);
+    double *d_taps = (double *)(scratch<char>(ctx, S_MISC) + 1024);
+    double *d_max = (double *)(scratch<char>(ctx, S_MISC) + 512);
+    unsigned *d_maxf = (unsigned *)(scratch<char>(ctx, S_MISC) + 520);
+    MAD_HIP(hipMemcpyAsync(d_atoms, atoms, (size_t)n * 24, hipMemcpyHostToDevice, ctx->stream));
+    MAD_HIP(hipMemcpyAsync(d_mass, mass, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+    MAD_HIP(hipMemcpyAsync(d_taps, taps, sizeof(double) * (2 * r + 1), hipMemcpyHostToDevice, ctx->stream));
+    MAD_HIP(hipMemsetAsync(d_max, 0, 16, ctx->stream));
+    MAD_HIP(hipMemsetAsync(bufA, 0, np_ * 8, ctx->stream));
+    mad_timer_begin(ctx, MAD_T_DENSITY);
+    hipLaunchKernelGGL(k_splat, dim3((unsigned)mad_ceil_div(n, 256)), dim3(256), 0, ctx->stream, d_atoms, d_mass, n, mn[0], mn[1],
+                       mn[2], voxsp, margin, p[0], p[1], p[2], bufA);
+    const int rb = (int)std::min<size_t>(mad_ceil_div((int64_t)np_, 256), (size_t)ctx->n_cu * 8);
+    hipLaunchKernelGGL(k_max_f64, dim3(rb), dim3(256), 0, ctx->stream, bufA, np_, d_max);
+    const int gb = ctx->n_cu * 8;
+    hipLaunchKernelGGL(k_blur_axis, dim3(gb), dim3(256), 0, ctx->stream, bufA, p[0], p[1], p[2], 0, r, d_taps, d_max, bufB);
+    hipLaunchKernelGGL(k_blur_axis, dim3(gb), dim3(256), 0, ctx->stream, bufB, p[0] + 2 * r, p[1], p[2], 1, r, d_taps,
+                       (const double *)nullptr, bufA);
+    hipLaunchKernelGGL(k_blur_axis, dim3(gb), dim3(256), 0, ctx->stream, bufA, p[0] + 2 * r, p[1] + 2 * r, p[2], 2, r, d_taps,
+                       (const double *)nullptr, bufB);
+    hipLaunchKernelGGL(k_to_f32, dim3(gb), dim3(256), 0, ctx->stream, bufB, no, d_out, d_maxf);
+    hipLaunchKernelGGL(k_norm_f32, dim3(gb), dim3(256), 0, ctx->stream, d_out, no, d_maxf, (float)isovalue);
+    mad_timer_end(ctx, MAD_T_DENSITY);
+    MAD_HIP(hipGetLastError());
+    MAD_HIP(hipMemcpyAsync(grid, d_out, no * 4, hipMemcpyDeviceToHost, ctx->stream));
+    MAD_HIP(hipStreamSynchronize(ctx->stream));
+    return MAD_OK;
+}
+
+// ---------------------------------------------------------------------------
+// cross-correlation
+// ---------------------------------------------------------------------------
+
+__global__ void k_clamp_f32(float *__restrict__ g, size_t n, float iso) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        if (g[i] < iso) g[i] = 0.f;
+}
+
+__global__ __launch_bounds__(256) void k_ccc(const float *__restrict__ g1, int a1, int a2, int s10, int s11, int s12,
+                                             const float *__restrict__ g2, int b1, int b2, int s20, int s21, int s22, int e0,
+                                             int e1, int e2, double *__restrict__ acc) {
+    __shared__ double wt[4][3];
+    const size_t n = (size_t)e0 * e1 * e2;
+    double o = 0, na = 0, nb = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int z = (int)(i % e2), y = (int)((i / e2) % e1), x = (int)(i / ((size_t)e2 * e1));
+        const double a = g1[((size_t)(s10 + x) * a1 + (s11 + y)) * a2 + (s12 + z)];
+        const double b = g2[((size_t)(s20 + x) * b1 + (s21 + y)) * b2 + (s22 + z)];
+        o += a * b; na += a * a; nb += b * b;
+    }
+    o = wave_sum_f64(o); na = wave_sum_f64(na); nb = wave_sum_f64(nb);
+    if (lane_id() == 0) { wt[threadIdx.x >> 6][0] = o; wt[threadIdx.x >> 6][1] = na; wt[threadIdx.x >> 6][2] = nb; }
+    __syncthreads();
+    if (threadIdx.x < 3) unsafeAtomicAdd(&acc[threadIdx.x], wt[0][threadIdx.x] + wt[1][threadIdx.x] + wt[2][threadIdx.x] + wt[3][threadIdx.x]);
+}
+
+static long py_round(double v) { return (long)nearbyint(v); }      // python round(): half to even
+
+extern "C" int mad_ccc(mad_ctx *ctx, float *grid1, const int32_t d1[3], const double o1[3], float *grid2,
+                       const int32_t d2[3], const double o2[3], double voxsp, double isovalue, double *ccc) {
+    if (!ctx || !grid1 || !grid2 || !d1 || !d2 || !o1 || !o2 || !ccc) return ctx ? mad_fail(ctx, MAD_EINVAL, "mad_ccc: NULL argument") : MAD_EINVAL;
+    *ccc = 0.0;
+    const size_t n1 = (size_t)d1[0] * d1[1] * d1[2], n2 = (size_t)d2[0] * d2[1] * d2[2];
+    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_TMP_H], n1 * 4));
+    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_TMP_I], n2 * 4));
+    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_MISC], 4096));
+    float *g1 = scratch<float>(ctx, S_TMP_H), *g2 = scratch<float>(ctx, S_TMP_I);
+    double *acc = (double *)(scratch<char>(ctx, S_MISC) + 2048);
+    MAD_HIP(hipMemcpyAsync(g1, grid1, n1 * 4, hipMemcpyHostToDevice, ctx->stream));
+    MAD_HIP(hipMemcpyAsync(g2, grid2, n2 * 4, hipMemcpyHostToDevice, ctx->stream));
+    MAD_HIP(hipMemsetAsync(acc, 0, 24, ctx->stream));
+    const int gb = ctx->n_cu * 8;
+    mad_timer_begin(ctx, MAD_T_CCC);
+    // Dmap.py:160-161: both grids are clamped in place
+    hipLaunchKernelGGL(k_clamp_f32, dim3(gb), dim3(256), 0, ctx->stream, g1, n1, (float)isovalue);
+    hipLaunchKernelGGL(k_clamp_f32, dim3(gb), dim3(256), 0, ctx->stream, g2, n2, (float)isovalue);
+    // Dmap.py:163-230 overlap box in voxel units
+    long mn1[3], mn2[3], mx1[3], mx2[3];
+    bool empty = false;
+    for (int d = 0; d < 3; d++) {
+        const double a = o1[d] / voxsp, b = o2[d] / voxsp;
+        if (a > b) { mn1[d] = 0; mn2[d] = py_round(a - b); }
+        else if (a < b) { mn1[d] = py_round(b - a); mn2[d] = 0; }
+        else { mn1[d] = 0; mn2[d] = 0; }
+        if (a + d1[d] > b + d2[d]) { mx1[d] = py_round(b + d2[d] - a); mx2[d] = d2[d]; }
+        else if (a + d1[d] < b + d2[d]) { mx1[d] = d1[d]; mx2[d] = py_round(a + d1[d] - b); }
+        else { mx1[d] = d1[d]; mx2[d] = d2[d]; }
+        if (mx1[d] - mn1[d] < 0) empty = true;      // Dmap.py:232-234
+    }
+    long e[3] = {0, 0, 0};
+    if (!empty) {
+        for (int d = 0; d < 3; d++) {      // python slice semantics
+            const long a0 = mn1[d] < 0 ? 0 : mn1[d], a1 = mx1[d] > d1[d] ? d1[d] : mx1[d];
+            const long b0 = mn2[d] < 0 ? 0 : mn2[d], b1 = mx2[d] > d2[d] ? d2[d] : mx2[d];
+            const long ea = a1 - a0 > 0 ? a1 - a0 : 0, eb = b1 - b0 > 0 ? b1 - b0 : 0;
+            e[d] = ea < eb ? ea : eb;
+            mn1[d] = a0; mn2[d] = b0;
+        }
+        if (e[0] > 0 && e[1] > 0 && e[2] > 0)
+            hipLaunchKernelGGL(k_ccc, dim3(gb), dim3(256), 0, ctx->stream, g1, d1[1], d1[2], (int)mn1[0], (int)mn1[1], (int)mn1[2],
+                               g2, d2[1], d2[2], (int)mn2[0], (int)mn2[1], (int)mn2[2], (int)e[0], (int)e[1], (int)e[2], acc);
+    }
+    mad_timer_end(ctx, MAD_T_CCC);
+    MAD_HIP(hipGetLastError());
+    double h[3] = {0, 0, 0};
+    MAD_HIP(hipMemcpyAsync(h, acc, 24, hipMemcpyDeviceToHost, ctx->stream));
+    MAD_HIP(hipMemcpyAsync(grid1, g1, n1 * 4, hipMemcpyDeviceToHost, ctx->stream));
+    MAD_HIP(hipMemcpyAsync(grid2, g2, n2 * 4, hipMemcpyDeviceToHost, ctx->stream));
+    MAD_HIP(hipStreamSynchronize(ctx->stream));
+    if (empty) { *ccc = 0.0; return MAD_OK; }
+    *ccc = h[0] / sqrt(h[1] * h[2]);      // 0/0 -> NaN for an empty but non-inverted box, as the reference
+    return MAD_OK;
+}

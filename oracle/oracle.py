@@ -1,0 +1,195 @@
+"""ctypes front-end of the CPU oracle (oracle/mad_oracle.c).  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this
+module.  The product package (mad_amd/) never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+_f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+_f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
+_i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+_i16p = np.ctypeslib.ndpointer(np.int16, flags="C_CONTIGUOUS")
+_i64p = np.ctypeslib.ndpointer(np.int64, flags="C_CONTIGUOUS")
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "libmad_oracle.so")
+    src = os.path.join(_HERE, "mad_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        _LIB.orc_ccc.restype = C.c_double
+    return _LIB
+
+
+def _c(a, dt):
+    return np.ascontiguousarray(a, dtype=dt)
+
+
+def _opt(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def belt_first(bounds):
+    bounds = _c(bounds, np.float64)
+    out = np.zeros(len(bounds), np.int32)
+    lib().orc_eqsp_belt_first(_opt(bounds), C.c_int(len(bounds)), _opt(out))
+    return out
+
+
+def to_dom_mat(centers, a):
+    centers = _c(centers, np.float64)
+    m = np.zeros(9)
+    lib().orc_to_dom_mat(_opt(centers), C.c_int(a), _opt(m))
+    return m.reshape(3, 3)
+
+
+def adj_sec_mat(bounds, centers, s):
+    bounds = _c(bounds, np.float64)
+    centers = _c(centers, np.float64)
+    m = np.zeros(9)
+    lib().orc_adj_sec_mat(_opt(bounds), _opt(centers), C.c_int(len(bounds)), C.c_int(s), _opt(m))
+    return m.reshape(3, 3)
+
+
+def orient(gx, gy, gz, octave, coords, bounds, centers, r=8, lim_main=6, lim_sec=6, want_counts=True):
+    gx, gy, gz = _c(gx, np.float32), _c(gy, np.float32), _c(gz, np.float32)
+    coords = _c(coords, np.int32).reshape(-1, 3)
+    bounds, centers = _c(bounds, np.float64), _c(centers, np.float64)
+    Z = len(bounds)
+    n = len(coords)
+    cap = max(1, n * lim_main * lim_sec)
+    ra, rm, rs = (np.zeros(cap, np.int32) for _ in range(3))
+    R = np.zeros((cap, 9))
+    cnt = np.zeros((cap, Z), np.int32) if want_counts else None
+    nrows = C.c_int64(0)
+    nrej = C.c_int32(0)
+    nx, ny, nz = gx.shape
+    rc = lib().orc_orient(_opt(gx), _opt(gy), _opt(gz), C.c_int(nx), C.c_int(ny), C.c_int(nz), C.c_int(octave),
+                          _opt(coords), C.c_int(n), C.c_int(r), C.c_int(lim_main), C.c_int(lim_sec),
+                          _opt(bounds), _opt(centers), C.c_int(Z),
+                          _opt(ra), _opt(rm), _opt(rs), _opt(R), _opt(cnt), C.byref(nrows), C.c_int64(cap), C.byref(nrej))
+    assert rc == 0
+    k = nrows.value
+    return dict(anchor=ra[:k].copy(), main=rm[:k].copy(), sec=rs[:k].copy(), R=R[:k].reshape(k, 3, 3).copy(),
+                counts=None if cnt is None else cnt[:k].copy(), n_reject=nrej.value)
+
+
+def describe(gx, gy, gz, octave, coords, R, bounds, r=8):
+    gx, gy, gz = _c(gx, np.float32), _c(gy, np.float32), _c(gz, np.float32)
+    coords = _c(coords, np.int32).reshape(-1, 3)
+    R = _c(R, np.float64).reshape(-1, 9)
+    bounds = _c(bounds, np.float64)
+    Z = len(bounds)
+    n = len(coords)
+    out = np.zeros((n, 64 * Z), np.int16)
+    nx, ny, nz = gx.shape
+    rc = lib().orc_describe(_opt(gx), _opt(gy), _opt(gz), C.c_int(nx), C.c_int(ny), C.c_int(nz), C.c_int(octave),
+                            _opt(coords), _opt(R), C.c_int64(n), C.c_int(r), _opt(bounds), C.c_int(Z), _opt(out))
+    assert rc == 0
+    return out
+
+
+def correlate(hi, lo, cc, want_scores=False):
+    hi, lo = _c(hi, np.int16), _c(lo, np.int16)
+    n_hi, D = hi.shape
+    n_lo = lo.shape[0]
+    scores = np.zeros((n_hi, n_lo)) if want_scores else None
+    cap = max(1, n_hi * n_lo)
+    ph, pl, ps = np.zeros(cap, np.int32), np.zeros(cap, np.int32), np.zeros(cap)
+    npairs = C.c_int64(0)
+    rc = lib().orc_correlate(_opt(hi), C.c_int64(n_hi), _opt(lo), C.c_int64(n_lo), C.c_int(D), C.c_double(cc),
+                             _opt(scores), _opt(ph), _opt(pl), _opt(ps), C.byref(npairs), C.c_int64(cap))
+    assert rc == 0
+    k = npairs.value
+    return ph[:k].copy(), pl[:k].copy(), ps[:k].copy(), scores
+
+
+def pose_score(pair_hi, pair_lo, pair_score, hi_p, hi_R, hi_meta, lo_p, lo_R, lo_meta, hi_cloud, lo_cloud, dist=4.0):
+    pair_hi, pair_lo = _c(pair_hi, np.int32), _c(pair_lo, np.int32)
+    pair_score = _c(pair_score, np.float64)
+    hi_p, lo_p = _c(hi_p, np.float64), _c(lo_p, np.float64)
+    hi_R, lo_R = _c(hi_R, np.float64).reshape(-1, 9), _c(lo_R, np.float64).reshape(-1, 9)
+    hi_meta, lo_meta = _c(hi_meta, np.int32), _c(lo_meta, np.int32)
+    hi_cloud, lo_cloud = _c(hi_cloud, np.float64), _c(lo_cloud, np.float64)
+    n = len(pair_hi)
+    res = np.zeros((n, 23))
+    cnt = np.zeros(n, np.int32)
+    rc = lib().orc_pose_score(_opt(pair_hi), _opt(pair_lo), _opt(pair_score), C.c_int64(n),
+                              _opt(hi_p), _opt(hi_R), _opt(hi_meta), _opt(lo_p), _opt(lo_R), _opt(lo_meta),
+                              _opt(hi_cloud), C.c_int64(len(hi_cloud)), _opt(lo_cloud), C.c_int64(len(lo_cloud)),
+                              C.c_double(dist), _opt(res), _opt(cnt))
+    assert rc == 0
+    return res, cnt
+
+
+def topk(counts, k):
+    counts = _c(counts, np.int32)
+    k = min(k, len(counts))
+    order = np.zeros(k, np.int64)
+    lib().orc_topk(_opt(counts), C.c_int64(len(counts)), C.c_int64(k), _opt(order))
+    return order
+
+
+def refine(grid, origin, vs, coords, n_steps=500, max_step=0.5, min_step=0.01, want_trace=False):
+    grid = _c(grid, np.float32)
+    coords = _c(coords, np.float64).copy()
+    nx, ny, nz = grid.shape
+    conv, last = C.c_int32(0), C.c_int32(0)
+    trace = np.full((n_steps, 13), np.nan) if want_trace else None
+    lib().orc_refine(_opt(grid), C.c_int(nx), C.c_int(ny), C.c_int(nz),
+                     C.c_double(origin[0]), C.c_double(origin[1]), C.c_double(origin[2]), C.c_double(vs),
+                     _opt(coords), C.c_int64(len(coords)), C.c_int(n_steps), C.c_double(max_step), C.c_double(min_step),
+                     C.byref(conv), C.byref(last), _opt(trace))
+    return coords, bool(conv.value), last.value, trace
+
+
+def splat(atoms, mass, vs, pad=0):
+    atoms, mass = _c(atoms, np.float64), _c(mass, np.float64)
+    dims = np.zeros(3, np.int32)
+    mn = np.zeros(3)
+    lib().orc_splat(_opt(atoms), _opt(mass), C.c_int64(len(atoms)), C.c_double(vs), C.c_int(pad), _opt(dims), _opt(mn), None)
+    grid = np.zeros(int(dims[0]) * int(dims[1]) * int(dims[2]))
+    lib().orc_splat(_opt(atoms), _opt(mass), C.c_int64(len(atoms)), C.c_double(vs), C.c_int(pad), _opt(dims), _opt(mn), _opt(grid))
+    return grid, dims, mn
+
+
+def blur(splat_grid, dims, resolution, vs, isovalue=0.0):
+    splat_grid = _c(splat_grid, np.float64)
+    dims = _c(dims, np.int32)
+    r = C.c_int32(0)
+    lib().orc_blur(_opt(splat_grid), _opt(dims), C.c_double(resolution), C.c_double(vs), C.c_double(isovalue), None, C.byref(r))
+    shape = tuple(int(d) + 2 * r.value for d in dims)
+    out = np.zeros(shape, np.float32)
+    lib().orc_blur(_opt(splat_grid), _opt(dims), C.c_double(resolution), C.c_double(vs), C.c_double(isovalue), _opt(out), C.byref(r))
+    return out, r.value
+
+
+def structure_to_density(atoms, mass, resolution, vs, isovalue=0.0, pad=0):
+    """PDB.structure_to_density (PDB.py:131-208): (grid f32[x][y][z], x0, y0, z0)."""
+    g, dims, mn = splat(atoms, mass, vs, pad)
+    out, r = blur(g, dims, resolution, vs, isovalue)
+    margin = 2 + pad
+    o = [mn[d] - (r + margin) * vs for d in range(3)]
+    return out, o[0], o[1], o[2]
+
+
+def ccc(g1, o1, g2, o2, vs, isovalue=0.0):
+    """Dmap.get_CCC_with_grid; g1 and g2 are clamped in place like the reference."""
+    assert g1.dtype == np.float32 and g2.dtype == np.float32 and g1.flags.c_contiguous and g2.flags.c_contiguous
+    d1, d2 = np.array(g1.shape, np.int32), np.array(g2.shape, np.int32)
+    o1, o2 = _c(o1, np.float64), _c(o2, np.float64)
+    return lib().orc_ccc(_opt(g1), _opt(d1), _opt(o1), _opt(g2), _opt(d2), _opt(o2), C.c_double(vs), C.c_double(isovalue))

@@ -1,0 +1,231 @@
+"""GPU parity tests, stage by stage: the HIP path (through the C-ABI) against the CPU
+oracle on the same seeded inputs.  Integer outputs must be identical; float64 outputs
+agree to the stated tolerance."""
+import numpy as np
+import pytest
+
+from mad_amd import synth
+from mad_amd.eqsp import EQSP_Sphere
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+E112 = EQSP_Sphere(112)
+E16 = EQSP_Sphere(16)
+
+
+def _field(shape, seed, hollow=0.25):
+    vol = synth.blob_volume(shape, n_blobs=40, seed=seed, sigma=(1.5, 3.5), hollow=hollow)
+    g = synth.gradient_field(vol)
+    return vol, np.ascontiguousarray(g[..., 0]), np.ascontiguousarray(g[..., 1]), np.ascontiguousarray(g[..., 2])
+
+
+@pytest.fixture(scope="module")
+def fields(lib):
+    out = {}
+    for octave, shape, seed in ((1, (40, 44, 48), 1), (0, (60, 64, 70), 2)):
+        vol, gx, gy, gz = _field(shape, seed)
+        slot = lib.new_slot()
+        lib.upload_field(slot, np.stack([gx, gy, gz]))
+        out[octave] = dict(slot=slot, gx=gx, gy=gy, gz=gz, shape=shape)
+    return out
+
+
+def _anchors(shape, octave, n, seed):
+    # include border cases that the reference rejects (Orientator.py:131-135)
+    margin = 8 if octave == 1 else 16
+    inner = synth.interior_anchors(shape, n, margin + 1, seed)
+    edge = np.array([[margin - 1, shape[1] // 2, shape[2] // 2], [shape[0] // 2, shape[1] - margin - 1, shape[2] // 2],
+                     [margin, margin, margin], [shape[0] - margin - 2, shape[1] - margin - 2, shape[2] - margin - 2]], np.int32)
+    return np.concatenate([inner[: n // 2], edge, inner[n // 2:]]).astype(np.int32)
+
+
+@pytest.mark.parametrize("octave", [1, 0])
+def test_orient_matches_oracle(lib, fields, octave):
+    f = fields[octave]
+    coords = _anchors(f["shape"], octave, 60, 10 + octave)
+    ref = O.orient(f["gx"], f["gy"], f["gz"], octave, coords, E112.sphere_eqsp, E112.p_centers_eqsp)
+    got = lib.orient(f["slot"], octave, coords)
+    assert len(ref["anchor"]) > 20, "test input produces too few rows to mean anything"
+    assert got["n_reject"] == ref["n_reject"] and ref["n_reject"] >= 2
+    np.testing.assert_array_equal(got["anchor"], ref["anchor"])
+    np.testing.assert_array_equal(got["main"], ref["main"])
+    np.testing.assert_array_equal(got["sec"], ref["sec"])
+    np.testing.assert_array_equal(got["counts"], ref["counts"])
+    np.testing.assert_allclose(got["R"], ref["R"], rtol=0, atol=1e-14)
+
+
+@pytest.mark.parametrize("octave", [1, 0])
+def test_describe_matches_oracle(lib, fields, octave):
+    f = fields[octave]
+    coords = _anchors(f["shape"], octave, 40, 20 + octave)
+    rows = O.orient(f["gx"], f["gy"], f["gz"], octave, coords, E112.sphere_eqsp, E112.p_centers_eqsp)
+    rc = coords[rows["anchor"]]
+    R = rows["R"]
+    # add rows whose sample cube leaves the grid (-> all-zero descriptor, Descriptor.py:140-149) and identity rotations
+    extra_c = np.array([[2, 3, 4], [f["shape"][0] - 3, 20, 20], rc[0], rc[1]], np.int32)
+    extra_R = np.stack([R[0], R[1], np.identity(3), np.identity(3)])
+    rc = np.concatenate([rc, extra_c])
+    R = np.concatenate([R, extra_R])
+    ref = O.describe(f["gx"], f["gy"], f["gz"], octave, rc, R, E16.sphere_eqsp)
+    got = lib.describe(f["slot"], octave, rc, R)
+    assert ref[:-4].sum() > 0 and ref[-4].sum() == 0 and ref[-3].sum() == 0 and ref[-1].sum() > 0
+    np.testing.assert_array_equal(got, ref)
+
+
+def _random_descriptors(n, seed, base=None):
+    rng = np.random.default_rng(seed)
+    d = np.zeros((n, 1024), np.int16)
+    for i in range(n):
+        # ~27 % non-zero entries, sub-cube sums <= 64 (what descriptors look like)
+        for sub in range(64):
+            k = rng.integers(0, 65)
+            z = rng.integers(0, 16, size=k)
+            np.add.at(d[i], sub * 16 + z, 1)
+    if base is not None:      # correlated copies so that some pairs pass the threshold
+        m = min(n, len(base))
+        noise = rng.integers(-1, 2, size=(m, 1024))
+        d[:m] = np.clip(base[:m].astype(np.int64) + noise * (rng.random((m, 1024)) < 0.3), 0, 64)
+    return d
+
+
+def test_correlate_matches_oracle(lib):
+    lo = _random_descriptors(300, 5)
+    hi = _random_descriptors(140, 6, base=lo[50:])
+    hi[3] = 0      # zero row: stays un-normalised, correlates to 0 (MaD.py:416)
+    for cc in (0.6, 0.3):
+        rh, rl, rs, _ = O.correlate(hi, lo, cc)
+        gh, gl, gs = lib.correlate(hi, lo, cc)
+        assert len(rh) > 50
+        np.testing.assert_array_equal(gh, rh)
+        np.testing.assert_array_equal(gl, rl)
+        np.testing.assert_allclose(gs, rs, rtol=1e-12, atol=0)
+
+
+def test_correlate_rejects_out_of_range(lib):
+    from mad_amd._lib import MadBackendError
+    hi = np.full((4, 1024), 200, np.int16)
+    with pytest.raises(MadBackendError, match="int8"):
+        lib.correlate(hi, hi, 0.5)
+
+
+def _pose_inputs(seed, n_hi_anchor=70, n_lo_anchor=160, n_pairs=4000):
+    rng = np.random.default_rng(seed)
+    lo_anchor_p = rng.uniform(0, 90, size=(n_lo_anchor, 3))
+    # hi anchors = a rigidly moved subset of the lo anchors + jitter, so that good poses exist
+    Rt = synth.random_rotation(rng)
+    sub = rng.choice(n_lo_anchor, n_hi_anchor, replace=False)
+    hi_anchor_p = (lo_anchor_p[sub] - 45.0) @ Rt.T + rng.normal(scale=0.8, size=(n_hi_anchor, 3))
+    n_hi, n_lo = 3 * n_hi_anchor, 3 * n_lo_anchor
+    hi_row_anchor = rng.integers(0, n_hi_anchor, n_hi)
+    lo_row_anchor = rng.integers(0, n_lo_anchor, n_lo)
+    hi_R = np.stack([synth.random_rotation(rng) for _ in range(n_hi)])
+    lo_R = np.stack([synth.random_rotation(rng) for _ in range(n_lo)])
+    # plant consistent rotations for a few pairs: inv(lo_R) @ hi_R == Rt.T-ish pose
+    pair_hi = rng.integers(0, n_hi, n_pairs).astype(np.int32)
+    pair_lo = rng.integers(0, n_lo, n_pairs).astype(np.int32)
+    for t in range(0, n_pairs, 7):
+        a = rng.integers(0, n_hi_anchor)
+        ih = int(np.flatnonzero(hi_row_anchor == a)[0]) if np.any(hi_row_anchor == a) else 0
+        il_c = np.flatnonzero(lo_row_anchor == sub[hi_row_anchor[ih]])
+        if len(il_c) == 0:
+            continue
+        il = int(il_c[0])
+        hi_R[ih] = lo_R[il] @ Rt.T
+        pair_hi[t], pair_lo[t] = ih, il
+    order = np.lexsort((pair_lo, pair_hi))
+    pair_hi, pair_lo = pair_hi[order], pair_lo[order]
+    score = rng.uniform(0.6, 1.0, n_pairs)
+    hi_meta = np.stack([hi_row_anchor, rng.integers(0, 2, n_hi), rng.integers(0, 112, n_hi)], 1).astype(np.int32)
+    lo_meta = np.stack([lo_row_anchor, rng.integers(0, 2, n_lo), rng.integers(0, 112, n_lo)], 1).astype(np.int32)
+    hi_p, lo_p = hi_anchor_p[hi_row_anchor], lo_anchor_p[lo_row_anchor]
+    hi_cloud = np.unique(hi_p[np.unique(pair_hi)], axis=0)
+    lo_cloud = np.unique(lo_p[np.unique(pair_lo)], axis=0)
+    return dict(pair_hi=pair_hi, pair_lo=pair_lo, pair_score=score, hi_p=hi_p, hi_R=hi_R, hi_meta=hi_meta,
+                lo_p=lo_p, lo_R=lo_R, lo_meta=lo_meta, hi_cloud=hi_cloud, lo_cloud=lo_cloud)
+
+
+def test_pose_score_matches_oracle(lib):
+    a = _pose_inputs(3)
+    ref_res, ref_cnt = O.pose_score(**a, dist=4.0)
+    got_res, got_cnt = lib.pose_score(**a, dist=4.0)
+    assert ref_cnt.max() > 20, "planted poses should bring many anchors into coincidence"
+    np.testing.assert_array_equal(got_cnt, ref_cnt)
+    np.testing.assert_allclose(got_res, ref_res, rtol=1e-12, atol=1e-12)
+
+
+def test_topk_order(lib):
+    rng = np.random.default_rng(0)
+    for n, k, hi in ((5000, 60, 40), (777, 777, 5), (20000, 840, 3), (50, 200, 9)):
+        counts = rng.integers(0, hi, n).astype(np.int32)
+        ref = O.topk(counts, k)
+        got = lib.topk(counts, k)
+        np.testing.assert_array_equal(got, ref)
+        # the oracle's order is python's stable sort by count, descending (MaD.py:480)
+        py = sorted(range(n), key=lambda i: counts[i], reverse=True)[: min(k, n)]
+        np.testing.assert_array_equal(ref, py)
+
+
+def _refine_case(seed, n_atoms=400):
+    coords, names, elems = synth.random_globule(n_atoms, 14.0, seed)
+    m = synth.masses(elems)
+    grid, x0, y0, z0 = O.structure_to_density(coords, m, 8.0, 1.5)
+    grid = np.pad(grid, 6)
+    origin = np.array([x0, y0, z0]) - 6 * 1.5
+    rng = np.random.default_rng(seed + 100)
+    ang = 0.12
+    ax = rng.normal(size=3)
+    ax /= np.linalg.norm(ax)
+    from mad_amd.math_utils import euler_rod_mat
+    R = euler_rod_mat(ax, ang)
+    start = (coords - coords.mean(0)) @ R + coords.mean(0) + rng.normal(scale=1.2, size=3)
+    return grid, origin, 1.5, coords, start
+
+
+def test_refine_matches_oracle(lib):
+    grid, origin, vs, truth, start = _refine_case(4)
+    lib.upload_density(grid, origin, vs)
+    for n_steps in (1, 2, 3, 8, 500):
+        ref, rconv, rlast, _ = O.refine(grid, origin, vs, start, n_steps=n_steps, max_step=1.0, min_step=0.1)
+        got, gconv, glast = lib.refine(start, n_steps=n_steps, max_step=1.0, min_step=0.1)
+        assert (gconv, glast) == (rconv, rlast)
+        np.testing.assert_allclose(got, ref, rtol=0, atol=1e-7)
+    # the refined pose moves towards the planted one
+    assert np.sqrt(((got - truth) ** 2).sum(1).mean()) < 0.6 * np.sqrt(((start - truth) ** 2).sum(1).mean())
+
+
+def test_refine_batch_of_candidates(lib):
+    grid, origin, vs, truth, start = _refine_case(5)
+    lib.upload_density(grid, origin, vs)
+    starts = np.stack([start, start + 0.7, truth + 30.0])      # the last one is mostly outside the map
+    got, conv, last = lib.refine(starts, n_steps=500, max_step=1.0, min_step=0.1)
+    for i in range(3):
+        ref, rconv, rlast, _ = O.refine(grid, origin, vs, starts[i], n_steps=500, max_step=1.0, min_step=0.1)
+        assert (bool(conv[i]), int(last[i])) == (rconv, rlast)
+        np.testing.assert_allclose(got[i], ref, rtol=0, atol=1e-7)
+
+
+def test_density_and_ccc_match_oracle(lib):
+    coords, names, elems = synth.random_globule(500, 15.0, 8)
+    m = synth.masses(elems)
+    for res, vs, iso in ((8.0, 1.5, 0.0), (6.0, 1.2, 0.05)):
+        ref, rx, ry, rz = O.structure_to_density(coords, m, res, vs, isovalue=iso)
+        got, gx, gy, gz = lib.structure_to_density(coords, m, res, vs, isovalue=iso)
+        assert got.shape == ref.shape and (gx, gy, gz) == (rx, ry, rz)
+        np.testing.assert_allclose(got, ref, rtol=0, atol=2e-7)
+    # CCC of the map against a shifted copy of the structure (partial overlap, negative voxels clamped)
+    big = np.pad(ref, 5).astype(np.float32)
+    big[2, 3, 4] = -0.5
+    o_big = np.array([rx, ry, rz]) - 5 * vs
+    sub, sx, sy, sz = O.structure_to_density(coords + np.array([3.1, -2.2, 1.4]), m, res, vs)
+    for shift in ((0, 0, 0), (40 * vs, 0, 0), (1000.0, 0, 0)):
+        o2 = np.array([sx, sy, sz]) + np.array(shift)
+        a1, b1, a2, b2 = big.copy(), sub.copy(), big.copy(), sub.copy()
+        r = O.ccc(a1, o_big, b1, o2, vs)
+        g = lib.ccc(a2, o_big, b2, o2, vs)
+        if np.isnan(r):
+            assert np.isnan(g)
+        else:
+            assert abs(g - r) <= 1e-9 * max(1.0, abs(r))
+        np.testing.assert_array_equal(a2, a1)      # clamped in place, like Dmap.py:160-161
+        assert a2[2, 3, 4] == 0.0
