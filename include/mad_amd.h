@@ -185,6 +185,8 @@ int mad_match_topk(mad_ctx *ctx, const mad_set *hi, const mad_set *lo, double cc
 /* After mad_match_topk: all pairs of that call (for MaD._match_dsc's full return value). */
 int mad_match_fetch(mad_ctx *ctx, int32_t *pair_hi, int32_t *pair_lo, double *pair_score,
                     int32_t *counts, int64_t cap);
+/* After mad_match_topk(hi, lo, ...): the MaD.py:451 rows of ALL pairs, row-major pair order (n_pairs x 23). */
+int mad_match_results(mad_ctx *ctx, const mad_set *hi, const mad_set *lo, double *results, int64_t cap);
 /* After mad_match_topk: which anchors of each set appear in a pair (uint8 flags). */
 int mad_match_used(mad_ctx *ctx, uint8_t *hi_anchor_used, int32_t n_hi_anchors,
                    uint8_t *lo_anchor_used, int32_t n_lo_anchors);

@@ -1,0 +1,69 @@
+"""Descriptor generation (hot path rows a9-a10).
+
+Same constructor and entry point as the reference's `Descriptor`
+(mad/Descriptor.py:14, :106): `Descriptor(subeqsp_size=16, dsc_radius=16,
+dsc_size=64).generate_descriptors(ms, df_list)` fills `lin_ar_subeqsp` (int16[1024]) on
+every oriented anchor and returns the list.  The arithmetic (step06,
+Descriptor.py:123-202) runs in the HIP kernel `k_describe` through `mad_describe`.
+
+Only the layout the reference actually uses is implemented on the device: 64 sub-cubes
+x 16 zones (`dsc_size` 27 / 8 / 1 exist in the reference's constructor but are never
+selected, MaD.py:362).
+"""
+import sys
+
+import numpy as np
+
+from . import _lib
+from .eqsp.eqsp import EQSP_Sphere
+
+
+class Descriptor(object):
+    def __init__(self, subeqsp_size=16, dsc_radius=16, dsc_size=64):
+        self.subeqsp_size = subeqsp_size
+        self.subeqsp = EQSP_Sphere(size=subeqsp_size)
+        self.cutoff_magn = 1e-12
+        if dsc_radius % 2:
+            print("MaD>> ERROR: radius %i invalid, must be even. Setting %i instead." % (dsc_radius, dsc_radius - 1))
+            dsc_radius -= 1
+        self.dsc_radius = dsc_radius // 2
+        self.dsc_size = dsc_size
+        if dsc_size not in (64, 27, 8, 1):
+            print("MaD>> ERROR: invalid dsc size %i" % dsc_size)
+            sys.exit(1)
+        if dsc_size != 64 or subeqsp_size != 16:
+            raise NotImplementedError("MaD> the device descriptor is 64 sub-cubes x 16 zones (the reference's only used layout)")
+        dr = self.dsc_radius
+        # sample lattices (Descriptor.py:34-35), kept for inspection
+        self.dsc_layout = {
+            0: np.rollaxis(np.array(np.mgrid[-2 * dr + 1:2 * dr + 1:2, -2 * dr + 1:2 * dr + 1:2, -2 * dr + 1:2 * dr + 1:2]), 0, 4),
+            1: np.rollaxis(np.array(np.mgrid[-dr + 0.5:dr + 0.5, -dr + 0.5:dr + 0.5, -dr + 0.5:dr + 0.5]), 0, 4),
+        }
+        self.time6 = 0
+
+    def _bind(self, lib):
+        key = ("dsc", self.subeqsp_size)
+        if lib._eq_loaded.get(1) != key:
+            lib.set_eqsp(1, self.subeqsp.sphere_eqsp)
+            lib._eq_loaded[1] = key
+
+    def generate_descriptors(self, ms, df_list):
+        print("MaD> Generating descriptors from %i oriented anchors..." % len(df_list))
+        lib = _lib.get_lib()
+        self._bind(lib)
+        slots = ms.device_slots(lib)
+        for octave in sorted(set(df.oct_scale for df in df_list)):
+            ids = [i for i, df in enumerate(df_list) if df.oct_scale == octave]
+            coords = np.array([df_list[i].coords for i in ids], dtype=np.int32).reshape(-1, 3)
+            R = np.array([df_list[i].Rfinal for i in ids], dtype=np.float64).reshape(-1, 9)
+            slot = slots[octave] if len(ms.grad_list) > 1 else slots[0]
+            lattice = octave if len(ms.grad_list) > 1 else (1 if ms.oct_mode == "base" else 0)
+            dsc = lib.describe(slot, lattice, coords, R, r=self.dsc_radius, Zd=self.subeqsp_size)
+            for j, i in enumerate(ids):
+                df = df_list[i]
+                df.set_descriptor_info(self.subeqsp_size, self.dsc_radius)
+                df.lin_ar_subeqsp = dsc[j].copy()
+        return df_list
+
+    def show_timing(self):
+        print("MaD> Step timing: description runs on the GPU; use Lib.timing_get('describe')")

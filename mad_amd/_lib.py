@@ -22,7 +22,7 @@ SYMBOLS = [
     "mad_set_eqsp", "mad_upload_field", "mad_upload_field_device", "mad_free_field",
     "mad_orient", "mad_describe", "mad_correlate", "mad_pose_score", "mad_topk",
     "mad_set_create", "mad_set_destroy", "mad_set_build", "mad_set_load", "mad_set_size", "mad_set_download",
-    "mad_match_topk", "mad_match_fetch", "mad_match_used",
+    "mad_match_topk", "mad_match_fetch", "mad_match_results", "mad_match_used",
     "mad_upload_density", "mad_refine", "mad_structure_to_density", "mad_ccc",
 ]
 
@@ -292,6 +292,11 @@ class Lib(object):
         ps, cn = np.zeros(n_pairs), np.zeros(n_pairs, np.int32)
         self._chk(self.dll.mad_match_fetch(self.ctx, _p(ph), _p(pl), _p(ps), _p(cn), C.c_int64(n_pairs)))
         return ph, pl, ps, cn
+
+    def match_results(self, hi, lo, n_pairs):
+        res = np.zeros((max(n_pairs, 1), RESULT_COLS))
+        self._chk(self.dll.mad_match_results(self.ctx, hi.h, lo.h, _p(res), C.c_int64(n_pairs)))
+        return res[:n_pairs]
 
     def match_used(self, n_hi_anchors, n_lo_anchors):
         uh, ul = np.zeros(max(n_hi_anchors, 1), np.uint8), np.zeros(max(n_lo_anchors, 1), np.uint8)

@@ -946,6 +946,35 @@ extern "C" int mad_match_fetch(mad_ctx *ctx, int32_t *pair_hi, int32_t *pair_lo,
     return MAD_OK;
 }
 
+extern "C" int mad_match_results(mad_ctx *ctx, const mad_set *hi, const mad_set *lo, double *results, int64_t cap) {
+    if (!ctx || !hi || !lo || !results) return MAD_EINVAL;
+    const int64_t np = ctx->match.n_pairs;
+    if (np > cap) return mad_fail(ctx, MAD_ENOSPC, "mad_match_results: %lld pairs, capacity %lld", (long long)np, (long long)cap);
+    if (np <= 0) return MAD_OK;
+    if (hi->n_anchors != ctx->match.n_hi_anchors || lo->n_anchors != ctx->match.n_lo_anchors)
+        return mad_fail(ctx, MAD_EINVAL, "mad_match_results: sets differ from the last mad_match_topk call");
+    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_TMP_G], (size_t)hi->n_rows * 12));
+    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_TMP_J], (size_t)lo->n_rows * 12));
+    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_RESULTS], (size_t)np * MAD_RESULT_COLS * 8));
+    int32_t *d_lhi = scratch<int32_t>(ctx, S_MISC) + 8;
+    hipLaunchKernelGGL(k_row_meta, dim3((unsigned)mad_ceil_div(hi->n_rows, 256)), dim3(256), 0, ctx->stream,
+                       (const int32_t *)hi->row_anchor.p, (const int32_t *)hi->row_main.p, (const int32_t *)hi->anc_index.p,
+                       (const int32_t *)hi->anc_octave.p, hi->n_rows, scratch<int32_t>(ctx, S_TMP_G));
+    hipLaunchKernelGGL(k_row_meta, dim3((unsigned)mad_ceil_div(lo->n_rows, 256)), dim3(256), 0, ctx->stream,
+                       (const int32_t *)lo->row_anchor.p, (const int32_t *)lo->row_main.p, (const int32_t *)lo->anc_index.p,
+                       (const int32_t *)lo->anc_octave.p, lo->n_rows, scratch<int32_t>(ctx, S_TMP_J));
+    hipLaunchKernelGGL(k_results, dim3((unsigned)mad_ceil_div(np, 256)), dim3(256), 0, ctx->stream, (const int64_t *)nullptr, np,
+                       scratch<int32_t>(ctx, S_PAIR_HI), scratch<int32_t>(ctx, S_PAIR_LO), scratch<double>(ctx, S_PAIR_SCORE),
+                       scratch<int32_t>(ctx, S_COUNTS), d_lhi, (const double *)hi->anc_subv.p, (const double *)hi->row_R.p,
+                       scratch<int32_t>(ctx, S_TMP_G), (const double *)lo->anc_subv.p, (const double *)lo->row_R.p,
+                       scratch<int32_t>(ctx, S_TMP_J), (const int32_t *)hi->row_anchor.p, (const int32_t *)lo->row_anchor.p,
+                       scratch<double>(ctx, S_RESULTS));
+    MAD_HIP(hipGetLastError());
+    MAD_HIP(hipMemcpyAsync(results, ctx->scratch[S_RESULTS].p, (size_t)np * MAD_RESULT_COLS * 8, hipMemcpyDeviceToHost, ctx->stream));
+    MAD_HIP(hipStreamSynchronize(ctx->stream));
+    return MAD_OK;
+}
+
 extern "C" int mad_match_used(mad_ctx *ctx, uint8_t *hi_used, int32_t n_hi_anchors, uint8_t *lo_used, int32_t n_lo_anchors) {
     if (!ctx) return MAD_EINVAL;
     if (n_hi_anchors != ctx->match.n_hi_anchors || n_lo_anchors != ctx->match.n_lo_anchors)

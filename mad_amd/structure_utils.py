@@ -1,0 +1,74 @@
+"""Rigid-body refinement and the structure helpers around it.
+
+`refine_pdb` has the reference's signature and return value
+(mad/structure_utils.py:58-161) and, like it, moves `pdb.coords` in place; the <= 500
+dependent gradient-ascent steps run in one persistent HIP workgroup (`k_refine`,
+through `mad_refine`).  `refine_many` refines several placements of one structure in a
+single launch (one workgroup each).  `move_structure` / `move_copy_structure` are plain
+bookkeeping; `get_overlap` belongs to assembly building (out of scope, SURVEY.md
+section 2).
+"""
+import numpy as np
+
+from . import _lib
+from .math_utils import euler_rod_mat
+from .PDB import PDB
+
+_uploaded = {"key": None}
+
+
+def _ensure_density(lib, dmap):
+    key = (id(lib), id(dmap), id(dmap.grid3d), dmap.xi, dmap.yi, dmap.zi, dmap.voxsp)
+    if _uploaded["key"] != key:
+        lib.upload_density(dmap.grid3d, (dmap.xi, dmap.yi, dmap.zi), dmap.voxsp)
+        _uploaded["key"] = key
+
+
+def _rmsd_before_after(pdb, before, after):
+    if len(pdb.CA_idx):
+        d = np.square(after[pdb.CA_idx, :] - before[pdb.CA_idx, :])
+    else:
+        d = np.square(after - before)
+    return np.sqrt(np.sum(d, axis=(0, 1)) / d.shape[0])
+
+
+def refine_pdb(dmap, pdb, n_steps=500, max_step_size=0.5, min_step_size=0.01, idx=-1):
+    """-> (CA-RMSD before/after, converged, last step); pdb.coords is updated in place."""
+    lib = _lib.get_lib()
+    _ensure_density(lib, dmap)
+    start = pdb.coords.copy()
+    coords, converged, step = lib.refine(start, n_steps=n_steps, max_step=max_step_size, min_step=min_step_size)
+    if np.any(np.isnan(coords)):
+        pdb.set_coords(coords)
+        return np.nan, False, step
+    pdb.set_coords(coords)
+    return _rmsd_before_after(pdb, start, coords), converged, step
+
+
+def refine_many(dmap, start_coords, n_steps=500, max_step_size=0.5, min_step_size=0.01):
+    """start_coords (n_cand, n_atoms, 3) -> (coords, converged[n_cand], last_step[n_cand])."""
+    lib = _lib.get_lib()
+    _ensure_density(lib, dmap)
+    return lib.refine(np.asarray(start_coords, dtype=np.float64), n_steps=n_steps, max_step=max_step_size, min_step=min_step_size)
+
+
+def move_structure(original_struct, t=None, a=0.375, b=1.735, c=2.452, suffix=""):
+    moved = original_struct.replace(".pdb", "_moved%s.pdb" % suffix)
+    pdb = PDB(original_struct)
+    for axis, ang in (([1, 0, 0], a), ([0, 1, 0], b), ([0, 0, 1], c)):
+        pdb.rotate_atoms(euler_rod_mat(axis, ang))
+    pdb.translate_atoms(-np.mean(pdb.get_coords(), axis=0) if t is None else t)
+    pdb.write_pdb(moved)
+    return moved
+
+
+def move_copy_structure(original_struct, moved_struct, transform=False, t=[150, 0, 0], a=0.375, b=1.735, c=2.452):
+    pdb = PDB(original_struct)
+    if transform:
+        for axis, ang in (([1, 0, 0], a), ([0, 1, 0], b), ([0, 0, 1], c)):
+            pdb.rotate_atoms(euler_rod_mat(axis, ang))
+        pdb.translate_atoms(-np.mean(pdb.get_coords(), axis=0))
+        if len(t):
+            pdb.translate_atoms(t)
+    pdb.write_pdb(moved_struct)
+    return moved_struct

@@ -1,0 +1,285 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors in tests/golden/*.npz by RUNNING THE REFERENCE.
+
+Runs only in the build container, where the reference checkout is mounted read-only at
+/root/reference.  The reference is imported unmodified; nothing of it is copied.  Two
+things the container lacks are handled like this:
+
+  * h5py and mrcfile (used by the reference only inside file read/write helpers) are
+    registered as empty placeholder modules so that `import` succeeds; none of their
+    attributes is ever touched by the functions called here;
+  * scikit-image (Detector.py:3, peak_local_max) is absent, so anchors are produced by
+    this repo's own detector and are INPUTS of the fixtures ("parity unpinned" for the
+    peak search, pinned from the anchor list onwards).
+
+Fixtures hold inputs and the reference's outputs only (numpy arrays).  Everything is
+seeded; re-running this script reproduces the files bit for bit on the same numpy /
+scipy build.
+
+Usage:  cd /root/repo && python tests/golden/make_golden.py
+"""
+import hashlib
+import os
+import sys
+import tempfile
+import types
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+REF = "/root/reference"
+OUT = os.path.join(REPO, "tests", "golden")
+sys.dont_write_bytecode = True
+
+
+def import_reference():
+    for name in ("h5py", "mrcfile"):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    sk = types.ModuleType("skimage")
+    skf = types.ModuleType("skimage.feature")
+    skf.peak_local_max = None      # never called: anchors come from mad_amd.Detector
+    sk.feature = skf
+    sys.modules.setdefault("skimage", sk)
+    sys.modules.setdefault("skimage.feature", skf)
+    # The reference's `mad` is a namespace package (no __init__.py); this repo also has a drop-in
+    # alias package called `mad`.  Keep the repo off sys.path until the reference is imported.
+    saved = list(sys.path)
+    sys.path[:] = [REF] + [p for p in saved if p and os.path.abspath(p) not in (REPO, os.getcwd())]
+    os.chdir(REF)      # the reference opens "mad/eqsp/*.txt" relative to the CWD (eqsp.py:16)
+    import mad.MaD as rMaD
+    import mad.Orientator as rOri
+    import mad.Descriptor as rDsc
+    import mad.DensityFeature as rDF
+    import mad.PDB as rPDB
+    import mad.Dmap as rDmap
+    import mad.MapSpace as rMS
+    import mad.structure_utils as rSU
+    import mad.math_utils as rMU
+    import mad.eqsp.eqsp as rEQ
+    assert rMaD.__file__.startswith(REF), rMaD.__file__
+    sys.path.insert(1, REPO)
+    return types.SimpleNamespace(MaD=rMaD, Ori=rOri, Dsc=rDsc, DF=rDF, PDB=rPDB, Dmap=rDmap, MS=rMS, SU=rSU, MU=rMU, EQ=rEQ)
+
+
+def sha(path):
+    with open(path, "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()
+
+
+def main():
+    from scipy.interpolate import RegularGridInterpolator as RGI
+    R = import_reference()
+    from mad_amd import synth
+    from mad_amd.Detector import Detector as MyDetector
+    os.makedirs(OUT, exist_ok=True)
+    work = tempfile.mkdtemp(prefix="mad_golden_")
+
+    # ---- G1: EQSP tables -----------------------------------------------------------
+    g1 = {}
+    for n in (16, 112):
+        e = R.EQ.EQSP_Sphere(size=n)
+        g1["bounds_%d" % n] = e.sphere_eqsp
+        g1["centers_%d" % n] = e.p_centers_eqsp
+        g1["c_centers_%d" % n] = e.c_centers_eqsp
+        g1["belt_sizes_%d" % n] = np.array([len(b) for b in e.belt_l])
+        g1["sha_sphere_%d" % n] = np.array(sha(os.path.join(REF, "mad/eqsp/sphere_%d.txt" % n)))
+        g1["sha_centers_%d" % n] = np.array(sha(os.path.join(REF, "mad/eqsp/centers_%d.txt" % n)))
+    # matrices of math_utils.euler_rod_mat / get_rototrans_SVD on seeded inputs
+    rng = np.random.default_rng(0)
+    axes = rng.normal(size=(6, 3))
+    angs = rng.uniform(-3, 3, 6)
+    g1["rod_axes"], g1["rod_angles"] = axes, angs
+    g1["rod_mats"] = np.stack([R.MU.euler_rod_mat(R.MU.unit_vector(a), t) for a, t in zip(axes, angs)])
+    mob = rng.normal(size=(40, 3)) * 10
+    Rr = synth.random_rotation(rng)
+    reff = mob @ Rr + np.array([3.0, -2.0, 7.5]) + rng.normal(scale=0.01, size=mob.shape)
+    kr, kt = R.MU.get_rototrans_SVD(mob, reff)
+    g1["kabsch_mobile"], g1["kabsch_reference"], g1["kabsch_R"], g1["kabsch_T"] = mob, reff, kr, kt
+    np.savez_compressed(os.path.join(OUT, "g1_eqsp_math.npz"), **g1)
+
+    # ---- G2/G3: orientation + description on small synthetic fields ---------------------
+    ori = R.Ori.Orientator()
+    ori.step1_reject = 0      # the reference never initialises it (Orientator.py:133)
+    dsc = R.Dsc.Descriptor()
+    g23 = {}
+    fields = {}
+    for octave, shape, seed in ((1, (36, 38, 40), 11), (0, (52, 54, 58), 12)):
+        vol = synth.blob_volume(shape, n_blobs=30, seed=seed, sigma=(1.5, 3.5), hollow=0.3)
+        grad = synth.gradient_field(vol)
+        fields[octave] = grad
+        g23["vol_%d" % octave] = vol
+    ms = types.SimpleNamespace(
+        grad_list=[fields[0], fields[1]],
+        rgi_space=[RGI(points=[np.arange(s) for s in fields[o].shape[:3]], values=fields[o], method="nearest") for o in (0, 1)])
+    for octave in (1, 0):
+        shape = fields[octave].shape[:3]
+        margin = 8 if octave == 1 else 16
+        inner = synth.interior_anchors(shape, 26, margin + 1, 100 + octave)
+        edge = np.array([[margin - 1, shape[1] // 2, shape[2] // 2], [shape[0] // 2, shape[1] - margin - 1, shape[2] // 2],
+                         [margin, margin, margin]], np.int32)
+        coords = np.concatenate([inner[:13], edge, inner[13:]]).astype(np.int32)
+        dfs = []
+        for i, c in enumerate(coords):
+            df = R.DF.DensityFeature()
+            df.set_detector_info(i, octave, [int(c[0]), int(c[1]), int(c[2])], np.array(c, float), np.array(c, float) + 0.25, 1.0)
+            dfs.append(df)
+        # the border-reject path of the reference crashes unless step1_reject exists; it does now
+        rows = ori.assign_orientations(ms, dfs)
+        assert len(rows) > 20
+        g23["coords_%d" % octave] = coords
+        g23["row_anchor_%d" % octave] = np.array([r.index for r in rows], np.int32)
+        g23["row_main_%d" % octave] = np.array([r.main_bin for r in rows], np.int32)
+        g23["row_sec_%d" % octave] = np.array([r.sec_bin for r in rows], np.int32)
+        g23["row_R_%d" % octave] = np.array([r.Rfinal for r in rows])
+        g23["row_dom_%d" % octave] = np.array([r.to_dom_mat for r in rows])
+        g23["row_adj_%d" % octave] = np.array([r.adj_sec_mat for r in rows])
+        g23["row_count_%d" % octave] = np.array([r.ar_count for r in rows], np.int32)
+        # descriptors of those rows + rows that leave the grid + identity rotations
+        extra = []
+        for c, Rf in (([2, 3, 4], rows[0].Rfinal), ([shape[0] - 3, 20, 20], rows[1].Rfinal),
+                      (rows[0].coords, np.identity(3)), (rows[1].coords, np.identity(3))):
+            df = R.DF.DensityFeature()
+            df.set_detector_info(0, octave, [int(v) for v in c], np.zeros(3), np.zeros(3), 1.0)
+            df.Rfinal = np.array(Rf)
+            extra.append(df)
+        allrows = rows + extra
+        dsc.generate_descriptors(ms, allrows)
+        g23["dsc_coords_%d" % octave] = np.array([r.coords for r in allrows], np.int32)
+        g23["dsc_R_%d" % octave] = np.array([r.Rfinal for r in allrows])
+        g23["dsc_%d" % octave] = np.array([r.lin_ar_subeqsp for r in allrows], np.int16)
+    g23["n_reject"] = np.array(ori.step1_reject)
+    np.savez_compressed(os.path.join(OUT, "g23_orient_describe.npz"), **g23)
+
+    # ---- realistic mini case: a dimer map and its subunit, all reference code from the grid on -------
+    rng = np.random.default_rng(5)
+    coords, names, elems = synth.random_globule(900, 13.0, seed=1)
+    sub_pdb = os.path.join(work, "sub.pdb")
+    synth.write_pdb(sub_pdb, coords, names, elems)
+    parts = [synth.place(coords, synth.random_rotation(rng), t) for t in ([0, 0, 0], [31, 5, -4])]
+    asm_pdb = os.path.join(work, "asm.pdb")
+    synth.write_pdb(asm_pdb, np.concatenate(parts), names * 2, elems * 2)
+    res, vs = 8.0, 1.5
+    asm = R.PDB.PDB(asm_pdb)
+    map_grid, mx, my, mz = asm.structure_to_density(res, vs)
+    map_sit = os.path.join(work, "map.sit")
+    synth.write_situs(map_sit, map_grid, (mx, my, mz), vs)
+
+    # G7: density simulation + CCC
+    sub = R.PDB.PDB(sub_pdb)
+    splat, pxb, pyb, pzb, minx, miny, minz = sub.interpolate_to_grid_massweighted(vs)
+    dens, dx, dy, dz = sub.structure_to_density(res, vs)
+    dens_iso, _, _, _ = sub.structure_to_density(6.0, 1.2, isovalue=0.05)
+    dmap = R.Dmap.Dmap(map_sit)
+    g7 = dict(atoms=sub.coords.copy(), elements=np.array(elems), res=res, vs=vs,
+              splat=np.reshape(splat, (pxb, pyb, pzb), order="F"), splat_min=np.array([minx, miny, minz]),
+              density=dens, density_origin=np.array([dx, dy, dz]), density_iso=dens_iso,
+              map_grid=dmap.grid3d.copy(), map_origin=np.array([dmap.xi, dmap.yi, dmap.zi]), map_vs=dmap.voxsp)
+    cccs, shifts = [], [(0.0, 0.0, 0.0), (4.5, -3.0, 1.5), (30.0, 0.0, 0.0), (400.0, 0.0, 0.0)]
+    for sh in shifts:
+        g2 = dens.copy()
+        with np.errstate(all="ignore"):
+            cccs.append(dmap.get_CCC_with_grid(g2, dx + sh[0], dy + sh[1], dz + sh[2]))
+    g7["ccc_shifts"], g7["ccc"] = np.array(shifts), np.array(cccs, dtype=np.float64)
+    np.savez_compressed(os.path.join(OUT, "g7_density_ccc.npz"), **g7)
+
+    # MapSpace of both structures (reference), anchors from this repo's detector
+    def describe(struct):
+        ms = R.MS.MapSpace(struct, resolution=res, voxelsp=vs, sig_init=2.0, sig_presmooth=1)
+        ms.build_space()
+        anchors = MyDetector().find_anchors(ms)
+        ref_anchors = []
+        for a in anchors:
+            df = R.DF.DensityFeature()
+            df.set_detector_info(a.index, a.oct_scale, a.coords, a.map_coords, a.subv_map_coords, a.voxel_val)
+            ref_anchors.append(df)
+        o = R.Ori.Orientator()
+        o.step1_reject = 0
+        rows = R.Dsc.Descriptor().generate_descriptors(ms, o.assign_orientations(ms, ref_anchors))
+        return ms, ref_anchors, rows
+
+    ms_map, anc_map, rows_map = describe(map_sit)
+    ms_sub, anc_sub, rows_sub = describe(sub_pdb)
+
+    def pack_rows(rows, prefix, d):
+        d[prefix + "dsc"] = np.array([r.lin_ar_subeqsp for r in rows], np.int16)
+        d[prefix + "index"] = np.array([r.index for r in rows], np.int32)
+        d[prefix + "oct"] = np.array([r.oct_scale for r in rows], np.int32)
+        d[prefix + "main"] = np.array([r.main_bin for r in rows], np.int32)
+        d[prefix + "sec"] = np.array([r.sec_bin for r in rows], np.int32)
+        d[prefix + "coords"] = np.array([r.coords for r in rows], np.int32)
+        d[prefix + "subv"] = np.array([r.subv_map_coords for r in rows], np.float64)
+        d[prefix + "R"] = np.array([r.Rfinal for r in rows], np.float64)
+
+    # samples of the MapSpace outputs (pins this repo's host MapSpace against the reference)
+    gms = dict(res=res, vs=vs, map_grid=map_grid, map_origin=np.array([mx, my, mz]))
+    srng = np.random.default_rng(9)
+    for o in (0, 1):
+        g = ms_map.grad_list[o]
+        idx = np.stack([srng.integers(0, s, 4000) for s in g.shape[:3]], 1)
+        gms["grad_idx_%d" % o] = idx
+        gms["grad_val_%d" % o] = g[idx[:, 0], idx[:, 1], idx[:, 2]]
+        gms["log_val_%d" % o] = ms_map.map_space[o][idx[:, 0], idx[:, 1], idx[:, 2]]
+        gms["grad_shape_%d" % o] = np.array(g.shape)
+    gms["origin"] = np.array([ms_map.xi, ms_map.yi, ms_map.zi])
+    gms["anchor_coords"] = np.array([a.coords for a in anc_map], np.int32)
+    gms["anchor_oct"] = np.array([a.oct_scale for a in anc_map], np.int32)
+    gms["anchor_subv"] = np.array([a.subv_map_coords for a in anc_map])
+    np.savez_compressed(os.path.join(OUT, "g_mapspace.npz"), **gms)
+
+    # G4: matching
+    m = R.MaD.MaD()
+    g4 = {}
+    pack_rows(rows_map, "lo_", g4)
+    pack_rows(rows_sub, "hi_", g4)
+    for cc in (0.6,):
+        results, lo_cloud, hi_cloud = m._match_dsc(rows_map, rows_sub, cc_threshold=cc)
+        g4["results"] = np.array(results)
+        g4["lo_cloud"], g4["hi_cloud"] = lo_cloud, hi_cloud
+        g4["cc"] = cc
+    assert len(g4["results"]) > 500, len(g4["results"])
+    np.savez_compressed(os.path.join(OUT, "g4_match.npz"), **g4)
+
+    # G5: filter
+    filtered = m._filter_dsc_pairs(sub_pdb, results, lo_cloud, hi_cloud, wthresh=4, n_samples=120)
+    g5 = dict(n=len(filtered),
+              hi_coord=np.array([f[0] for f in filtered]), lo_coord=np.array([f[1] for f in filtered]),
+              R=np.array([f[2] for f in filtered]), cc=np.array([f[3] for f in filtered]),
+              weight=np.array([f[4] for f in filtered]), repeat=np.array([f[5] for f in filtered]),
+              placed=np.array([f[7].coords for f in filtered]), atoms=sub.coords.copy())
+    np.savez_compressed(os.path.join(OUT, "g5_filter.npz"), **g5)
+
+    # G6: refinement (final coordinates after n_steps, for a ladder of n_steps)
+    g6 = dict(map_grid=dmap.grid3d.copy(), map_origin=np.array([dmap.xi, dmap.yi, dmap.zi]), map_vs=dmap.voxsp)
+    start = filtered[0][7].coords.copy() if filtered else parts[0] + 1.0
+    pert = R.MU.euler_rod_mat(R.MU.unit_vector([0.3, -0.5, 0.8]), 0.15)
+    start2 = (parts[1] - parts[1].mean(0)) @ pert + parts[1].mean(0) + np.array([1.2, -0.8, 0.9])
+    for tag, st in (("a", start), ("b", start2)):
+        g6["start_" + tag] = st
+        for n_steps in (1, 2, 3, 4, 5, 8, 500):
+            pdb = R.PDB.PDB(sub_pdb)
+            pdb.set_coords(st)
+            rmsd, conv, step = R.SU.refine_pdb(dmap, pdb, n_steps=n_steps, max_step_size=1, min_step_size=0.1)
+            g6["final_%s_%d" % (tag, n_steps)] = pdb.coords.copy()
+            g6["ret_%s_%d" % (tag, n_steps)] = np.array([rmsd, float(conv), float(step)])
+    g6["ca_idx"] = np.array(sub.CA_idx)
+    np.savez_compressed(os.path.join(OUT, "g6_refine.npz"), **g6)
+
+    # G8: end of the path -- refined solutions table for the dimer
+    m.processed_map = map_sit
+    m.resolution = res
+    final = m._refine_filtered_solutions(sub_pdb, filtered, lo_cloud, hi_cloud)
+    g8 = dict(n=len(final), repeat=np.array([f[2] for f in final]), weight=np.array([f[3] for f in final]),
+              ccc=np.array([f[4] for f in final], dtype=np.float64), score=np.array([f[6] for f in final], dtype=np.float64),
+              coords=np.array([f[0].coords for f in final]), truth=np.stack(parts))
+    np.savez_compressed(os.path.join(OUT, "g8_solutions.npz"), **g8)
+
+    sizes = {f: os.path.getsize(os.path.join(OUT, f)) for f in sorted(os.listdir(OUT)) if f.endswith(".npz")}
+    print("fixtures:", sizes, "total %.1f MB" % (sum(sizes.values()) / 1e6))
+    print("rows map/sub:", len(rows_map), len(rows_sub), "pairs:", len(results), "filtered:", len(filtered), "final:", len(final))
+    for f in final:
+        print("  solution: repeat %.2f weight %d ccc %.4f" % (f[2], f[3], f[4]))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,133 @@
+"""The CPU oracle (oracle/mad_oracle.c) against the golden vectors the REFERENCE produced
+(tests/golden/make_golden.py).  This is what pins the oracle; the GPU tests then compare
+the HIP path with the oracle and with the same fixtures.  Runs without a GPU."""
+import os
+
+import numpy as np
+import pytest
+
+from mad_amd import synth
+from oracle import oracle as O
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    with np.load(os.path.join(G, name), allow_pickle=False) as z:
+        return {k: z[k] for k in z.files}
+
+
+@pytest.fixture(scope="module")
+def g1():
+    return load("g1_eqsp_math.npz")
+
+
+def test_belts_and_matrices(g1):
+    for n in (16, 112):
+        bf = O.belt_first(g1["bounds_%d" % n])
+        sizes = np.bincount(np.unique(bf, return_inverse=True)[1])
+        np.testing.assert_array_equal(sizes, g1["belt_sizes_%d" % n])
+
+
+@pytest.mark.parametrize("octave", [1, 0])
+def test_orient_against_reference(g1, octave):
+    g = load("g23_orient_describe.npz")
+    grad = synth.gradient_field(g["vol_%d" % octave])
+    got = O.orient(grad[..., 0], grad[..., 1], grad[..., 2], octave, g["coords_%d" % octave], g1["bounds_112"], g1["centers_112"])
+    np.testing.assert_array_equal(got["anchor"], g["row_anchor_%d" % octave])
+    np.testing.assert_array_equal(got["main"], g["row_main_%d" % octave])
+    np.testing.assert_array_equal(got["sec"], g["row_sec_%d" % octave])
+    np.testing.assert_array_equal(got["counts"], g["row_count_%d" % octave])
+    np.testing.assert_allclose(got["R"], g["row_R_%d" % octave], rtol=0, atol=1e-14)
+    for k in range(len(got["main"])):
+        np.testing.assert_allclose(O.to_dom_mat(g1["centers_112"], int(got["main"][k])), g["row_dom_%d" % octave][k], atol=1e-14)
+        np.testing.assert_allclose(O.adj_sec_mat(g1["bounds_112"], g1["centers_112"], int(got["sec"][k])), g["row_adj_%d" % octave][k], atol=1e-14)
+
+
+def test_orient_rejects_counted():
+    g = load("g23_orient_describe.npz")
+    g1 = load("g1_eqsp_math.npz")
+    tot = 0
+    for octave in (1, 0):
+        grad = synth.gradient_field(g["vol_%d" % octave])
+        tot += O.orient(grad[..., 0], grad[..., 1], grad[..., 2], octave, g["coords_%d" % octave], g1["bounds_112"], g1["centers_112"])["n_reject"]
+    assert tot == int(g["n_reject"]) and tot >= 2
+
+
+@pytest.mark.parametrize("octave", [1, 0])
+def test_describe_against_reference(g1, octave):
+    g = load("g23_orient_describe.npz")
+    grad = synth.gradient_field(g["vol_%d" % octave])
+    got = O.describe(grad[..., 0], grad[..., 1], grad[..., 2], octave, g["dsc_coords_%d" % octave], g["dsc_R_%d" % octave], g1["bounds_16"])
+    ref = g["dsc_%d" % octave]
+    assert ref[-4].sum() == 0 and ref[-3].sum() == 0 and ref[-1].sum() > 0      # out-of-grid rows are zero, identity rows are not
+    np.testing.assert_array_equal(got, ref)
+
+
+def _meta(g, p):
+    return np.stack([g[p + "index"], g[p + "oct"], g[p + "main"]], 1).astype(np.int32)
+
+
+def test_match_against_reference():
+    g = load("g4_match.npz")
+    ref = g["results"]
+    ph, pl, ps, _ = O.correlate(g["hi_dsc"], g["lo_dsc"], float(g["cc"]))
+    assert len(ph) == len(ref) > 500
+    np.testing.assert_allclose(ps, ref[:, 0], rtol=1e-12)
+    # clouds as MaD.py:427-428
+    hi_cloud = np.unique(g["hi_subv"][np.unique(ph)], axis=0)
+    lo_cloud = np.unique(g["lo_subv"][np.unique(pl)], axis=0)
+    np.testing.assert_array_equal(hi_cloud, g["hi_cloud"])
+    np.testing.assert_array_equal(lo_cloud, g["lo_cloud"])
+    res, cnt = O.pose_score(ph, pl, ps, g["hi_subv"], g["hi_R"], _meta(g, "hi_"), g["lo_subv"], g["lo_R"], _meta(g, "lo_"), hi_cloud, lo_cloud, 4.0)
+    np.testing.assert_array_equal(res[:, 2:8], ref[:, 2:8])
+    np.testing.assert_array_equal(res[:, 1], ref[:, 1])                  # repeatability: an integer count / l
+    np.testing.assert_allclose(res[:, 8:14], ref[:, 8:14], rtol=0, atol=0)
+    np.testing.assert_allclose(res[:, 14:], ref[:, 14:], rtol=0, atol=1e-13)
+    # the sort MaD._filter_dsc_pairs applies (MaD.py:480)
+    order = O.topk(cnt, 120)
+    py = sorted(range(len(ref)), key=lambda i: ref[i][1], reverse=True)[:120]
+    np.testing.assert_array_equal(order, py)
+
+
+def test_refine_against_reference():
+    g = load("g6_refine.npz")
+    origin, vs = g["map_origin"], float(g["map_vs"])
+    for tag in ("a", "b"):
+        for n in (1, 2, 3, 4, 5, 8, 500):
+            ref = g["final_%s_%d" % (tag, n)]
+            rmsd, conv, step = g["ret_%s_%d" % (tag, n)]
+            got, gconv, glast, _ = O.refine(g["map_grid"], origin, vs, g["start_" + tag], n_steps=n, max_step=1.0, min_step=0.1)
+            assert (gconv, glast) == (bool(conv), int(step)), (tag, n)
+            np.testing.assert_allclose(got, ref, rtol=0, atol=1e-8 if n <= 8 else 1e-6)
+            ca = g["ca_idx"]
+            assert abs(np.sqrt(np.sum((got[ca] - g["start_" + tag][ca]) ** 2) / len(ca)) - rmsd) < 1e-6
+
+
+def test_density_against_reference():
+    g = load("g7_density_ccc.npz")
+    m = synth.masses([str(e) for e in g["elements"]])
+    vs, res = float(g["vs"]), float(g["res"])
+    sp, dims, mn = O.splat(g["atoms"], m, vs)
+    ref_sp = g["splat"]
+    assert tuple(dims) == ref_sp.shape
+    np.testing.assert_allclose(mn, g["splat_min"], atol=0)
+    np.testing.assert_allclose(np.reshape(sp, ref_sp.shape, order="F"), ref_sp, rtol=0, atol=1e-15)
+    dens, x0, y0, z0 = O.structure_to_density(g["atoms"], m, res, vs)
+    np.testing.assert_allclose([x0, y0, z0], g["density_origin"], atol=0)
+    np.testing.assert_allclose(dens, g["density"], rtol=0, atol=1.5e-7)
+    dens2, _, _, _ = O.structure_to_density(g["atoms"], m, 6.0, 1.2, isovalue=0.05)
+    np.testing.assert_allclose(dens2, g["density_iso"], rtol=0, atol=1.5e-7)
+    assert np.all((dens2 == 0) == (g["density_iso"] == 0))
+
+
+def test_ccc_against_reference():
+    g = load("g7_density_ccc.npz")
+    for sh, ref in zip(g["ccc_shifts"], g["ccc"]):
+        a, b = g["map_grid"].copy(), g["density"].copy()
+        got = O.ccc(a, g["map_origin"], b, g["density_origin"] + sh, float(g["map_vs"]))
+        if np.isnan(ref):
+            assert np.isnan(got)
+        else:
+            assert abs(got - ref) <= 1e-5 * max(abs(ref), 1e-3), (sh, got, ref)
+    assert g["ccc"][0] > 0.5 and g["ccc"][-1] == 0
