@@ -1,0 +1,381 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the MaD hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|small]
+
+One "step" = one pass of the hot path over one batch of synthetic input already resident
+in HBM: orientation + description of the map and of every subunit (mad_set_build),
+then, per subunit, int8-MFMA correlation, pair compaction, pose scoring and top-k
+(mad_match_topk).  Metric = (sum over subunits of N_hi_rows x N_lo_rows) / wall time,
+"anchor-pair x rotation correlations/s" (BASELINE.json; unit definition SURVEY.md 8(d)).
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): weak scaling -- every rank
+holds the same map and its OWN 4 subunits, so per-GPU work is fixed; the one exchange of
+the path, the all-gather of the per-subunit top-k poses (RCCL over xGMI), is inside the
+timed region.  value = correlations of all ranks / max-over-ranks time.
+
+Inputs are synthetic (seeded pseudo-atom assemblies).  The density grids
+come from this library's own GPU density simulation; the scale-space preparation
+(upsampling, smoothing, LoG peaks -- MapSpace/Detector, upstream of the hot path) is done
+with torch ops on the device as untimed setup.
+
+The JSON line also carries `roofline` (dominant kernel, HIP-event timed on the library's
+stream inside the timed region) and `cpu_baseline` (the CPU oracle timed on a bounded
+sample of the same workload, rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: map size N, voxel spacing, resolution, subunits per rank, atoms per subunit, globule radius, lattice
+    "c3": dict(N=256, vs=1.2, res=7.0, n_sub=4, n_atoms=26000, radius=46.0, grid=(2, 2, 1), desc="C3: 256^3 map, 4 subunits, EQSP-112/16"),
+    "c2": dict(N=128, vs=1.5, res=8.0, n_sub=4, n_atoms=14000, radius=34.0, grid=(2, 2, 1), desc="C2: 128^3 tetramer map"),
+    "small": dict(N=64, vs=2.0, res=10.0, n_sub=2, n_atoms=1500, radius=16.0, grid=(2, 1, 1), desc="C1: 64^3 dimer map"),
+}
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+I8_PEAK_TOPS = 5000.0      # dense int8 MFMA = 2x bf16 (~2.5 PF)
+ORIENT_BYTES = 58956       # 17^3 x 3 x f32 read per anchor
+DESCRIBE_BYTES = 51200     # 4096 x 12 B gathered + 2048 B written per row
+
+
+# --------------------------------------------------------------------------------------------
+# untimed setup: synthetic structures and their scale-space fields (torch = plumbing)
+# --------------------------------------------------------------------------------------------
+
+def gaussian_blur(t, sigma):
+    """Separable Gaussian (reflect boundary, truncated at 4 sigma) by shifted adds."""
+    import torch
+    import torch.nn.functional as F
+    r = int(4.0 * sigma + 0.5)
+    x = torch.arange(-r, r + 1, device=t.device, dtype=torch.float32)
+    w = torch.exp(-0.5 * (x / sigma) ** 2)
+    w = (w / w.sum()).tolist()
+    for ax in range(3):
+        pad = [0, 0, 0, 0, 0, 0]
+        pad[2 * (2 - ax)] = r
+        pad[2 * (2 - ax) + 1] = r
+        p = F.pad(t[None, None], pad, mode="reflect")[0, 0]
+        acc = torch.zeros_like(t)
+        n = t.shape[ax]
+        for k in range(2 * r + 1):
+            acc += w[k] * p.narrow(ax, k, n)
+        t = acc
+        del p
+    return t
+
+
+def scale_space(grid, pad=9, sig=2.0, presmooth=1.0):
+    """-> per octave (0 = upsampled, 1 = base): gradient field [3,X,Y,Z] f32 and LoG volume."""
+    import torch
+    import torch.nn.functional as F
+    g = F.pad(grid, (pad,) * 6)
+    up = F.interpolate(g[None, None], size=tuple(2 * s - 1 for s in g.shape), mode="trilinear", align_corners=True)[0, 0]
+    up = gaussian_blur(up, presmooth)
+    out = []
+    for vol in (up, g):
+        sm = gaussian_blur(vol, sig)
+        lap = -6.0 * sm
+        for ax in range(3):
+            lap = lap + torch.roll(sm, 1, ax) + torch.roll(sm, -1, ax)
+        log = torch.clamp(-lap * sig * sig, min=0.0)
+        grad = torch.stack(torch.gradient(sm))
+        out.append((grad.contiguous(), log))
+        del sm, lap
+    return out
+
+
+def find_anchors(log, border=12, thresh=5e-2):
+    """3x3x3 local maxima of the LoG above the threshold, strongest first (Detector.py:28-29)."""
+    import torch
+    import torch.nn.functional as F
+    mx = F.max_pool3d(log[None, None], 3, 1, 1)[0, 0]
+    ok = (log == mx) & (log > thresh)
+    ok[:border] = False
+    ok[-border:] = False
+    ok[:, :border] = False
+    ok[:, -border:] = False
+    ok[:, :, :border] = False
+    ok[:, :, -border:] = False
+    idx = torch.nonzero(ok)
+    vals = log[idx[:, 0], idx[:, 1], idx[:, 2]]
+    order = torch.argsort(vals, descending=True, stable=True)
+    return idx[order].to(torch.int32).cpu().numpy()
+
+
+class Structure(object):
+    """Device-resident fields + anchors of one structure."""
+
+    def __init__(self, lib, torch, atoms, mass, res, vs, N=None):
+        grid, x0, y0, z0 = lib.structure_to_density(atoms, mass, res, vs)
+        origin = np.array([x0, y0, z0])
+        if N is not None:      # centre the simulated density in an exactly N^3 box
+            assert max(grid.shape) <= N, "assembly of %s voxels does not fit %d^3" % (grid.shape, N)
+            lo = [(N - s) // 2 for s in grid.shape]
+            big = np.zeros((N, N, N), np.float32)
+            big[lo[0]:lo[0] + grid.shape[0], lo[1]:lo[1] + grid.shape[1], lo[2]:lo[2] + grid.shape[2]] = grid
+            origin = origin - np.array(lo) * vs
+            grid = big
+        self.shape = grid.shape
+        dev = torch.device("cuda", lib.device)
+        octs = scale_space(torch.from_numpy(grid).to(dev))
+        torch.cuda.synchronize()
+        self.slots, coords, octave, subv = [], [], [], []
+        self.field_host = {}
+        pad_origin = origin - 9 * vs
+        for o, (grad, log) in enumerate(octs):
+            s = lib.new_slot()
+            lib.upload_field_device(s, grad.data_ptr(), *grad.shape[1:])
+            self.slots.append(s)
+            a = find_anchors(log)
+            coords.append(a)
+            octave.append(np.full(len(a), o, np.int32))
+            subv.append(a.astype(np.float64) * (vs / 2 if o == 0 else vs) + pad_origin)
+            if o == 1:
+                self.field_host[1] = grad.cpu().numpy()      # base octave, for the CPU baseline sample
+        del octs
+        torch.cuda.empty_cache()
+        self.coords = np.concatenate(coords).astype(np.int32)
+        self.octave = np.concatenate(octave)
+        self.subv = np.concatenate(subv)
+        self.index = np.arange(len(self.coords), dtype=np.int32)
+
+
+def build_inputs(lib, torch, W, rank):
+    from mad_amd import synth
+    rng = np.random.default_rng(1234)
+    subs, placed, placed_mass = [], [], []
+    sp = 2.2 * W["radius"]
+    cells = [(i, j, k) for i in range(W["grid"][0]) for j in range(W["grid"][1]) for k in range(W["grid"][2])]
+    centre = (np.array(W["grid"]) - 1) * sp / 2
+    for s in range(W["n_sub"]):
+        # the map is the same on every rank (seeds 20..); every rank docks its own subunits into it
+        atoms, names, elems = synth.random_globule(W["n_atoms"], W["radius"], seed=20 + s)
+        placed.append(synth.place(atoms, synth.random_rotation(rng), np.array(cells[s]) * sp - centre + rng.normal(scale=2.0, size=3)))
+        placed_mass.append(synth.masses(elems))
+        if rank == 0:
+            subs.append((atoms, synth.masses(elems)))
+        else:
+            a2, _, e2 = synth.random_globule(W["n_atoms"], W["radius"], seed=1000 * rank + 20 + s)
+            subs.append((a2, synth.masses(e2)))
+    mass_all = np.concatenate(placed_mass)
+    t0 = time.time()
+    the_map = Structure(lib, torch, np.concatenate(placed), mass_all, W["res"], W["vs"], N=W["N"])
+    sub_structs = [Structure(lib, torch, a, m, W["res"], W["vs"]) for a, m in subs]
+    return the_map, sub_structs, time.time() - t0
+
+
+# --------------------------------------------------------------------------------------------
+# the timed step
+# --------------------------------------------------------------------------------------------
+
+def hot_path_step(lib, the_map, subs, cc, dist, k):
+    """Returns (correlations, [top-k result rows per subunit], stats)."""
+    lo = lib.set_build(the_map.slots, the_map.coords, the_map.octave, the_map.subv, the_map.index)
+    n_lo, _ = lo.size()
+    corr, tops, stats = 0, [], []
+    for s in subs:
+        hi = lib.set_build(s.slots, s.coords, s.octave, s.subv, s.index)
+        n_hi, _ = hi.size()
+        top, idx, st = lib.match_topk(hi, lo, cc, dist, k)
+        corr += n_hi * n_lo
+        st["n_hi"], st["n_lo"] = n_hi, n_lo
+        tops.append(top)
+        stats.append(st)
+        hi.close()
+    lo.close()
+    return corr, tops, stats
+
+
+def cpu_baseline(the_map, sub, cc, dist, k, lib, n_lo_anchor=260, n_hi_anchor=70):
+    """The CPU oracle on a bounded sample of the same workload: base-octave anchors only."""
+    from mad_amd.eqsp import EQSP_Sphere
+    from oracle import oracle as O
+    e112, e16 = EQSP_Sphere(112), EQSP_Sphere(16)
+
+    def sample(st, n):
+        sel = np.flatnonzero(st.octave == 1)[:n]
+        g = st.field_host[1]
+        return g[0], g[1], g[2], st.coords[sel], st.subv[sel], sel
+
+    out = {}
+    t0 = time.perf_counter()
+    sets = []
+    for st, n in ((the_map, n_lo_anchor), (sub, n_hi_anchor)):
+        gx, gy, gz, coords, subv, sel = sample(st, n)
+        rows = O.orient(gx, gy, gz, 1, coords, e112.sphere_eqsp, e112.p_centers_eqsp, want_counts=False)
+        dsc = O.describe(gx, gy, gz, 1, coords[rows["anchor"]], rows["R"], e16.sphere_eqsp)
+        sets.append(dict(rows=rows, dsc=dsc, subv=subv, coords=coords, sel=sel))
+    lo_s, hi_s = sets
+    ph, pl, ps, _ = O.correlate(hi_s["dsc"], lo_s["dsc"], cc)
+    hi_p, lo_p = hi_s["subv"][hi_s["rows"]["anchor"]], lo_s["subv"][lo_s["rows"]["anchor"]]
+    order = np.zeros(0, np.int64)
+    if len(ph):
+        hi_cloud = np.unique(hi_p[np.unique(ph)], axis=0)
+        lo_cloud = np.unique(lo_p[np.unique(pl)], axis=0)
+        meta_h = np.stack([hi_s["rows"]["anchor"], np.ones_like(hi_s["rows"]["anchor"]), hi_s["rows"]["main"]], 1)
+        meta_l = np.stack([lo_s["rows"]["anchor"], np.ones_like(lo_s["rows"]["anchor"]), lo_s["rows"]["main"]], 1)
+        res, cnt = O.pose_score(ph, pl, ps, hi_p, hi_s["rows"]["R"], meta_h, lo_p, lo_s["rows"]["R"], meta_l, hi_cloud, lo_cloud, dist)
+        order = O.topk(cnt, k)
+    dt = time.perf_counter() - t0
+    n_corr = len(hi_s["dsc"]) * len(lo_s["dsc"])
+    # the same sample through the GPU path: top-k pose agreement (identity and order)
+    agree = None
+    if len(ph):
+        lo_d = lib.set_build(the_map.slots, lo_s["coords"], np.ones(len(lo_s["coords"]), np.int32), lo_s["subv"], np.arange(len(lo_s["coords"])))
+        hi_d = lib.set_build(sub.slots, hi_s["coords"], np.ones(len(hi_s["coords"]), np.int32), hi_s["subv"], np.arange(len(hi_s["coords"])))
+        top, idx, st = lib.match_topk(hi_d, lo_d, cc, dist, k)
+        agree = bool(st["n_pairs"] == len(ph) and np.array_equal(idx, order) and np.array_equal(top[:, 1], res[order][:, 1]))
+        lo_d.close()
+        hi_d.close()
+    out = dict(value=n_corr / dt, unit="correlations/s", cores=1, kind="port",
+               sample="CPU oracle (scalar C, 1 thread) on %d map x %d subunit base-octave anchors of the same workload: "
+                      "%d x %d rows, %d pairs, %.1f s" % (len(lo_s["coords"]), len(hi_s["coords"]), len(hi_s["dsc"]), len(lo_s["dsc"]), len(ph), dt))
+    return out, agree
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 or world > 1:
+        assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    from mad_amd import _lib
+    from mad_amd.eqsp import EQSP_Sphere
+    from mad_amd.orient_tables import orientation_matrices
+    lib = _lib.Lib(local)
+    e112, e16 = EQSP_Sphere(112), EQSP_Sphere(16)
+    dom, adj = orientation_matrices(e112)
+    lib.set_eqsp(0, e112.sphere_eqsp, dom, adj)
+    lib.set_eqsp(1, e16.sphere_eqsp)
+
+    W = WORKLOADS[args.workload]
+    cc, dist_thr, k = 0.6, 4.0, 60
+    the_map, subs, t_setup = build_inputs(lib, torch, W, rank)
+
+    def barrier():
+        torch.cuda.synchronize()
+        lib.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    def exchange(tops):
+        """The path's one exchange: every rank gets every rank's top-k poses (RCCL all-gather)."""
+        if world == 1:
+            return tops
+        buf = torch.zeros((len(tops), k, 23), dtype=torch.float64, device="cuda")
+        for i, t in enumerate(tops):
+            if len(t):
+                buf[i, :len(t)] = torch.from_numpy(t).to(buf.device)
+        out = torch.empty((world,) + tuple(buf.shape), dtype=torch.float64, device="cuda")
+        dist.all_gather_into_tensor(out, buf)
+        return out
+
+    for _ in range(args.warmup):
+        corr, tops, stats = hot_path_step(lib, the_map, subs, cc, dist_thr, k)
+        exchange(tops)
+    lib.timing_enable(True)
+    lib.timing_reset()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        corr, tops, stats = hot_path_step(lib, the_map, subs, cc, dist_thr, k)
+        gathered = exchange(tops)
+    barrier()
+    dt = time.perf_counter() - t0
+    lib.timing_enable(False)
+
+    t_all = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    c_all = torch.tensor([float(corr)], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t_all, op=dist.ReduceOp.MAX)
+        dist.all_reduce(c_all, op=dist.ReduceOp.SUM)
+    t_max, corr_total = float(t_all.item()), float(c_all.item())
+
+    if rank == 0:
+        groups = {}
+        for gname in ("orient", "describe", "correlate", "pairs", "pose", "topk"):
+            ms, n = lib.timing_get(gname)
+            groups[gname] = dict(ms_total=ms, launches=n)
+        n_anchor_lo = len(the_map.coords)
+        rows_lo = stats[0]["n_lo"]
+        rows_hi = sum(s["n_hi"] for s in stats)
+        anchors_hi = sum(len(s.coords) for s in subs)
+        pairs = sum(s["n_pairs"] for s in stats)
+        # dominant kernel = largest share of device time
+        dom_name = max(groups, key=lambda g: groups[g]["ms_total"])
+        dom_ms = groups[dom_name]["ms_total"] / max(groups[dom_name]["launches"], 1)
+        per_step = 1.0 / args.steps
+        if dom_name == "describe":
+            alg = DESCRIBE_BYTES * (rows_lo + rows_hi) / max(groups[dom_name]["launches"] * per_step, 1)
+            roof = dict(kernel="k_describe", bound="hbm", achieved=alg / (dom_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")
+        elif dom_name == "orient":
+            alg = ORIENT_BYTES * (n_anchor_lo + anchors_hi) / max(groups[dom_name]["launches"] * per_step, 1)
+            roof = dict(kernel="k_orient", bound="hbm", achieved=alg / (dom_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")
+        elif dom_name == "correlate":
+            ops = 2.0 * 1024 * corr / max(groups[dom_name]["launches"] * per_step, 1)
+            roof = dict(kernel="k_corr_gemm", bound="mfma", achieved=ops / (dom_ms * 1e-3) / 1e12, peak=I8_PEAK_TOPS, unit="TOP/s")
+        else:
+            # pose / pairs / topk move few HBM bytes per pair; priced by the bytes they must touch
+            per_pair = {"pose": 4 + 4 + 4, "pairs": 0, "topk": 4}[dom_name]
+            alg = (per_pair * pairs + (4.0 * corr if dom_name == "pairs" else 0)) / max(groups[dom_name]["launches"] * per_step, 1)
+            roof = dict(kernel="k_" + dom_name, bound="hbm", achieved=alg / (dom_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")
+        roof["frac"] = roof["achieved"] / roof["peak"]
+        roof["traffic"] = None
+        roof["avg_launch_ms"] = dom_ms
+        roof["kernel_ms_per_step"] = {g: groups[g]["ms_total"] / args.steps for g in groups}
+
+        cpu, agree = (None, None)
+        if world == 1 and not args.no_cpu_baseline:
+            cpu, agree = cpu_baseline(the_map, subs[0], cc, dist_thr, k, lib)
+
+        line = {
+            "metric": "anchor-pair x rotation correlations/sec on 256^3 map; top-k pose agreement",
+            "value": corr_total * args.steps / t_max,
+            "unit": "correlations/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * t_max / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "i8 (correlation, exact int32 accumulate) / f64 (binning, pose scoring)",
+            "data": "synthetic",
+            "config": {"workload": W["desc"], "map": "%d^3 @ %.1f A/voxel, %.0f A" % (W["N"], W["vs"], W["res"]),
+                       "subunits_per_gpu": W["n_sub"], "map_anchors": n_anchor_lo, "map_rows": rows_lo,
+                       "subunit_anchors": anchors_hi, "subunit_rows": rows_hi, "pairs_over_cc": pairs,
+                       "cc_threshold": cc, "top_k": k, "correlations_per_step_per_gpu": corr,
+                       "parallelism": "1 process per GPU, subunits sharded, RCCL all-gather of top-k" if world > 1 else "single GPU",
+                       "topk_agrees_with_cpu_oracle": agree, "setup_s": t_setup},
+            "roofline": roof,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    lib.close()
+
+
+if __name__ == "__main__":
+    main()
