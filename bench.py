@@ -283,16 +283,10 @@ def main():
             dist.barrier()
 
     def exchange(tops):
-        """The path's one exchange: every rank gets every rank's top-k poses (RCCL all-gather)."""
-        if world == 1:
-            return tops
-        buf = torch.zeros((len(tops), k, 23), dtype=torch.float64, device="cuda")
-        for i, t in enumerate(tops):
-            if len(t):
-                buf[i, :len(t)] = torch.from_numpy(t).to(buf.device)
-        out = torch.empty((world,) + tuple(buf.shape), dtype=torch.float64, device="cuda")
-        dist.all_gather_into_tensor(out, buf)
-        return out
+        """The path's one exchange: every rank receives every rank's per-subunit top-k poses
+        (one fused RCCL all-gather of world x n_sub x k x 23 float64, mad_amd/dist.py)."""
+        from mad_amd import dist as mdist
+        return mdist.all_gather_topk(tops, k, world * W["n_sub"], rank, world)
 
     for _ in range(args.warmup):
         corr, tops, stats = hot_path_step(lib, the_map, subs, cc, dist_thr, k)

@@ -1,0 +1,91 @@
+"""Multi-GPU layer: one process per GPU, `torch.distributed` for the exchanges
+("nccl" = RCCL over xGMI on the node, "gloo" in the CPU tests).
+
+The hot path shards by independent units: every subunit is docked
+against the same map, so subunits are dealt round-robin to the ranks and each rank runs
+orient / describe / correlate / pose / top-k for its own subunits with no data-path
+collective.  The one exchange is the all-gather of the per-subunit top-k pose rows
+(k x 23 float64, <= 155 KB per rank): latency-bound, so it is a single fused collective
+per step rather than one per subunit.
+
+`merge_topk` is the reduction for the other sharding the survey describes (the pair grid
+of ONE subunit split into column blocks of map rows): it merges per-shard top-k lists
+into the global top-k in the reference's order (count descending, row-major pair rank
+ascending, MaD.py:480).
+"""
+import numpy as np
+
+RESULT_COLS = 23
+
+
+def shard_round_robin(items, rank, world):
+    """The items (subunit keys, candidate ids ...) this rank owns."""
+    return [it for i, it in enumerate(items) if i % world == rank]
+
+
+def owner_of(index, world):
+    return index % world
+
+
+def pack_topk(tops, k):
+    """list of (<=k, 23) arrays -> (n, k, 23) float64 block + (n,) valid counts."""
+    block = np.zeros((len(tops), k, RESULT_COLS), dtype=np.float64)
+    valid = np.zeros(len(tops), dtype=np.int64)
+    for i, t in enumerate(tops):
+        t = np.asarray(t, dtype=np.float64).reshape(-1, RESULT_COLS)[:k]
+        block[i, :len(t)] = t
+        valid[i] = len(t)
+    return block, valid
+
+
+def all_gather_topk(tops, k, n_items_total, rank, world, group=None, device=None):
+    """Every rank contributes the top-k rows of ITS items (round-robin owner) and receives all.
+
+    tops: list of (<=k, 23) arrays for shard_round_robin(range(n_items_total), rank, world), in that order.
+    Returns a list of n_items_total arrays (item order), identical on every rank."""
+    import torch
+    import torch.distributed as dist
+    per_rank = (n_items_total + world - 1) // world
+    mine = list(tops) + [np.zeros((0, RESULT_COLS))] * (per_rank - len(tops))
+    block, valid = pack_topk(mine, k)
+    if world == 1:
+        return [block[i, :valid[i]] for i in range(n_items_total)]
+    dev = device if device is not None else ("cuda" if dist.get_backend(group) == "nccl" else "cpu")
+    payload = torch.from_numpy(np.concatenate([block.reshape(-1), valid.astype(np.float64)])).to(dev)
+    out = torch.empty(world * payload.numel(), dtype=torch.float64, device=dev)
+    dist.all_gather_into_tensor(out, payload, group=group)      # flat output: accepted by gloo and by RCCL
+    out = out.view(world, payload.numel()).cpu().numpy()
+    res = []
+    for item in range(n_items_total):
+        r, slot = owner_of(item, world), item // world
+        blk = out[r, :per_rank * k * RESULT_COLS].reshape(per_rank, k, RESULT_COLS)
+        nv = int(out[r, per_rank * k * RESULT_COLS + slot])
+        res.append(blk[slot, :nv].copy())
+    return res
+
+
+def merge_topk(shard_rows, shard_counts, shard_pair_rank, k):
+    """Merge per-shard top-k lists of ONE subunit into the global top-k.
+
+    shard_rows[s]: (m_s, 23) rows, shard_counts[s]: (m_s,) integer match counts,
+    shard_pair_rank[s]: (m_s,) GLOBAL row-major pair rank (hi_row * N_lo + lo_row).
+    Order: count descending, then pair rank ascending -- python's stable sort of the
+    row-major pair list by repeatability (MaD.py:480)."""
+    rows = np.concatenate([np.asarray(r, dtype=np.float64).reshape(-1, RESULT_COLS) for r in shard_rows])
+    cnt = np.concatenate([np.asarray(c, dtype=np.int64).reshape(-1) for c in shard_counts])
+    rank = np.concatenate([np.asarray(p, dtype=np.int64).reshape(-1) for p in shard_pair_rank])
+    order = np.lexsort((rank, -cnt))[:k]
+    return rows[order], cnt[order], rank[order]
+
+
+def or_reduce_flags(flags, group=None, device=None):
+    """Bitwise-OR all-reduce of a uint8 flag vector (the "row takes part in a pair" masks that make the
+    hi / lo clouds global when the pair grid of one subunit is sharded, MaD.py:427-428)."""
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return np.asarray(flags, dtype=np.uint8).copy()
+    dev = device if device is not None else ("cuda" if dist.get_backend(group) == "nccl" else "cpu")
+    t = torch.from_numpy(np.asarray(flags, dtype=np.int32).copy()).to(dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return t.cpu().numpy().astype(np.uint8)

@@ -1,0 +1,160 @@
+"""Host-side logic without a GPU: the C-ABI library loads and exports every symbol the header
+declares, the file formats round-trip, and the host stages either side of the hot path
+(MapSpace, Detector, _filter_dsc_pairs, Kabsch) reproduce the reference's golden outputs."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from mad_amd import _lib, mapio, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+
+
+def load(name):
+    with np.load(os.path.join(G, name), allow_pickle=False) as z:
+        return {k: z[k] for k in z.files}
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "mad_amd.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(mad_[a-z0-9_]+)\s*\(", header)))
+    assert len(declared) >= 30
+    assert sorted(_lib.SYMBOLS) == declared, "mad_amd/_lib.py SYMBOLS and include/mad_amd.h disagree"
+    dll = _lib.load_library()
+    missing = [s for s in declared if not hasattr(dll, s)]
+    assert not missing, missing
+
+
+def test_no_cpu_fallback_without_a_gpu():
+    import torch
+    if torch.cuda.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(_lib.MadBackendError, match="MI355X"):
+        _lib.Lib(0)
+
+
+def test_product_never_imports_the_oracle():
+    bad = []
+    for base, _, files in os.walk(os.path.join(ROOT, "mad_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(base, f), errors="ignore").read()
+                if re.search(r"^\s*(from|import)\s+oracle\b|mad_oracle|libmad_oracle", txt, flags=re.M):
+                    bad.append(f)
+    assert not bad, "product files reference the test oracle: %s" % bad
+
+
+def test_volume_formats_round_trip(tmp_path):
+    vol = synth.blob_volume((11, 13, 9), 5, 3)
+    org = (-12.5, 3.25, 40.0)
+    p = str(tmp_path / "v.mrc")
+    mapio.write_mrc(p, vol, org, 1.5)
+    grid, vs, o, dims = mapio.load_mrc_as_xyz(p)
+    np.testing.assert_array_equal(grid, vol)
+    assert abs(vs - 1.5) < 1e-6 and dims == vol.shape
+    assert o == (-12.0, 3.0, 40.0)      # the reference truncates MRC origins to integers (Dmap.py:38)
+    s = str(tmp_path / "v.sit")
+    mapio.write_situs(s, vol, org, 1.5)
+    g2, vs2, o2 = mapio.read_situs(s)
+    assert g2.shape == vol.shape and vs2 == 1.5 and o2 == org
+    np.testing.assert_allclose(g2, vol, atol=5e-7)
+
+
+def test_pdb_round_trip(tmp_path):
+    from mad_amd.PDB import PDB
+    coords, names, elems = synth.random_globule(50, 8.0, 2)
+    p = str(tmp_path / "a.pdb")
+    synth.write_pdb(p, coords, names, elems)
+    pdb = PDB(p)
+    np.testing.assert_array_equal(pdb.coords, coords)
+    assert pdb.CA_idx == tuple(range(1, 50, 4)) and pdb.n_atoms == 50
+    assert [r[5] for r in pdb.info[:4]] == ["N", "C", "C", "O"]
+    q = str(tmp_path / "b.pdb")
+    pdb.rotate_atoms(np.array([[0, 1, 0], [-1, 0, 0], [0, 0, 1.0]]))
+    pdb.translate_atoms([1, 2, 3])
+    pdb.write_pdb(q)
+    np.testing.assert_allclose(PDB(q).coords, pdb.coords, atol=5e-4)
+    np.testing.assert_allclose(pdb.atom_masses()[:4], [14.0067, 12.011, 12.011, 15.9994])
+
+
+def test_math_utils_against_reference():
+    from mad_amd.math_utils import euler_rod_mat, get_rototrans_SVD, unit_vector
+    g = load("g1_eqsp_math.npz")
+    for a, t, m in zip(g["rod_axes"], g["rod_angles"], g["rod_mats"]):
+        np.testing.assert_array_equal(euler_rod_mat(unit_vector(a), t), m)
+    R, T = get_rototrans_SVD(g["kabsch_mobile"], g["kabsch_reference"])
+    np.testing.assert_allclose(R, g["kabsch_R"], atol=1e-14)
+    np.testing.assert_allclose(T, g["kabsch_T"], atol=1e-12)
+
+
+def test_mapspace_and_detector_against_reference(tmp_path):
+    from mad_amd.Detector import Detector
+    from mad_amd.MapSpace import MapSpace
+    g = load("g_mapspace.npz")
+    sit = str(tmp_path / "map.sit")
+    open(sit, "w").write("x")      # only the extension is inspected before build_from_grid
+    ms = MapSpace(sit, sig_init=2.0, sig_presmooth=1)
+    ms.voxelsp = float(g["vs"])
+    grid = g["map_grid"].astype(np.float64)
+    grid = grid / np.amax(grid).astype(np.float32)      # what MapSpace.py:96 does to a situs map
+    ms.build_from_grid(grid, *[float(v) for v in g["map_origin"]])
+    np.testing.assert_allclose([ms.xi, ms.yi, ms.zi], g["origin"], atol=1e-12)
+    for o in (0, 1):
+        idx = g["grad_idx_%d" % o]
+        assert tuple(g["grad_shape_%d" % o]) == ms.grad_list[o].shape
+        # the fixture's map went through a 6-decimal situs text file; this one did not
+        np.testing.assert_allclose(ms.grad_list[o][idx[:, 0], idx[:, 1], idx[:, 2]], g["grad_val_%d" % o], rtol=0, atol=2e-6)
+        np.testing.assert_allclose(ms.map_space[o][idx[:, 0], idx[:, 1], idx[:, 2]], g["log_val_%d" % o], rtol=0, atol=2e-6)
+    anchors = Detector().find_anchors(ms)
+    # same anchors as at fixture time up to the text round-off of the map: same count, same voxels
+    assert abs(len(anchors) - len(g["anchor_coords"])) <= 2
+    got = {(a.oct_scale,) + tuple(a.coords) for a in anchors}
+    ref = {(int(o),) + tuple(int(v) for v in c) for o, c in zip(g["anchor_oct"], g["anchor_coords"])}
+    assert len(got & ref) >= len(ref) - 2
+    # nearest-gradient lookup object: tie rule and bounds of the reference's interpolator
+    rgi = ms.rgi_space[1]
+    np.testing.assert_array_equal(rgi(np.array([[3.5, 4.5, 5.5], [3.51, 4.0, 5.0]])), ms.grad_list[1][[3, 4], [4, 4], [5, 5]])
+    with pytest.raises(ValueError):
+        rgi(np.array([[-0.1, 1, 1]]))
+
+
+def test_filter_dsc_pairs_against_reference(tmp_path):
+    from mad_amd.MaD import MaD
+    g4, g5, g7 = load("g4_match.npz"), load("g5_filter.npz"), load("g7_density_ccc.npz")
+    names = [synth.ATOM_CYCLE[i % 4][0] for i in range(len(g5["atoms"]))]
+    pdbfile = str(tmp_path / "sub.pdb")
+    synth.write_pdb(pdbfile, g5["atoms"], names, [str(e) for e in g7["elements"]])
+    filt = MaD()._filter_dsc_pairs(pdbfile, list(g4["results"]), g4["lo_cloud"], g4["hi_cloud"], wthresh=4, n_samples=120)
+    assert len(filt) == int(g5["n"]) >= 1
+    np.testing.assert_array_equal([f[4] for f in filt], g5["weight"])
+    np.testing.assert_array_equal([f[5] for f in filt], g5["repeat"])
+    np.testing.assert_array_equal([f[3] for f in filt], g5["cc"])
+    np.testing.assert_allclose([f[2] for f in filt], g5["R"], atol=0)
+    np.testing.assert_allclose([f[7].coords for f in filt], g5["placed"], rtol=0, atol=1e-10)
+
+
+def test_descriptor_cache_round_trip(tmp_path, monkeypatch):
+    from mad_amd.DensityFeature import DensityFeature
+    from mad_amd.MaD import MaD
+    g = load("g4_match.npz")
+    rows = []
+    for i in range(10):
+        df = DensityFeature()
+        df.set_from_file_dsc(int(g["hi_index"][i]), int(g["hi_main"][i]), int(g["hi_sec"][i]), int(g["hi_oct"][i]), 112, 16,
+                             g["hi_coords"][i].astype(float), g["hi_subv"][i], g["hi_subv"][i], g["hi_R"][i], g["hi_dsc"][i])
+        rows.append(df)
+    m = MaD()
+    name = str(tmp_path / "x_res8.0.h5")
+    m._save_descriptors(rows, name)
+    assert m._cache_exists(name)
+    back = m._load_descriptors(name)
+    assert len(back) == 10
+    for a, b in zip(rows, back):
+        assert (a.index, a.main_bin, a.sec_bin, a.oct_scale) == (b.index, b.main_bin, b.sec_bin, b.oct_scale)
+        np.testing.assert_array_equal(a.lin_ar_subeqsp, b.lin_ar_subeqsp)
+        np.testing.assert_array_equal(a.Rfinal, b.Rfinal)
+        np.testing.assert_array_equal(a.subv_map_coords, b.subv_map_coords)
