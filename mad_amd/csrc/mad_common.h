@@ -14,6 +14,8 @@
 #include "../../include/mad_amd.h"
 
 #define MAD_WAVE 64
+#define MAD_ZLUT 1024
+#define MAD_MAX_BELT 32
 
 // ---------------------------------------------------------------------------
 // device-side tables
@@ -35,7 +37,21 @@ struct EqspDev {
     int belt_count[MAD_MAX_Z];   // per belt: number of zones
     double to_dom[MAD_MAX_Z][9];
     double adj_sec[MAD_MAX_Z][9];
+    // Guard-banded float32 tables of the fast classifier (eqsp_fast32): a direction that lies at
+    // least MAD_EQSP_GUARD radians inside a zone's open (theta, phi) rectangle is classified with a
+    // table look-up, a polynomial angle guess and two cross products, all in float32; everything
+    // closer to a bound (or to a pole) goes through the exact float64 path (eqsp_classify).
+    unsigned char zlut[MAD_ZLUT];   // z bin -> belt holding the bin centre
+    float z_in_lo[MAD_MAX_BELT];    // per belt: inside needs z <  z_in_lo  (cos(ph_lo + guard), rounded inwards)
+    float z_in_hi[MAD_MAX_BELT];    // per belt: inside needs z >  z_in_hi  (cos(ph_hi - guard), rounded inwards)
+    float belt_lo0[MAD_MAX_BELT];   // per belt: theta_min of its first zone
+    float belt_inv_w[MAD_MAX_BELT]; // per belt: zones / 2pi
+    int belt_first32[MAD_MAX_BELT];
+    int belt_count32[MAD_MAX_BELT];
+    float g32[MAD_MAX_Z][4];        // per zone: cos, sin of (theta_min + guard), cos, sin of (theta_max - guard)
 };
+
+#define MAD_EQSP_GUARD 1e-4
 
 // One octave's gradient field: a texel is {gx, gy, gz, |g|} (|g| in float32 exactly
 // as numpy forms it: sqrt((gx*gx + gy*gy) + gz*gz), Orientator.py:139).
@@ -115,6 +131,7 @@ struct mad_set {
     // cell list over ALL anchors of the set (used when the set is the map side)
     DevBuf cell_start, cell_pts, cell_ids;
     double cell_min[3] = {0, 0, 0};
+    double bb_min[3] = {0, 0, 0}, bb_max[3] = {0, 0, 0};      // bounding box of all anchors
     double cell_size = 0;
     int cell_dim[3] = {0, 0, 0};
     bool cells_ready = false;
@@ -128,7 +145,7 @@ enum {
     S_PAIR_HI, S_PAIR_LO, S_PAIR_SCORE, S_COUNTS, S_USED_HI, S_USED_LO, S_HI_CLOUD, S_MISC,
     S_HIST, S_SEL, S_RESULTS, S_TMP_A, S_TMP_B, S_TMP_C, S_TMP_D, S_TMP_E, S_TMP_F, S_TMP_G,
     S_TIE_FLAG, S_TIE_OFF, S_SEL_OUT, S_TMP_H, S_TMP_I, S_TMP_J,
-    S_CELL_START, S_CELL_PTS, S_CELL_IDS, S_N_SLOTS
+    S_CELL_START, S_CELL_PTS, S_CELL_IDS, S_PG_START, S_PG_PTS, S_N_SLOTS
 };
 static_assert(S_N_SLOTS <= 64, "grow mad_ctx::scratch");
 
@@ -241,5 +258,59 @@ __device__ __forceinline__ void eqsp_classify(const EqspDev *t, double th, doubl
 }
 
 #define MAD_TWO_PI 6.283185307179586476925286766559
+
+// Tables the fast classifier reads per lane, staged in LDS by the kernels.
+struct EqspFastLds {
+    float g32[MAD_MAX_Z][4];
+    float z_in_lo[MAD_MAX_BELT], z_in_hi[MAD_MAX_BELT], belt_lo0[MAD_MAX_BELT], belt_inv_w[MAD_MAX_BELT];
+    int belt_first[MAD_MAX_BELT], belt_count[MAD_MAX_BELT];
+    unsigned char zlut[MAD_ZLUT];
+};
+
+__device__ __forceinline__ void eqsp_fast_stage(const EqspDev *t, EqspFastLds *l) {
+    for (int i = threadIdx.x; i < t->Z; i += blockDim.x) {
+        l->g32[i][0] = t->g32[i][0]; l->g32[i][1] = t->g32[i][1]; l->g32[i][2] = t->g32[i][2]; l->g32[i][3] = t->g32[i][3];
+    }
+    for (int i = threadIdx.x; i < MAD_MAX_BELT; i += blockDim.x) {
+        l->z_in_lo[i] = t->z_in_lo[i]; l->z_in_hi[i] = t->z_in_hi[i];
+        l->belt_lo0[i] = t->belt_lo0[i]; l->belt_inv_w[i] = t->belt_inv_w[i];
+        l->belt_first[i] = t->belt_first32[i]; l->belt_count[i] = t->belt_count32[i];
+    }
+    for (int i = threadIdx.x; i < MAD_ZLUT; i += blockDim.x) l->zlut[i] = t->zlut[i];
+}
+
+// atan2 in [0, 2pi) to ~2e-6 rad (odd minimax polynomial on [0, 1] + octant unfolding): a GUESS only
+__device__ __forceinline__ float approx_angle(float x, float y) {
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+    const float q = mn * __frcp_rn(fmaxf(mx, 1e-30f));
+    const float q2 = q * q;
+    float a = q * (0.999979854f + q2 * (-0.332655430f + q2 * (0.193669885f + q2 * (-0.116649978f + q2 * (0.052822195f + q2 * -0.011769974f)))));
+    if (ay > ax) a = 1.57079637f - a;
+    if (x < 0.f) a = 3.14159274f - a;
+    if (y < 0.f) a = 6.28318548f - a;
+    return a;
+}
+
+// Fast float32 classification of the (approximately unit) direction (x, y, z), z = cos(phi).
+// Returns the one zone that contains it with a margin of MAD_EQSP_GUARD on every side, or -1 when
+// it is closer than that to a bound, near a pole, or not finite; the caller then runs the exact
+// test.  Inputs may carry float32 rounding noise (<= ~1e-6 rad): inside the margin the exact
+// float64 test on the un-noised direction gives this same zone and no other, because the noise
+// is 100x smaller than the guard and neighbouring zones overlap by < 2e-5 rad at most.
+__device__ __forceinline__ int eqsp_fast32(const EqspFastLds *l, float x, float y, float z) {
+    const int bin = min(max((int)((z + 1.0f) * (0.5f * MAD_ZLUT)), 0), MAD_ZLUT - 1);
+    const int b = l->zlut[bin];
+    if (!(z < l->z_in_lo[b] && z > l->z_in_hi[b])) return -1;
+    const int cnt = l->belt_count[b], first = l->belt_first[b];
+    if (cnt == 1) return first;                       // polar caps span every azimuth
+    float u = approx_angle(x, y) - l->belt_lo0[b];
+    if (u < 0.f) u += 6.28318548f;
+    const int a = first + min(max((int)(u * l->belt_inv_w[b]), 0), cnt - 1);
+    const float4 g = *(const float4 *)l->g32[a];
+    const float c1 = g.x * y - g.y * x;      // > 0: counter-clockwise of theta_min + guard
+    const float c2 = x * g.w - y * g.z;      // > 0: clockwise of theta_max - guard
+    return (c1 > 0.f && c2 > 0.f) ? a : -1;
+}
 
 #endif  // __HIPCC__

@@ -3,6 +3,7 @@
 #include "mad_common.h"
 
 static char g_init_err[512] = "";
+#define MAD_TWO_PI_H 6.283185307179586476925286766559
 
 int mad_fail(mad_ctx *ctx, int code, const char *fmt, ...) {
     char *dst = ctx ? ctx->err : g_init_err;
@@ -208,6 +209,32 @@ extern "C" int mad_set_eqsp(mad_ctx *ctx, int which, int Z, const double *bounds
         h.belt_count[nb]++;
     }
     h.nbelt = nb + 1;
+    if (h.nbelt > MAD_MAX_BELT) return mad_fail(ctx, MAD_EINVAL, "mad_set_eqsp: %d belts", h.nbelt);
+    for (int b = 0; b < h.nbelt; b++) {
+        // inner thresholds, rounded towards the inside of the belt and kept off the poles
+        float lo = nextafterf((float)cos(h.ph_lo[b] + MAD_EQSP_GUARD), -2.0f);
+        float hi = nextafterf((float)cos(h.ph_hi[b] - MAD_EQSP_GUARD), 2.0f);
+        if (lo > 1.0f - 1e-6f) lo = 1.0f - 1e-6f;
+        if (hi < -1.0f + 1e-6f) hi = -1.0f + 1e-6f;
+        h.z_in_lo[b] = lo;
+        h.z_in_hi[b] = hi;
+        h.belt_lo0[b] = (float)h.th_lo[h.belt_first[b]];
+        h.belt_inv_w[b] = (float)(h.belt_count[b] / MAD_TWO_PI_H);
+        h.belt_first32[b] = h.belt_first[b];
+        h.belt_count32[b] = h.belt_count[b];
+    }
+    for (int i = 0; i < MAD_ZLUT; i++) {
+        const double zc = -1.0 + (i + 0.5) * (2.0 / MAD_ZLUT);
+        const double ph = acos(zc);
+        int best = 0;
+        for (int b = 0; b < h.nbelt; b++)
+            if (ph >= h.ph_lo[b] && ph < h.ph_hi[b]) best = b;
+        h.zlut[i] = (unsigned char)best;
+    }
+    for (int a = 0; a < Z; a++) {
+        h.g32[a][0] = (float)cos(h.th_lo[a] + MAD_EQSP_GUARD); h.g32[a][1] = (float)sin(h.th_lo[a] + MAD_EQSP_GUARD);
+        h.g32[a][2] = (float)cos(h.th_hi[a] - MAD_EQSP_GUARD); h.g32[a][3] = (float)sin(h.th_hi[a] - MAD_EQSP_GUARD);
+    }
     if (to_dom) memcpy(h.to_dom, to_dom, sizeof(double) * 9 * Z);
     if (adj_sec) memcpy(h.adj_sec, adj_sec, sizeof(double) * 9 * Z);
     MAD_HIP(hipMemcpyAsync(ctx->eq[which], &h, sizeof(EqspDev), hipMemcpyHostToDevice, ctx->stream));

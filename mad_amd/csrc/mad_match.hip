@@ -287,6 +287,147 @@ __global__ __launch_bounds__(POSE_THREADS) void k_pose(const int32_t *__restrict
     }
 }
 
+
+// ---- LDS-resident variant -----------------------------------------------------------------
+// The lo cloud of one match (the used map anchors, a few thousand points at most) is binned
+// into cells of edge >= 2 * dist, so the ball of radius dist around a query point meets at
+// most 2 cells per axis (<= 4 z-runs).  Cloud, cell offsets (uint16) and the hi cloud all sit
+// in LDS: a query costs LDS reads only.  Same predicate as k_pose, hence the same counts.
+#define POSE_LDS_THREADS 1024
+
+struct PoseGrid {
+    double mn[3];
+    double inv_cell[3];
+    int dim[3];
+    int ncell;
+};
+
+__device__ __forceinline__ int pg_cell(double v, double mn, double inv, int dim) {
+    const int c = (int)floor((v - mn) * inv);
+    return min(max(c, 0), dim - 1);
+}
+
+// one workgroup: counting sort of the used points into cells; sorted points and offsets to global
+__global__ __launch_bounds__(1024) void k_pose_grid_build(const double *__restrict__ pts, const uint8_t *__restrict__ used, int n,
+                                                          PoseGrid G, int32_t *__restrict__ cell_start, double *__restrict__ sorted,
+                                                          int32_t *__restrict__ n_used) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    int *cnt = (int *)smem;
+    __shared__ int wt[17];
+    __shared__ int carry;
+    for (int c = threadIdx.x; c < G.ncell; c += 1024) cnt[c] = 0;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += 1024)
+        if (!used || used[i]) {
+            const int c = (pg_cell(pts[3 * i], G.mn[0], G.inv_cell[0], G.dim[0]) * G.dim[1] +
+                           pg_cell(pts[3 * i + 1], G.mn[1], G.inv_cell[1], G.dim[1])) * G.dim[2] +
+                          pg_cell(pts[3 * i + 2], G.mn[2], G.inv_cell[2], G.dim[2]);
+            atomicAdd(&cnt[c], 1);
+        }
+    __syncthreads();
+    for (int base = 0; base < G.ncell; base += 1024) {
+        const int c = base + threadIdx.x;
+        const int v = c < G.ncell ? cnt[c] : 0;
+        int tot;
+        const int ex = block_excl_scan(v, wt, &tot);
+        if (c < G.ncell) { cnt[c] = carry + ex; cell_start[c] = carry + ex; }
+        __syncthreads();
+        if (threadIdx.x == 0) carry += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { cell_start[G.ncell] = carry; *n_used = carry; }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += 1024)
+        if (!used || used[i]) {
+            const int c = (pg_cell(pts[3 * i], G.mn[0], G.inv_cell[0], G.dim[0]) * G.dim[1] +
+                           pg_cell(pts[3 * i + 1], G.mn[1], G.inv_cell[1], G.dim[1])) * G.dim[2] +
+                          pg_cell(pts[3 * i + 2], G.mn[2], G.inv_cell[2], G.dim[2]);
+            const int o = atomicAdd(&cnt[c], 1);
+            sorted[3 * o] = pts[3 * i]; sorted[3 * o + 1] = pts[3 * i + 1]; sorted[3 * o + 2] = pts[3 * i + 2];
+        }
+}
+
+__global__ __launch_bounds__(POSE_LDS_THREADS) void k_pose_lds(const int32_t *__restrict__ pair_hi, const int32_t *__restrict__ pair_lo,
+                                                           int64_t n_pairs, const double *__restrict__ hi_p,
+                                                           const double *__restrict__ hi_R, const double *__restrict__ lo_p,
+                                                           const double *__restrict__ lo_R, const int32_t *__restrict__ hi_row_anchor,
+                                                           const int32_t *__restrict__ lo_row_anchor,
+                                                           const double *__restrict__ hi_cloud, const int32_t *__restrict__ l_hi_ptr,
+                                                           const double *__restrict__ lo_sorted, const int32_t *__restrict__ cell_start,
+                                                           PoseGrid G, int l_hi_cap, int l_lo_cap, double dist,
+                                                           int32_t *__restrict__ counts) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    double *cl = (double *)smem;                                   // hi cloud
+    double *lp = cl + 3 * (size_t)l_hi_cap;                        // sorted lo cloud
+    unsigned short *cs = (unsigned short *)(lp + 3 * (size_t)l_lo_cap);      // cell offsets
+    const int l_hi = *l_hi_ptr;
+    const int l_lo = cell_start[G.ncell];
+    for (int i = threadIdx.x; i < 3 * l_hi; i += POSE_LDS_THREADS) cl[i] = hi_cloud[i];
+    for (int i = threadIdx.x; i < 3 * l_lo; i += POSE_LDS_THREADS) lp[i] = lo_sorted[i];
+    for (int i = threadIdx.x; i <= G.ncell; i += POSE_LDS_THREADS) cs[i] = (unsigned short)cell_start[i];
+    __syncthreads();
+    const int lane = lane_id();
+    const int64_t wave = (int64_t)blockIdx.x * (POSE_LDS_THREADS / MAD_WAVE) + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * (POSE_LDS_THREADS / MAD_WAVE);
+    for (int64_t p = wave; p < n_pairs; p += nwaves) {
+        const int ih = pair_hi[p], il = pair_lo[p];
+        const double *m = lo_R + 9 * il;
+        const double *h = hi_R + 9 * ih;
+        const double c00 = m[4] * m[8] - m[5] * m[7];
+        const double c01 = m[5] * m[6] - m[3] * m[8];
+        const double c02 = m[3] * m[7] - m[4] * m[6];
+        const double det = m[0] * c00 + m[1] * c01 + m[2] * c02;
+        const double id = 1.0 / det;
+        double iv[9];
+        iv[0] = c00 * id; iv[1] = (m[2] * m[7] - m[1] * m[8]) * id; iv[2] = (m[1] * m[5] - m[2] * m[4]) * id;
+        iv[3] = c01 * id; iv[4] = (m[0] * m[8] - m[2] * m[6]) * id; iv[5] = (m[2] * m[3] - m[0] * m[5]) * id;
+        iv[6] = c02 * id; iv[7] = (m[1] * m[6] - m[0] * m[7]) * id; iv[8] = (m[0] * m[4] - m[1] * m[3]) * id;
+        double R[9];
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) R[3 * i + j] = iv[3 * i] * h[j] + iv[3 * i + 1] * h[3 + j] + iv[3 * i + 2] * h[6 + j];
+        const int ah = hi_row_anchor ? hi_row_anchor[ih] : ih, al = lo_row_anchor ? lo_row_anchor[il] : il;
+        const double ph0 = hi_p[3 * ah], ph1 = hi_p[3 * ah + 1], ph2 = hi_p[3 * ah + 2];
+        const double pl0 = lo_p[3 * al], pl1 = lo_p[3 * al + 1], pl2 = lo_p[3 * al + 2];
+        int cnt = 0;
+        for (int a = lane; a < l_hi; a += MAD_WAVE) {
+            const double d0 = cl[3 * a] - ph0, d1 = cl[3 * a + 1] - ph1, d2 = cl[3 * a + 2] - ph2;
+            const double x = (d0 * R[0] + d1 * R[1] + d2 * R[2]) + pl0;
+            const double y = (d0 * R[3] + d1 * R[4] + d2 * R[5]) + pl1;
+            const double z = (d0 * R[6] + d1 * R[7] + d2 * R[8]) + pl2;
+            // cells met by the ball of radius dist (monotone in the coordinate, so no neighbour is missed)
+            const int x0 = (int)floor(((x - dist) - G.mn[0]) * G.inv_cell[0]), x1 = (int)floor(((x + dist) - G.mn[0]) * G.inv_cell[0]);
+            const int y0 = (int)floor(((y - dist) - G.mn[1]) * G.inv_cell[1]), y1 = (int)floor(((y + dist) - G.mn[1]) * G.inv_cell[1]);
+            const int z0 = (int)floor(((z - dist) - G.mn[2]) * G.inv_cell[2]), z1 = (int)floor(((z + dist) - G.mn[2]) * G.inv_cell[2]);
+            bool hit = false;
+            if (x1 >= 0 && x0 < G.dim[0] && y1 >= 0 && y0 < G.dim[1] && z1 >= 0 && z0 < G.dim[2]) {
+                const int zz0 = max(z0, 0), zz1 = min(z1, G.dim[2] - 1) + 1;
+                const int xa = max(x0, 0), xb = min(x1, G.dim[0] - 1), ya = max(y0, 0), yb = min(y1, G.dim[1] - 1);
+                // the ball meets at most 2 x 2 columns: fetch all four z-runs before walking any of them
+                const int c00 = (xa * G.dim[1] + ya) * G.dim[2], c01 = (xa * G.dim[1] + yb) * G.dim[2];
+                const int c10 = (xb * G.dim[1] + ya) * G.dim[2], c11 = (xb * G.dim[1] + yb) * G.dim[2];
+                int s[4], e[4];
+                s[0] = cs[c00 + zz0]; e[0] = cs[c00 + zz1];
+                s[1] = cs[c01 + zz0]; e[1] = (yb != ya) ? cs[c01 + zz1] : s[1];
+                s[2] = cs[c10 + zz0]; e[2] = (xb != xa) ? cs[c10 + zz1] : s[2];
+                s[3] = cs[c11 + zz0]; e[3] = (xb != xa && yb != ya) ? cs[c11 + zz1] : s[3];
+#pragma unroll
+                for (int c = 0; c < 4; c++)
+                    for (int q = s[c]; q < e[c] && !hit; q++) {
+                        const double e0 = lp[3 * q] - x, e1 = lp[3 * q + 1] - y, e2 = lp[3 * q + 2] - z;
+                        const double dd = e0 * e0 + e1 * e1 + e2 * e2;
+                        hit = sqrt(dd) < dist;
+                    }
+            }
+            cnt += hit ? 1 : 0;
+        }
+        cnt = wave_sum_i32(cnt);
+        if (lane == 0) counts[p] = cnt;
+    }
+}
+
 // rows of MaD.py:451 for the pairs listed in sel (or all pairs when sel == nullptr)
 __global__ void k_results(const int64_t *__restrict__ sel, int64_t n_sel, const int32_t *__restrict__ pair_hi,
                           const int32_t *__restrict__ pair_lo, const double *__restrict__ pair_score,
@@ -326,13 +467,18 @@ __global__ void k_results(const int64_t *__restrict__ sel, int64_t n_sel, const 
 // top-k by (count desc, pair index asc)
 // ---------------------------------------------------------------------------
 
-__global__ void k_count_hist(const int32_t *__restrict__ counts, int64_t n, int32_t *__restrict__ hist, int nbins) {
+// per-workgroup LDS histogram first: the counts crowd into a few bins, global atomics on them serialise
+__global__ __launch_bounds__(256) void k_count_hist(const int32_t *__restrict__ counts, int64_t n, int32_t *__restrict__ hist, int nbins) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    int *h = (int *)smem;
+    for (int b = threadIdx.x; b < nbins; b += 256) h[b] = 0;
+    __syncthreads();
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t step = (int64_t)gridDim.x * blockDim.x;
-    for (; i < n; i += step) {
-        const int c = counts[i];
-        atomicAdd(&hist[min(max(c, 0), nbins - 1)], 1);
-    }
+    for (; i < n; i += step) atomicAdd(&h[min(max(counts[i], 0), nbins - 1)], 1);
+    __syncthreads();
+    for (int b = threadIdx.x; b < nbins; b += 256)
+        if (h[b]) atomicAdd(&hist[b], h[b]);
 }
 
 // info[0] = threshold count c*, info[1] = number of pairs with count > c*, info[2] = ties to take at c*
@@ -409,8 +555,9 @@ static int topk_device(mad_ctx *ctx, const int32_t *d_counts, int64_t n, int64_t
     int32_t *n_keys = info + 3;
     MAD_HIP(hipMemsetAsync(hist, 0, (size_t)(nbins + 8) * 4, ctx->stream));
     mad_timer_begin(ctx, MAD_T_TOPK);
-    const int blocks = (int)std::min<int64_t>(mad_ceil_div(n, 256), (int64_t)ctx->n_cu * 8);
-    hipLaunchKernelGGL(k_count_hist, dim3(blocks), dim3(256), 0, ctx->stream, d_counts, n, hist, nbins);
+    if (nbins > 16384) return mad_fail(ctx, MAD_EINVAL, "top-k: %d count bins", nbins);
+    const int blocks = (int)std::min<int64_t>(mad_ceil_div(n, 1024), (int64_t)ctx->n_cu * 2);
+    hipLaunchKernelGGL(k_count_hist, dim3(blocks), dim3(256), (size_t)nbins * 4, ctx->stream, d_counts, n, hist, nbins);
     hipLaunchKernelGGL(k_topk_threshold, dim3(1), dim3(64), 0, ctx->stream, hist, nbins, k, info);
     const unsigned nb = (unsigned)mad_ceil_div(n, 256);
     hipLaunchKernelGGL(k_tie_flags, dim3(nb), dim3(256), 0, ctx->stream, d_counts, n, info, scratch<int32_t>(ctx, S_TIE_FLAG));
@@ -499,6 +646,12 @@ static int build_cells(mad_ctx *ctx, const double *h_pts, const double *d_pts, i
 }
 
 int mad_build_cells(mad_ctx *ctx, mad_set *set, const double *h_subv, double cell) {
+    for (int i = 0; i < set->n_anchors; i++)
+        for (int d = 0; d < 3; d++) {
+            const double v = h_subv[3 * i + d];
+            if (i == 0 || v < set->bb_min[d]) set->bb_min[d] = v;
+            if (i == 0 || v > set->bb_max[d]) set->bb_max[d] = v;
+        }
     MAD_TRY(build_cells(ctx, h_subv, (const double *)set->anc_subv.p, set->n_anchors, cell, set->cell_start, set->cell_pts,
                         set->cell_ids, set->cell_min, set->cell_dim));
     set->cell_size = cell;
@@ -601,21 +754,65 @@ extern "C" int mad_correlate(mad_ctx *ctx, const int16_t *hi, int64_t n_hi, cons
 // pose scoring drivers
 // ---------------------------------------------------------------------------
 
+// lo cloud = the points of d_lo_pts whose flag is set (all if d_lo_used == nullptr); bounding box from the host.
 static int pose_device(mad_ctx *ctx, const int32_t *d_pair_hi, const int32_t *d_pair_lo, int64_t n_pairs,
                        const double *d_hi_p, const double *d_hi_R, const double *d_lo_p, const double *d_lo_R,
                        const int32_t *d_hi_row_anchor, const int32_t *d_lo_row_anchor, const double *d_hi_cloud,
-                       const int32_t *d_l_hi, int l_hi_max, CellGrid G, double dist, int32_t *d_counts) {
+                       const int32_t *d_l_hi, int l_hi_max, const double *d_lo_pts, const uint8_t *d_lo_used, int n_lo_pts,
+                       const double bb_min[3], const double bb_max[3], const CellGrid *fallback, double dist,
+                       int32_t *d_counts, int32_t *d_l_lo) {
     if (n_pairs <= 0) return MAD_OK;
-    const size_t lds = (size_t)l_hi_max * 24;
-    if (lds > 150 * 1024) return mad_fail(ctx, MAD_EINVAL, "pose: hi cloud of %d anchors does not fit LDS", l_hi_max);
-    if (lds > 64 * 1024)
-        MAD_HIP(hipFuncSetAttribute((const void *)k_pose, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const int64_t waves_needed = n_pairs;
-    int blocks = (int)std::min<int64_t>(mad_ceil_div(waves_needed, POSE_THREADS / MAD_WAVE), (int64_t)ctx->n_cu * 8);
+    // cells of edge >= 2 dist, at most 24 per axis
+    PoseGrid G;
+    G.ncell = 1;
+    for (int d = 0; d < 3; d++) {
+        const double ext = bb_max[d] - bb_min[d];
+        double cell = 2.0 * dist;
+        if (ext / cell > 24.0) cell = ext / 24.0;
+        G.mn[d] = bb_min[d];
+        G.inv_cell[d] = 1.0 / cell;
+        G.dim[d] = (int)floor(ext / cell) + 1;
+        if (G.dim[d] < 1) G.dim[d] = 1;
+        G.ncell *= G.dim[d];
+    }
+    const size_t lds = (size_t)(l_hi_max + n_lo_pts) * 24 + (size_t)(G.ncell + 1) * 2 + 16;
+    int blocks = (int)std::min<int64_t>(mad_ceil_div(n_pairs, POSE_THREADS / MAD_WAVE), (int64_t)ctx->n_cu * 8);
     if (blocks < 1) blocks = 1;
+    if (lds <= 150 * 1024 && n_lo_pts < 65535 && G.ncell <= 30000) {
+        MAD_TRY(mad_reserve(ctx, ctx->scratch[S_PG_START], (size_t)(G.ncell + 2) * 4));
+        MAD_TRY(mad_reserve(ctx, ctx->scratch[S_PG_PTS], (size_t)(n_lo_pts + 1) * 24));
+        mad_timer_begin(ctx, MAD_T_POSE);
+        hipLaunchKernelGGL(k_pose_grid_build, dim3(1), dim3(1024), (size_t)G.ncell * 4, ctx->stream, d_lo_pts, d_lo_used, n_lo_pts, G,
+                           scratch<int32_t>(ctx, S_PG_START), scratch<double>(ctx, S_PG_PTS), d_l_lo);
+        static bool attr_set = false;
+        if (!attr_set) {
+            MAD_HIP(hipFuncSetAttribute((const void *)k_pose_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            MAD_HIP(hipFuncSetAttribute((const void *)k_pose_grid_build, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+            attr_set = true;
+        }
+        const int lblocks = (int)std::max<int64_t>(1, std::min<int64_t>(mad_ceil_div(n_pairs, POSE_LDS_THREADS / MAD_WAVE), (int64_t)ctx->n_cu * 2));
+        hipLaunchKernelGGL(k_pose_lds, dim3(lblocks), dim3(POSE_LDS_THREADS), lds, ctx->stream, d_pair_hi, d_pair_lo, n_pairs, d_hi_p,
+                           d_hi_R, d_lo_p, d_lo_R, d_hi_row_anchor, d_lo_row_anchor, d_hi_cloud, d_l_hi,
+                           scratch<double>(ctx, S_PG_PTS), scratch<int32_t>(ctx, S_PG_START), G, l_hi_max, n_lo_pts, dist,
+                           d_counts);
+        mad_timer_end(ctx, MAD_T_POSE);
+        MAD_HIP(hipGetLastError());
+        return MAD_OK;
+    }
+    // clouds too large for LDS: global cell list (cell = dist) with the used flags
+    if (!fallback) return mad_fail(ctx, MAD_EINVAL, "pose: clouds of %d + %d points need the global cell list", l_hi_max, n_lo_pts);
+    const size_t lds2 = (size_t)l_hi_max * 24;
+    if (lds2 > 150 * 1024) return mad_fail(ctx, MAD_EINVAL, "pose: hi cloud of %d anchors does not fit LDS", l_hi_max);
+    if (lds2 > 64 * 1024)
+        MAD_HIP(hipFuncSetAttribute((const void *)k_pose, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+    MAD_HIP(hipMemsetAsync(d_l_lo, 0, 4, ctx->stream));
+    if (d_lo_used)
+        hipLaunchKernelGGL(k_count_flags, dim3((unsigned)mad_ceil_div(n_lo_pts, 256)), dim3(256), 0, ctx->stream, d_lo_used, n_lo_pts, d_l_lo);
+    else
+        MAD_HIP(hipMemcpyAsync(d_l_lo, &n_lo_pts, 4, hipMemcpyHostToDevice, ctx->stream));
     mad_timer_begin(ctx, MAD_T_POSE);
-    hipLaunchKernelGGL(k_pose, dim3(blocks), dim3(POSE_THREADS), lds, ctx->stream, d_pair_hi, d_pair_lo, n_pairs, d_hi_p,
-                       d_hi_R, d_lo_p, d_lo_R, d_hi_row_anchor, d_lo_row_anchor, d_hi_cloud, d_l_hi, G, dist, d_counts);
+    hipLaunchKernelGGL(k_pose, dim3(blocks), dim3(POSE_THREADS), lds2, ctx->stream, d_pair_hi, d_pair_lo, n_pairs, d_hi_p,
+                       d_hi_R, d_lo_p, d_lo_R, d_hi_row_anchor, d_lo_row_anchor, d_hi_cloud, d_l_hi, *fallback, dist, d_counts);
     mad_timer_end(ctx, MAD_T_POSE);
     MAD_HIP(hipGetLastError());
     return MAD_OK;
@@ -648,7 +845,14 @@ extern "C" int mad_pose_score(mad_ctx *ctx, const int32_t *pair_hi, const int32_
     int32_t *d_lhi = scratch<int32_t>(ctx, S_MISC) + 8;
     const int32_t lh = (int32_t)l_hi;
     MAD_HIP(hipMemcpyAsync(d_lhi, &lh, 4, hipMemcpyHostToDevice, ctx->stream));
-    // cell list over the lo cloud
+    // bounding box of the lo cloud; the global cell list (cell = dist) is only built when the clouds do not fit LDS
+    double bmn[3] = {0, 0, 0}, bmx[3] = {0, 0, 0};
+    for (int64_t i = 0; i < l_lo; i++)
+        for (int d = 0; d < 3; d++) {
+            const double v = lo_cloud[3 * i + d];
+            if (i == 0 || v < bmn[d]) bmn[d] = v;
+            if (i == 0 || v > bmx[d]) bmx[d] = v;
+        }
     DevBuf &b_start = ctx->scratch[S_CELL_START], &b_pts = ctx->scratch[S_CELL_PTS], &b_ids = ctx->scratch[S_CELL_IDS];
     double mn[3];
     int dim[3];
@@ -659,8 +863,9 @@ extern "C" int mad_pose_score(mad_ctx *ctx, const int32_t *pair_hi, const int32_
     G.cell = dist;
     MAD_TRY(pose_device(ctx, scratch<int32_t>(ctx, S_PAIR_HI), scratch<int32_t>(ctx, S_PAIR_LO), n_pairs,
                         scratch<double>(ctx, S_TMP_E), scratch<double>(ctx, S_TMP_F), scratch<double>(ctx, S_TMP_H),
-                        scratch<double>(ctx, S_TMP_I), nullptr, nullptr, scratch<double>(ctx, S_HI_CLOUD), d_lhi, (int)l_hi, G,
-                        dist, scratch<int32_t>(ctx, S_COUNTS)));
+                        scratch<double>(ctx, S_TMP_I), nullptr, nullptr, scratch<double>(ctx, S_HI_CLOUD), d_lhi, (int)l_hi,
+                        scratch<double>(ctx, S_USED_LO), nullptr, (int)l_lo, bmn, bmx, &G, dist, scratch<int32_t>(ctx, S_COUNTS),
+                        d_lhi + 1));
     if (results) {
         MAD_TRY(mad_reserve(ctx, ctx->scratch[S_RESULTS], (size_t)n_pairs * MAD_RESULT_COLS * 8));
         hipLaunchKernelGGL(k_results, dim3((unsigned)mad_ceil_div(n_pairs, 256)), dim3(256), 0, ctx->stream, nullptr, n_pairs,
@@ -884,8 +1089,6 @@ extern "C" int mad_match_topk(mad_ctx *ctx, const mad_set *hi, const mad_set *lo
     MAD_HIP(hipMemsetAsync(d_llo, 0, 4, ctx->stream));
     hipLaunchKernelGGL(k_compact_cloud, dim3(1), dim3(1024), 0, ctx->stream, (const double *)hi->anc_subv.p, used_hi,
                        hi->n_anchors, scratch<double>(ctx, S_HI_CLOUD), d_lhi);
-    hipLaunchKernelGGL(k_count_flags, dim3((unsigned)mad_ceil_div(lo->n_anchors, 256)), dim3(256), 0, ctx->stream, used_lo,
-                       lo->n_anchors, d_llo);
     MAD_TRY(mad_reserve(ctx, ctx->scratch[S_COUNTS], (size_t)np * 4));
     CellGrid G;
     G.start = (const int32_t *)lo->cell_start.p; G.pts = (const double *)lo->cell_pts.p; G.ids = (const int32_t *)lo->cell_ids.p;
@@ -895,7 +1098,8 @@ extern "C" int mad_match_topk(mad_ctx *ctx, const mad_set *hi, const mad_set *lo
     MAD_TRY(pose_device(ctx, scratch<int32_t>(ctx, S_PAIR_HI), scratch<int32_t>(ctx, S_PAIR_LO), np,
                         (const double *)hi->anc_subv.p, (const double *)hi->row_R.p, (const double *)lo->anc_subv.p,
                         (const double *)lo->row_R.p, (const int32_t *)hi->row_anchor.p, (const int32_t *)lo->row_anchor.p,
-                        scratch<double>(ctx, S_HI_CLOUD), d_lhi, hi->n_anchors, G, dist, scratch<int32_t>(ctx, S_COUNTS)));
+                        scratch<double>(ctx, S_HI_CLOUD), d_lhi, hi->n_anchors, (const double *)lo->anc_subv.p, used_lo,
+                        lo->n_anchors, lo->bb_min, lo->bb_max, &G, dist, scratch<int32_t>(ctx, S_COUNTS), d_llo));
     MAD_HIP(hipMemcpyAsync(&ctx->pinned[4], d_lhi, 8, hipMemcpyDeviceToHost, ctx->stream));      // l_hi and l_lo
     // top-k
     MAD_TRY(mad_reserve(ctx, ctx->scratch[S_SEL_OUT], (size_t)(k + 8) * 8));

@@ -81,18 +81,32 @@ __device__ __forceinline__ int quantise_wave0(const int *hist, int *q, int Z) {
     return mx;
 }
 
+// exact zone test of one rotated direction in float64 (the reference's arithmetic); f(zone) per match
+template <class F>
+__device__ __forceinline__ void classify_exact64(const EqspDev *eq, double rx, double ry, double rz, F &&f) {
+    double th = atan2(ry, rx);
+    if (th < 0) th += MAD_TWO_PI;
+    const double sth = th + MAD_TWO_PI;
+    rz = rz > 1.0 ? 1.0 : (rz < -1.0 ? -1.0 : rz);
+    const double ph = acos(rz);
+    eqsp_classify(eq, th, sth, ph, f);
+}
+
 __global__ __launch_bounds__(ORI_THREADS) void k_orient(OrientArgs A) {
     extern __shared__ __align__(16) unsigned char smem[];
     float *vx = (float *)smem;
     float *vy = vx + A.nmask;
     float *vz = vy + A.nmask;
-    __shared__ int hist[MAD_MAX_Z];
-    __shared__ int q0[MAD_MAX_Z];
-    __shared__ int q1[MAD_MAX_Z];
+    int *queue = (int *)(vz + A.nmask);                 // (voxel | candidate << 16) the fast classifier could not decide
+    __shared__ int hist[ORI_MAX_MAIN + 1][MAD_MAX_Z];   // [0]: first pass; [1 + c]: main-bin candidate c
+    __shared__ int qz[ORI_MAX_MAIN + 1][MAD_MAX_Z];     // quantised counts, same indexing
     __shared__ int main_list[MAD_MAX_Z];
-    __shared__ int sec_list[MAD_MAX_Z];
-    __shared__ int s_nvox, s_nmain, s_mx, s_nsec, s_ok;
-    __shared__ double s_dom[9];
+    __shared__ int sec_list[ORI_MAX_MAIN][ORI_MAX_FAN];
+    __shared__ int sec_cnt[ORI_MAX_MAIN];
+    __shared__ int s_nvox, s_nmain, s_mx, s_nq;
+    __shared__ double s_dom[ORI_MAX_MAIN][9];
+    __shared__ float s_domf[ORI_MAX_MAIN][9];
+    __shared__ EqspFastLds fast;
 
     const int a = blockIdx.x;
     const int tid = threadIdx.x;
@@ -112,8 +126,9 @@ __global__ __launch_bounds__(ORI_THREADS) void k_orient(OrientArgs A) {
             return;
         }
     }
-    if (tid == 0) s_nvox = 0;
-    for (int i = tid; i < MAD_MAX_Z; i += ORI_THREADS) hist[i] = 0;
+    if (tid == 0) { s_nvox = 0; s_nq = 0; }
+    for (int i = tid; i < (ORI_MAX_MAIN + 1) * MAD_MAX_Z; i += ORI_THREADS) (&hist[0][0])[i] = 0;
+    eqsp_fast_stage(A.eq, &fast);
     __syncthreads();
 
     // step01: fetch, normalise (float32, Orientator.py:139-147), keep weighted voxels only
@@ -132,31 +147,40 @@ __global__ __launch_bounds__(ORI_THREADS) void k_orient(OrientArgs A) {
     __syncthreads();
     const int nvox = s_nvox;
 
-    // step02: first binning on the float32 box (Orientator.py:307-334)
+    // step02: first binning on the float32 box (Orientator.py:307-334).  Directions well inside a zone
+    // take the guard-banded float32 path; the few near a bound are queued for the exact test.
+    for (int v = tid; v < nvox; v += ORI_THREADS) {
+        const int zn = eqsp_fast32(&fast, vx[v], vy[v], vz[v]);
+        if (zn >= 0) atomicAdd(&hist[0][zn], 1);
+        else queue[atomicAdd(&s_nq, 1)] = v;
+    }
+    __syncthreads();
     {
         const float two_pi_f = (float)MAD_TWO_PI;
-        for (int v = tid; v < nvox; v += ORI_THREADS) {
+        const int nq = s_nq;
+        for (int qi = tid; qi < nq; qi += ORI_THREADS) {      // the reference's float32 arithmetic
+            const int v = queue[qi];
             float th = (float)atan2((double)vy[v], (double)vx[v]);
             if (th < 0.0f) th = __fadd_rn(th, two_pi_f);
             const float sth = __fadd_rn(th, two_pi_f);
             double cz = (double)vz[v];
             cz = cz > 1.0 ? 1.0 : (cz < -1.0 ? -1.0 : cz);
             const float ph = (float)acos(cz);
-            eqsp_classify(A.eq, (double)th, (double)sth, (double)ph, [&](int zn) { atomicAdd(&hist[zn], 1); });
+            eqsp_classify(A.eq, (double)th, (double)sth, (double)ph, [&](int zn) { atomicAdd(&hist[0][zn], 1); });
         }
     }
     __syncthreads();
     if (tid < MAD_WAVE) {
-        const int mx = quantise_wave0(hist, q0, Z);
+        const int mx = quantise_wave0(hist[0], qz[0], Z);
         // main bins: quantised count > 0.8 * max (Orientator.py:181)
         const int lane = lane_id();
-        const bool p0 = lane < Z && (double)q0[lane] > 50 * 0.8;
-        const bool p1 = lane + 64 < Z && (double)q0[lane + 64] > 50 * 0.8;
+        const bool p0 = lane < Z && (double)qz[0][lane] > 50 * 0.8;
+        const bool p1 = lane + 64 < Z && (double)qz[0][lane + 64] > 50 * 0.8;
         const unsigned long long m0 = __ballot(p0), m1 = __ballot(p1);
         const int n0 = __popcll(m0);
         if (p0) main_list[__popcll(m0 & lanemask_lt())] = lane;
         if (p1) main_list[n0 + __popcll(m1 & lanemask_lt())] = lane + 64;
-        if (lane == 0) { s_mx = mx; s_nmain = n0 + __popcll(m1); }
+        if (lane == 0) { s_mx = mx; s_nmain = n0 + __popcll(m1); s_nq = 0; }
     }
     __syncthreads();
     const int nmain = s_nmain;
@@ -165,68 +189,86 @@ __global__ __launch_bounds__(ORI_THREADS) void k_orient(OrientArgs A) {
         return;
     }
 
-    int produced = 0;      // rows emitted so far (uniform across the block)
-    int hist_rows = 0;
-    for (int mi = 0; mi < nmain; mi++) {
-        const int mb = main_list[mi];
-        __syncthreads();
-        if (mb != 0) {
-            // step03: rotate by to_dom (float64) and re-bin (Orientator.py:204-206, 303)
-            if (tid < 9) s_dom[tid] = A.eq->to_dom[mb][tid];
-            for (int i = tid; i < MAD_MAX_Z; i += ORI_THREADS) hist[i] = 0;
-            __syncthreads();
-            const double d0 = s_dom[0], d1 = s_dom[1], d2 = s_dom[2], d3 = s_dom[3], d4 = s_dom[4], d5 = s_dom[5],
-                         d6 = s_dom[6], d7 = s_dom[7], d8 = s_dom[8];
-            for (int v = tid; v < nvox; v += ORI_THREADS) {
-                const double g0 = vx[v], g1 = vy[v], g2 = vz[v];
-                const double rx = g0 * d0 + g1 * d1 + g2 * d2;
-                const double ry = g0 * d3 + g1 * d4 + g2 * d5;
-                double rz = g0 * d6 + g1 * d7 + g2 * d8;
-                double th = atan2(ry, rx);
-                if (th < 0) th += MAD_TWO_PI;
-                const double sth = th + MAD_TWO_PI;
-                rz = rz > 1.0 ? 1.0 : (rz < -1.0 ? -1.0 : rz);
-                const double ph = acos(rz);
-                eqsp_classify(A.eq, th, sth, ph, [&](int zn) { atomicAdd(&hist[zn], 1); });
-            }
-            __syncthreads();
-            if (tid < MAD_WAVE) quantise_wave0(hist, q1, Z);
-        } else {
-            for (int i = tid; i < Z; i += ORI_THREADS) q1[i] = q0[i];      // Orientator.py:211: no re-binning
+    // step03 for every main-bin candidate at once: rotate by to_dom (Orientator.py:204-206, 303) and re-bin
+    for (int i = tid; i < nmain * 9; i += ORI_THREADS) {
+        const double d = A.eq->to_dom[main_list[i / 9]][i % 9];
+        s_dom[i / 9][i % 9] = d;
+        s_domf[i / 9][i % 9] = (float)d;
+    }
+    __syncthreads();
+    for (int v = tid; v < nvox; v += ORI_THREADS) {
+        const float g0 = vx[v], g1 = vy[v], g2 = vz[v];
+        for (int c = 0; c < nmain; c++) {
+            if (main_list[c] == 0) continue;               // Orientator.py:211: the pole keeps the first binning
+            const float *d = s_domf[c];
+            const float rx = g0 * d[0] + g1 * d[1] + g2 * d[2];
+            const float ry = g0 * d[3] + g1 * d[4] + g2 * d[5];
+            const float rz = g0 * d[6] + g1 * d[7] + g2 * d[8];
+            const int zn = eqsp_fast32(&fast, rx, ry, rz);
+            if (zn >= 0) { atomicAdd(&hist[1 + c][zn], 1); continue; }
+            const int slot = atomicAdd(&s_nq, 1);
+            if (slot < A.nmask) { queue[slot] = v | (c << 16); continue; }
+            // queue full (only if nearly every direction sat on a bound): exact test in place
+            const double *dd = s_dom[c];
+            const double e0 = g0, e1 = g1, e2 = g2;
+            classify_exact64(A.eq, e0 * dd[0] + e1 * dd[1] + e2 * dd[2], e0 * dd[3] + e1 * dd[4] + e2 * dd[5],
+                             e0 * dd[6] + e1 * dd[7] + e2 * dd[8], [&](int z2) { atomicAdd(&hist[1 + c][z2], 1); });
         }
-        __syncthreads();
-        // step04: secondary bins among the non-pole zones (Orientator.py:228-239)
-        if (tid < MAD_WAVE) {
-            const int lane = lane_id();
-            const int i0 = lane, i1 = lane + 64;
-            const bool in0 = i0 >= 1 && i0 < Z - 1, in1 = i1 >= 1 && i1 < Z - 1;
-            const int c0 = in0 ? q1[i0] : 0, c1 = in1 ? q1[i1] : 0;
-            const int mx = wave_max_i32(max(c0, c1));
-            bool p0 = false, p1 = false;
-            if (mx > 0) {
-                p0 = in0 && (double)((int)((double)c0 / (double)mx * 50.0)) > 50 * 0.8;
-                p1 = in1 && (double)((int)((double)c1 / (double)mx * 50.0)) > 50 * 0.8;
-            }
-            const unsigned long long m0 = __ballot(p0), m1 = __ballot(p1);
-            const int n0 = __popcll(m0), ns = n0 + __popcll(m1);
-            if (p0) sec_list[__popcll(m0 & lanemask_lt())] = i0;
-            if (p1) sec_list[n0 + __popcll(m1 & lanemask_lt())] = i1;
-            if (lane == 0) { s_nsec = ns; s_ok = (mx > 0 && ns <= A.lim_sec) ? 1 : 0; }
+    }
+    __syncthreads();
+    {
+        const int nq = min(s_nq, A.nmask);      // ~0.1 % of nvox * nmain in practice; capacity is nmask
+        for (int qi = tid; qi < nq; qi += ORI_THREADS) {
+            const int v = queue[qi] & 0xffff, c = queue[qi] >> 16;
+            const double *d = s_dom[c];
+            const double g0 = vx[v], g1 = vy[v], g2 = vz[v];
+            const double rx = g0 * d[0] + g1 * d[1] + g2 * d[2];
+            const double ry = g0 * d[3] + g1 * d[4] + g2 * d[5];
+            const double rz = g0 * d[6] + g1 * d[7] + g2 * d[8];
+            classify_exact64(A.eq, rx, ry, rz, [&](int zn) { atomicAdd(&hist[1 + c][zn], 1); });
         }
-        __syncthreads();
-        if (s_ok) {
-            const int ns = s_nsec;
-            if (tid < ns) {
-                const size_t o = (size_t)a * A.fan + produced + tid;
-                A.slot_main[o] = mb;
-                A.slot_sec[o] = sec_list[tid];
-                A.slot_hidx[o] = hist_rows;
-            }
-            if (A.slot_hist)
-                for (int i = tid; i < Z; i += ORI_THREADS) A.slot_hist[((size_t)a * A.lim_main + hist_rows) * Z + i] = q1[i];
-            produced += ns;
-            hist_rows++;
+    }
+    __syncthreads();
+    // quantise + step04 (Orientator.py:228-239) per candidate, one wave each
+    for (int c = tid >> 6; c < nmain; c += ORI_THREADS / MAD_WAVE) {
+        const int lane = lane_id();
+        int *q1 = qz[1 + c];
+        if (main_list[c] != 0) quantise_wave0(hist[1 + c], q1, Z);
+        else { if (lane < Z) q1[lane] = qz[0][lane]; if (lane + 64 < Z) q1[lane + 64] = qz[0][lane + 64]; }
+        const int i0 = lane, i1 = lane + 64;
+        const bool in0 = i0 >= 1 && i0 < Z - 1, in1 = i1 >= 1 && i1 < Z - 1;
+        const int c0 = in0 ? q1[i0] : 0, c1 = in1 ? q1[i1] : 0;
+        const int mx = wave_max_i32(max(c0, c1));
+        bool p0 = false, p1 = false;
+        if (mx > 0) {
+            p0 = in0 && (double)((int)((double)c0 / (double)mx * 50.0)) > 50 * 0.8;
+            p1 = in1 && (double)((int)((double)c1 / (double)mx * 50.0)) > 50 * 0.8;
         }
+        const unsigned long long m0 = __ballot(p0), m1 = __ballot(p1);
+        const int n0 = __popcll(m0), ns = n0 + __popcll(m1);
+        const bool ok = mx > 0 && ns <= A.lim_sec;
+        if (ok) {
+            if (p0) sec_list[c][__popcll(m0 & lanemask_lt())] = i0;
+            if (p1) sec_list[c][n0 + __popcll(m1 & lanemask_lt())] = i1;
+        }
+        if (lane == 0) sec_cnt[c] = ok ? ns : -1;
+    }
+    __syncthreads();
+    // emit rows: candidates in ascending main bin, secondary bins ascending (Orientator.py:90-106)
+    int produced = 0, hist_rows = 0;
+    for (int c = 0; c < nmain; c++) {
+        const int ns = sec_cnt[c];
+        if (ns < 0) continue;
+        if (tid < ns) {
+            const size_t o = (size_t)a * A.fan + produced + tid;
+            A.slot_main[o] = main_list[c];
+            A.slot_sec[o] = sec_list[c][tid];
+            A.slot_hidx[o] = hist_rows;
+        }
+        if (A.slot_hist)
+            for (int i = tid; i < Z; i += ORI_THREADS) A.slot_hist[((size_t)a * A.lim_main + hist_rows) * Z + i] = qz[1 + c][i];
+        produced += ns;
+        hist_rows++;
     }
     if (tid == 0) A.slot_cnt[a] = produced;
 }
@@ -308,7 +350,7 @@ int mad_orient_device(mad_ctx *ctx, FieldDev f0, FieldDev f1, const int32_t *d_c
     MAD_HIP(hipMemsetAsync(d_nrej, 0, 4, ctx->stream));
 
     mad_timer_begin(ctx, MAD_T_ORIENT);
-    const size_t lds = (size_t)ctx->mask_n * 3 * sizeof(float);
+    const size_t lds = (size_t)ctx->mask_n * 4 * sizeof(float);      // unit gradients (SoA) + the undecided-voxel queue
     hipLaunchKernelGGL(k_orient, dim3(n), dim3(ORI_THREADS), lds, ctx->stream, A);
     mad_timer_end(ctx, MAD_T_ORIENT);
     hipLaunchKernelGGL(k_slot_counts, dim3((unsigned)mad_ceil_div(n, 256)), dim3(256), 0, ctx->stream, A.slot_cnt, d_cnt,
@@ -372,6 +414,7 @@ extern "C" int mad_orient(mad_ctx *ctx, int slot, int octave, const int32_t *coo
 // ---------------------------------------------------------------------------
 
 #define DSC_THREADS 256
+#define DSC_QUEUE 256
 
 struct DescribeArgs {
     FieldDev f[2];
@@ -386,12 +429,35 @@ struct DescribeArgs {
     int16_t *dsc;                  // n_rows x 64*Z
 };
 
+// The reference's arithmetic for one sample (Descriptor.py:153-187): float32 normalisation, float64
+// rotation by Rfinal, atan2 / arccos against the table; default zone 0, the last matching zone wins.
+__device__ __forceinline__ int describe_exact(const EqspDev *eq, float4 t, const double *R) {
+    float gx = t.x, gy = t.y, gz = t.z;
+    if (t.w > 1e-12f) { gx = __fdiv_rn(gx, t.w); gy = __fdiv_rn(gy, t.w); gz = __fdiv_rn(gz, t.w); }
+    const double g0 = gx, g1 = gy, g2 = gz;
+    const double rx = g0 * R[0] + g1 * R[1] + g2 * R[2];
+    const double ry = g0 * R[3] + g1 * R[4] + g2 * R[5];
+    const double rz = g0 * R[6] + g1 * R[7] + g2 * R[8];
+    int zone = 0;
+    classify_exact64(eq, rx, ry, rz, [&](int zn) { zone = zn; });
+    return zone;
+}
+
 template <int S>
 __global__ __launch_bounds__(DSC_THREADS) void k_describe(DescribeArgs A) {
     __shared__ int hist[64 * 16];
     __shared__ double sR[9], sInv[9];
-    __shared__ int s_oob;
-    const int64_t row = blockIdx.x;
+    __shared__ int s_oob, s_nq;
+    __shared__ EqspFastLds fast;
+    __shared__ float4 qv[DSC_QUEUE];         // texels the fast classifier could not decide
+    __shared__ int qsub[DSC_QUEUE];
+    __shared__ float sRf[9];
+    // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs (b and b + 8 share one), so give
+    // each XCD a contiguous run of rows.  Consecutive rows belong to the same anchor (fan-out ~5) or to
+    // neighbours in the anchor list and sample the same neighbourhood: they then meet in ONE L2.
+    const int64_t chunk = (A.n_rows + 7) / 8;
+    const int64_t row = (int64_t)(blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+    if (row >= A.n_rows) return;
     const int tid = threadIdx.x;
     const int a = A.row_anchor ? A.row_anchor[row] : (int)row;
     const int oct = A.anc_octave ? A.anc_octave[a] : A.uniform_octave;
@@ -411,26 +477,49 @@ __global__ __launch_bounds__(DSC_THREADS) void k_describe(DescribeArgs A) {
         sInv[0] = c00 * id; sInv[1] = (m[2] * m[7] - m[1] * m[8]) * id; sInv[2] = (m[1] * m[5] - m[2] * m[4]) * id;
         sInv[3] = c01 * id; sInv[4] = (m[0] * m[8] - m[2] * m[6]) * id; sInv[5] = (m[2] * m[3] - m[0] * m[5]) * id;
         sInv[6] = c02 * id; sInv[7] = (m[1] * m[6] - m[0] * m[7]) * id; sInv[8] = (m[0] * m[4] - m[1] * m[3]) * id;
-        for (int i = 0; i < 9; i++) sR[i] = m[i];
+        for (int i = 0; i < 9; i++) { sR[i] = m[i]; sRf[i] = (float)m[i]; }
         s_oob = 0;
+        s_nq = 0;
     }
     for (int i = tid; i < D; i += DSC_THREADS) hist[i] = 0;
+    eqsp_fast_stage(A.eq, &fast);
     __syncthreads();
 
-    const double c0 = (double)A.anc_coords[3 * a], c1 = (double)A.anc_coords[3 * a + 1], c2 = (double)A.anc_coords[3 * a + 2];
+    const int ic0 = A.anc_coords[3 * a], ic1 = A.anc_coords[3 * a + 1], ic2 = A.anc_coords[3 * a + 2];
+    const double c0 = (double)ic0, c1 = (double)ic1, c2 = (double)ic2;
     const double i0 = sInv[0], i1 = sInv[1], i2 = sInv[2], i3 = sInv[3], i4 = sInv[4], i5 = sInv[5], i6 = sInv[6],
                  i7 = sInv[7], i8 = sInv[8];
+    const float h0 = (float)i0, h1 = (float)i1, h2 = (float)i2, h3 = (float)i3, h4 = (float)i4, h5 = (float)i5, h6 = (float)i6,
+                h7 = (float)i7, h8 = (float)i8;
     // this thread's (j, k) column of the S^3 lattice; threads beyond S*S idle (S <= 16)
     const int j = tid / S, k = tid % S;
     const bool active = tid < S * S;
     unsigned idx[S];
     bool oob = false;
     if (active) {
+        const float fc0 = (float)ic0, fc1 = (float)ic1, fc2 = (float)ic2;
+        const float lim0 = (float)(F.nx - 1) - 1e-3f, lim1 = (float)(F.ny - 1) - 1e-3f, lim2 = (float)(F.nz - 1) - 1e-3f;
 #pragma unroll
         for (int i = 0; i < S; i++) {
             double l0, l1, l2;      // Descriptor.py:34-35
             if (oct == 0) { l0 = -2 * A.r + 1 + 2 * i; l1 = -2 * A.r + 1 + 2 * j; l2 = -2 * A.r + 1 + 2 * k; }
             else { l0 = -A.r + 0.5 + i; l1 = -A.r + 0.5 + j; l2 = -A.r + 0.5 + k; }
+            // float32 guess of the offset from the anchor voxel: |error| < 1e-5 voxel, so the nearest
+            // voxel is known unless the fraction is within 2e-4 of the 0.5 tie or the point is within
+            // 1e-3 of the grid edge; only then is the reference's float64 expression evaluated.
+            const float m0 = (float)l0, m1 = (float)l1, m2 = (float)l2;
+            const float a0 = m0 * h0 + m1 * h1 + m2 * h2, a1 = m0 * h3 + m1 * h4 + m2 * h5, a2 = m0 * h6 + m1 * h7 + m2 * h8;
+            const float fl0 = floorf(a0), fl1 = floorf(a1), fl2 = floorf(a2);
+            const float fr0 = a0 - fl0, fr1 = a1 - fl1, fr2 = a2 - fl2;
+            const float q0 = a0 + fc0, q1 = a1 + fc1, q2 = a2 + fc2;
+            const bool safe = fabsf(fr0 - 0.5f) > 2e-4f && fabsf(fr1 - 0.5f) > 2e-4f && fabsf(fr2 - 0.5f) > 2e-4f &&
+                              q0 > 1e-3f && q0 < lim0 && q1 > 1e-3f && q1 < lim1 && q2 > 1e-3f && q2 < lim2;
+            if (safe) {
+                const int n0 = ic0 + (int)fl0 + (fr0 > 0.5f ? 1 : 0), n1 = ic1 + (int)fl1 + (fr1 > 0.5f ? 1 : 0),
+                          n2 = ic2 + (int)fl2 + (fr2 > 0.5f ? 1 : 0);
+                idx[i] = (unsigned)(((size_t)n0 * F.ny + n1) * F.nz + n2);
+                continue;
+            }
             const double p0 = (l0 * i0 + l1 * i1 + l2 * i2) + c0;      // Descriptor.py:132-133
             const double p1 = (l0 * i3 + l1 * i4 + l2 * i5) + c1;
             const double p2 = (l0 * i6 + l1 * i7 + l2 * i8) + c2;
@@ -441,11 +530,11 @@ __global__ __launch_bounds__(DSC_THREADS) void k_describe(DescribeArgs A) {
                 idx[i] = 0;
                 continue;
             }
-            int a0 = min((int)floor(p0), F.nx - 2), a1 = min((int)floor(p1), F.ny - 2), a2 = min((int)floor(p2), F.nz - 2);
-            a0 = (p0 - (double)a0 <= 0.5) ? a0 : a0 + 1;
-            a1 = (p1 - (double)a1 <= 0.5) ? a1 : a1 + 1;
-            a2 = (p2 - (double)a2 <= 0.5) ? a2 : a2 + 1;
-            idx[i] = (unsigned)(((size_t)a0 * F.ny + a1) * F.nz + a2);
+            int a0i = min((int)floor(p0), F.nx - 2), a1i = min((int)floor(p1), F.ny - 2), a2i = min((int)floor(p2), F.nz - 2);
+            a0i = (p0 - (double)a0i <= 0.5) ? a0i : a0i + 1;
+            a1i = (p1 - (double)a1i <= 0.5) ? a1i : a1i + 1;
+            a2i = (p2 - (double)a2i <= 0.5) ? a2i : a2i + 1;
+            idx[i] = (unsigned)(((size_t)a0i * F.ny + a1i) * F.nz + a2i);
         }
     }
     if (oob) s_oob = 1;
@@ -458,27 +547,34 @@ __global__ __launch_bounds__(DSC_THREADS) void k_describe(DescribeArgs A) {
         float4 t[S];
 #pragma unroll
         for (int i = 0; i < S; i++) t[i] = F.tex[idx[i]];
-        const double r0 = sR[0], r1 = sR[1], r2 = sR[2], r3 = sR[3], r4 = sR[4], r5 = sR[5], r6 = sR[6], r7 = sR[7], r8 = sR[8];
+        const float f0 = sRf[0], f1 = sRf[1], f2 = sRf[2], f3 = sRf[3], f4 = sRf[4], f5 = sRf[5], f6 = sRf[6], f7 = sRf[7], f8 = sRf[8];
 #pragma unroll
         for (int i = 0; i < S; i++) {
             const float magn = t[i].w;
             if (magn < 1e-5f) continue;                                   // Descriptor.py:190 (zone -1)
-            float gx = t[i].x, gy = t[i].y, gz = t[i].z;
-            if (magn > 1e-12f) { gx = __fdiv_rn(gx, magn); gy = __fdiv_rn(gy, magn); gz = __fdiv_rn(gz, magn); }
-            const double g0 = gx, g1 = gy, g2 = gz;                       // Descriptor.py:155 g @ R.T
-            const double rx = g0 * r0 + g1 * r1 + g2 * r2;
-            const double ry = g0 * r3 + g1 * r4 + g2 * r5;
-            double rz = g0 * r6 + g1 * r7 + g2 * r8;
-            double th = atan2(ry, rx);
-            if (th < 0) th += MAD_TWO_PI;
-            const double sth = th + MAD_TWO_PI;
-            rz = rz > 1.0 ? 1.0 : (rz < -1.0 ? -1.0 : rz);
-            const double ph = acos(rz);
-            int zone = 0;                                                 // Descriptor.py:173 default, :187 last wins
-            eqsp_classify(A.eq, th, sth, ph, [&](int zn) { zone = zn; });
+            // fast path: approximate unit direction, rotated in float32 (a guess, verified with guard bands)
+            const float inv = __frcp_rn(magn);
+            const float gx = t[i].x * inv, gy = t[i].y * inv, gz = t[i].z * inv;
+            const float rx = gx * f0 + gy * f1 + gz * f2;
+            const float ry = gx * f3 + gy * f4 + gz * f5;
+            const float rz = gx * f6 + gy * f7 + gz * f8;
             const int sub = (j / q4) * 16 + (i / q4) * 4 + (k / q4);      // Descriptor.py:44-64
+            int zone = eqsp_fast32(&fast, rx, ry, rz);
+            if (zone < 0) {
+                const int slot = atomicAdd(&s_nq, 1);
+                if (slot < DSC_QUEUE) {      // decide later with the exact arithmetic, with full lanes
+                    qv[slot] = t[i]; qsub[slot] = sub;
+                    continue;
+                }
+                zone = describe_exact(A.eq, t[i], sR);      // queue full (not seen in practice)
+            }
             atomicAdd(&hist[sub * Z + zone], 1);
         }
+    }
+    __syncthreads();
+    {
+        const int nq = min(s_nq, DSC_QUEUE);
+        for (int qi = tid; qi < nq; qi += DSC_THREADS) atomicAdd(&hist[qsub[qi] * Z + describe_exact(A.eq, qv[qi], sR)], 1);
     }
     __syncthreads();
     for (int i = tid; i < D; i += DSC_THREADS) A.dsc[row * D + i] = (int16_t)hist[i];
@@ -501,11 +597,12 @@ int mad_describe_device(mad_ctx *ctx, FieldDev f0, FieldDev f1, const int32_t *d
     A.anc_coords = d_anc_coords; A.anc_octave = d_anc_octave; A.uniform_octave = uniform_octave;
     A.row_anchor = d_row_anchor; A.row_R = d_row_R; A.n_rows = n_rows; A.r = r; A.eq = ctx->eq[1]; A.dsc = d_dsc;
     mad_timer_begin(ctx, MAD_T_DESCRIBE);
+    const unsigned nblk = (unsigned)(((n_rows + 7) / 8) * 8);
     switch (2 * r) {
-        case 4: hipLaunchKernelGGL(k_describe<4>, dim3((unsigned)n_rows), dim3(DSC_THREADS), 0, ctx->stream, A); break;
-        case 8: hipLaunchKernelGGL(k_describe<8>, dim3((unsigned)n_rows), dim3(DSC_THREADS), 0, ctx->stream, A); break;
-        case 12: hipLaunchKernelGGL(k_describe<12>, dim3((unsigned)n_rows), dim3(DSC_THREADS), 0, ctx->stream, A); break;
-        default: hipLaunchKernelGGL(k_describe<16>, dim3((unsigned)n_rows), dim3(DSC_THREADS), 0, ctx->stream, A); break;
+        case 4: hipLaunchKernelGGL(k_describe<4>, dim3(nblk), dim3(DSC_THREADS), 0, ctx->stream, A); break;
+        case 8: hipLaunchKernelGGL(k_describe<8>, dim3(nblk), dim3(DSC_THREADS), 0, ctx->stream, A); break;
+        case 12: hipLaunchKernelGGL(k_describe<12>, dim3(nblk), dim3(DSC_THREADS), 0, ctx->stream, A); break;
+        default: hipLaunchKernelGGL(k_describe<16>, dim3(nblk), dim3(DSC_THREADS), 0, ctx->stream, A); break;
     }
     mad_timer_end(ctx, MAD_T_DESCRIBE);
     MAD_HIP(hipGetLastError());
