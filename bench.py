@@ -176,21 +176,21 @@ def build_inputs(lib, torch, W, rank):
 # the timed step
 # --------------------------------------------------------------------------------------------
 
-def hot_path_step(lib, the_map, subs, cc, dist, k):
-    """Returns (correlations, [top-k result rows per subunit], stats)."""
-    lo = lib.set_build(the_map.slots, the_map.coords, the_map.octave, the_map.subv, the_map.index)
-    n_lo, _ = lo.size()
+def hot_path_step(lib, the_map, subs, cc, dist, k, sets):
+    """Returns (correlations, [top-k result rows per subunit], stats).  Everything is enqueued
+    asynchronously; the only host round trip is the result read-back that ends each match.
+    `sets` holds the device-resident row sets, rebuilt in place every step."""
+    lo = lib.set_build(the_map.slots, the_map.coords, the_map.octave, the_map.subv, the_map.index, into=sets[0])
+    his = [lib.set_build(s.slots, s.coords, s.octave, s.subv, s.index, into=d) for s, d in zip(subs, sets[1:])]
     corr, tops, stats = 0, [], []
-    for s in subs:
-        hi = lib.set_build(s.slots, s.coords, s.octave, s.subv, s.index)
-        n_hi, _ = hi.size()
+    for hi in his:
         top, idx, st = lib.match_topk(hi, lo, cc, dist, k)
-        corr += n_hi * n_lo
-        st["n_hi"], st["n_lo"] = n_hi, n_lo
+        corr += st["n_corr"]
         tops.append(top)
         stats.append(st)
-        hi.close()
-    lo.close()
+    for hi, st in zip(his, stats):
+        st["n_hi"], _ = hi.size()
+        st["n_lo"] = st["n_corr"] // max(st["n_hi"], 1)
     return corr, tops, stats
 
 
@@ -288,15 +288,16 @@ def main():
         from mad_amd import dist as mdist
         return mdist.all_gather_topk(tops, k, world * W["n_sub"], rank, world)
 
+    sets = [_lib.DeviceSet(lib) for _ in range(1 + len(subs))]
     for _ in range(args.warmup):
-        corr, tops, stats = hot_path_step(lib, the_map, subs, cc, dist_thr, k)
+        corr, tops, stats = hot_path_step(lib, the_map, subs, cc, dist_thr, k, sets)
         exchange(tops)
     lib.timing_enable(True)
     lib.timing_reset()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        corr, tops, stats = hot_path_step(lib, the_map, subs, cc, dist_thr, k)
+        corr, tops, stats = hot_path_step(lib, the_map, subs, cc, dist_thr, k, sets)
         gathered = exchange(tops)
     barrier()
     dt = time.perf_counter() - t0

@@ -249,8 +249,10 @@ class Lib(object):
         return order[:k]
 
     # -- device-resident pipeline -------------------------------------------------------
-    def set_build(self, slots, anc_coords, anc_octave, anc_subv, anc_index, r=8, lim_main=6, lim_sec=6):
-        s = DeviceSet(self)
+    def set_build(self, slots, anc_coords, anc_octave, anc_subv, anc_index, r=8, lim_main=6, lim_sec=6, into=None):
+        """Orient + describe the anchors into a device-resident set.  Asynchronous; pass `into` to rebuild an
+        existing set in place (its device buffers are reused)."""
+        s = into if into is not None else DeviceSet(self)
         slots = (C.c_int * 2)(int(slots[0]), int(slots[1]))
         anc_coords = _c(anc_coords, np.int32).reshape(-1, 3)
         anc_octave = _c(anc_octave, np.int32)

@@ -90,10 +90,12 @@ struct DensityDev {
     double vs = 0;
 };
 
-struct MatchState {            // buffers of the most recent mad_match_topk call
+struct MatchState {            // the most recent mad_match_topk call
     int64_t n_pairs = 0;
     int32_t l_hi = 0, l_lo = 0;
     int32_t n_hi_anchors = 0, n_lo_anchors = 0;
+    int64_t cap_c = 0;         // capacity hints carried from call to call (elements of the int32 score matrix,
+    int64_t cap_pairs = 0;     // number of pairs); the device raises a flag when one is too small
 };
 
 struct mad_ctx {
@@ -111,7 +113,8 @@ struct mad_ctx {
     // named grow-only scratch buffers
     DevBuf scratch[64];
     // host pinned staging for small read-backs
-    int64_t *pinned = nullptr;
+    int64_t *pinned = nullptr;     // 512 slots: [0..15] scratch read-backs, [16..] one per mad_set
+    int next_pinned = 16;
     DensityDev dens;
     MatchState match;
     bool timing = false;
@@ -121,14 +124,21 @@ struct mad_ctx {
 
 struct mad_set {
     int32_t n_anchors = 0;
-    int64_t n_rows = 0;
-    int64_t n_rows_pad = 0;      // rows rounded up to the GEMM tile
+    int64_t cap_rows = 0;        // capacity of the row buffers (rows are produced on the device; see dev_n)
     int D = 0;
     // per anchor
     DevBuf anc_coords, anc_octave, anc_subv, anc_index;
     // per row
-    DevBuf row_anchor, row_main, row_sec, row_R, dsc, dsc8, norm;
-    // cell list over ALL anchors of the set (used when the set is the map side)
+    DevBuf row_anchor, row_main, row_sec, row_R, row_Rinv, row_meta, dsc, dsc8, norm;
+    DevBuf dev_n;                // int32[4] on the device: [0] = number of rows
+    int64_t n_rows_host = -1;    // host copy of dev_n[0]; -1 until the asynchronous read-back has been waited for
+    int64_t rows_hint = 0;       // row count of the previous build of this set (sizes the describe launch)
+    // what mad_set_build needs to repeat the describe stage when the hint was too small
+    FieldDev last_f[2];
+    int last_r = 0;
+    int pinned_slot = 0;
+    hipEvent_t ready = nullptr;  // recorded behind the read-back of dev_n
+    // cell list over ALL anchors (cell = dist), only built when a cloud does not fit LDS
     DevBuf cell_start, cell_pts, cell_ids;
     double cell_min[3] = {0, 0, 0};
     double bb_min[3] = {0, 0, 0}, bb_max[3] = {0, 0, 0};      // bounding box of all anchors
@@ -160,14 +170,23 @@ void mad_timer_end(mad_ctx *ctx, int group);
 // exclusive prefix sum of n int32 on the ctx stream; out[n] receives the total (out has n+1 entries)
 int mad_scan_i32(mad_ctx *ctx, const int32_t *in, int32_t *out, int64_t n);
 
-// implemented in mad_orient.hip; used by the set API in mad_match.hip
+// single-launch exclusive scan for n <= 65536 with the length read on the device; out[*n] = total, also to *total_out
+void mad_scan_small(mad_ctx *ctx, const int32_t *in, int32_t *out, const int32_t *d_n, int32_t *total_out);
+
+// implemented in mad_orient.hip; used by the set API in mad_match.hip.  Both are fully asynchronous.
+struct OrientOut {
+    int32_t *row_anchor, *row_main, *row_sec;
+    double *row_R;
+    int32_t *row_count;      // nullable: Z quantised counts per row
+    int32_t *d_n_rows;       // device: number of rows produced
+    int32_t *d_n_reject;     // device, nullable: anchors refused at the border
+};
 int mad_orient_device(mad_ctx *ctx, FieldDev f0, FieldDev f1, const int32_t *d_coords, const int32_t *d_octave,
-                      int uniform_octave, int n, int r, int lim_main, int lim_sec, bool want_hist,
-                      int64_t *n_rows_out, int32_t *n_reject_out);
+                      int uniform_octave, int n, int r, int lim_main, int lim_sec, OrientOut out);
 int mad_describe_device(mad_ctx *ctx, FieldDev f0, FieldDev f1, const int32_t *d_anc_coords, const int32_t *d_anc_octave,
-                        int uniform_octave, const int32_t *d_row_anchor, const double *d_row_R, int64_t n_rows,
-                        int r, int16_t *d_dsc);
-int mad_build_cells(mad_ctx *ctx, mad_set *set, const double *h_subv, double cell);
+                        int uniform_octave, const int32_t *d_row_anchor, const double *d_row_R, const int32_t *d_n_rows,
+                        int64_t grid_rows, int32_t *d_overflow, int r, int16_t *d_dsc);
+int mad_build_cells(mad_ctx *ctx, mad_set *set, double cell);
 
 #define MAD_HIP(call)                                                                            \
     do {                                                                                         \

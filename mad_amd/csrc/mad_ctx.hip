@@ -68,7 +68,7 @@ extern "C" int mad_init(int device, mad_ctx **out) {
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
         hipMalloc((void **)&ctx->eq[0], sizeof(EqspDev)) != hipSuccess ||
         hipMalloc((void **)&ctx->eq[1], sizeof(EqspDev)) != hipSuccess ||
-        hipHostMalloc((void **)&ctx->pinned, 4096) != hipSuccess) {
+        hipHostMalloc((void **)&ctx->pinned, 8192) != hipSuccess) {
         mad_fail(nullptr, MAD_EHIP, "mad_init: stream / table allocation failed");
         delete ctx;
         return MAD_EHIP;
@@ -400,4 +400,32 @@ int mad_scan_i32(mad_ctx *ctx, const int32_t *in, int32_t *out, int64_t n) {
     hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, ctx->stream, in, out, n, sums, nb);
     MAD_HIP(hipGetLastError());
     return MAD_OK;
+}
+
+// one workgroup, length on the device: the launch-cheap form for the short scans of the pipeline
+__global__ __launch_bounds__(1024) void k_scan_small(const int32_t *__restrict__ in, int32_t *__restrict__ out,
+                                                     const int32_t *__restrict__ d_n, int32_t *__restrict__ total_out) {
+    __shared__ int wt[1024 / MAD_WAVE + 1];
+    __shared__ int carry;
+    const int n = *d_n;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + threadIdx.x;
+        const int v = (i < n) ? in[i] : 0;
+        int tot;
+        const int ex = block_excl_scan(v, wt, &tot);
+        if (i < n) out[i] = carry + ex;
+        __syncthreads();
+        if (threadIdx.x == 0) carry += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        out[n] = carry;
+        if (total_out) *total_out = carry;
+    }
+}
+
+void mad_scan_small(mad_ctx *ctx, const int32_t *in, int32_t *out, const int32_t *d_n, int32_t *total_out) {
+    hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(1024), 0, ctx->stream, in, out, d_n, total_out);
 }

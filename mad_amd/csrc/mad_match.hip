@@ -7,36 +7,86 @@
 //              int32 accumulation; score = dot / (|h| |l|) in float64.
 //  pairs     : per hi row, ordered compaction of the columns whose score exceeds cc
 //              (row-major order of np.where, MaD.py:423).
-//  pose      : one wavefront per pair; the used hi anchors sit in LDS, the lo anchors
-//              in a uniform cell list (cell = dist) so that "nearest lo anchor closer
-//              than dist" needs 9 contiguous cell runs instead of a k-d tree.
+//  pose      : one wavefront per pair; the used hi anchors, the used lo anchors (binned into
+//              cells of edge > 2 dist) and the cell offsets all sit in LDS.
 //  top-k     : histogram of the integer match counts -> threshold count -> ordered
 //              pick of the ties -> one-workgroup bitonic sort of the k survivors.
+//
+// The whole match is enqueued without a host round trip: row counts, pair counts and cloud
+// sizes stay on the device (kernels read them through pointers and are persistent / grid-
+// stride), buffers are sized from capacity hints, and the device raises a flag when a hint
+// was too small -- the host then grows the buffer and re-runs (only ever on a first call).
 #include "mad_common.h"
 
+// status words of one match, on the device (int32)
+// [ST_NHI .. +3] and [ST_NLO .. +3] mirror the two sets' dev_n words {rows, range flag, border rejects, describe overflow}
+enum { ST_NPAIRS = 0, ST_LHI, ST_LLO, ST_NKEYS, ST_FLAG_C, ST_FLAG_PAIRS, ST_BAD, ST_PAD, ST_NHI = 8, ST_NLO = 12, ST_COUNT = 16 };
+
 // ---------------------------------------------------------------------------
-// int16 -> int8 packing + row norms
+// per-row auxiliaries: int8 rows + norms, inverse rotations, result-row meta
 // ---------------------------------------------------------------------------
 
-// one wave per row: int8 copy, sqrt of the exact integer sum of squares, range check
-__global__ __launch_bounds__(256) void k_pack_rows(const int16_t *__restrict__ src, int64_t n_rows, int D,
+// one wave per row: int8 copy, sqrt of the exact integer sum of squares, range check;
+// rows in [n, roundup(n, 128)) are zero-filled so that the GEMM may read whole tiles
+__global__ __launch_bounds__(256) void k_pack_rows(const int16_t *__restrict__ src, const int32_t *__restrict__ n_ptr, int D,
                                                    int8_t *__restrict__ dst, double *__restrict__ norm,
                                                    int32_t *__restrict__ bad) {
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= n_rows) return;
+    const int64_t n = *n_ptr;
+    const int64_t n_pad = (n + 127) / 128 * 128;
     const int lane = lane_id();
-    long long ss = 0;
-    int oob = 0;
-    for (int k = lane; k < D; k += MAD_WAVE) {
-        const int v = src[row * D + k];
-        if (v > 127 || v < -128) oob = 1;
-        dst[row * D + k] = (int8_t)v;
-        ss += (long long)v * v;
-    }
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (int64_t)gridDim.x * 4;
+    for (int64_t row = wave; row < n_pad; row += nw) {
+        if (row >= n) {
+            for (int k = lane; k < D; k += MAD_WAVE) dst[row * D + k] = 0;
+            if (lane == 0) norm[row] = 0.0;
+            continue;
+        }
+        long long ss = 0;
+        int oob = 0;
+        for (int k = lane; k < D; k += MAD_WAVE) {
+            const int v = src[row * D + k];
+            if (v > 127 || v < -128) oob = 1;
+            dst[row * D + k] = (int8_t)v;
+            ss += (long long)v * v;
+        }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, MAD_WAVE);
-    if (__any(oob) && lane == 0) atomicExch(bad, 1);
-    if (lane == 0) norm[row] = sqrt((double)ss);
+        for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, MAD_WAVE);
+        if (bad && __any(oob) && lane == 0) atomicExch(bad, 1);
+        if (lane == 0) norm[row] = sqrt((double)ss);
+    }
+}
+
+__device__ __forceinline__ void mat3_inv(const double *m, double *o) {      // cofactors (np.linalg.inv, MaD.py:438)
+    const double c00 = m[4] * m[8] - m[5] * m[7];
+    const double c01 = m[5] * m[6] - m[3] * m[8];
+    const double c02 = m[3] * m[7] - m[4] * m[6];
+    const double det = m[0] * c00 + m[1] * c01 + m[2] * c02;
+    const double id = 1.0 / det;
+    o[0] = c00 * id; o[1] = (m[2] * m[7] - m[1] * m[8]) * id; o[2] = (m[1] * m[5] - m[2] * m[4]) * id;
+    o[3] = c01 * id; o[4] = (m[0] * m[8] - m[2] * m[6]) * id; o[5] = (m[2] * m[3] - m[0] * m[5]) * id;
+    o[6] = c02 * id; o[7] = (m[1] * m[6] - m[0] * m[7]) * id; o[8] = (m[0] * m[4] - m[1] * m[3]) * id;
+}
+
+__device__ __forceinline__ void mat3_mul(const double *a, const double *b, double *o) {
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) o[3 * i + j] = a[3 * i] * b[j] + a[3 * i + 1] * b[3 + j] + a[3 * i + 2] * b[6 + j];
+}
+
+// inverse of every row's Rfinal; meta = {anchor index, octave, main bin} (MaD.py:451) when the set supplies them
+__global__ void k_row_aux(const double *__restrict__ row_R, const int32_t *__restrict__ n_ptr, double *__restrict__ row_Rinv,
+                          const int32_t *__restrict__ row_anchor, const int32_t *__restrict__ row_main,
+                          const int32_t *__restrict__ anc_index, const int32_t *__restrict__ anc_octave,
+                          int32_t *__restrict__ meta) {
+    const int64_t n = *n_ptr;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        mat3_inv(row_R + 9 * i, row_Rinv + 9 * i);
+        if (meta) {
+            const int a = row_anchor[i];
+            meta[3 * i] = anc_index[a]; meta[3 * i + 1] = anc_octave[a]; meta[3 * i + 2] = row_main[i];
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -51,65 +101,77 @@ __global__ __launch_bounds__(256) void k_pack_rows(const int16_t *__restrict__ s
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 
+// persistent over 128 x 128 tiles; the row counts (hence the tile grid and ldc) are read on the device
 __global__ __launch_bounds__(GEMM_THREADS) void k_corr_gemm(const int8_t *__restrict__ A, const int8_t *__restrict__ B,
-                                                            int K, int32_t *__restrict__ C, int64_t ldc) {
+                                                            int K, int32_t *__restrict__ C, const int32_t *__restrict__ n_hi_ptr,
+                                                            const int32_t *__restrict__ n_lo_ptr, int64_t cap_c,
+                                                            int32_t *__restrict__ status) {
     __shared__ __align__(16) int8_t sA[GEMM_BM * GEMM_LDA];
     __shared__ __align__(16) int8_t sB[GEMM_BN * GEMM_LDA];
+    const int64_t hp = ((int64_t)*n_hi_ptr + GEMM_BM - 1) / GEMM_BM * GEMM_BM;
+    const int64_t lp = ((int64_t)*n_lo_ptr + GEMM_BN - 1) / GEMM_BN * GEMM_BN;
+    if (hp * lp > cap_c) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) status[ST_FLAG_C] = 1;
+        return;
+    }
+    const int64_t tiles_n = lp / GEMM_BN, tiles = (hp / GEMM_BM) * tiles_n;
     const int tid = threadIdx.x;
     const int lane = tid & 63, w = tid >> 6;
     const int wm = w >> 1, wn = w & 1;
-    const int64_t row0 = (int64_t)blockIdx.y * GEMM_BM, col0 = (int64_t)blockIdx.x * GEMM_BN;
-    v4i acc[4][4];
+    for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+        const int64_t row0 = (t / tiles_n) * GEMM_BM, col0 = (t % tiles_n) * GEMM_BN;
+        v4i acc[4][4];
 #pragma unroll
-    for (int m = 0; m < 4; m++)
+        for (int m = 0; m < 4; m++)
 #pragma unroll
-        for (int n = 0; n < 4; n++) acc[m][n] = (v4i){0, 0, 0, 0};
-
-    for (int k0 = 0; k0 < K; k0 += GEMM_BK) {
-        // stage 128 rows x 128 B of each operand: 1024 16-byte chunks per operand, 4 per thread
-        v4i ra[4], rb[4];
+            for (int n = 0; n < 4; n++) acc[m][n] = (v4i){0, 0, 0, 0};
+        for (int k0 = 0; k0 < K; k0 += GEMM_BK) {
+            // stage 128 rows x 128 B of each operand: 1024 16-byte chunks per operand, 4 per thread
+            v4i ra[4], rb[4];
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int c = tid + GEMM_THREADS * i;
-            const int r = c >> 3, q = c & 7;
-            ra[i] = *(const v4i *)(A + (row0 + r) * K + k0 + q * 16);
-            rb[i] = *(const v4i *)(B + (col0 + r) * K + k0 + q * 16);
-        }
-        __syncthreads();      // previous stage fully consumed
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int c = tid + GEMM_THREADS * i;
-            const int r = c >> 3, q = c & 7;
-            *(v4i *)(sA + r * GEMM_LDA + q * 16) = ra[i];
-            *(v4i *)(sB + r * GEMM_LDA + q * 16) = rb[i];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int kk = 0; kk < GEMM_BK / 64; kk++) {
-            v4i fa[4], fb[4];
-            const int koff = kk * 64 + (lane >> 4) * 16;
-#pragma unroll
-            for (int m = 0; m < 4; m++) fa[m] = *(const v4i *)(sA + (wm * 64 + m * 16 + (lane & 15)) * GEMM_LDA + koff);
-#pragma unroll
-            for (int n = 0; n < 4; n++) fb[n] = *(const v4i *)(sB + (wn * 64 + n * 16 + (lane & 15)) * GEMM_LDA + koff);
-#pragma unroll
-            for (int m = 0; m < 4; m++)
-#pragma unroll
-                for (int n = 0; n < 4; n++)
-                    acc[m][n] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[m], fb[n], acc[m][n], 0, 0, 0);
-        }
-    }
-    // C/D layout of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg
-#pragma unroll
-    for (int m = 0; m < 4; m++)
-#pragma unroll
-        for (int n = 0; n < 4; n++)
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int64_t r = row0 + wm * 64 + m * 16 + (lane >> 4) * 4 + j;
-                const int64_t c = col0 + wn * 64 + n * 16 + (lane & 15);
-                C[r * ldc + c] = acc[m][n][j];
+            for (int i = 0; i < 4; i++) {
+                const int c = tid + GEMM_THREADS * i;
+                const int r = c >> 3, q = c & 7;
+                ra[i] = *(const v4i *)(A + (row0 + r) * K + k0 + q * 16);
+                rb[i] = *(const v4i *)(B + (col0 + r) * K + k0 + q * 16);
             }
+            __syncthreads();      // previous stage fully consumed
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int c = tid + GEMM_THREADS * i;
+                const int r = c >> 3, q = c & 7;
+                *(v4i *)(sA + r * GEMM_LDA + q * 16) = ra[i];
+                *(v4i *)(sB + r * GEMM_LDA + q * 16) = rb[i];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int kk = 0; kk < GEMM_BK / 64; kk++) {
+                v4i fa[4], fb[4];
+                const int koff = kk * 64 + (lane >> 4) * 16;
+#pragma unroll
+                for (int m = 0; m < 4; m++) fa[m] = *(const v4i *)(sA + (wm * 64 + m * 16 + (lane & 15)) * GEMM_LDA + koff);
+#pragma unroll
+                for (int n = 0; n < 4; n++) fb[n] = *(const v4i *)(sB + (wn * 64 + n * 16 + (lane & 15)) * GEMM_LDA + koff);
+#pragma unroll
+                for (int m = 0; m < 4; m++)
+#pragma unroll
+                    for (int n = 0; n < 4; n++)
+                        acc[m][n] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[m], fb[n], acc[m][n], 0, 0, 0);
+            }
+        }
+        // C/D layout of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg
+#pragma unroll
+        for (int m = 0; m < 4; m++)
+#pragma unroll
+            for (int n = 0; n < 4; n++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int64_t r = row0 + wm * 64 + m * 16 + (lane >> 4) * 4 + j;
+                    const int64_t c = col0 + wn * 64 + n * 16 + (lane & 15);
+                    C[r * lp + c] = acc[m][n][j];
+                }
+        __syncthreads();
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -121,68 +183,73 @@ __device__ __forceinline__ double corr_score(int dot, double nh, double nl) {
     return (double)dot / ((nh > 0 ? nh : 1.0) * (nl > 0 ? nl : 1.0));
 }
 
-__global__ __launch_bounds__(256) void k_pair_count(const int32_t *__restrict__ C, int64_t ldc, int64_t n_hi, int64_t n_lo,
-                                                    const double *__restrict__ hn, const double *__restrict__ ln, double cc,
-                                                    int32_t *__restrict__ row_cnt) {
+__global__ __launch_bounds__(256) void k_pair_count(const int32_t *__restrict__ C, const int32_t *__restrict__ n_hi_ptr,
+                                                    const int32_t *__restrict__ n_lo_ptr, const double *__restrict__ hn,
+                                                    const double *__restrict__ ln, double cc, int32_t *__restrict__ row_cnt,
+                                                    const int32_t *__restrict__ status) {
     __shared__ int wt[4];
-    const int64_t i = blockIdx.x;
-    const double nh = hn[i];
-    int c = 0;
-    for (int64_t j = threadIdx.x; j < n_lo; j += 256) c += corr_score(C[i * ldc + j], nh, ln[j]) > cc ? 1 : 0;
-    c = wave_sum_i32(c);
-    if (lane_id() == 0) wt[threadIdx.x >> 6] = c;
-    __syncthreads();
-    if (threadIdx.x == 0) row_cnt[i] = wt[0] + wt[1] + wt[2] + wt[3];
+    if (status[ST_FLAG_C]) return;
+    const int64_t n_hi = *n_hi_ptr, n_lo = *n_lo_ptr;
+    const int64_t ldc = (n_lo + GEMM_BN - 1) / GEMM_BN * GEMM_BN;
+    for (int64_t i = blockIdx.x; i < n_hi; i += gridDim.x) {
+        const double nh = hn[i];
+        int c = 0;
+        for (int64_t j = threadIdx.x; j < n_lo; j += 256) c += corr_score(C[i * ldc + j], nh, ln[j]) > cc ? 1 : 0;
+        c = wave_sum_i32(c);
+        __syncthreads();
+        if (lane_id() == 0) wt[threadIdx.x >> 6] = c;
+        __syncthreads();
+        if (threadIdx.x == 0) row_cnt[i] = wt[0] + wt[1] + wt[2] + wt[3];
+    }
 }
 
-__global__ __launch_bounds__(256) void k_pair_emit(const int32_t *__restrict__ C, int64_t ldc, int64_t n_hi, int64_t n_lo,
-                                                   const double *__restrict__ hn, const double *__restrict__ ln, double cc,
-                                                   const int32_t *__restrict__ row_off, int32_t *__restrict__ pair_hi,
-                                                   int32_t *__restrict__ pair_lo, double *__restrict__ pair_score,
-                                                   const int32_t *__restrict__ hi_row_anchor,
-                                                   const int32_t *__restrict__ lo_row_anchor,
-                                                   uint8_t *__restrict__ used_hi, uint8_t *__restrict__ used_lo) {
+__global__ __launch_bounds__(256) void k_pair_emit(const int32_t *__restrict__ C, const int32_t *__restrict__ n_hi_ptr,
+                                                   const int32_t *__restrict__ n_lo_ptr, const double *__restrict__ hn,
+                                                   const double *__restrict__ ln, double cc, const int32_t *__restrict__ row_off,
+                                                   int64_t cap_pairs, int32_t *__restrict__ pair_hi, int32_t *__restrict__ pair_lo,
+                                                   double *__restrict__ pair_score, const int32_t *__restrict__ hi_row_anchor,
+                                                   const int32_t *__restrict__ lo_row_anchor, uint8_t *__restrict__ used_hi,
+                                                   uint8_t *__restrict__ used_lo, int32_t *__restrict__ status) {
     __shared__ int wt[5];
-    const int64_t i = blockIdx.x;
-    const double nh = hn[i];
-    int64_t base = row_off[i];
-    bool any = false;
-    for (int64_t j0 = 0; j0 < n_lo; j0 += 256) {
-        const int64_t j = j0 + threadIdx.x;
-        double s = 0;
-        bool p = false;
-        if (j < n_lo) {
-            s = corr_score(C[i * ldc + j], nh, ln[j]);
-            p = s > cc;
-        }
-        int tot;
-        const int pos = block_excl_scan(p ? 1 : 0, wt, &tot);
-        if (p) {
-            const int64_t o = base + pos;
-            pair_hi[o] = (int32_t)i;
-            pair_lo[o] = (int32_t)j;
-            pair_score[o] = s;
-            if (used_lo) used_lo[lo_row_anchor ? lo_row_anchor[j] : j] = 1;
-            any = true;
-        }
-        base += tot;
+    if (status[ST_FLAG_C]) return;
+    const int64_t n_hi = *n_hi_ptr, n_lo = *n_lo_ptr;
+    const int64_t ldc = (n_lo + GEMM_BN - 1) / GEMM_BN * GEMM_BN;
+    if (row_off[n_hi] > cap_pairs) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) status[ST_FLAG_PAIRS] = 1;
+        return;
     }
-    if (any && used_hi) used_hi[hi_row_anchor ? hi_row_anchor[i] : i] = 1;
+    for (int64_t i = blockIdx.x; i < n_hi; i += gridDim.x) {
+        const double nh = hn[i];
+        int64_t base = row_off[i];
+        if (row_off[i + 1] == base) continue;
+        bool any = false;
+        for (int64_t j0 = 0; j0 < n_lo; j0 += 256) {
+            const int64_t j = j0 + threadIdx.x;
+            double s = 0;
+            bool p = false;
+            if (j < n_lo) {
+                s = corr_score(C[i * ldc + j], nh, ln[j]);
+                p = s > cc;
+            }
+            int tot;
+            const int pos = block_excl_scan(p ? 1 : 0, wt, &tot);
+            if (p) {
+                const int64_t o = base + pos;
+                pair_hi[o] = (int32_t)i;
+                pair_lo[o] = (int32_t)j;
+                pair_score[o] = s;
+                if (used_lo) used_lo[lo_row_anchor ? lo_row_anchor[j] : j] = 1;
+                any = true;
+            }
+            base += tot;
+        }
+        if (any && used_hi) used_hi[hi_row_anchor ? hi_row_anchor[i] : i] = 1;
+    }
 }
 
 // ---------------------------------------------------------------------------
 // pose scoring
 // ---------------------------------------------------------------------------
-
-struct CellGrid {
-    const int32_t *start;      // ncell + 1 offsets into pts
-    const double *pts;         // sorted points, xyz
-    const int32_t *ids;        // sorted point -> anchor id
-    const uint8_t *used;       // per anchor: takes part in the lo cloud (or nullptr = all)
-    double mn[3];
-    double cell;
-    int dim[3];
-};
 
 // compact the used anchors' coordinates (order immaterial for the count)
 __global__ __launch_bounds__(1024) void k_compact_cloud(const double *__restrict__ subv, const uint8_t *__restrict__ used,
@@ -214,90 +281,13 @@ __global__ void k_count_flags(const uint8_t *__restrict__ used, int n, int32_t *
     if (lane_id() == 0 && s) atomicAdd(count, s);
 }
 
-#define POSE_THREADS 256
-
-// MaD.py:433-448.  One wave per pair, lanes over the hi cloud (held in LDS).
-__global__ __launch_bounds__(POSE_THREADS) void k_pose(const int32_t *__restrict__ pair_hi, const int32_t *__restrict__ pair_lo,
-                                                       int64_t n_pairs, const double *__restrict__ hi_p,
-                                                       const double *__restrict__ hi_R, const double *__restrict__ lo_p,
-                                                       const double *__restrict__ lo_R, const int32_t *__restrict__ hi_row_anchor,
-                                                       const int32_t *__restrict__ lo_row_anchor,
-                                                       const double *__restrict__ hi_cloud, const int32_t *__restrict__ l_hi_ptr,
-                                                       CellGrid G, double dist, int32_t *__restrict__ counts) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    double *cl = (double *)smem;
-    const int l_hi = *l_hi_ptr;
-    for (int i = threadIdx.x; i < 3 * l_hi; i += POSE_THREADS) cl[i] = hi_cloud[i];
-    __syncthreads();
-    const int lane = lane_id();
-    const int64_t wave = (int64_t)blockIdx.x * (POSE_THREADS / MAD_WAVE) + (threadIdx.x >> 6);
-    const int64_t nwaves = (int64_t)gridDim.x * (POSE_THREADS / MAD_WAVE);
-    const double inv_cell = 1.0 / G.cell;
-    for (int64_t p = wave; p < n_pairs; p += nwaves) {
-        const int ih = pair_hi[p], il = pair_lo[p];
-        // R = inv(lo.Rfinal) @ hi.Rfinal (MaD.py:438); every lane computes it (uniform values)
-        const double *m = lo_R + 9 * il;
-        const double *h = hi_R + 9 * ih;
-        const double c00 = m[4] * m[8] - m[5] * m[7];
-        const double c01 = m[5] * m[6] - m[3] * m[8];
-        const double c02 = m[3] * m[7] - m[4] * m[6];
-        const double det = m[0] * c00 + m[1] * c01 + m[2] * c02;
-        const double id = 1.0 / det;
-        double iv[9];
-        iv[0] = c00 * id; iv[1] = (m[2] * m[7] - m[1] * m[8]) * id; iv[2] = (m[1] * m[5] - m[2] * m[4]) * id;
-        iv[3] = c01 * id; iv[4] = (m[0] * m[8] - m[2] * m[6]) * id; iv[5] = (m[2] * m[3] - m[0] * m[5]) * id;
-        iv[6] = c02 * id; iv[7] = (m[1] * m[6] - m[0] * m[7]) * id; iv[8] = (m[0] * m[4] - m[1] * m[3]) * id;
-        double R[9];
-#pragma unroll
-        for (int i = 0; i < 3; i++)
-#pragma unroll
-            for (int j = 0; j < 3; j++) R[3 * i + j] = iv[3 * i] * h[j] + iv[3 * i + 1] * h[3 + j] + iv[3 * i + 2] * h[6 + j];
-        const int ah = hi_row_anchor ? hi_row_anchor[ih] : ih, al = lo_row_anchor ? lo_row_anchor[il] : il;
-        const double ph0 = hi_p[3 * ah], ph1 = hi_p[3 * ah + 1], ph2 = hi_p[3 * ah + 2];
-        const double pl0 = lo_p[3 * al], pl1 = lo_p[3 * al + 1], pl2 = lo_p[3 * al + 2];
-        int cnt = 0;
-        for (int a = lane; a < l_hi; a += MAD_WAVE) {
-            const double d0 = cl[3 * a] - ph0, d1 = cl[3 * a + 1] - ph1, d2 = cl[3 * a + 2] - ph2;
-            const double x = (d0 * R[0] + d1 * R[1] + d2 * R[2]) + pl0;      // MaD.py:440-444
-            const double y = (d0 * R[3] + d1 * R[4] + d2 * R[5]) + pl1;
-            const double z = (d0 * R[6] + d1 * R[7] + d2 * R[8]) + pl2;
-            const int cx = (int)floor((x - G.mn[0]) * inv_cell), cy = (int)floor((y - G.mn[1]) * inv_cell),
-                      cz = (int)floor((z - G.mn[2]) * inv_cell);
-            bool hit = false;
-            if (cx >= -1 && cx <= G.dim[0] && cy >= -1 && cy <= G.dim[1] && cz >= -1 && cz <= G.dim[2]) {
-                const int z0 = max(cz - 1, 0), z1 = min(cz + 1, G.dim[2] - 1);
-                if (z0 <= z1) {
-                    for (int ex = max(cx - 1, 0); ex <= min(cx + 1, G.dim[0] - 1) && !hit; ex++)
-                        for (int ey = max(cy - 1, 0); ey <= min(cy + 1, G.dim[1] - 1) && !hit; ey++) {
-                            const size_t col = ((size_t)ex * G.dim[1] + ey) * G.dim[2];
-                            const int s0 = G.start[col + z0], s1 = G.start[col + z1 + 1];
-                            for (int q = s0; q < s1; q++) {
-                                if (G.used && !G.used[G.ids[q]]) continue;
-                                const double e0 = G.pts[3 * q] - x, e1 = G.pts[3 * q + 1] - y, e2 = G.pts[3 * q + 2] - z;
-                                const double dd = e0 * e0 + e1 * e1 + e2 * e2;
-                                if (sqrt(dd) < dist) { hit = true; break; }      // MaD.py:447-448
-                            }
-                        }
-                }
-            }
-            cnt += hit ? 1 : 0;
-        }
-        cnt = wave_sum_i32(cnt);
-        if (lane == 0) counts[p] = cnt;
-    }
-}
-
-
-// ---- LDS-resident variant -----------------------------------------------------------------
-// The lo cloud of one match (the used map anchors, a few thousand points at most) is binned
-// into cells of edge >= 2 * dist, so the ball of radius dist around a query point meets at
-// most 2 cells per axis (<= 4 z-runs).  Cloud, cell offsets (uint16) and the hi cloud all sit
-// in LDS: a query costs LDS reads only.  Same predicate as k_pose, hence the same counts.
-#define POSE_LDS_THREADS 1024
-
+// The lo cloud of one match (the used map anchors, a few thousand points at most) is binned into
+// cells of edge > 2 * reach, so the ball around a query point meets at most 2 cells per axis
+// (<= 4 z-runs).  Cloud, cell offsets (uint16) and the hi cloud all sit in LDS.
 struct PoseGrid {
     double mn[3];
     double inv_cell[3];
+    float inv_cell_f[3];
     int dim[3];
     int ncell;
 };
@@ -348,20 +338,26 @@ __global__ __launch_bounds__(1024) void k_pose_grid_build(const double *__restri
         }
 }
 
+#define POSE_LDS_THREADS 1024
+
+// MaD.py:433-448.  One wave per pair, lanes over the hi cloud.  `dd_lim` is the smallest double whose
+// square root is >= dist, so dd < dd_lim is exactly the reference's sqrt(dd) < dist without the root.
 __global__ __launch_bounds__(POSE_LDS_THREADS) void k_pose_lds(const int32_t *__restrict__ pair_hi, const int32_t *__restrict__ pair_lo,
-                                                           int64_t n_pairs, const double *__restrict__ hi_p,
-                                                           const double *__restrict__ hi_R, const double *__restrict__ lo_p,
-                                                           const double *__restrict__ lo_R, const int32_t *__restrict__ hi_row_anchor,
-                                                           const int32_t *__restrict__ lo_row_anchor,
-                                                           const double *__restrict__ hi_cloud, const int32_t *__restrict__ l_hi_ptr,
-                                                           const double *__restrict__ lo_sorted, const int32_t *__restrict__ cell_start,
-                                                           PoseGrid G, int l_hi_cap, int l_lo_cap, double dist,
-                                                           int32_t *__restrict__ counts) {
+                                                               const int32_t *__restrict__ status, int64_t cap_pairs,
+                                                               const double *__restrict__ hi_p, const double *__restrict__ hi_R,
+                                                               const double *__restrict__ lo_p, const double *__restrict__ lo_Rinv,
+                                                               const int32_t *__restrict__ hi_row_anchor,
+                                                               const int32_t *__restrict__ lo_row_anchor,
+                                                               const double *__restrict__ hi_cloud, const double *__restrict__ lo_sorted,
+                                                               const int32_t *__restrict__ cell_start, PoseGrid G, int l_hi_cap,
+                                                               int l_lo_cap, float reach, double dd_lim, int32_t *__restrict__ counts) {
     extern __shared__ __align__(16) unsigned char smem[];
+    if (status[ST_FLAG_C] || status[ST_FLAG_PAIRS]) return;
     double *cl = (double *)smem;                                   // hi cloud
     double *lp = cl + 3 * (size_t)l_hi_cap;                        // sorted lo cloud
     unsigned short *cs = (unsigned short *)(lp + 3 * (size_t)l_lo_cap);      // cell offsets
-    const int l_hi = *l_hi_ptr;
+    const int64_t n_pairs = min((int64_t)status[ST_NPAIRS], cap_pairs);
+    const int l_hi = status[ST_LHI];
     const int l_lo = cell_start[G.ncell];
     for (int i = threadIdx.x; i < 3 * l_hi; i += POSE_LDS_THREADS) cl[i] = hi_cloud[i];
     for (int i = threadIdx.x; i < 3 * l_lo; i += POSE_LDS_THREADS) lp[i] = lo_sorted[i];
@@ -370,37 +366,25 @@ __global__ __launch_bounds__(POSE_LDS_THREADS) void k_pose_lds(const int32_t *__
     const int lane = lane_id();
     const int64_t wave = (int64_t)blockIdx.x * (POSE_LDS_THREADS / MAD_WAVE) + (threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * (POSE_LDS_THREADS / MAD_WAVE);
+    const float mnx = (float)G.mn[0], mny = (float)G.mn[1], mnz = (float)G.mn[2];
     for (int64_t p = wave; p < n_pairs; p += nwaves) {
         const int ih = pair_hi[p], il = pair_lo[p];
-        const double *m = lo_R + 9 * il;
-        const double *h = hi_R + 9 * ih;
-        const double c00 = m[4] * m[8] - m[5] * m[7];
-        const double c01 = m[5] * m[6] - m[3] * m[8];
-        const double c02 = m[3] * m[7] - m[4] * m[6];
-        const double det = m[0] * c00 + m[1] * c01 + m[2] * c02;
-        const double id = 1.0 / det;
-        double iv[9];
-        iv[0] = c00 * id; iv[1] = (m[2] * m[7] - m[1] * m[8]) * id; iv[2] = (m[1] * m[5] - m[2] * m[4]) * id;
-        iv[3] = c01 * id; iv[4] = (m[0] * m[8] - m[2] * m[6]) * id; iv[5] = (m[2] * m[3] - m[0] * m[5]) * id;
-        iv[6] = c02 * id; iv[7] = (m[1] * m[6] - m[0] * m[7]) * id; iv[8] = (m[0] * m[4] - m[1] * m[3]) * id;
-        double R[9];
-#pragma unroll
-        for (int i = 0; i < 3; i++)
-#pragma unroll
-            for (int j = 0; j < 3; j++) R[3 * i + j] = iv[3 * i] * h[j] + iv[3 * i + 1] * h[3 + j] + iv[3 * i + 2] * h[6 + j];
+        double R[9];      // R = inv(lo.Rfinal) @ hi.Rfinal (MaD.py:438)
+        mat3_mul(lo_Rinv + 9 * il, hi_R + 9 * ih, R);
         const int ah = hi_row_anchor ? hi_row_anchor[ih] : ih, al = lo_row_anchor ? lo_row_anchor[il] : il;
         const double ph0 = hi_p[3 * ah], ph1 = hi_p[3 * ah + 1], ph2 = hi_p[3 * ah + 2];
         const double pl0 = lo_p[3 * al], pl1 = lo_p[3 * al + 1], pl2 = lo_p[3 * al + 2];
         int cnt = 0;
         for (int a = lane; a < l_hi; a += MAD_WAVE) {
             const double d0 = cl[3 * a] - ph0, d1 = cl[3 * a + 1] - ph1, d2 = cl[3 * a + 2] - ph2;
-            const double x = (d0 * R[0] + d1 * R[1] + d2 * R[2]) + pl0;
+            const double x = (d0 * R[0] + d1 * R[1] + d2 * R[2]) + pl0;      // MaD.py:440-444
             const double y = (d0 * R[3] + d1 * R[4] + d2 * R[5]) + pl1;
             const double z = (d0 * R[6] + d1 * R[7] + d2 * R[8]) + pl2;
-            // cells met by the ball of radius dist (monotone in the coordinate, so no neighbour is missed)
-            const int x0 = (int)floor(((x - dist) - G.mn[0]) * G.inv_cell[0]), x1 = (int)floor(((x + dist) - G.mn[0]) * G.inv_cell[0]);
-            const int y0 = (int)floor(((y - dist) - G.mn[1]) * G.inv_cell[1]), y1 = (int)floor(((y + dist) - G.mn[1]) * G.inv_cell[1]);
-            const int z0 = (int)floor(((z - dist) - G.mn[2]) * G.inv_cell[2]), z1 = (int)floor(((z + dist) - G.mn[2]) * G.inv_cell[2]);
+            // cells met by a slightly larger ball (reach = dist + 0.01), in float32: a superset is harmless
+            const float xf = (float)x - mnx, yf = (float)y - mny, zf = (float)z - mnz;
+            const int x0 = (int)floorf((xf - reach) * G.inv_cell_f[0]), x1 = (int)floorf((xf + reach) * G.inv_cell_f[0]);
+            const int y0 = (int)floorf((yf - reach) * G.inv_cell_f[1]), y1 = (int)floorf((yf + reach) * G.inv_cell_f[1]);
+            const int z0 = (int)floorf((zf - reach) * G.inv_cell_f[2]), z1 = (int)floorf((zf + reach) * G.inv_cell_f[2]);
             bool hit = false;
             if (x1 >= 0 && x0 < G.dim[0] && y1 >= 0 && y0 < G.dim[1] && z1 >= 0 && z0 < G.dim[2]) {
                 const int zz0 = max(z0, 0), zz1 = min(z1, G.dim[2] - 1) + 1;
@@ -417,8 +401,7 @@ __global__ __launch_bounds__(POSE_LDS_THREADS) void k_pose_lds(const int32_t *__
                 for (int c = 0; c < 4; c++)
                     for (int q = s[c]; q < e[c] && !hit; q++) {
                         const double e0 = lp[3 * q] - x, e1 = lp[3 * q + 1] - y, e2 = lp[3 * q + 2] - z;
-                        const double dd = e0 * e0 + e1 * e1 + e2 * e2;
-                        hit = sqrt(dd) < dist;
+                        hit = (e0 * e0 + e1 * e1 + e2 * e2) < dd_lim;      // MaD.py:447-448
                     }
             }
             cnt += hit ? 1 : 0;
@@ -428,89 +411,186 @@ __global__ __launch_bounds__(POSE_LDS_THREADS) void k_pose_lds(const int32_t *__
     }
 }
 
+// ---- fallback for clouds that do not fit LDS: uniform cell list (cell = dist) in global memory -------------
+
+struct CellGrid {
+    const int32_t *start;      // ncell + 1 offsets into pts
+    const double *pts;         // sorted points, xyz
+    const int32_t *ids;        // sorted point -> index in the unsorted array
+    const uint8_t *used;       // per point: takes part in the lo cloud (or nullptr = all)
+    double mn[3];
+    double cell;
+    int dim[3];
+};
+
+#define POSE_THREADS 256
+
+__global__ __launch_bounds__(POSE_THREADS) void k_pose(const int32_t *__restrict__ pair_hi, const int32_t *__restrict__ pair_lo,
+                                                       const int32_t *__restrict__ status, int64_t cap_pairs,
+                                                       const double *__restrict__ hi_p, const double *__restrict__ hi_R,
+                                                       const double *__restrict__ lo_p, const double *__restrict__ lo_Rinv,
+                                                       const int32_t *__restrict__ hi_row_anchor,
+                                                       const int32_t *__restrict__ lo_row_anchor,
+                                                       const double *__restrict__ hi_cloud, CellGrid G, double dd_lim,
+                                                       int32_t *__restrict__ counts) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    if (status[ST_FLAG_C] || status[ST_FLAG_PAIRS]) return;
+    double *cl = (double *)smem;
+    const int64_t n_pairs = min((int64_t)status[ST_NPAIRS], cap_pairs);
+    const int l_hi = status[ST_LHI];
+    for (int i = threadIdx.x; i < 3 * l_hi; i += POSE_THREADS) cl[i] = hi_cloud[i];
+    __syncthreads();
+    const int lane = lane_id();
+    const int64_t wave = (int64_t)blockIdx.x * (POSE_THREADS / MAD_WAVE) + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * (POSE_THREADS / MAD_WAVE);
+    const double inv_cell = 1.0 / G.cell;
+    for (int64_t p = wave; p < n_pairs; p += nwaves) {
+        const int ih = pair_hi[p], il = pair_lo[p];
+        double R[9];
+        mat3_mul(lo_Rinv + 9 * il, hi_R + 9 * ih, R);
+        const int ah = hi_row_anchor ? hi_row_anchor[ih] : ih, al = lo_row_anchor ? lo_row_anchor[il] : il;
+        const double ph0 = hi_p[3 * ah], ph1 = hi_p[3 * ah + 1], ph2 = hi_p[3 * ah + 2];
+        const double pl0 = lo_p[3 * al], pl1 = lo_p[3 * al + 1], pl2 = lo_p[3 * al + 2];
+        int cnt = 0;
+        for (int a = lane; a < l_hi; a += MAD_WAVE) {
+            const double d0 = cl[3 * a] - ph0, d1 = cl[3 * a + 1] - ph1, d2 = cl[3 * a + 2] - ph2;
+            const double x = (d0 * R[0] + d1 * R[1] + d2 * R[2]) + pl0;
+            const double y = (d0 * R[3] + d1 * R[4] + d2 * R[5]) + pl1;
+            const double z = (d0 * R[6] + d1 * R[7] + d2 * R[8]) + pl2;
+            const int cx = (int)floor((x - G.mn[0]) * inv_cell), cy = (int)floor((y - G.mn[1]) * inv_cell),
+                      cz = (int)floor((z - G.mn[2]) * inv_cell);
+            bool hit = false;
+            if (cx >= -1 && cx <= G.dim[0] && cy >= -1 && cy <= G.dim[1] && cz >= -1 && cz <= G.dim[2]) {
+                const int z0 = max(cz - 1, 0), z1 = min(cz + 1, G.dim[2] - 1);
+                if (z0 <= z1) {
+                    for (int ex = max(cx - 1, 0); ex <= min(cx + 1, G.dim[0] - 1) && !hit; ex++)
+                        for (int ey = max(cy - 1, 0); ey <= min(cy + 1, G.dim[1] - 1) && !hit; ey++) {
+                            const size_t col = ((size_t)ex * G.dim[1] + ey) * G.dim[2];
+                            const int s0 = G.start[col + z0], s1 = G.start[col + z1 + 1];
+                            for (int q = s0; q < s1; q++) {
+                                if (G.used && !G.used[G.ids[q]]) continue;
+                                const double e0 = G.pts[3 * q] - x, e1 = G.pts[3 * q + 1] - y, e2 = G.pts[3 * q + 2] - z;
+                                if ((e0 * e0 + e1 * e1 + e2 * e2) < dd_lim) { hit = true; break; }
+                            }
+                        }
+                }
+            }
+            cnt += hit ? 1 : 0;
+        }
+        cnt = wave_sum_i32(cnt);
+        if (lane == 0) counts[p] = cnt;
+    }
+}
+
 // rows of MaD.py:451 for the pairs listed in sel (or all pairs when sel == nullptr)
-__global__ void k_results(const int64_t *__restrict__ sel, int64_t n_sel, const int32_t *__restrict__ pair_hi,
-                          const int32_t *__restrict__ pair_lo, const double *__restrict__ pair_score,
-                          const int32_t *__restrict__ counts, const int32_t *__restrict__ l_hi_ptr,
-                          const double *__restrict__ hi_p, const double *__restrict__ hi_R, const int32_t *__restrict__ hi_meta,
-                          const double *__restrict__ lo_p, const double *__restrict__ lo_R, const int32_t *__restrict__ lo_meta,
-                          const int32_t *__restrict__ hi_row_anchor, const int32_t *__restrict__ lo_row_anchor,
-                          double *__restrict__ out) {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_sel) return;
-    const int64_t p = sel ? sel[t] : t;
-    const int ih = pair_hi[p], il = pair_lo[p];
-    const double *m = lo_R + 9 * il, *h = hi_R + 9 * ih;
-    const double c00 = m[4] * m[8] - m[5] * m[7];
-    const double c01 = m[5] * m[6] - m[3] * m[8];
-    const double c02 = m[3] * m[7] - m[4] * m[6];
-    const double det = m[0] * c00 + m[1] * c01 + m[2] * c02;
-    const double id = 1.0 / det;
-    double iv[9];
-    iv[0] = c00 * id; iv[1] = (m[2] * m[7] - m[1] * m[8]) * id; iv[2] = (m[1] * m[5] - m[2] * m[4]) * id;
-    iv[3] = c01 * id; iv[4] = (m[0] * m[8] - m[2] * m[6]) * id; iv[5] = (m[2] * m[3] - m[0] * m[5]) * id;
-    iv[6] = c02 * id; iv[7] = (m[1] * m[6] - m[0] * m[7]) * id; iv[8] = (m[0] * m[4] - m[1] * m[3]) * id;
-    double *o = out + MAD_RESULT_COLS * t;
-    const int ah = hi_row_anchor ? hi_row_anchor[ih] : ih, al = lo_row_anchor ? lo_row_anchor[il] : il;
-    o[0] = pair_score[p];
-    o[1] = 100.0 * (double)counts[p] / (double)(*l_hi_ptr);
-    // meta is {index, oct_scale, main_bin}: index and octave per anchor, main bin per row
-    o[2] = lo_meta[3 * il]; o[3] = lo_meta[3 * il + 1]; o[4] = lo_meta[3 * il + 2];
-    o[5] = hi_meta[3 * ih]; o[6] = hi_meta[3 * ih + 1]; o[7] = hi_meta[3 * ih + 2];
-    o[8] = hi_p[3 * ah]; o[9] = hi_p[3 * ah + 1]; o[10] = hi_p[3 * ah + 2];
-    o[11] = lo_p[3 * al]; o[12] = lo_p[3 * al + 1]; o[13] = lo_p[3 * al + 2];
-    for (int i = 0; i < 3; i++)
-        for (int j = 0; j < 3; j++) o[14 + 3 * i + j] = iv[3 * i] * h[j] + iv[3 * i + 1] * h[3 + j] + iv[3 * i + 2] * h[6 + j];
+__global__ void k_results(const int64_t *__restrict__ sel, const int32_t *__restrict__ n_sel_ptr, int64_t n_sel_cap,
+                          const int32_t *__restrict__ pair_hi, const int32_t *__restrict__ pair_lo,
+                          const double *__restrict__ pair_score, const int32_t *__restrict__ counts,
+                          const int32_t *__restrict__ status, const double *__restrict__ hi_p, const double *__restrict__ hi_R,
+                          const int32_t *__restrict__ hi_meta, const double *__restrict__ lo_p, const double *__restrict__ lo_Rinv,
+                          const int32_t *__restrict__ lo_meta, const int32_t *__restrict__ hi_row_anchor,
+                          const int32_t *__restrict__ lo_row_anchor, double *__restrict__ out) {
+    if (status[ST_FLAG_C] || status[ST_FLAG_PAIRS]) return;
+    const int64_t n_sel = min((int64_t)*n_sel_ptr, n_sel_cap);
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n_sel; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t p = sel ? sel[t] : t;
+        const int ih = pair_hi[p], il = pair_lo[p];
+        double *o = out + MAD_RESULT_COLS * t;
+        const int ah = hi_row_anchor ? hi_row_anchor[ih] : ih, al = lo_row_anchor ? lo_row_anchor[il] : il;
+        o[0] = pair_score[p];
+        o[1] = 100.0 * (double)counts[p] / (double)status[ST_LHI];      // MaD.py:448
+        o[2] = lo_meta[3 * il]; o[3] = lo_meta[3 * il + 1]; o[4] = lo_meta[3 * il + 2];
+        o[5] = hi_meta[3 * ih]; o[6] = hi_meta[3 * ih + 1]; o[7] = hi_meta[3 * ih + 2];
+        o[8] = hi_p[3 * ah]; o[9] = hi_p[3 * ah + 1]; o[10] = hi_p[3 * ah + 2];
+        o[11] = lo_p[3 * al]; o[12] = lo_p[3 * al + 1]; o[13] = lo_p[3 * al + 2];
+        mat3_mul(lo_Rinv + 9 * il, hi_R + 9 * ih, o + 14);
+    }
 }
 
 // ---------------------------------------------------------------------------
-// top-k by (count desc, pair index asc)
+// top-k by (count desc, pair index asc), lengths on the device
 // ---------------------------------------------------------------------------
 
+#define TK_CHUNK 1024      // pairs per workgroup in the tie-ranking passes
+
 // per-workgroup LDS histogram first: the counts crowd into a few bins, global atomics on them serialise
-__global__ __launch_bounds__(256) void k_count_hist(const int32_t *__restrict__ counts, int64_t n, int32_t *__restrict__ hist, int nbins) {
+__global__ __launch_bounds__(256) void k_count_hist(const int32_t *__restrict__ counts, const int32_t *__restrict__ status,
+                                                    int64_t cap_pairs, int32_t *__restrict__ hist, int nbins) {
     extern __shared__ __align__(16) unsigned char smem[];
+    if (status[ST_FLAG_C] || status[ST_FLAG_PAIRS]) return;
     int *h = (int *)smem;
+    const int64_t n = min((int64_t)status[ST_NPAIRS], cap_pairs);
     for (int b = threadIdx.x; b < nbins; b += 256) h[b] = 0;
     __syncthreads();
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t step = (int64_t)gridDim.x * blockDim.x;
-    for (; i < n; i += step) atomicAdd(&h[min(max(counts[i], 0), nbins - 1)], 1);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        atomicAdd(&h[min(max(counts[i], 0), nbins - 1)], 1);
     __syncthreads();
     for (int b = threadIdx.x; b < nbins; b += 256)
         if (h[b]) atomicAdd(&hist[b], h[b]);
 }
 
-// info[0] = threshold count c*, info[1] = number of pairs with count > c*, info[2] = ties to take at c*
-__global__ void k_topk_threshold(const int32_t *__restrict__ hist, int nbins, int64_t k, int32_t *__restrict__ info) {
+// info[0] = threshold count c*, info[1] = pairs with count > c*, info[2] = ties to take at c*, info[3] = min(k, n)
+__global__ void k_topk_threshold(const int32_t *__restrict__ hist, int nbins, int64_t k, const int32_t *__restrict__ status,
+                                 int64_t cap_pairs, int32_t *__restrict__ info) {
     if (threadIdx.x || blockIdx.x) return;
+    const int64_t n = (status[ST_FLAG_C] || status[ST_FLAG_PAIRS]) ? 0 : min((int64_t)status[ST_NPAIRS], cap_pairs);
+    if (k > n) k = n;
+    info[3] = (int32_t)k;
+    if (k <= 0) { info[0] = nbins; info[1] = 0; info[2] = 0; return; }
     int64_t above = 0;
     int c = nbins - 1;
     for (; c >= 0; c--) {
         if (above + hist[c] >= k) break;
         above += hist[c];
     }
-    if (c < 0) { info[0] = -1; info[1] = (int32_t)above; info[2] = 0; return; }      // fewer than k pairs: take all
+    if (c < 0) { info[0] = -1; info[1] = (int32_t)above; info[2] = 0; return; }
     info[0] = c; info[1] = (int32_t)above; info[2] = (int32_t)(k - above);
 }
 
-__global__ void k_tie_flags(const int32_t *__restrict__ counts, int64_t n, const int32_t *__restrict__ info,
-                            int32_t *__restrict__ flag) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) flag[i] = (counts[i] == info[0]) ? 1 : 0;
+// ties per chunk of TK_CHUNK consecutive pairs
+__global__ __launch_bounds__(256) void k_tie_chunks(const int32_t *__restrict__ counts, const int32_t *__restrict__ status,
+                                                    int64_t cap_pairs, const int32_t *__restrict__ info,
+                                                    int32_t *__restrict__ chunk_cnt, int32_t *__restrict__ n_chunks) {
+    __shared__ int wt[4];
+    const int64_t n = (status[ST_FLAG_C] || status[ST_FLAG_PAIRS]) ? 0 : min((int64_t)status[ST_NPAIRS], cap_pairs);
+    const int64_t nch = (n + TK_CHUNK - 1) / TK_CHUNK;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *n_chunks = (int32_t)nch;
+    const int cstar = info[0];
+    for (int64_t ch = blockIdx.x; ch < nch; ch += gridDim.x) {
+        int c = 0;
+        for (int t = threadIdx.x; t < TK_CHUNK; t += 256) {
+            const int64_t i = ch * TK_CHUNK + t;
+            c += (i < n && counts[i] == cstar) ? 1 : 0;
+        }
+        c = wave_sum_i32(c);
+        __syncthreads();
+        if (lane_id() == 0) wt[threadIdx.x >> 6] = c;
+        __syncthreads();
+        if (threadIdx.x == 0) chunk_cnt[ch] = wt[0] + wt[1] + wt[2] + wt[3];
+    }
 }
 
-// keys = ((maxc - count) << 40) | pair index; survivors appended in any order, sorted afterwards
-__global__ void k_topk_select(const int32_t *__restrict__ counts, int64_t n, const int32_t *__restrict__ info,
-                              const int32_t *__restrict__ tie_rank, int maxc, unsigned long long *__restrict__ keys,
-                              int32_t *__restrict__ n_keys) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int c = counts[i];
-    const bool take = (c > info[0]) || (c == info[0] && tie_rank[i] < info[2]);
-    if (take) {
-        const int o = atomicAdd(n_keys, 1);
-        keys[o] = ((unsigned long long)(maxc - c) << 40) | (unsigned long long)i;
+// keys = ((maxc - count) << 40) | pair index; survivors appended in any order, sorted afterwards.
+// A tie is taken when its rank among the ties (in pair order) is below info[2].
+__global__ __launch_bounds__(TK_CHUNK) void k_topk_select(const int32_t *__restrict__ counts, const int32_t *__restrict__ status,
+                                                          int64_t cap_pairs, const int32_t *__restrict__ info,
+                                                          const int32_t *__restrict__ chunk_off, int maxc,
+                                                          unsigned long long *__restrict__ keys, int32_t *__restrict__ n_keys) {
+    __shared__ int wt[TK_CHUNK / MAD_WAVE + 1];
+    const int64_t n = (status[ST_FLAG_C] || status[ST_FLAG_PAIRS]) ? 0 : min((int64_t)status[ST_NPAIRS], cap_pairs);
+    const int64_t nch = (n + TK_CHUNK - 1) / TK_CHUNK;
+    const int cstar = info[0], need = info[2];
+    for (int64_t ch = blockIdx.x; ch < nch; ch += gridDim.x) {
+        const int64_t i = ch * TK_CHUNK + threadIdx.x;
+        const int c = i < n ? counts[i] : -1;
+        const bool tie = i < n && c == cstar;
+        int tot;
+        const int rank = chunk_off[ch] + block_excl_scan(tie ? 1 : 0, wt, &tot);
+        const bool take = i < n && (c > cstar || (tie && rank < need));
+        if (take) {
+            const int o = atomicAdd(n_keys, 1);
+            keys[o] = ((unsigned long long)(maxc - c) << 40) | (unsigned long long)i;
+        }
     }
 }
 
@@ -519,7 +599,7 @@ __global__ __launch_bounds__(1024) void k_topk_sort(const unsigned long long *__
                                                     const int32_t *__restrict__ n_keys, int cap, int64_t *__restrict__ order) {
     extern __shared__ __align__(16) unsigned char smem[];
     unsigned long long *s = (unsigned long long *)smem;
-    const int n = *n_keys;
+    const int n = min(*n_keys, cap);
     for (int i = threadIdx.x; i < cap; i += 1024) s[i] = i < n ? keys[i] : ~0ull;
     __syncthreads();
     for (int k = 2; k <= cap; k <<= 1)
@@ -537,45 +617,44 @@ __global__ __launch_bounds__(1024) void k_topk_sort(const unsigned long long *__
     for (int i = threadIdx.x; i < n; i += 1024) order[i] = (int64_t)(s[i] & ((1ull << 40) - 1));
 }
 
-// Selects the first k pairs of the (count desc, index asc) order; order_dev gets them sorted.
-static int topk_device(mad_ctx *ctx, const int32_t *d_counts, int64_t n, int64_t k, int maxc, int64_t *d_order,
-                       int64_t *n_out) {
-    *n_out = 0;
-    if (n <= 0 || k <= 0) return MAD_OK;
-    if (k > n) k = n;
+// Selects the first k pairs of the (count desc, index asc) order into d_order (sorted); their number goes to
+// status[ST_NKEYS].  Everything is enqueued; nothing is read back.
+static int topk_device(mad_ctx *ctx, const int32_t *d_counts, int32_t *d_status, int64_t cap_pairs, int64_t k, int maxc,
+                       int64_t *d_order) {
     if (k > 8192) return mad_fail(ctx, MAD_EINVAL, "top-k: k = %lld exceeds 8192", (long long)k);
-    if (n >= ((int64_t)1 << 31)) return mad_fail(ctx, MAD_EINVAL, "top-k: %lld pairs", (long long)n);
+    if (cap_pairs >= ((int64_t)1 << 31)) return mad_fail(ctx, MAD_EINVAL, "top-k: %lld pairs", (long long)cap_pairs);
     const int nbins = maxc + 1;
-    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_HIST], (size_t)(nbins + 8) * 4));
-    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_TIE_FLAG], (size_t)n * 4));
-    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_TIE_OFF], (size_t)(n + 1) * 4));
+    if (nbins > 16384) return mad_fail(ctx, MAD_EINVAL, "top-k: %d count bins", nbins);
+    const int64_t max_chunks = mad_ceil_div(cap_pairs, TK_CHUNK) + 1;
+    if (max_chunks > 65536) return mad_fail(ctx, MAD_EINVAL, "top-k: %lld pairs exceed the tie-ranking capacity", (long long)cap_pairs);
+    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_HIST], (size_t)(nbins + 16) * 4));
+    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_TIE_FLAG], (size_t)(max_chunks + 2) * 4));
+    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_TIE_OFF], (size_t)(max_chunks + 2) * 4));
     MAD_TRY(mad_reserve(ctx, ctx->scratch[S_SEL], (size_t)(k + 8) * 8));
     int32_t *hist = scratch<int32_t>(ctx, S_HIST);
-    int32_t *info = hist + nbins;            // 3 ints + n_keys
-    int32_t *n_keys = info + 3;
-    MAD_HIP(hipMemsetAsync(hist, 0, (size_t)(nbins + 8) * 4, ctx->stream));
+    int32_t *info = hist + nbins;            // 4 ints, then the chunk count
+    int32_t *n_chunks = info + 4;
+    MAD_HIP(hipMemsetAsync(hist, 0, (size_t)(nbins + 16) * 4, ctx->stream));
     mad_timer_begin(ctx, MAD_T_TOPK);
-    if (nbins > 16384) return mad_fail(ctx, MAD_EINVAL, "top-k: %d count bins", nbins);
-    const int blocks = (int)std::min<int64_t>(mad_ceil_div(n, 1024), (int64_t)ctx->n_cu * 2);
-    hipLaunchKernelGGL(k_count_hist, dim3(blocks), dim3(256), (size_t)nbins * 4, ctx->stream, d_counts, n, hist, nbins);
-    hipLaunchKernelGGL(k_topk_threshold, dim3(1), dim3(64), 0, ctx->stream, hist, nbins, k, info);
-    const unsigned nb = (unsigned)mad_ceil_div(n, 256);
-    hipLaunchKernelGGL(k_tie_flags, dim3(nb), dim3(256), 0, ctx->stream, d_counts, n, info, scratch<int32_t>(ctx, S_TIE_FLAG));
-    MAD_TRY(mad_scan_i32(ctx, scratch<int32_t>(ctx, S_TIE_FLAG), scratch<int32_t>(ctx, S_TIE_OFF), n));
-    hipLaunchKernelGGL(k_topk_select, dim3(nb), dim3(256), 0, ctx->stream, d_counts, n, info,
-                       scratch<int32_t>(ctx, S_TIE_OFF), maxc, scratch<unsigned long long>(ctx, S_SEL), n_keys);
+    const int gs = ctx->n_cu * 2;
+    hipLaunchKernelGGL(k_count_hist, dim3(gs), dim3(256), (size_t)nbins * 4, ctx->stream, d_counts, d_status, cap_pairs, hist, nbins);
+    hipLaunchKernelGGL(k_topk_threshold, dim3(1), dim3(64), 0, ctx->stream, hist, nbins, k, d_status, cap_pairs, info);
+    hipLaunchKernelGGL(k_tie_chunks, dim3(gs), dim3(256), 0, ctx->stream, d_counts, d_status, cap_pairs, info,
+                       scratch<int32_t>(ctx, S_TIE_FLAG), n_chunks);
+    mad_scan_small(ctx, scratch<int32_t>(ctx, S_TIE_FLAG), scratch<int32_t>(ctx, S_TIE_OFF), n_chunks, nullptr);
+    hipLaunchKernelGGL(k_topk_select, dim3(gs), dim3(TK_CHUNK), 0, ctx->stream, d_counts, d_status, cap_pairs, info,
+                       scratch<int32_t>(ctx, S_TIE_OFF), maxc, scratch<unsigned long long>(ctx, S_SEL), d_status + ST_NKEYS);
     int cap = 1;
     while (cap < k) cap <<= 1;
     hipLaunchKernelGGL(k_topk_sort, dim3(1), dim3(1024), (size_t)cap * 8, ctx->stream,
-                       scratch<unsigned long long>(ctx, S_SEL), n_keys, cap, d_order);
+                       scratch<unsigned long long>(ctx, S_SEL), d_status + ST_NKEYS, cap, d_order);
     mad_timer_end(ctx, MAD_T_TOPK);
     MAD_HIP(hipGetLastError());
-    *n_out = k;
     return MAD_OK;
 }
 
 // ---------------------------------------------------------------------------
-// cell list over a set of points (built on the device, dimensions from the host)
+// global cell list (fallback path only)
 // ---------------------------------------------------------------------------
 
 __device__ __forceinline__ int cell_of(double v, double mn, double inv_cell, int dim) {
@@ -604,21 +683,13 @@ __global__ void k_cell_fill(const double *__restrict__ pts, int n, const int32_t
     ids[o] = i;
 }
 
-// h_pts: n x 3 host copy (for the bounding box); d_pts: the same on the device
-static int build_cells(mad_ctx *ctx, const double *h_pts, const double *d_pts, int n, double cell, DevBuf &b_start,
-                       DevBuf &b_pts, DevBuf &b_ids, double mn_out[3], int dim_out[3]) {
-    double mn[3] = {0, 0, 0}, mx[3] = {0, 0, 0};
-    for (int i = 0; i < n; i++)
-        for (int d = 0; d < 3; d++) {
-            const double v = h_pts[3 * i + d];
-            if (i == 0 || v < mn[d]) mn[d] = v;
-            if (i == 0 || v > mx[d]) mx[d] = v;
-        }
+static int build_cells(mad_ctx *ctx, const double bb_min[3], const double bb_max[3], const double *d_pts, int n, double cell,
+                       DevBuf &b_start, DevBuf &b_pts, DevBuf &b_ids, double mn_out[3], int dim_out[3]) {
     size_t ncell = 1;
     for (int d = 0; d < 3; d++) {
-        dim_out[d] = (int)floor((mx[d] - mn[d]) / cell) + 1;
+        dim_out[d] = (int)floor((bb_max[d] - bb_min[d]) / cell) + 1;
         if (dim_out[d] < 1) dim_out[d] = 1;
-        mn_out[d] = mn[d];
+        mn_out[d] = bb_min[d];
         ncell *= (size_t)dim_out[d];
     }
     if (ncell > ((size_t)1 << 28)) return mad_fail(ctx, MAD_EINVAL, "cell list of %zu cells is too large", ncell);
@@ -632,7 +703,7 @@ static int build_cells(mad_ctx *ctx, const double *h_pts, const double *d_pts, i
     MAD_HIP(hipMemsetAsync(cnt, 0, (ncell + 1) * 4, ctx->stream));
     if (n > 0) {
         const unsigned nb = (unsigned)mad_ceil_div(n, 256);
-        hipLaunchKernelGGL(k_cell_count, dim3(nb), dim3(256), 0, ctx->stream, d_pts, n, mn[0], mn[1], mn[2], 1.0 / cell,
+        hipLaunchKernelGGL(k_cell_count, dim3(nb), dim3(256), 0, ctx->stream, d_pts, n, bb_min[0], bb_min[1], bb_min[2], 1.0 / cell,
                            dim_out[0], dim_out[1], dim_out[2], cnt, pt_cell);
         MAD_TRY(mad_scan_i32(ctx, cnt, (int32_t *)b_start.p, (int64_t)ncell));
         MAD_HIP(hipMemsetAsync(cnt, 0, (ncell + 1) * 4, ctx->stream));
@@ -645,79 +716,153 @@ static int build_cells(mad_ctx *ctx, const double *h_pts, const double *d_pts, i
     return MAD_OK;
 }
 
-int mad_build_cells(mad_ctx *ctx, mad_set *set, const double *h_subv, double cell) {
-    for (int i = 0; i < set->n_anchors; i++)
-        for (int d = 0; d < 3; d++) {
-            const double v = h_subv[3 * i + d];
-            if (i == 0 || v < set->bb_min[d]) set->bb_min[d] = v;
-            if (i == 0 || v > set->bb_max[d]) set->bb_max[d] = v;
-        }
-    MAD_TRY(build_cells(ctx, h_subv, (const double *)set->anc_subv.p, set->n_anchors, cell, set->cell_start, set->cell_pts,
-                        set->cell_ids, set->cell_min, set->cell_dim));
+int mad_build_cells(mad_ctx *ctx, mad_set *set, double cell) {
+    MAD_TRY(build_cells(ctx, set->bb_min, set->bb_max, (const double *)set->anc_subv.p, set->n_anchors, cell, set->cell_start,
+                        set->cell_pts, set->cell_ids, set->cell_min, set->cell_dim));
     set->cell_size = cell;
     set->cells_ready = true;
     return MAD_OK;
 }
 
+// smallest double whose (correctly rounded) square root is >= dist: dd < limit  <=>  sqrt(dd) < dist
+static double sqrt_limit(double dist) {
+    double t = dist * dist;
+    while (sqrt(nextafter(t, 0.0)) >= dist) t = nextafter(t, 0.0);
+    while (sqrt(t) < dist) t = nextafter(t, INFINITY);
+    return t;
+}
+
 // ---------------------------------------------------------------------------
-// correlation driver shared by the stage API and the set API
+// the match pipeline (shared by the stage API and the set API)
 // ---------------------------------------------------------------------------
 
-struct PairBufs {
-    int64_t n_pairs;
+struct Side {      // one side of a match, all device pointers
+    const int8_t *dsc8;
+    const double *norm;
+    const double *R;            // per row
+    const double *Rinv;         // per row
+    const int32_t *meta;        // per row x 3
+    const int32_t *row_anchor;  // row -> entry of `p` (nullptr: identity)
+    const double *p;            // sub-voxel coordinates (per anchor, or per row when row_anchor == nullptr)
+    const int32_t *n_rows;      // device
+    int64_t cap_rows;           // upper bound of *n_rows
 };
 
-// d_hi8/d_lo8 padded to the GEMM tile (zero rows), norms per row.  Fills S_PAIR_* and S_ROWOFF.
-static int correlate_device(mad_ctx *ctx, const int8_t *d_hi8, int64_t n_hi, const int8_t *d_lo8, int64_t n_lo, int D,
-                            const double *d_hn, const double *d_ln, double cc, const int32_t *d_hi_row_anchor,
-                            const int32_t *d_lo_row_anchor, uint8_t *d_used_hi, uint8_t *d_used_lo, int64_t *n_pairs_out) {
-    const int64_t hp = mad_ceil_div(n_hi, GEMM_BM) * GEMM_BM, lp = mad_ceil_div(n_lo, GEMM_BN) * GEMM_BN;
+// correlate + compact: fills S_PAIR_*; status[ST_NPAIRS]; used flags (nullable)
+static int correlate_device(mad_ctx *ctx, const Side &hi, const Side &lo, int D, double cc, int32_t *d_status, int64_t cap_c,
+                            int64_t cap_pairs, uint8_t *d_used_hi, uint8_t *d_used_lo) {
     if (D % GEMM_BK) return mad_fail(ctx, MAD_EINVAL, "correlate: D = %d is not a multiple of %d", D, GEMM_BK);
-    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_CMAT], (size_t)hp * lp * 4));
-    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_ROWCNT], (size_t)(n_hi + 1) * 4));
-    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_ROWOFF], (size_t)(n_hi + 2) * 4));
+    if (hi.cap_rows > 65000) return mad_fail(ctx, MAD_EINVAL, "correlate: %lld hi rows exceed the single-launch scan", (long long)hi.cap_rows);
+    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_CMAT], (size_t)cap_c * 4));
+    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_ROWCNT], (size_t)(hi.cap_rows + 2) * 4));
+    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_ROWOFF], (size_t)(hi.cap_rows + 2) * 4));
+    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_PAIR_HI], (size_t)cap_pairs * 4));
+    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_PAIR_LO], (size_t)cap_pairs * 4));
+    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_PAIR_SCORE], (size_t)cap_pairs * 8));
     int32_t *C = scratch<int32_t>(ctx, S_CMAT);
     mad_timer_begin(ctx, MAD_T_CORRELATE);
-    hipLaunchKernelGGL(k_corr_gemm, dim3((unsigned)(lp / GEMM_BN), (unsigned)(hp / GEMM_BM)), dim3(GEMM_THREADS), 0,
-                       ctx->stream, d_hi8, d_lo8, D, C, lp);
+    hipLaunchKernelGGL(k_corr_gemm, dim3(ctx->n_cu * 4), dim3(GEMM_THREADS), 0, ctx->stream, hi.dsc8, lo.dsc8, D, C, hi.n_rows,
+                       lo.n_rows, cap_c, d_status);
     mad_timer_end(ctx, MAD_T_CORRELATE);
     mad_timer_begin(ctx, MAD_T_PAIRS);
-    hipLaunchKernelGGL(k_pair_count, dim3((unsigned)n_hi), dim3(256), 0, ctx->stream, C, lp, n_hi, n_lo, d_hn, d_ln, cc,
-                       scratch<int32_t>(ctx, S_ROWCNT));
-    MAD_TRY(mad_scan_i32(ctx, scratch<int32_t>(ctx, S_ROWCNT), scratch<int32_t>(ctx, S_ROWOFF), n_hi));
-    MAD_HIP(hipMemcpyAsync(&ctx->pinned[0], scratch<int32_t>(ctx, S_ROWOFF) + n_hi, 4, hipMemcpyDeviceToHost, ctx->stream));
-    MAD_HIP(hipStreamSynchronize(ctx->stream));
-    const int64_t np = *(int32_t *)&ctx->pinned[0];
-    *n_pairs_out = np;
-    if (np > 0) {
-        MAD_TRY(mad_reserve(ctx, ctx->scratch[S_PAIR_HI], (size_t)np * 4));
-        MAD_TRY(mad_reserve(ctx, ctx->scratch[S_PAIR_LO], (size_t)np * 4));
-        MAD_TRY(mad_reserve(ctx, ctx->scratch[S_PAIR_SCORE], (size_t)np * 8));
-        hipLaunchKernelGGL(k_pair_emit, dim3((unsigned)n_hi), dim3(256), 0, ctx->stream, C, lp, n_hi, n_lo, d_hn, d_ln, cc,
-                           scratch<int32_t>(ctx, S_ROWOFF), scratch<int32_t>(ctx, S_PAIR_HI),
-                           scratch<int32_t>(ctx, S_PAIR_LO), scratch<double>(ctx, S_PAIR_SCORE), d_hi_row_anchor,
-                           d_lo_row_anchor, d_used_hi, d_used_lo);
-    }
+    hipLaunchKernelGGL(k_pair_count, dim3(ctx->n_cu * 8), dim3(256), 0, ctx->stream, C, hi.n_rows, lo.n_rows, hi.norm, lo.norm, cc,
+                       scratch<int32_t>(ctx, S_ROWCNT), d_status);
+    mad_scan_small(ctx, scratch<int32_t>(ctx, S_ROWCNT), scratch<int32_t>(ctx, S_ROWOFF), hi.n_rows, d_status + ST_NPAIRS);
+    hipLaunchKernelGGL(k_pair_emit, dim3(ctx->n_cu * 8), dim3(256), 0, ctx->stream, C, hi.n_rows, lo.n_rows, hi.norm, lo.norm, cc,
+                       scratch<int32_t>(ctx, S_ROWOFF), cap_pairs, scratch<int32_t>(ctx, S_PAIR_HI), scratch<int32_t>(ctx, S_PAIR_LO),
+                       scratch<double>(ctx, S_PAIR_SCORE), hi.row_anchor, lo.row_anchor, d_used_hi, d_used_lo, d_status);
     mad_timer_end(ctx, MAD_T_PAIRS);
     MAD_HIP(hipGetLastError());
     return MAD_OK;
 }
 
-// int16 rows on the device -> padded int8 + norms
-static int pack_rows(mad_ctx *ctx, const int16_t *d_src, int64_t n, int D, DevBuf &b8, DevBuf &bn, int64_t tile) {
-    const int64_t np = mad_ceil_div(n > 0 ? n : 1, tile) * tile;
-    MAD_TRY(mad_reserve(ctx, b8, (size_t)np * D));
-    MAD_TRY(mad_reserve(ctx, bn, (size_t)np * 8));
-    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_MISC], 256));
-    int32_t *bad = scratch<int32_t>(ctx, S_MISC);
-    MAD_HIP(hipMemsetAsync(bad, 0, 4, ctx->stream));
-    MAD_HIP(hipMemsetAsync((int8_t *)b8.p + (size_t)n * D, 0, (size_t)(np - n) * D, ctx->stream));
-    if (n > 0)
-        hipLaunchKernelGGL(k_pack_rows, dim3((unsigned)mad_ceil_div(n, 4)), dim3(256), 0, ctx->stream, d_src, n, D,
-                           (int8_t *)b8.p, (double *)bn.p, bad);
-    MAD_HIP(hipMemcpyAsync(&ctx->pinned[2], bad, 4, hipMemcpyDeviceToHost, ctx->stream));
-    MAD_HIP(hipStreamSynchronize(ctx->stream));
-    if (*(int32_t *)&ctx->pinned[2]) return mad_fail(ctx, MAD_EDOM, "descriptor count outside the int8 range");
+// Scores the pairs in S_PAIR_* into S_COUNTS.  The lo cloud is the set of points `d_cloud[0..n_cloud)` whose flag in
+// `d_cloud_used` is set (all when nullptr); `fallback` (cell = dist, built over the same points) is used when the clouds
+// do not fit LDS.
+static int pose_device(mad_ctx *ctx, const Side &hi, const Side &lo, int32_t *d_status, int64_t cap_pairs,
+                       const double *d_hi_cloud, int l_hi_max, const double *d_cloud, int n_cloud, const uint8_t *d_cloud_used,
+                       const double bb_min[3], const double bb_max[3], const CellGrid *fallback, double dist) {
+    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_COUNTS], (size_t)cap_pairs * 4));
+    const double dd_lim = sqrt_limit(dist);
+    const double reach = dist + 0.01;
+    PoseGrid G;
+    G.ncell = 1;
+    for (int d = 0; d < 3; d++) {
+        const double ext = bb_max[d] - bb_min[d];
+        double cell = 2.0 * reach + 0.05;      // > 2 * reach: the enlarged ball meets at most 2 cells per axis
+        if (ext / cell > 24.0) cell = ext / 24.0;
+        G.mn[d] = bb_min[d];
+        G.inv_cell[d] = 1.0 / cell;
+        G.inv_cell_f[d] = (float)(1.0 / cell);
+        G.dim[d] = (int)floor(ext / cell) + 1;
+        if (G.dim[d] < 1) G.dim[d] = 1;
+        G.ncell *= G.dim[d];
+    }
+    const size_t lds = (size_t)(l_hi_max + n_cloud) * 24 + (size_t)(G.ncell + 1) * 2 + 16;
+    if (!fallback && lds <= 150 * 1024 && n_cloud < 65535 && G.ncell <= 30000) {
+        MAD_TRY(mad_reserve(ctx, ctx->scratch[S_PG_START], (size_t)(G.ncell + 2) * 4));
+        MAD_TRY(mad_reserve(ctx, ctx->scratch[S_PG_PTS], (size_t)(n_cloud + 1) * 24));
+        static bool attr_set = false;
+        if (!attr_set) {
+            MAD_HIP(hipFuncSetAttribute((const void *)k_pose_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            MAD_HIP(hipFuncSetAttribute((const void *)k_pose_grid_build, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+            attr_set = true;
+        }
+        mad_timer_begin(ctx, MAD_T_POSE);
+        hipLaunchKernelGGL(k_pose_grid_build, dim3(1), dim3(1024), (size_t)G.ncell * 4, ctx->stream, d_cloud, d_cloud_used, n_cloud, G,
+                           scratch<int32_t>(ctx, S_PG_START), scratch<double>(ctx, S_PG_PTS), d_status + ST_LLO);
+        hipLaunchKernelGGL(k_pose_lds, dim3(ctx->n_cu * 2), dim3(POSE_LDS_THREADS), lds, ctx->stream, scratch<int32_t>(ctx, S_PAIR_HI),
+                           scratch<int32_t>(ctx, S_PAIR_LO), d_status, cap_pairs, hi.p, hi.R, lo.p, lo.Rinv, hi.row_anchor,
+                           lo.row_anchor, d_hi_cloud, scratch<double>(ctx, S_PG_PTS), scratch<int32_t>(ctx, S_PG_START), G,
+                           l_hi_max, n_cloud, (float)reach, dd_lim, scratch<int32_t>(ctx, S_COUNTS));
+        mad_timer_end(ctx, MAD_T_POSE);
+        MAD_HIP(hipGetLastError());
+        return MAD_OK;
+    }
+    if (!fallback) return mad_fail(ctx, MAD_EINVAL, "pose: clouds of %d + %d points need the global cell list", l_hi_max, n_cloud);
+    const size_t lds2 = (size_t)l_hi_max * 24;
+    if (lds2 > 150 * 1024) return mad_fail(ctx, MAD_EINVAL, "pose: hi cloud of %d anchors does not fit LDS", l_hi_max);
+    MAD_HIP(hipFuncSetAttribute((const void *)k_pose, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MAD_HIP(hipMemsetAsync(d_status + ST_LLO, 0, 4, ctx->stream));
+    if (d_cloud_used)
+        hipLaunchKernelGGL(k_count_flags, dim3((unsigned)mad_ceil_div(n_cloud, 256)), dim3(256), 0, ctx->stream, d_cloud_used, n_cloud,
+                           d_status + ST_LLO);
+    else
+        MAD_HIP(hipMemcpyAsync(d_status + ST_LLO, &n_cloud, 4, hipMemcpyHostToDevice, ctx->stream));
+    mad_timer_begin(ctx, MAD_T_POSE);
+    hipLaunchKernelGGL(k_pose, dim3(ctx->n_cu * 8), dim3(POSE_THREADS), lds2, ctx->stream, scratch<int32_t>(ctx, S_PAIR_HI),
+                       scratch<int32_t>(ctx, S_PAIR_LO), d_status, cap_pairs, hi.p, hi.R, lo.p, lo.Rinv, hi.row_anchor, lo.row_anchor,
+                       d_hi_cloud, *fallback, dd_lim, scratch<int32_t>(ctx, S_COUNTS));
+    mad_timer_end(ctx, MAD_T_POSE);
+    MAD_HIP(hipGetLastError());
+    return MAD_OK;
+}
+
+static bool clouds_fit_lds(int64_t l_hi, int64_t l_lo) {      // with the largest cell table (30 000 cells)
+    return (size_t)(l_hi + l_lo) * 24 + 60016 <= 150 * 1024 && l_lo < 65535;
+}
+
+static int32_t *status_words(mad_ctx *ctx) {      // inside S_MISC
+    return scratch<int32_t>(ctx, S_MISC) + 64;
+}
+
+// ---------------------------------------------------------------------------
+// stage API
+// ---------------------------------------------------------------------------
+
+// int16 rows from the host -> padded int8 + norms on the device; n to a device word
+static int stage_rows(mad_ctx *ctx, const int16_t *h_rows, int64_t n, int D, int slot16, int slot8, int slotn, int32_t *d_n,
+                      int32_t *d_bad) {
+    const int64_t n_pad = mad_ceil_div(n > 0 ? n : 1, GEMM_BM) * GEMM_BM;
+    MAD_TRY(mad_reserve(ctx, ctx->scratch[slot16], (size_t)n * D * 2));
+    MAD_TRY(mad_reserve(ctx, ctx->scratch[slot8], (size_t)n_pad * D));
+    MAD_TRY(mad_reserve(ctx, ctx->scratch[slotn], (size_t)n_pad * 8));
+    const int32_t n32 = (int32_t)n;
+    MAD_HIP(hipMemcpyAsync(d_n, &n32, 4, hipMemcpyHostToDevice, ctx->stream));
+    MAD_HIP(hipMemcpyAsync(ctx->scratch[slot16].p, h_rows, (size_t)n * D * 2, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_pack_rows, dim3((unsigned)std::min<int64_t>(mad_ceil_div(n_pad, 4), 4096)), dim3(256), 0, ctx->stream,
+                       scratch<int16_t>(ctx, slot16), d_n, D, scratch<int8_t>(ctx, slot8), scratch<double>(ctx, slotn), d_bad);
+    MAD_HIP(hipGetLastError());
     return MAD_OK;
 }
 
@@ -729,17 +874,28 @@ extern "C" int mad_correlate(mad_ctx *ctx, const int16_t *hi, int64_t n_hi, cons
     if (n_hi <= 0 || n_lo <= 0) return MAD_OK;
     if (!hi || !lo) return mad_fail(ctx, MAD_EINVAL, "mad_correlate: NULL descriptors");
     if (n_hi * n_lo >= ((int64_t)1 << 31)) return mad_fail(ctx, MAD_EINVAL, "mad_correlate: %lld x %lld too large", (long long)n_hi, (long long)n_lo);
-    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_HI16], (size_t)n_hi * D * 2));
-    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_LO16], (size_t)n_lo * D * 2));
-    MAD_HIP(hipMemcpyAsync(ctx->scratch[S_HI16].p, hi, (size_t)n_hi * D * 2, hipMemcpyHostToDevice, ctx->stream));
-    MAD_HIP(hipMemcpyAsync(ctx->scratch[S_LO16].p, lo, (size_t)n_lo * D * 2, hipMemcpyHostToDevice, ctx->stream));
-    MAD_TRY(pack_rows(ctx, scratch<int16_t>(ctx, S_HI16), n_hi, D, ctx->scratch[S_HI8], ctx->scratch[S_HNORM], GEMM_BM));
-    MAD_TRY(pack_rows(ctx, scratch<int16_t>(ctx, S_LO16), n_lo, D, ctx->scratch[S_LO8], ctx->scratch[S_LNORM], GEMM_BN));
-    int64_t np = 0;
-    MAD_TRY(correlate_device(ctx, scratch<int8_t>(ctx, S_HI8), n_hi, scratch<int8_t>(ctx, S_LO8), n_lo, D,
-                             scratch<double>(ctx, S_HNORM), scratch<double>(ctx, S_LNORM), cc, nullptr, nullptr, nullptr,
-                             nullptr, &np));
-    *n_pairs = np;
+    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_MISC], 4096));
+    int32_t *st = status_words(ctx);
+    MAD_HIP(hipMemsetAsync(st, 0, ST_COUNT * 4, ctx->stream));
+    MAD_TRY(stage_rows(ctx, hi, n_hi, D, S_HI16, S_HI8, S_HNORM, st + ST_NHI, st + ST_BAD));
+    MAD_TRY(stage_rows(ctx, lo, n_lo, D, S_LO16, S_LO8, S_LNORM, st + ST_NLO, st + ST_BAD));
+    const int64_t hp = mad_ceil_div(n_hi, GEMM_BM) * GEMM_BM, lp = mad_ceil_div(n_lo, GEMM_BN) * GEMM_BN;
+    const Side H = {scratch<int8_t>(ctx, S_HI8), scratch<double>(ctx, S_HNORM), nullptr, nullptr, nullptr, nullptr, nullptr, st + ST_NHI, n_hi};
+    const Side L = {scratch<int8_t>(ctx, S_LO8), scratch<double>(ctx, S_LNORM), nullptr, nullptr, nullptr, nullptr, nullptr, st + ST_NLO, n_lo};
+    const int32_t *hs = (const int32_t *)&ctx->pinned[0];
+    int64_t cap_pairs = std::max<int64_t>(cap, 1);
+    for (int attempt = 0; attempt < 2; attempt++) {
+        MAD_TRY(correlate_device(ctx, H, L, D, cc, st, hp * lp, cap_pairs, nullptr, nullptr));
+        MAD_HIP(hipMemcpyAsync(&ctx->pinned[0], st, ST_COUNT * 4, hipMemcpyDeviceToHost, ctx->stream));
+        MAD_HIP(hipStreamSynchronize(ctx->stream));
+        if (hs[ST_BAD]) return mad_fail(ctx, MAD_EDOM, "descriptor count outside the int8 range");
+        *n_pairs = hs[ST_NPAIRS];
+        if (!hs[ST_FLAG_PAIRS]) break;
+        if (*n_pairs > cap) return mad_fail(ctx, MAD_ENOSPC, "mad_correlate: %lld pairs, capacity %lld", (long long)*n_pairs, (long long)cap);
+        cap_pairs = *n_pairs;
+        MAD_HIP(hipMemsetAsync(st + ST_FLAG_PAIRS, 0, 4, ctx->stream));
+    }
+    const int64_t np = *n_pairs;
     if (np > cap) return mad_fail(ctx, MAD_ENOSPC, "mad_correlate: %lld pairs, capacity %lld", (long long)np, (long long)cap);
     if (np > 0) {
         if (pair_hi) MAD_HIP(hipMemcpyAsync(pair_hi, ctx->scratch[S_PAIR_HI].p, np * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -747,74 +903,6 @@ extern "C" int mad_correlate(mad_ctx *ctx, const int16_t *hi, int64_t n_hi, cons
         if (pair_score) MAD_HIP(hipMemcpyAsync(pair_score, ctx->scratch[S_PAIR_SCORE].p, np * 8, hipMemcpyDeviceToHost, ctx->stream));
         MAD_HIP(hipStreamSynchronize(ctx->stream));
     }
-    return MAD_OK;
-}
-
-// ---------------------------------------------------------------------------
-// pose scoring drivers
-// ---------------------------------------------------------------------------
-
-// lo cloud = the points of d_lo_pts whose flag is set (all if d_lo_used == nullptr); bounding box from the host.
-static int pose_device(mad_ctx *ctx, const int32_t *d_pair_hi, const int32_t *d_pair_lo, int64_t n_pairs,
-                       const double *d_hi_p, const double *d_hi_R, const double *d_lo_p, const double *d_lo_R,
-                       const int32_t *d_hi_row_anchor, const int32_t *d_lo_row_anchor, const double *d_hi_cloud,
-                       const int32_t *d_l_hi, int l_hi_max, const double *d_lo_pts, const uint8_t *d_lo_used, int n_lo_pts,
-                       const double bb_min[3], const double bb_max[3], const CellGrid *fallback, double dist,
-                       int32_t *d_counts, int32_t *d_l_lo) {
-    if (n_pairs <= 0) return MAD_OK;
-    // cells of edge >= 2 dist, at most 24 per axis
-    PoseGrid G;
-    G.ncell = 1;
-    for (int d = 0; d < 3; d++) {
-        const double ext = bb_max[d] - bb_min[d];
-        double cell = 2.0 * dist;
-        if (ext / cell > 24.0) cell = ext / 24.0;
-        G.mn[d] = bb_min[d];
-        G.inv_cell[d] = 1.0 / cell;
-        G.dim[d] = (int)floor(ext / cell) + 1;
-        if (G.dim[d] < 1) G.dim[d] = 1;
-        G.ncell *= G.dim[d];
-    }
-    const size_t lds = (size_t)(l_hi_max + n_lo_pts) * 24 + (size_t)(G.ncell + 1) * 2 + 16;
-    int blocks = (int)std::min<int64_t>(mad_ceil_div(n_pairs, POSE_THREADS / MAD_WAVE), (int64_t)ctx->n_cu * 8);
-    if (blocks < 1) blocks = 1;
-    if (lds <= 150 * 1024 && n_lo_pts < 65535 && G.ncell <= 30000) {
-        MAD_TRY(mad_reserve(ctx, ctx->scratch[S_PG_START], (size_t)(G.ncell + 2) * 4));
-        MAD_TRY(mad_reserve(ctx, ctx->scratch[S_PG_PTS], (size_t)(n_lo_pts + 1) * 24));
-        mad_timer_begin(ctx, MAD_T_POSE);
-        hipLaunchKernelGGL(k_pose_grid_build, dim3(1), dim3(1024), (size_t)G.ncell * 4, ctx->stream, d_lo_pts, d_lo_used, n_lo_pts, G,
-                           scratch<int32_t>(ctx, S_PG_START), scratch<double>(ctx, S_PG_PTS), d_l_lo);
-        static bool attr_set = false;
-        if (!attr_set) {
-            MAD_HIP(hipFuncSetAttribute((const void *)k_pose_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            MAD_HIP(hipFuncSetAttribute((const void *)k_pose_grid_build, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-            attr_set = true;
-        }
-        const int lblocks = (int)std::max<int64_t>(1, std::min<int64_t>(mad_ceil_div(n_pairs, POSE_LDS_THREADS / MAD_WAVE), (int64_t)ctx->n_cu * 2));
-        hipLaunchKernelGGL(k_pose_lds, dim3(lblocks), dim3(POSE_LDS_THREADS), lds, ctx->stream, d_pair_hi, d_pair_lo, n_pairs, d_hi_p,
-                           d_hi_R, d_lo_p, d_lo_R, d_hi_row_anchor, d_lo_row_anchor, d_hi_cloud, d_l_hi,
-                           scratch<double>(ctx, S_PG_PTS), scratch<int32_t>(ctx, S_PG_START), G, l_hi_max, n_lo_pts, dist,
-                           d_counts);
-        mad_timer_end(ctx, MAD_T_POSE);
-        MAD_HIP(hipGetLastError());
-        return MAD_OK;
-    }
-    // clouds too large for LDS: global cell list (cell = dist) with the used flags
-    if (!fallback) return mad_fail(ctx, MAD_EINVAL, "pose: clouds of %d + %d points need the global cell list", l_hi_max, n_lo_pts);
-    const size_t lds2 = (size_t)l_hi_max * 24;
-    if (lds2 > 150 * 1024) return mad_fail(ctx, MAD_EINVAL, "pose: hi cloud of %d anchors does not fit LDS", l_hi_max);
-    if (lds2 > 64 * 1024)
-        MAD_HIP(hipFuncSetAttribute((const void *)k_pose, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-    MAD_HIP(hipMemsetAsync(d_l_lo, 0, 4, ctx->stream));
-    if (d_lo_used)
-        hipLaunchKernelGGL(k_count_flags, dim3((unsigned)mad_ceil_div(n_lo_pts, 256)), dim3(256), 0, ctx->stream, d_lo_used, n_lo_pts, d_l_lo);
-    else
-        MAD_HIP(hipMemcpyAsync(d_l_lo, &n_lo_pts, 4, hipMemcpyHostToDevice, ctx->stream));
-    mad_timer_begin(ctx, MAD_T_POSE);
-    hipLaunchKernelGGL(k_pose, dim3(blocks), dim3(POSE_THREADS), lds2, ctx->stream, d_pair_hi, d_pair_lo, n_pairs, d_hi_p,
-                       d_hi_R, d_lo_p, d_lo_R, d_hi_row_anchor, d_lo_row_anchor, d_hi_cloud, d_l_hi, *fallback, dist, d_counts);
-    mad_timer_end(ctx, MAD_T_POSE);
-    MAD_HIP(hipGetLastError());
     return MAD_OK;
 }
 
@@ -840,43 +928,49 @@ extern "C" int mad_pose_score(mad_ctx *ctx, const int32_t *pair_hi, const int32_
         MAD_TRY(mad_reserve(ctx, ctx->scratch[u.slot], u.bytes));
         MAD_HIP(hipMemcpyAsync(ctx->scratch[u.slot].p, u.src, u.bytes, hipMemcpyHostToDevice, ctx->stream));
     }
-    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_COUNTS], (size_t)n_pairs * 4));
-    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_MISC], 256));
-    int32_t *d_lhi = scratch<int32_t>(ctx, S_MISC) + 8;
-    const int32_t lh = (int32_t)l_hi;
-    MAD_HIP(hipMemcpyAsync(d_lhi, &lh, 4, hipMemcpyHostToDevice, ctx->stream));
-    // bounding box of the lo cloud; the global cell list (cell = dist) is only built when the clouds do not fit LDS
-    double bmn[3] = {0, 0, 0}, bmx[3] = {0, 0, 0};
+    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_TMP_A], (size_t)n_lo * 72));
+    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_MISC], 4096));
+    int32_t *st = status_words(ctx);
+    int32_t hs[ST_COUNT] = {0};
+    hs[ST_NPAIRS] = (int32_t)n_pairs; hs[ST_LHI] = (int32_t)l_hi; hs[ST_NHI] = (int32_t)n_hi; hs[ST_NLO] = (int32_t)n_lo;
+    MAD_HIP(hipMemcpyAsync(st, hs, sizeof(hs), hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_row_aux, dim3(64), dim3(256), 0, ctx->stream, scratch<double>(ctx, S_TMP_I), st + ST_NLO,
+                       scratch<double>(ctx, S_TMP_A), (const int32_t *)nullptr, (const int32_t *)nullptr, (const int32_t *)nullptr,
+                       (const int32_t *)nullptr, (int32_t *)nullptr);
+    double bmn[3] = {0, 0, 0}, bmx[3] = {0, 0, 0};      // bounding box of the lo cloud
     for (int64_t i = 0; i < l_lo; i++)
         for (int d = 0; d < 3; d++) {
             const double v = lo_cloud[3 * i + d];
             if (i == 0 || v < bmn[d]) bmn[d] = v;
             if (i == 0 || v > bmx[d]) bmx[d] = v;
         }
-    DevBuf &b_start = ctx->scratch[S_CELL_START], &b_pts = ctx->scratch[S_CELL_PTS], &b_ids = ctx->scratch[S_CELL_IDS];
-    double mn[3];
-    int dim[3];
-    MAD_TRY(build_cells(ctx, lo_cloud, scratch<double>(ctx, S_USED_LO), (int)l_lo, dist, b_start, b_pts, b_ids, mn, dim));
+    const Side H = {nullptr, nullptr, scratch<double>(ctx, S_TMP_F), nullptr, scratch<int32_t>(ctx, S_TMP_G), nullptr,
+                    scratch<double>(ctx, S_TMP_E), st + ST_NHI, n_hi};
+    const Side L = {nullptr, nullptr, scratch<double>(ctx, S_TMP_I), scratch<double>(ctx, S_TMP_A), scratch<int32_t>(ctx, S_TMP_J),
+                    nullptr, scratch<double>(ctx, S_TMP_H), st + ST_NLO, n_lo};
     CellGrid G;
-    G.start = (const int32_t *)b_start.p; G.pts = (const double *)b_pts.p; G.ids = (const int32_t *)b_ids.p; G.used = nullptr;
-    for (int d = 0; d < 3; d++) { G.mn[d] = mn[d]; G.dim[d] = dim[d]; }
-    G.cell = dist;
-    MAD_TRY(pose_device(ctx, scratch<int32_t>(ctx, S_PAIR_HI), scratch<int32_t>(ctx, S_PAIR_LO), n_pairs,
-                        scratch<double>(ctx, S_TMP_E), scratch<double>(ctx, S_TMP_F), scratch<double>(ctx, S_TMP_H),
-                        scratch<double>(ctx, S_TMP_I), nullptr, nullptr, scratch<double>(ctx, S_HI_CLOUD), d_lhi, (int)l_hi,
-                        scratch<double>(ctx, S_USED_LO), nullptr, (int)l_lo, bmn, bmx, &G, dist, scratch<int32_t>(ctx, S_COUNTS),
-                        d_lhi + 1));
+    const bool fits = clouds_fit_lds(l_hi, l_lo);
+    if (!fits) {      // global cell list (cell = dist) over the lo cloud
+        double mn[3];
+        int dim[3];
+        MAD_TRY(build_cells(ctx, bmn, bmx, scratch<double>(ctx, S_USED_LO), (int)l_lo, dist, ctx->scratch[S_CELL_START],
+                            ctx->scratch[S_CELL_PTS], ctx->scratch[S_CELL_IDS], mn, dim));
+        G.start = scratch<int32_t>(ctx, S_CELL_START); G.pts = scratch<double>(ctx, S_CELL_PTS); G.ids = scratch<int32_t>(ctx, S_CELL_IDS);
+        G.used = nullptr;
+        for (int d = 0; d < 3; d++) { G.mn[d] = mn[d]; G.dim[d] = dim[d]; }
+        G.cell = dist;
+    }
+    MAD_TRY(pose_device(ctx, H, L, st, n_pairs, scratch<double>(ctx, S_HI_CLOUD), (int)l_hi, scratch<double>(ctx, S_USED_LO), (int)l_lo,
+                        nullptr, bmn, bmx, fits ? nullptr : &G, dist));
     if (results) {
         MAD_TRY(mad_reserve(ctx, ctx->scratch[S_RESULTS], (size_t)n_pairs * MAD_RESULT_COLS * 8));
-        hipLaunchKernelGGL(k_results, dim3((unsigned)mad_ceil_div(n_pairs, 256)), dim3(256), 0, ctx->stream, nullptr, n_pairs,
-                           scratch<int32_t>(ctx, S_PAIR_HI), scratch<int32_t>(ctx, S_PAIR_LO),
-                           scratch<double>(ctx, S_PAIR_SCORE), scratch<int32_t>(ctx, S_COUNTS), d_lhi,
-                           scratch<double>(ctx, S_TMP_E), scratch<double>(ctx, S_TMP_F), scratch<int32_t>(ctx, S_TMP_G),
-                           scratch<double>(ctx, S_TMP_H), scratch<double>(ctx, S_TMP_I), scratch<int32_t>(ctx, S_TMP_J),
-                           nullptr, nullptr, scratch<double>(ctx, S_RESULTS));
+        hipLaunchKernelGGL(k_results, dim3((unsigned)std::min<int64_t>(mad_ceil_div(n_pairs, 256), 4096)), dim3(256), 0, ctx->stream,
+                           (const int64_t *)nullptr, st + ST_NPAIRS, n_pairs, scratch<int32_t>(ctx, S_PAIR_HI),
+                           scratch<int32_t>(ctx, S_PAIR_LO), scratch<double>(ctx, S_PAIR_SCORE), scratch<int32_t>(ctx, S_COUNTS), st,
+                           H.p, H.R, H.meta, L.p, L.Rinv, L.meta, (const int32_t *)nullptr, (const int32_t *)nullptr,
+                           scratch<double>(ctx, S_RESULTS));
         MAD_HIP(hipGetLastError());
-        MAD_HIP(hipMemcpyAsync(results, ctx->scratch[S_RESULTS].p, (size_t)n_pairs * MAD_RESULT_COLS * 8,
-                               hipMemcpyDeviceToHost, ctx->stream));
+        MAD_HIP(hipMemcpyAsync(results, ctx->scratch[S_RESULTS].p, (size_t)n_pairs * MAD_RESULT_COLS * 8, hipMemcpyDeviceToHost, ctx->stream));
     }
     if (counts) MAD_HIP(hipMemcpyAsync(counts, ctx->scratch[S_COUNTS].p, (size_t)n_pairs * 4, hipMemcpyDeviceToHost, ctx->stream));
     MAD_HIP(hipStreamSynchronize(ctx->stream));
@@ -892,12 +986,17 @@ extern "C" int mad_topk(mad_ctx *ctx, const int32_t *counts, int64_t n, int64_t 
         if (counts[i] < 0) return mad_fail(ctx, MAD_EINVAL, "mad_topk: negative count");
         if (counts[i] > maxc) maxc = counts[i];
     }
+    if (k > n) k = n;
     MAD_TRY(mad_reserve(ctx, ctx->scratch[S_COUNTS], (size_t)n * 4));
     MAD_TRY(mad_reserve(ctx, ctx->scratch[S_SEL_OUT], (size_t)(k + 8) * 8));
+    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_MISC], 4096));
+    int32_t *st = status_words(ctx);
+    int32_t hs[ST_COUNT] = {0};
+    hs[ST_NPAIRS] = (int32_t)n;
+    MAD_HIP(hipMemcpyAsync(st, hs, sizeof(hs), hipMemcpyHostToDevice, ctx->stream));
     MAD_HIP(hipMemcpyAsync(ctx->scratch[S_COUNTS].p, counts, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
-    int64_t got = 0;
-    MAD_TRY(topk_device(ctx, scratch<int32_t>(ctx, S_COUNTS), n, k, maxc, scratch<int64_t>(ctx, S_SEL_OUT), &got));
-    MAD_HIP(hipMemcpyAsync(order, ctx->scratch[S_SEL_OUT].p, (size_t)got * 8, hipMemcpyDeviceToHost, ctx->stream));
+    MAD_TRY(topk_device(ctx, scratch<int32_t>(ctx, S_COUNTS), st, n, k, maxc, scratch<int64_t>(ctx, S_SEL_OUT)));
+    MAD_HIP(hipMemcpyAsync(order, ctx->scratch[S_SEL_OUT].p, (size_t)k * 8, hipMemcpyDeviceToHost, ctx->stream));
     MAD_HIP(hipStreamSynchronize(ctx->stream));
     return MAD_OK;
 }
@@ -908,7 +1007,14 @@ extern "C" int mad_topk(mad_ctx *ctx, const int32_t *counts, int64_t n, int64_t 
 
 extern "C" int mad_set_create(mad_ctx *ctx, mad_set **out) {
     if (!ctx || !out) return MAD_EINVAL;
-    *out = new mad_set();
+    mad_set *s = new mad_set();
+    if (hipEventCreateWithFlags(&s->ready, hipEventDisableTiming) != hipSuccess) {
+        delete s;
+        return mad_fail(ctx, MAD_EHIP, "mad_set_create: event creation failed");
+    }
+    s->pinned_slot = ctx->next_pinned;
+    ctx->next_pinned = 16 + (ctx->next_pinned - 16 + 2) % 1000;      // two 8-byte slots per set
+    *out = s;
     return MAD_OK;
 }
 
@@ -916,9 +1022,36 @@ extern "C" void mad_set_destroy(mad_ctx *ctx, mad_set *s) {
     if (!s) return;
     if (ctx) (void)hipStreamSynchronize(ctx->stream);
     DevBuf *bufs[] = {&s->anc_coords, &s->anc_octave, &s->anc_subv, &s->anc_index, &s->row_anchor, &s->row_main, &s->row_sec,
-                      &s->row_R, &s->dsc, &s->dsc8, &s->norm, &s->cell_start, &s->cell_pts, &s->cell_ids};
+                      &s->row_R, &s->row_Rinv, &s->row_meta, &s->dsc, &s->dsc8, &s->norm, &s->dev_n, &s->cell_start, &s->cell_pts,
+                      &s->cell_ids};
     for (DevBuf *b : bufs) mad_release(*b);
+    if (s->ready) (void)hipEventDestroy(s->ready);
     delete s;
+}
+
+static int set_finish_rows(mad_ctx *ctx, mad_set *s, bool check_range);
+
+// waits for the asynchronous read-back once; repeats the describe stage if its launch had been sized too small
+static int set_rows(mad_ctx *ctx, const mad_set *cs, int64_t *n_rows) {
+    mad_set *s = const_cast<mad_set *>(cs);
+    if (s->n_rows_host < 0) {
+        MAD_HIP(hipEventSynchronize(s->ready));
+        const int32_t *h = (const int32_t *)&ctx->pinned[s->pinned_slot];
+        s->n_rows_host = h[0];
+        s->rows_hint = h[0];
+        if (h[3] && s->last_r > 0) {
+            MAD_HIP(hipMemsetAsync((int32_t *)s->dev_n.p + 3, 0, 4, ctx->stream));
+            MAD_TRY(mad_describe_device(ctx, s->last_f[0], s->last_f[1], (const int32_t *)s->anc_coords.p,
+                                        (const int32_t *)s->anc_octave.p, 0, (const int32_t *)s->row_anchor.p,
+                                        (const double *)s->row_R.p, (const int32_t *)s->dev_n.p, s->cap_rows,
+                                        (int32_t *)s->dev_n.p + 3, s->last_r, (int16_t *)s->dsc.p));
+            MAD_TRY(set_finish_rows(ctx, s, false));
+            MAD_HIP(hipEventSynchronize(s->ready));
+            s->n_rows_host = h[0];
+        }
+    }
+    *n_rows = s->n_rows_host;
+    return MAD_OK;
 }
 
 static int set_upload_anchors(mad_ctx *ctx, mad_set *s, const int32_t *anc_coords, const int32_t *anc_octave,
@@ -929,29 +1062,57 @@ static int set_upload_anchors(mad_ctx *ctx, mad_set *s, const int32_t *anc_coord
     MAD_TRY(mad_reserve(ctx, s->anc_octave, m * 4));
     MAD_TRY(mad_reserve(ctx, s->anc_subv, m * 24));
     MAD_TRY(mad_reserve(ctx, s->anc_index, m * 4));
+    MAD_TRY(mad_reserve(ctx, s->dev_n, 64));
+    MAD_HIP(hipMemsetAsync(s->dev_n.p, 0, 64, ctx->stream));
     if (n > 0) {
         if (anc_coords) MAD_HIP(hipMemcpyAsync(s->anc_coords.p, anc_coords, (size_t)n * 12, hipMemcpyHostToDevice, ctx->stream));
         MAD_HIP(hipMemcpyAsync(s->anc_octave.p, anc_octave, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
         MAD_HIP(hipMemcpyAsync(s->anc_subv.p, anc_subv, (size_t)n * 24, hipMemcpyHostToDevice, ctx->stream));
         MAD_HIP(hipMemcpyAsync(s->anc_index.p, anc_index, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
     }
+    for (int i = 0; i < n; i++)
+        for (int d = 0; d < 3; d++) {
+            const double v = anc_subv[3 * i + d];
+            if (i == 0 || v < s->bb_min[d]) s->bb_min[d] = v;
+            if (i == 0 || v > s->bb_max[d]) s->bb_max[d] = v;
+        }
     s->cells_ready = false;
+    s->n_rows_host = -1;
     return MAD_OK;
 }
 
-// per-row meta {anchor index, octave, main bin} gathered on the fly by k_results through
-// row_anchor; stored packed here so that one kernel serves both APIs
-__global__ void k_row_meta(const int32_t *row_anchor, const int32_t *row_main, const int32_t *anc_index,
-                           const int32_t *anc_octave, int64_t n, int32_t *meta) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int a = row_anchor[i];
-    meta[3 * i] = anc_index[a]; meta[3 * i + 1] = anc_octave[a]; meta[3 * i + 2] = row_main[i];
+static int set_reserve_rows(mad_ctx *ctx, mad_set *s, int64_t cap) {
+    const int64_t cap_pad = mad_ceil_div(cap > 0 ? cap : 1, GEMM_BM) * GEMM_BM;
+    s->cap_rows = cap;
+    MAD_TRY(mad_reserve(ctx, s->row_anchor, (size_t)cap_pad * 4));
+    MAD_TRY(mad_reserve(ctx, s->row_main, (size_t)cap_pad * 4));
+    MAD_TRY(mad_reserve(ctx, s->row_sec, (size_t)cap_pad * 4));
+    MAD_TRY(mad_reserve(ctx, s->row_R, (size_t)cap_pad * 72));
+    MAD_TRY(mad_reserve(ctx, s->row_Rinv, (size_t)cap_pad * 72));
+    MAD_TRY(mad_reserve(ctx, s->row_meta, (size_t)cap_pad * 12));
+    MAD_TRY(mad_reserve(ctx, s->dsc, (size_t)cap_pad * s->D * 2));
+    MAD_TRY(mad_reserve(ctx, s->dsc8, (size_t)cap_pad * s->D));
+    MAD_TRY(mad_reserve(ctx, s->norm, (size_t)cap_pad * 8));
+    return MAD_OK;
 }
 
-static int set_finish_rows(mad_ctx *ctx, mad_set *s) {
-    s->n_rows_pad = mad_ceil_div(s->n_rows > 0 ? s->n_rows : 1, GEMM_BM) * GEMM_BM;
-    MAD_TRY(pack_rows(ctx, (const int16_t *)s->dsc.p, s->n_rows, s->D, s->dsc8, s->norm, GEMM_BM));
+// int8 rows + norms, inverse rotations, result meta; then the asynchronous read-back of the row count
+static int set_finish_rows(mad_ctx *ctx, mad_set *s, bool check_range) {
+    int32_t *d_n = (int32_t *)s->dev_n.p;
+    int32_t *bad = d_n + 1;
+    MAD_HIP(hipMemsetAsync(bad, 0, 4, ctx->stream));
+    const int64_t cap_pad = mad_ceil_div(s->cap_rows > 0 ? s->cap_rows : 1, GEMM_BM) * GEMM_BM;
+    hipLaunchKernelGGL(k_pack_rows, dim3((unsigned)std::min<int64_t>(mad_ceil_div(cap_pad, 4), (int64_t)ctx->n_cu * 8)), dim3(256), 0,
+                       ctx->stream, (const int16_t *)s->dsc.p, d_n, s->D, (int8_t *)s->dsc8.p, (double *)s->norm.p,
+                       check_range ? bad : (int32_t *)nullptr);
+    hipLaunchKernelGGL(k_row_aux, dim3((unsigned)std::min<int64_t>(mad_ceil_div(cap_pad, 256), 1024)), dim3(256), 0, ctx->stream,
+                       (const double *)s->row_R.p, d_n, (double *)s->row_Rinv.p, (const int32_t *)s->row_anchor.p,
+                       (const int32_t *)s->row_main.p, (const int32_t *)s->anc_index.p, (const int32_t *)s->anc_octave.p,
+                       (int32_t *)s->row_meta.p);
+    MAD_HIP(hipGetLastError());
+    MAD_HIP(hipMemcpyAsync(&ctx->pinned[s->pinned_slot], d_n, 16, hipMemcpyDeviceToHost, ctx->stream));
+    MAD_HIP(hipEventRecord(s->ready, ctx->stream));
+    s->n_rows_host = -1;
     return MAD_OK;
 }
 
@@ -960,6 +1121,7 @@ extern "C" int mad_set_build(mad_ctx *ctx, mad_set *s, const int *slot_of_octave
                              int lim_main, int lim_sec) {
     if (!ctx || !s || !slot_of_octave) return MAD_EINVAL;
     if (n > 0 && (!anc_coords || !anc_octave || !anc_subv || !anc_index)) return mad_fail(ctx, MAD_EINVAL, "mad_set_build: NULL anchors");
+    if (lim_main < 1 || lim_sec < 1 || lim_main * lim_sec > 64) return mad_fail(ctx, MAD_EINVAL, "mad_set_build: lim_main=%d lim_sec=%d", lim_main, lim_sec);
     FieldDev f[2] = {FieldDev{nullptr, 0, 0, 0}, FieldDev{nullptr, 0, 0, 0}};
     for (int o = 0; o < 2; o++) {
         const int sl = slot_of_octave[o];
@@ -974,28 +1136,21 @@ extern "C" int mad_set_build(mad_ctx *ctx, mad_set *s, const int *slot_of_octave
     }
     MAD_TRY(set_upload_anchors(ctx, s, anc_coords, anc_octave, anc_subv, anc_index, n));
     s->D = 64 * ctx->eq_host[1].Z;
-    s->n_rows = 0;
-    int64_t rows = 0;
+    MAD_TRY(set_reserve_rows(ctx, s, (int64_t)n * lim_main * lim_sec));
+    OrientOut out;
+    out.row_anchor = (int32_t *)s->row_anchor.p; out.row_main = (int32_t *)s->row_main.p; out.row_sec = (int32_t *)s->row_sec.p;
+    out.row_R = (double *)s->row_R.p; out.row_count = nullptr;
+    out.d_n_rows = (int32_t *)s->dev_n.p; out.d_n_reject = (int32_t *)s->dev_n.p + 2;
     MAD_TRY(mad_orient_device(ctx, f[0], f[1], (const int32_t *)s->anc_coords.p, (const int32_t *)s->anc_octave.p, 0, n, r,
-                              lim_main, lim_sec, false, &rows, nullptr));
-    s->n_rows = rows;
-    const size_t m = (size_t)(rows > 0 ? rows : 1);
-    MAD_TRY(mad_reserve(ctx, s->row_anchor, m * 4));
-    MAD_TRY(mad_reserve(ctx, s->row_main, m * 4));
-    MAD_TRY(mad_reserve(ctx, s->row_sec, m * 4));
-    MAD_TRY(mad_reserve(ctx, s->row_R, m * 72));
-    MAD_TRY(mad_reserve(ctx, s->dsc, m * s->D * 2));
-    if (rows > 0) {
-        MAD_HIP(hipMemcpyAsync(s->row_anchor.p, ctx->scratch[S_ROW_ANCHOR].p, rows * 4, hipMemcpyDeviceToDevice, ctx->stream));
-        MAD_HIP(hipMemcpyAsync(s->row_main.p, ctx->scratch[S_ROW_MAIN].p, rows * 4, hipMemcpyDeviceToDevice, ctx->stream));
-        MAD_HIP(hipMemcpyAsync(s->row_sec.p, ctx->scratch[S_ROW_SEC].p, rows * 4, hipMemcpyDeviceToDevice, ctx->stream));
-        MAD_HIP(hipMemcpyAsync(s->row_R.p, ctx->scratch[S_ROW_R].p, rows * 72, hipMemcpyDeviceToDevice, ctx->stream));
-        MAD_TRY(mad_describe_device(ctx, f[0], f[1], (const int32_t *)s->anc_coords.p, (const int32_t *)s->anc_octave.p, 0,
-                                    (const int32_t *)s->row_anchor.p, (const double *)s->row_R.p, rows, r, (int16_t *)s->dsc.p));
-    }
-    MAD_TRY(set_finish_rows(ctx, s));
-    MAD_TRY(mad_build_cells(ctx, s, anc_subv, 4.0));
-    return MAD_OK;
+                              lim_main, lim_sec, out));
+    // the describe launch is sized from the row count of this set's previous build when there is one
+    const int64_t grid_rows = s->rows_hint > 0 ? std::min<int64_t>(s->cap_rows, s->rows_hint + s->rows_hint / 8 + 64) : s->cap_rows;
+    MAD_HIP(hipMemsetAsync((int32_t *)s->dev_n.p + 3, 0, 4, ctx->stream));
+    MAD_TRY(mad_describe_device(ctx, f[0], f[1], (const int32_t *)s->anc_coords.p, (const int32_t *)s->anc_octave.p, 0,
+                                (const int32_t *)s->row_anchor.p, (const double *)s->row_R.p, (const int32_t *)s->dev_n.p,
+                                grid_rows, (int32_t *)s->dev_n.p + 3, r, (int16_t *)s->dsc.p));
+    s->last_f[0] = f[0]; s->last_f[1] = f[1]; s->last_r = r;
+    return set_finish_rows(ctx, s, false);      // counts come from k_describe: <= 64 by construction
 }
 
 extern "C" int mad_set_load(mad_ctx *ctx, mad_set *s, int64_t n_rows, const int32_t *row_anchor, const int32_t *row_main,
@@ -1008,13 +1163,9 @@ extern "C" int mad_set_load(mad_ctx *ctx, mad_set *s, int64_t n_rows, const int3
         if (row_anchor[i] < 0 || row_anchor[i] >= n_anchors) return mad_fail(ctx, MAD_EINVAL, "mad_set_load: row %lld -> anchor %d", (long long)i, row_anchor[i]);
     MAD_TRY(set_upload_anchors(ctx, s, nullptr, anc_octave, anc_subv, anc_index, n_anchors));
     s->D = D;
-    s->n_rows = n_rows;
-    const size_t m = (size_t)(n_rows > 0 ? n_rows : 1);
-    MAD_TRY(mad_reserve(ctx, s->row_anchor, m * 4));
-    MAD_TRY(mad_reserve(ctx, s->row_main, m * 4));
-    MAD_TRY(mad_reserve(ctx, s->row_sec, m * 4));
-    MAD_TRY(mad_reserve(ctx, s->row_R, m * 72));
-    MAD_TRY(mad_reserve(ctx, s->dsc, m * D * 2));
+    MAD_TRY(set_reserve_rows(ctx, s, n_rows));
+    const int32_t n32 = (int32_t)n_rows;
+    MAD_HIP(hipMemcpyAsync(s->dev_n.p, &n32, 4, hipMemcpyHostToDevice, ctx->stream));
     if (n_rows > 0) {
         MAD_HIP(hipMemcpyAsync(s->row_anchor.p, row_anchor, n_rows * 4, hipMemcpyHostToDevice, ctx->stream));
         MAD_HIP(hipMemcpyAsync(s->row_main.p, row_main, n_rows * 4, hipMemcpyHostToDevice, ctx->stream));
@@ -1022,14 +1173,17 @@ extern "C" int mad_set_load(mad_ctx *ctx, mad_set *s, int64_t n_rows, const int3
         MAD_HIP(hipMemcpyAsync(s->row_R.p, row_R, n_rows * 72, hipMemcpyHostToDevice, ctx->stream));
         MAD_HIP(hipMemcpyAsync(s->dsc.p, dsc, (size_t)n_rows * D * 2, hipMemcpyHostToDevice, ctx->stream));
     }
-    MAD_TRY(set_finish_rows(ctx, s));
-    MAD_TRY(mad_build_cells(ctx, s, anc_subv, 4.0));
+    MAD_TRY(set_finish_rows(ctx, s, true));
+    MAD_HIP(hipStreamSynchronize(ctx->stream));      // the host arrays may go away; also fetch the range check
+    if (((const int32_t *)&ctx->pinned[s->pinned_slot])[1]) return mad_fail(ctx, MAD_EDOM, "descriptor count outside the int8 range");
     return MAD_OK;
 }
 
 extern "C" int mad_set_size(mad_ctx *ctx, const mad_set *s, int64_t *n_rows, int32_t *n_anchors) {
     if (!ctx || !s) return MAD_EINVAL;
-    if (n_rows) *n_rows = s->n_rows;
+    int64_t n = 0;
+    MAD_TRY(set_rows(ctx, s, &n));
+    if (n_rows) *n_rows = n;
     if (n_anchors) *n_anchors = s->n_anchors;
     return MAD_OK;
 }
@@ -1037,7 +1191,8 @@ extern "C" int mad_set_size(mad_ctx *ctx, const mad_set *s, int64_t *n_rows, int
 extern "C" int mad_set_download(mad_ctx *ctx, const mad_set *s, int32_t *row_anchor, int32_t *row_main, int32_t *row_sec,
                                 double *row_R, int16_t *dsc) {
     if (!ctx || !s) return MAD_EINVAL;
-    const int64_t n = s->n_rows;
+    int64_t n = 0;
+    MAD_TRY(set_rows(ctx, s, &n));
     if (n <= 0) return MAD_OK;
     if (row_anchor) MAD_HIP(hipMemcpyAsync(row_anchor, s->row_anchor.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
     if (row_main) MAD_HIP(hipMemcpyAsync(row_main, s->row_main.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -1048,91 +1203,107 @@ extern "C" int mad_set_download(mad_ctx *ctx, const mad_set *s, int32_t *row_anc
     return MAD_OK;
 }
 
+static Side side_of(const mad_set *s) {
+    Side x;
+    x.dsc8 = (const int8_t *)s->dsc8.p; x.norm = (const double *)s->norm.p; x.R = (const double *)s->row_R.p;
+    x.Rinv = (const double *)s->row_Rinv.p; x.meta = (const int32_t *)s->row_meta.p; x.row_anchor = (const int32_t *)s->row_anchor.p;
+    x.p = (const double *)s->anc_subv.p; x.n_rows = (const int32_t *)s->dev_n.p; x.cap_rows = s->cap_rows;
+    return x;
+}
+
 extern "C" int mad_match_topk(mad_ctx *ctx, const mad_set *hi, const mad_set *lo, double cc, double dist, int64_t k,
                               double *results, int64_t *pair_index, int64_t *n_out, int64_t *stats) {
     if (!ctx || !hi || !lo || !n_out) return MAD_EINVAL;
     *n_out = 0;
+    const int64_t keep_c = ctx->match.cap_c, keep_p = ctx->match.cap_pairs;
     ctx->match = MatchState();
+    ctx->match.cap_c = keep_c; ctx->match.cap_pairs = keep_p;
     ctx->match.n_hi_anchors = hi->n_anchors;
     ctx->match.n_lo_anchors = lo->n_anchors;
-    if (stats) { stats[0] = 0; stats[1] = 0; stats[2] = 0; stats[3] = hi->n_rows * lo->n_rows; }
-    if (hi->n_rows <= 0 || lo->n_rows <= 0) return MAD_OK;
+    if (stats) { stats[0] = 0; stats[1] = 0; stats[2] = 0; stats[3] = 0; }
+    if (hi->cap_rows <= 0 || lo->cap_rows <= 0 || hi->n_anchors <= 0 || lo->n_anchors <= 0) return MAD_OK;
     if (hi->D != lo->D) return mad_fail(ctx, MAD_EINVAL, "mad_match_topk: descriptor lengths %d vs %d", hi->D, lo->D);
     if (!(dist > 0)) return mad_fail(ctx, MAD_EINVAL, "mad_match_topk: dist must be positive");
-    if (hi->n_rows * lo->n_rows >= ((int64_t)1 << 31)) return mad_fail(ctx, MAD_EINVAL, "mad_match_topk: %lld x %lld rows too large", (long long)hi->n_rows, (long long)lo->n_rows);
-    if (!lo->cells_ready || lo->cell_size != dist) {
-        // the cell list was built for another radius: rebuild it from a host copy of the anchors
-        mad_set *l = const_cast<mad_set *>(lo);
-        double *h = (double *)malloc((size_t)lo->n_anchors * 24 + 24);
-        if (!h) return mad_fail(ctx, MAD_ENOMEM, "host allocation failed");
-        hipError_t e = hipMemcpy(h, lo->anc_subv.p, (size_t)lo->n_anchors * 24, hipMemcpyDeviceToHost);
-        int rc = e == hipSuccess ? mad_build_cells(ctx, l, h, dist) : mad_fail(ctx, MAD_EHIP, "anchor read-back failed");
-        free(h);
-        MAD_TRY(rc);
-    }
-    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_USED_HI], (size_t)hi->n_anchors + 16));
-    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_USED_LO], (size_t)lo->n_anchors + 16));
-    uint8_t *used_hi = scratch<uint8_t>(ctx, S_USED_HI), *used_lo = scratch<uint8_t>(ctx, S_USED_LO);
-    MAD_HIP(hipMemsetAsync(used_hi, 0, (size_t)hi->n_anchors + 16, ctx->stream));
-    MAD_HIP(hipMemsetAsync(used_lo, 0, (size_t)lo->n_anchors + 16, ctx->stream));
-    int64_t np = 0;
-    MAD_TRY(correlate_device(ctx, (const int8_t *)hi->dsc8.p, hi->n_rows, (const int8_t *)lo->dsc8.p, lo->n_rows, hi->D,
-                             (const double *)hi->norm.p, (const double *)lo->norm.p, cc, (const int32_t *)hi->row_anchor.p,
-                             (const int32_t *)lo->row_anchor.p, used_hi, used_lo, &np));
-    ctx->match.n_pairs = np;
-    if (stats) stats[0] = np;
-    if (np == 0) return MAD_OK;
-    // clouds: anchors that take part in at least one pair (MaD.py:427-428)
+    if (k < 1) k = 1;
+    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_MISC], 4096));
+    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_USED_HI], (size_t)hi->n_anchors + lo->n_anchors + 64));
     MAD_TRY(mad_reserve(ctx, ctx->scratch[S_HI_CLOUD], (size_t)hi->n_anchors * 24 + 24));
-    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_MISC], 256));
-    int32_t *d_lhi = scratch<int32_t>(ctx, S_MISC) + 8, *d_llo = scratch<int32_t>(ctx, S_MISC) + 9;
-    MAD_HIP(hipMemsetAsync(d_llo, 0, 4, ctx->stream));
-    hipLaunchKernelGGL(k_compact_cloud, dim3(1), dim3(1024), 0, ctx->stream, (const double *)hi->anc_subv.p, used_hi,
-                       hi->n_anchors, scratch<double>(ctx, S_HI_CLOUD), d_lhi);
-    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_COUNTS], (size_t)np * 4));
-    CellGrid G;
-    G.start = (const int32_t *)lo->cell_start.p; G.pts = (const double *)lo->cell_pts.p; G.ids = (const int32_t *)lo->cell_ids.p;
-    G.used = used_lo;
-    for (int d = 0; d < 3; d++) { G.mn[d] = lo->cell_min[d]; G.dim[d] = lo->cell_dim[d]; }
-    G.cell = lo->cell_size;
-    MAD_TRY(pose_device(ctx, scratch<int32_t>(ctx, S_PAIR_HI), scratch<int32_t>(ctx, S_PAIR_LO), np,
-                        (const double *)hi->anc_subv.p, (const double *)hi->row_R.p, (const double *)lo->anc_subv.p,
-                        (const double *)lo->row_R.p, (const int32_t *)hi->row_anchor.p, (const int32_t *)lo->row_anchor.p,
-                        scratch<double>(ctx, S_HI_CLOUD), d_lhi, hi->n_anchors, (const double *)lo->anc_subv.p, used_lo,
-                        lo->n_anchors, lo->bb_min, lo->bb_max, &G, dist, scratch<int32_t>(ctx, S_COUNTS), d_llo));
-    MAD_HIP(hipMemcpyAsync(&ctx->pinned[4], d_lhi, 8, hipMemcpyDeviceToHost, ctx->stream));      // l_hi and l_lo
-    // top-k
     MAD_TRY(mad_reserve(ctx, ctx->scratch[S_SEL_OUT], (size_t)(k + 8) * 8));
-    int64_t got = 0;
-    MAD_TRY(topk_device(ctx, scratch<int32_t>(ctx, S_COUNTS), np, k, hi->n_anchors, scratch<int64_t>(ctx, S_SEL_OUT), &got));
-    if (got > 0 && results) {
-        // per-row meta for both sides
-        MAD_TRY(mad_reserve(ctx, ctx->scratch[S_TMP_G], (size_t)hi->n_rows * 12));
-        MAD_TRY(mad_reserve(ctx, ctx->scratch[S_TMP_J], (size_t)lo->n_rows * 12));
-        hipLaunchKernelGGL(k_row_meta, dim3((unsigned)mad_ceil_div(hi->n_rows, 256)), dim3(256), 0, ctx->stream,
-                           (const int32_t *)hi->row_anchor.p, (const int32_t *)hi->row_main.p, (const int32_t *)hi->anc_index.p,
-                           (const int32_t *)hi->anc_octave.p, hi->n_rows, scratch<int32_t>(ctx, S_TMP_G));
-        hipLaunchKernelGGL(k_row_meta, dim3((unsigned)mad_ceil_div(lo->n_rows, 256)), dim3(256), 0, ctx->stream,
-                           (const int32_t *)lo->row_anchor.p, (const int32_t *)lo->row_main.p, (const int32_t *)lo->anc_index.p,
-                           (const int32_t *)lo->anc_octave.p, lo->n_rows, scratch<int32_t>(ctx, S_TMP_J));
-        MAD_TRY(mad_reserve(ctx, ctx->scratch[S_RESULTS], (size_t)got * MAD_RESULT_COLS * 8));
-        hipLaunchKernelGGL(k_results, dim3((unsigned)mad_ceil_div(got, 256)), dim3(256), 0, ctx->stream,
-                           scratch<int64_t>(ctx, S_SEL_OUT), got, scratch<int32_t>(ctx, S_PAIR_HI),
-                           scratch<int32_t>(ctx, S_PAIR_LO), scratch<double>(ctx, S_PAIR_SCORE),
-                           scratch<int32_t>(ctx, S_COUNTS), d_lhi, (const double *)hi->anc_subv.p, (const double *)hi->row_R.p,
-                           scratch<int32_t>(ctx, S_TMP_G), (const double *)lo->anc_subv.p, (const double *)lo->row_R.p,
-                           scratch<int32_t>(ctx, S_TMP_J), (const int32_t *)hi->row_anchor.p,
-                           (const int32_t *)lo->row_anchor.p, scratch<double>(ctx, S_RESULTS));
-        MAD_HIP(hipGetLastError());
-        MAD_HIP(hipMemcpyAsync(results, ctx->scratch[S_RESULTS].p, (size_t)got * MAD_RESULT_COLS * 8, hipMemcpyDeviceToHost, ctx->stream));
+    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_RESULTS], (size_t)(k + 1) * MAD_RESULT_COLS * 8));
+    int32_t *st = status_words(ctx);
+    uint8_t *used_hi = scratch<uint8_t>(ctx, S_USED_HI), *used_lo = used_hi + ((hi->n_anchors + 31) & ~31);
+    const Side H = side_of(hi), L = side_of(lo);
+    // capacity hints: the score matrix for ~8 rows per anchor, pairs for 2 % of the matrix; both grow on demand
+    const int64_t full_c = (mad_ceil_div(hi->cap_rows, 128) * 128) * (mad_ceil_div(lo->cap_rows, 128) * 128);
+    int64_t cap_c = std::max<int64_t>(ctx->match.cap_c, std::min<int64_t>((int64_t)(hi->n_anchors * 8 + 128) * (lo->n_anchors * 8 + 128), full_c));
+    int64_t cap_pairs = std::max<int64_t>(ctx->match.cap_pairs, std::max<int64_t>(cap_c / 50, 1 << 16));
+    // the global cell list is only needed when the clouds cannot live in LDS
+    const bool fits = clouds_fit_lds(hi->n_anchors, lo->n_anchors);
+    CellGrid G;
+    if (!fits) {
+        if (!lo->cells_ready || lo->cell_size != dist) MAD_TRY(mad_build_cells(ctx, const_cast<mad_set *>(lo), dist));
+        G.start = (const int32_t *)lo->cell_start.p; G.pts = (const double *)lo->cell_pts.p; G.ids = (const int32_t *)lo->cell_ids.p;
+        G.used = used_lo;
+        for (int d = 0; d < 3; d++) { G.mn[d] = lo->cell_min[d]; G.dim[d] = lo->cell_dim[d]; }
+        G.cell = lo->cell_size;
     }
-    if (got > 0 && pair_index) MAD_HIP(hipMemcpyAsync(pair_index, ctx->scratch[S_SEL_OUT].p, (size_t)got * 8, hipMemcpyDeviceToHost, ctx->stream));
-    MAD_HIP(hipStreamSynchronize(ctx->stream));
-    const int32_t *ll = (const int32_t *)&ctx->pinned[4];
-    ctx->match.l_hi = ll[0];
-    ctx->match.l_lo = ll[1];
-    if (stats) { stats[1] = ll[0]; stats[2] = ll[1]; }
-    *n_out = got;
+    const int32_t *hs = (const int32_t *)&ctx->pinned[0];
+    for (int attempt = 0; attempt < 4; attempt++) {
+        if (cap_c >= ((int64_t)1 << 31)) return mad_fail(ctx, MAD_EINVAL, "mad_match_topk: score matrix of %lld entries", (long long)cap_c);
+        MAD_HIP(hipMemsetAsync(st, 0, ST_COUNT * 4, ctx->stream));
+        MAD_HIP(hipMemsetAsync(used_hi, 0, (size_t)hi->n_anchors + lo->n_anchors + 64, ctx->stream));
+        MAD_HIP(hipMemcpyAsync(st + ST_NHI, hi->dev_n.p, 16, hipMemcpyDeviceToDevice, ctx->stream));
+        MAD_HIP(hipMemcpyAsync(st + ST_NLO, lo->dev_n.p, 16, hipMemcpyDeviceToDevice, ctx->stream));
+        MAD_TRY(correlate_device(ctx, H, L, hi->D, cc, st, cap_c, cap_pairs, used_hi, used_lo));
+        // clouds: anchors that take part in at least one pair (MaD.py:427-428)
+        hipLaunchKernelGGL(k_compact_cloud, dim3(1), dim3(1024), 0, ctx->stream, (const double *)hi->anc_subv.p, used_hi,
+                           hi->n_anchors, scratch<double>(ctx, S_HI_CLOUD), st + ST_LHI);
+        MAD_TRY(pose_device(ctx, H, L, st, cap_pairs, scratch<double>(ctx, S_HI_CLOUD), hi->n_anchors, (const double *)lo->anc_subv.p,
+                            lo->n_anchors, used_lo, lo->bb_min, lo->bb_max, fits ? nullptr : &G, dist));
+        MAD_TRY(topk_device(ctx, scratch<int32_t>(ctx, S_COUNTS), st, cap_pairs, k, hi->n_anchors, scratch<int64_t>(ctx, S_SEL_OUT)));
+        if (results) {
+            hipLaunchKernelGGL(k_results, dim3((unsigned)mad_ceil_div(k, 256)), dim3(256), 0, ctx->stream,
+                               scratch<int64_t>(ctx, S_SEL_OUT), st + ST_NKEYS, k, scratch<int32_t>(ctx, S_PAIR_HI),
+                               scratch<int32_t>(ctx, S_PAIR_LO), scratch<double>(ctx, S_PAIR_SCORE), scratch<int32_t>(ctx, S_COUNTS),
+                               st, H.p, H.R, H.meta, L.p, L.Rinv, L.meta, H.row_anchor, L.row_anchor, scratch<double>(ctx, S_RESULTS));
+            MAD_HIP(hipGetLastError());
+            MAD_HIP(hipMemcpyAsync(results, ctx->scratch[S_RESULTS].p, (size_t)k * MAD_RESULT_COLS * 8, hipMemcpyDeviceToHost, ctx->stream));
+        }
+        if (pair_index) MAD_HIP(hipMemcpyAsync(pair_index, ctx->scratch[S_SEL_OUT].p, (size_t)k * 8, hipMemcpyDeviceToHost, ctx->stream));
+        MAD_HIP(hipMemcpyAsync(&ctx->pinned[0], st, ST_COUNT * 4, hipMemcpyDeviceToHost, ctx->stream));
+        MAD_HIP(hipStreamSynchronize(ctx->stream));      // the one host round trip of a match
+        if (hs[ST_NHI + 3] || hs[ST_NLO + 3]) {
+            // a set's describe launch had been sized from a stale hint: repair the set(s), then match again
+            int64_t dummy;
+            const_cast<mad_set *>(hi)->n_rows_host = -1;
+            const_cast<mad_set *>(lo)->n_rows_host = -1;
+            MAD_TRY(set_rows(ctx, hi, &dummy));
+            MAD_TRY(set_rows(ctx, lo, &dummy));
+            continue;
+        }
+        if (hs[ST_FLAG_C]) {
+            const int64_t hp = mad_ceil_div((int64_t)hs[ST_NHI], 128) * 128, lp = mad_ceil_div((int64_t)hs[ST_NLO], 128) * 128;
+            cap_c = hp * lp;
+            continue;
+        }
+        if (hs[ST_FLAG_PAIRS]) {
+            cap_pairs = (int64_t)hs[ST_NPAIRS] + hs[ST_NPAIRS] / 8 + 1024;
+            continue;
+        }
+        break;
+    }
+    if (hs[ST_FLAG_C] || hs[ST_FLAG_PAIRS]) return mad_fail(ctx, MAD_EHIP, "mad_match_topk: capacity negotiation did not converge");
+    ctx->match.cap_c = cap_c;
+    ctx->match.cap_pairs = cap_pairs;
+    ctx->match.n_pairs = hs[ST_NPAIRS];
+    ctx->match.l_hi = hs[ST_LHI];
+    ctx->match.l_lo = hs[ST_LLO];
+    const_cast<mad_set *>(hi)->n_rows_host = hs[ST_NHI];
+    const_cast<mad_set *>(lo)->n_rows_host = hs[ST_NLO];
+    const_cast<mad_set *>(hi)->rows_hint = hs[ST_NHI];
+    const_cast<mad_set *>(lo)->rows_hint = hs[ST_NLO];
+    if (stats) { stats[0] = hs[ST_NPAIRS]; stats[1] = hs[ST_LHI]; stats[2] = hs[ST_LLO]; stats[3] = (int64_t)hs[ST_NHI] * hs[ST_NLO]; }
+    *n_out = hs[ST_NPAIRS] > 0 ? hs[ST_NKEYS] : 0;
     return MAD_OK;
 }
 
@@ -1157,22 +1328,13 @@ extern "C" int mad_match_results(mad_ctx *ctx, const mad_set *hi, const mad_set 
     if (np <= 0) return MAD_OK;
     if (hi->n_anchors != ctx->match.n_hi_anchors || lo->n_anchors != ctx->match.n_lo_anchors)
         return mad_fail(ctx, MAD_EINVAL, "mad_match_results: sets differ from the last mad_match_topk call");
-    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_TMP_G], (size_t)hi->n_rows * 12));
-    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_TMP_J], (size_t)lo->n_rows * 12));
     MAD_TRY(mad_reserve(ctx, ctx->scratch[S_RESULTS], (size_t)np * MAD_RESULT_COLS * 8));
-    int32_t *d_lhi = scratch<int32_t>(ctx, S_MISC) + 8;
-    hipLaunchKernelGGL(k_row_meta, dim3((unsigned)mad_ceil_div(hi->n_rows, 256)), dim3(256), 0, ctx->stream,
-                       (const int32_t *)hi->row_anchor.p, (const int32_t *)hi->row_main.p, (const int32_t *)hi->anc_index.p,
-                       (const int32_t *)hi->anc_octave.p, hi->n_rows, scratch<int32_t>(ctx, S_TMP_G));
-    hipLaunchKernelGGL(k_row_meta, dim3((unsigned)mad_ceil_div(lo->n_rows, 256)), dim3(256), 0, ctx->stream,
-                       (const int32_t *)lo->row_anchor.p, (const int32_t *)lo->row_main.p, (const int32_t *)lo->anc_index.p,
-                       (const int32_t *)lo->anc_octave.p, lo->n_rows, scratch<int32_t>(ctx, S_TMP_J));
-    hipLaunchKernelGGL(k_results, dim3((unsigned)mad_ceil_div(np, 256)), dim3(256), 0, ctx->stream, (const int64_t *)nullptr, np,
-                       scratch<int32_t>(ctx, S_PAIR_HI), scratch<int32_t>(ctx, S_PAIR_LO), scratch<double>(ctx, S_PAIR_SCORE),
-                       scratch<int32_t>(ctx, S_COUNTS), d_lhi, (const double *)hi->anc_subv.p, (const double *)hi->row_R.p,
-                       scratch<int32_t>(ctx, S_TMP_G), (const double *)lo->anc_subv.p, (const double *)lo->row_R.p,
-                       scratch<int32_t>(ctx, S_TMP_J), (const int32_t *)hi->row_anchor.p, (const int32_t *)lo->row_anchor.p,
-                       scratch<double>(ctx, S_RESULTS));
+    int32_t *st = status_words(ctx);
+    const Side H = side_of(hi), L = side_of(lo);
+    hipLaunchKernelGGL(k_results, dim3((unsigned)std::min<int64_t>(mad_ceil_div(np, 256), 4096)), dim3(256), 0, ctx->stream,
+                       (const int64_t *)nullptr, st + ST_NPAIRS, np, scratch<int32_t>(ctx, S_PAIR_HI), scratch<int32_t>(ctx, S_PAIR_LO),
+                       scratch<double>(ctx, S_PAIR_SCORE), scratch<int32_t>(ctx, S_COUNTS), st, H.p, H.R, H.meta, L.p, L.Rinv, L.meta,
+                       H.row_anchor, L.row_anchor, scratch<double>(ctx, S_RESULTS));
     MAD_HIP(hipGetLastError());
     MAD_HIP(hipMemcpyAsync(results, ctx->scratch[S_RESULTS].p, (size_t)np * MAD_RESULT_COLS * 8, hipMemcpyDeviceToHost, ctx->stream));
     MAD_HIP(hipStreamSynchronize(ctx->stream));
@@ -1183,8 +1345,9 @@ extern "C" int mad_match_used(mad_ctx *ctx, uint8_t *hi_used, int32_t n_hi_ancho
     if (!ctx) return MAD_EINVAL;
     if (n_hi_anchors != ctx->match.n_hi_anchors || n_lo_anchors != ctx->match.n_lo_anchors)
         return mad_fail(ctx, MAD_EINVAL, "mad_match_used: anchor counts do not match the last mad_match_topk call");
-    if (hi_used && n_hi_anchors > 0) MAD_HIP(hipMemcpyAsync(hi_used, ctx->scratch[S_USED_HI].p, n_hi_anchors, hipMemcpyDeviceToHost, ctx->stream));
-    if (lo_used && n_lo_anchors > 0) MAD_HIP(hipMemcpyAsync(lo_used, ctx->scratch[S_USED_LO].p, n_lo_anchors, hipMemcpyDeviceToHost, ctx->stream));
+    const uint8_t *d_hi = scratch<uint8_t>(ctx, S_USED_HI), *d_lo = d_hi + ((n_hi_anchors + 31) & ~31);
+    if (hi_used && n_hi_anchors > 0) MAD_HIP(hipMemcpyAsync(hi_used, d_hi, n_hi_anchors, hipMemcpyDeviceToHost, ctx->stream));
+    if (lo_used && n_lo_anchors > 0) MAD_HIP(hipMemcpyAsync(lo_used, d_lo, n_lo_anchors, hipMemcpyDeviceToHost, ctx->stream));
     MAD_HIP(hipStreamSynchronize(ctx->stream));
     return MAD_OK;
 }

@@ -62,7 +62,8 @@ struct OrientArgs {
     const EqspDev *eq;
     int lim_main, lim_sec;
     int fan;                       // lim_main * lim_sec
-    int32_t *slot_cnt;             // n: rows produced, -1 = rejected at the border
+    int32_t *slot_cnt;             // n: rows produced (0 for anchors rejected at the border)
+    int32_t *n_reject;             // device counter of border rejects (nullable)
     int32_t *slot_main;            // n x fan
     int32_t *slot_sec;             // n x fan
     int32_t *slot_hist;            // n x lim_main x Z quantised counts per accepted main bin (or nullptr)
@@ -122,7 +123,10 @@ __global__ __launch_bounds__(ORI_THREADS) void k_orient(OrientArgs A) {
         const int xm = x - r * stride, ym = y - r * stride, zm = z - r * stride;
         const int xp = x + r * stride + 1, yp = y + r * stride + 1, zp = z + r * stride + 1;
         if (xm < 0 || ym < 0 || zm < 0 || xp > F.nx - 1 || yp > F.ny - 1 || zp > F.nz - 1) {
-            if (tid == 0) A.slot_cnt[a] = -1;
+            if (tid == 0) {
+                A.slot_cnt[a] = 0;
+                if (A.n_reject) atomicAdd(A.n_reject, 1);
+            }
             return;
         }
     }
@@ -273,15 +277,6 @@ __global__ __launch_bounds__(ORI_THREADS) void k_orient(OrientArgs A) {
     if (tid == 0) A.slot_cnt[a] = produced;
 }
 
-// clamp the "rejected" marker to 0 rows, count rejects
-__global__ void k_slot_counts(const int32_t *slot_cnt, int32_t *cnt, int n, int32_t *n_reject) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int c = slot_cnt[i];
-    cnt[i] = c < 0 ? 0 : c;
-    if (c < 0) atomicAdd(n_reject, 1);
-}
-
 // expand the per-anchor slots into the compact row list; Rfinal = adj_sec @ to_dom (Orientator.py:105)
 __global__ void k_orient_rows(const int32_t *slot_cnt, const int32_t *slot_main, const int32_t *slot_sec,
                               const int32_t *slot_hist, const int32_t *slot_hidx, const int32_t *row_off, int n, int fan,
@@ -308,28 +303,29 @@ __global__ void k_orient_rows(const int32_t *slot_cnt, const int32_t *slot_main,
     }
 }
 
-// Runs a1-a8 for n anchors whose coordinates (and octaves) are already on the device.
-// Leaves the rows in scratch S_ROW_ANCHOR / S_ROW_MAIN / S_ROW_SEC / S_ROW_R (/ S_ROW_COUNT).
+// Runs a1-a8 for n anchors whose coordinates (and octaves) are already on the device and writes the rows to
+// `out` (capacity n * lim_main * lim_sec rows).  Asynchronous: the row count stays on the device.
 int mad_orient_device(mad_ctx *ctx, FieldDev f0, FieldDev f1, const int32_t *d_coords, const int32_t *d_octave,
-                      int uniform_octave, int n, int r, int lim_main, int lim_sec, bool want_hist,
-                      int64_t *n_rows_out, int32_t *n_reject_out) {
+                      int uniform_octave, int n, int r, int lim_main, int lim_sec, OrientOut out) {
     if (!ctx->eq_set[0]) return mad_fail(ctx, MAD_EINVAL, "mad_orient: orientation EQSP table not set");
     if (r < 1 || r > 10) return mad_fail(ctx, MAD_EINVAL, "mad_orient: box_side %d outside 1..10", r);
     if (lim_main < 1 || lim_main > ORI_MAX_MAIN || lim_sec < 1 || lim_main * lim_sec > ORI_MAX_FAN)
         return mad_fail(ctx, MAD_EINVAL, "mad_orient: lim_main=%d lim_sec=%d unsupported", lim_main, lim_sec);
-    *n_rows_out = 0;
-    if (n_reject_out) *n_reject_out = 0;
-    if (n <= 0) return MAD_OK;
+    if (n <= 0) {
+        MAD_HIP(hipMemsetAsync(out.d_n_rows, 0, 4, ctx->stream));
+        if (out.d_n_reject) MAD_HIP(hipMemsetAsync(out.d_n_reject, 0, 4, ctx->stream));
+        return MAD_OK;
+    }
     MAD_TRY(ensure_mask(ctx, r));
     const int Z = ctx->eq_host[0].Z;
     const int fan = lim_main * lim_sec;
-    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_SLOT_CNT], (size_t)n * 4));
+    const bool want_hist = out.row_count != nullptr;
+    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_SLOT_CNT], (size_t)(n + 4) * 4));
     MAD_TRY(mad_reserve(ctx, ctx->scratch[S_SLOT_MAIN], (size_t)n * fan * 4));
     MAD_TRY(mad_reserve(ctx, ctx->scratch[S_SLOT_SEC], (size_t)n * fan * 4));
     MAD_TRY(mad_reserve(ctx, ctx->scratch[S_TMP_A], (size_t)n * fan * 4));
     if (want_hist) MAD_TRY(mad_reserve(ctx, ctx->scratch[S_SLOT_HIST], (size_t)n * lim_main * Z * 4));
-    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_ROW_OFF], (size_t)(n + 1) * 4 + 16));
-    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_TMP_B], (size_t)n * 4 + 16));
+    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_ROW_OFF], (size_t)(n + 2) * 4));
 
     OrientArgs A;
     A.f[0] = f0; A.f[1] = f1;
@@ -337,45 +333,30 @@ int mad_orient_device(mad_ctx *ctx, FieldDev f0, FieldDev f1, const int32_t *d_c
     A.n = n; A.r = r; A.nmask = ctx->mask_n; A.mask_off = ctx->mask_off; A.eq = ctx->eq[0];
     A.lim_main = lim_main; A.lim_sec = lim_sec; A.fan = fan;
     A.slot_cnt = scratch<int32_t>(ctx, S_SLOT_CNT);
+    A.n_reject = out.d_n_reject;
     A.slot_main = scratch<int32_t>(ctx, S_SLOT_MAIN);
     A.slot_sec = scratch<int32_t>(ctx, S_SLOT_SEC);
     A.slot_hist = want_hist ? scratch<int32_t>(ctx, S_SLOT_HIST) : nullptr;
     A.slot_hidx = scratch<int32_t>(ctx, S_TMP_A);
-
-    int32_t *d_cnt = scratch<int32_t>(ctx, S_TMP_B);
-    int32_t *d_nrej = d_cnt + n;      // one spare int behind the counts
-    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_TMP_B], (size_t)(n + 4) * 4));
-    d_cnt = scratch<int32_t>(ctx, S_TMP_B);
-    d_nrej = d_cnt + n;
-    MAD_HIP(hipMemsetAsync(d_nrej, 0, 4, ctx->stream));
+    int32_t *d_n = A.slot_cnt + n;      // the anchor count, for the device-length scan
+    MAD_HIP(hipMemcpyAsync(d_n, &n, 4, hipMemcpyHostToDevice, ctx->stream));
+    if (out.d_n_reject) MAD_HIP(hipMemsetAsync(out.d_n_reject, 0, 4, ctx->stream));
 
     mad_timer_begin(ctx, MAD_T_ORIENT);
     const size_t lds = (size_t)ctx->mask_n * 4 * sizeof(float);      // unit gradients (SoA) + the undecided-voxel queue
     hipLaunchKernelGGL(k_orient, dim3(n), dim3(ORI_THREADS), lds, ctx->stream, A);
     mad_timer_end(ctx, MAD_T_ORIENT);
-    hipLaunchKernelGGL(k_slot_counts, dim3((unsigned)mad_ceil_div(n, 256)), dim3(256), 0, ctx->stream, A.slot_cnt, d_cnt,
-                       n, d_nrej);
-    MAD_HIP(hipGetLastError());
     int32_t *row_off = scratch<int32_t>(ctx, S_ROW_OFF);
-    MAD_TRY(mad_scan_i32(ctx, d_cnt, row_off, n));
-    MAD_HIP(hipMemcpyAsync(&ctx->pinned[0], row_off + n, 4, hipMemcpyDeviceToHost, ctx->stream));
-    MAD_HIP(hipMemcpyAsync(&ctx->pinned[1], d_nrej, 4, hipMemcpyDeviceToHost, ctx->stream));
-    MAD_HIP(hipStreamSynchronize(ctx->stream));
-    const int64_t rows = *(int32_t *)&ctx->pinned[0];
-    if (n_reject_out) *n_reject_out = *(int32_t *)&ctx->pinned[1];
-    *n_rows_out = rows;
-    if (rows == 0) return MAD_OK;
-    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_ROW_ANCHOR], (size_t)rows * 4));
-    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_ROW_MAIN], (size_t)rows * 4));
-    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_ROW_SEC], (size_t)rows * 4));
-    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_ROW_R], (size_t)rows * 9 * 8));
-    if (want_hist) MAD_TRY(mad_reserve(ctx, ctx->scratch[S_ROW_COUNT], (size_t)rows * Z * 4));
+    if (n <= 65536) {
+        mad_scan_small(ctx, A.slot_cnt, row_off, d_n, out.d_n_rows);
+    } else {
+        MAD_TRY(mad_scan_i32(ctx, A.slot_cnt, row_off, n));
+        MAD_HIP(hipMemcpyAsync(out.d_n_rows, row_off + n, 4, hipMemcpyDeviceToDevice, ctx->stream));
+    }
     const int64_t total = (int64_t)n * fan;
     hipLaunchKernelGGL(k_orient_rows, dim3((unsigned)mad_ceil_div(total, 256)), dim3(256), 0, ctx->stream, A.slot_cnt,
                        A.slot_main, A.slot_sec, A.slot_hist, A.slot_hidx, row_off, n, fan, lim_main, ctx->eq[0],
-                       scratch<int32_t>(ctx, S_ROW_ANCHOR), scratch<int32_t>(ctx, S_ROW_MAIN),
-                       scratch<int32_t>(ctx, S_ROW_SEC), scratch<double>(ctx, S_ROW_R),
-                       want_hist ? scratch<int32_t>(ctx, S_ROW_COUNT) : nullptr);
+                       out.row_anchor, out.row_main, out.row_sec, out.row_R, out.row_count);
     MAD_HIP(hipGetLastError());
     return MAD_OK;
 }
@@ -390,21 +371,37 @@ extern "C" int mad_orient(mad_ctx *ctx, int slot, int octave, const int32_t *coo
     if (n > 0 && !coords) return mad_fail(ctx, MAD_EINVAL, "mad_orient: coords is NULL");
     *n_rows = 0;
     if (n <= 0) { if (n_reject) *n_reject = 0; return MAD_OK; }
+    if (lim_main < 1 || lim_sec < 1 || lim_main * lim_sec > ORI_MAX_FAN) return mad_fail(ctx, MAD_EINVAL, "mad_orient: lim_main=%d lim_sec=%d", lim_main, lim_sec);
+    const int Z = ctx->eq_host[0].Z;
+    const int64_t rows_cap = (int64_t)n * lim_main * lim_sec;
     MAD_TRY(mad_reserve(ctx, ctx->scratch[S_COORDS], (size_t)n * 12));
+    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_ROW_ANCHOR], (size_t)rows_cap * 4));
+    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_ROW_MAIN], (size_t)rows_cap * 4));
+    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_ROW_SEC], (size_t)rows_cap * 4));
+    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_ROW_R], (size_t)rows_cap * 72));
+    if (row_count) MAD_TRY(mad_reserve(ctx, ctx->scratch[S_ROW_COUNT], (size_t)rows_cap * Z * 4));
+    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_MISC], 256));
     MAD_HIP(hipMemcpyAsync(ctx->scratch[S_COORDS].p, coords, (size_t)n * 12, hipMemcpyHostToDevice, ctx->stream));
-    int64_t rows = 0;
+    OrientOut out;
+    out.row_anchor = scratch<int32_t>(ctx, S_ROW_ANCHOR); out.row_main = scratch<int32_t>(ctx, S_ROW_MAIN);
+    out.row_sec = scratch<int32_t>(ctx, S_ROW_SEC); out.row_R = scratch<double>(ctx, S_ROW_R);
+    out.row_count = row_count ? scratch<int32_t>(ctx, S_ROW_COUNT) : nullptr;
+    out.d_n_rows = scratch<int32_t>(ctx, S_MISC) + 16; out.d_n_reject = scratch<int32_t>(ctx, S_MISC) + 17;
     FieldDev f = ctx->fields[slot];
-    MAD_TRY(mad_orient_device(ctx, f, f, scratch<int32_t>(ctx, S_COORDS), nullptr, octave, n, r, lim_main, lim_sec,
-                              row_count != nullptr, &rows, n_reject));
+    MAD_TRY(mad_orient_device(ctx, f, f, scratch<int32_t>(ctx, S_COORDS), nullptr, octave, n, r, lim_main, lim_sec, out));
+    MAD_HIP(hipMemcpyAsync(&ctx->pinned[0], out.d_n_rows, 8, hipMemcpyDeviceToHost, ctx->stream));
+    MAD_HIP(hipStreamSynchronize(ctx->stream));
+    const int32_t *hv = (const int32_t *)&ctx->pinned[0];
+    const int64_t rows = hv[0];
+    if (n_reject) *n_reject = hv[1];
     *n_rows = rows;
     if (rows > cap) return mad_fail(ctx, MAD_ENOSPC, "mad_orient: %lld rows, capacity %lld", (long long)rows, (long long)cap);
     if (rows == 0) return MAD_OK;
-    const int Z = ctx->eq_host[0].Z;
-    if (row_anchor) MAD_HIP(hipMemcpyAsync(row_anchor, ctx->scratch[S_ROW_ANCHOR].p, rows * 4, hipMemcpyDeviceToHost, ctx->stream));
-    if (row_main) MAD_HIP(hipMemcpyAsync(row_main, ctx->scratch[S_ROW_MAIN].p, rows * 4, hipMemcpyDeviceToHost, ctx->stream));
-    if (row_sec) MAD_HIP(hipMemcpyAsync(row_sec, ctx->scratch[S_ROW_SEC].p, rows * 4, hipMemcpyDeviceToHost, ctx->stream));
-    if (row_R) MAD_HIP(hipMemcpyAsync(row_R, ctx->scratch[S_ROW_R].p, rows * 72, hipMemcpyDeviceToHost, ctx->stream));
-    if (row_count) MAD_HIP(hipMemcpyAsync(row_count, ctx->scratch[S_ROW_COUNT].p, rows * Z * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (row_anchor) MAD_HIP(hipMemcpyAsync(row_anchor, out.row_anchor, rows * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (row_main) MAD_HIP(hipMemcpyAsync(row_main, out.row_main, rows * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (row_sec) MAD_HIP(hipMemcpyAsync(row_sec, out.row_sec, rows * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (row_R) MAD_HIP(hipMemcpyAsync(row_R, out.row_R, rows * 72, hipMemcpyDeviceToHost, ctx->stream));
+    if (row_count) MAD_HIP(hipMemcpyAsync(row_count, out.row_count, rows * Z * 4, hipMemcpyDeviceToHost, ctx->stream));
     MAD_HIP(hipStreamSynchronize(ctx->stream));
     return MAD_OK;
 }
@@ -423,7 +420,8 @@ struct DescribeArgs {
     int uniform_octave;
     const int32_t *row_anchor;     // row -> anchor, or nullptr (identity)
     const double *row_R;           // n_rows x 9
-    int64_t n_rows;
+    const int32_t *n_rows;         // device: number of rows
+    int32_t *overflow;             // device: set when the grid was too small for *n_rows
     int r;
     const EqspDev *eq;
     int16_t *dsc;                  // n_rows x 64*Z
@@ -454,11 +452,18 @@ __global__ __launch_bounds__(DSC_THREADS) void k_describe(DescribeArgs A) {
     __shared__ float sRf[9];
     // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs (b and b + 8 share one), so give
     // each XCD a contiguous run of rows.  Consecutive rows belong to the same anchor (fan-out ~5) or to
-    // neighbours in the anchor list and sample the same neighbourhood: they then meet in ONE L2.
-    const int64_t chunk = (A.n_rows + 7) / 8;
-    const int64_t row = (int64_t)(blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
-    if (row >= A.n_rows) return;
+    // neighbours in the anchor list and sample the same neighbourhood: running side by side on ONE XCD
+    // they meet in its L2.  The row count lives on the device; the grid is an upper bound of it.
+    const int64_t n_rows = *A.n_rows;
+    const int64_t chunk = (n_rows + 7) / 8;
     const int tid = threadIdx.x;
+    if (8 * chunk > (int64_t)gridDim.x) {      // the launch was sized from a stale hint: tell the host
+        if (blockIdx.x == 0 && tid == 0) *A.overflow = 1;
+        return;
+    }
+    const int64_t row = (int64_t)(blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+    if ((int64_t)(blockIdx.x >> 3) >= chunk || row >= n_rows) return;
+    eqsp_fast_stage(A.eq, &fast);
     const int a = A.row_anchor ? A.row_anchor[row] : (int)row;
     const int oct = A.anc_octave ? A.anc_octave[a] : A.uniform_octave;
     const FieldDev F = A.f[oct == 1 ? 1 : 0];
@@ -482,7 +487,6 @@ __global__ __launch_bounds__(DSC_THREADS) void k_describe(DescribeArgs A) {
         s_nq = 0;
     }
     for (int i = tid; i < D; i += DSC_THREADS) hist[i] = 0;
-    eqsp_fast_stage(A.eq, &fast);
     __syncthreads();
 
     const int ic0 = A.anc_coords[3 * a], ic1 = A.anc_coords[3 * a + 1], ic2 = A.anc_coords[3 * a + 2];
@@ -581,12 +585,13 @@ __global__ __launch_bounds__(DSC_THREADS) void k_describe(DescribeArgs A) {
 }
 
 int mad_describe_device(mad_ctx *ctx, FieldDev f0, FieldDev f1, const int32_t *d_anc_coords, const int32_t *d_anc_octave,
-                        int uniform_octave, const int32_t *d_row_anchor, const double *d_row_R, int64_t n_rows, int r,
-                        int16_t *d_dsc) {
+                        int uniform_octave, const int32_t *d_row_anchor, const double *d_row_R, const int32_t *d_n_rows,
+                        int64_t grid_rows, int32_t *d_overflow, int r, int16_t *d_dsc) {
+    const int64_t cap_rows = grid_rows;
     if (!ctx->eq_set[1]) return mad_fail(ctx, MAD_EINVAL, "mad_describe: descriptor EQSP table not set");
     if (ctx->eq_host[1].Z != 16) return mad_fail(ctx, MAD_EINVAL, "mad_describe: kernel is built for 16 descriptor zones");
     if (r < 2 || r > 8 || (r % 2)) return mad_fail(ctx, MAD_EINVAL, "mad_describe: dsc radius %d must be 2, 4, 6 or 8", r);
-    if (n_rows <= 0) return MAD_OK;
+    if (cap_rows <= 0) return MAD_OK;
     for (int o = 0; o < 2; o++) {
         const FieldDev &f = o ? f1 : f0;
         if (f.tex && (size_t)f.nx * f.ny * f.nz >= (size_t)1 << 32)
@@ -595,9 +600,10 @@ int mad_describe_device(mad_ctx *ctx, FieldDev f0, FieldDev f1, const int32_t *d
     DescribeArgs A;
     A.f[0] = f0; A.f[1] = f1;
     A.anc_coords = d_anc_coords; A.anc_octave = d_anc_octave; A.uniform_octave = uniform_octave;
-    A.row_anchor = d_row_anchor; A.row_R = d_row_R; A.n_rows = n_rows; A.r = r; A.eq = ctx->eq[1]; A.dsc = d_dsc;
+    A.row_anchor = d_row_anchor; A.row_R = d_row_R; A.n_rows = d_n_rows; A.overflow = d_overflow; A.r = r; A.eq = ctx->eq[1]; A.dsc = d_dsc;
     mad_timer_begin(ctx, MAD_T_DESCRIBE);
-    const unsigned nblk = (unsigned)(((n_rows + 7) / 8) * 8);
+    // enough workgroups to fill the chip a few times over, never more than one per possible row
+    const unsigned nblk = (unsigned)(((cap_rows + 7) / 8) * 8 + 8);      // one workgroup per possible row
     switch (2 * r) {
         case 4: hipLaunchKernelGGL(k_describe<4>, dim3(nblk), dim3(DSC_THREADS), 0, ctx->stream, A); break;
         case 8: hipLaunchKernelGGL(k_describe<8>, dim3(nblk), dim3(DSC_THREADS), 0, ctx->stream, A); break;
@@ -624,8 +630,12 @@ extern "C" int mad_describe(mad_ctx *ctx, int slot, int octave, const int32_t *c
     MAD_HIP(hipMemcpyAsync(ctx->scratch[S_ROW_COORDS].p, coords, (size_t)n_rows * 12, hipMemcpyHostToDevice, ctx->stream));
     MAD_HIP(hipMemcpyAsync(ctx->scratch[S_ROW_R].p, R, (size_t)n_rows * 72, hipMemcpyHostToDevice, ctx->stream));
     FieldDev f = ctx->fields[slot];
+    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_MISC], 256));
+    int32_t *d_n = scratch<int32_t>(ctx, S_MISC) + 18;
+    const int32_t n32 = (int32_t)n_rows;
+    MAD_HIP(hipMemcpyAsync(d_n, &n32, 4, hipMemcpyHostToDevice, ctx->stream));
     MAD_TRY(mad_describe_device(ctx, f, f, scratch<int32_t>(ctx, S_ROW_COORDS), nullptr, octave, nullptr,
-                                scratch<double>(ctx, S_ROW_R), n_rows, r, scratch<int16_t>(ctx, S_DSC)));
+                                scratch<double>(ctx, S_ROW_R), d_n, n_rows, d_n + 1, r, scratch<int16_t>(ctx, S_DSC)));
     MAD_HIP(hipMemcpyAsync(dsc, ctx->scratch[S_DSC].p, (size_t)n_rows * D * 2, hipMemcpyDeviceToHost, ctx->stream));
     MAD_HIP(hipStreamSynchronize(ctx->stream));
     return MAD_OK;
