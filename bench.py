@@ -176,18 +176,24 @@ def build_inputs(lib, torch, W, rank):
 # the timed step
 # --------------------------------------------------------------------------------------------
 
+HOST_T = {}
+
+
 def hot_path_step(lib, the_map, subs, cc, dist, k, sets):
     """Returns (correlations, [top-k result rows per subunit], stats).  Everything is enqueued
     asynchronously; the only host round trip is the result read-back that ends each match.
     `sets` holds the device-resident row sets, rebuilt in place every step."""
+    t0 = time.perf_counter()
     lo = lib.set_build(the_map.slots, the_map.coords, the_map.octave, the_map.subv, the_map.index, into=sets[0])
     his = [lib.set_build(s.slots, s.coords, s.octave, s.subv, s.index, into=d) for s, d in zip(subs, sets[1:])]
+    HOST_T["build_enqueue"] = HOST_T.get("build_enqueue", 0.0) + time.perf_counter() - t0
+    t0 = time.perf_counter()
     corr, tops, stats = 0, [], []
-    for hi in his:
-        top, idx, st = lib.match_topk(hi, lo, cc, dist, k)
+    for top, idx, st in lib.match_topk_many(his, lo, cc, dist, k):
         corr += st["n_corr"]
         tops.append(top)
         stats.append(st)
+    HOST_T["match"] = HOST_T.get("match", 0.0) + time.perf_counter() - t0
     for hi, st in zip(his, stats):
         st["n_hi"], _ = hi.size()
         st["n_lo"] = st["n_corr"] // max(st["n_hi"], 1)
@@ -294,6 +300,7 @@ def main():
         exchange(tops)
     lib.timing_enable(True)
     lib.timing_reset()
+    HOST_T.clear()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -342,6 +349,7 @@ def main():
         roof["traffic"] = None
         roof["avg_launch_ms"] = dom_ms
         roof["kernel_ms_per_step"] = {g: groups[g]["ms_total"] / args.steps for g in groups}
+        roof["host_ms_per_step"] = {k_: 1e3 * v / args.steps for k_, v in HOST_T.items()}
 
         cpu, agree = (None, None)
         if world == 1 and not args.no_cpu_baseline:

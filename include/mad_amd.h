@@ -182,6 +182,13 @@ int mad_set_download(mad_ctx *ctx, const mad_set *set, int32_t *row_anchor, int3
  */
 int mad_match_topk(mad_ctx *ctx, const mad_set *hi, const mad_set *lo, double cc, double dist,
                    int64_t k, double *results, int64_t *pair_index, int64_t *n_out, int64_t *stats);
+/*
+ * The same for n subunit sets against one map set, with up to 4 matches in flight before the host waits for
+ * the oldest.  results: n x k x 23; pair_index (nullable): n x k; n_out: n; stats (nullable): n x 4.
+ * mad_match_fetch / _results / _used afterwards refer to the LAST match of the batch.
+ */
+int mad_match_topk_many(mad_ctx *ctx, int n, const mad_set *const *hi, const mad_set *lo, double cc, double dist,
+                        int64_t k, double *results, int64_t *pair_index, int64_t *n_out, int64_t *stats);
 /* After mad_match_topk: all pairs of that call (for MaD._match_dsc's full return value). */
 int mad_match_fetch(mad_ctx *ctx, int32_t *pair_hi, int32_t *pair_lo, double *pair_score,
                     int32_t *counts, int64_t cap);

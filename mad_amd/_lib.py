@@ -22,7 +22,7 @@ SYMBOLS = [
     "mad_set_eqsp", "mad_upload_field", "mad_upload_field_device", "mad_free_field",
     "mad_orient", "mad_describe", "mad_correlate", "mad_pose_score", "mad_topk",
     "mad_set_create", "mad_set_destroy", "mad_set_build", "mad_set_load", "mad_set_size", "mad_set_download",
-    "mad_match_topk", "mad_match_fetch", "mad_match_results", "mad_match_used",
+    "mad_match_topk", "mad_match_topk_many", "mad_match_fetch", "mad_match_results", "mad_match_used",
     "mad_upload_density", "mad_refine", "mad_structure_to_density", "mad_ccc",
 ]
 
@@ -288,6 +288,24 @@ class Lib(object):
                                           C.byref(n_out), _p(stats)))
         g = n_out.value
         return res[:g], idx[:g], dict(n_pairs=int(stats[0]), l_hi=int(stats[1]), l_lo=int(stats[2]), n_corr=int(stats[3]))
+
+    def match_topk_many(self, his, lo, cc, dist, k):
+        """[(rows, pair_index, stats)] for every subunit set of `his` against `lo`; see mad_match_topk_many."""
+        k = int(k)
+        n = len(his)
+        res = np.zeros((max(n, 1), max(k, 1), RESULT_COLS))
+        idx = np.zeros((max(n, 1), max(k, 1)), np.int64)
+        n_out = np.zeros(max(n, 1), np.int64)
+        stats = np.zeros((max(n, 1), 4), np.int64)
+        arr = (C.c_void_p * max(n, 1))(*[h.h.value for h in his])
+        self._chk(self.dll.mad_match_topk_many(self.ctx, C.c_int(n), arr, lo.h, C.c_double(cc), C.c_double(dist), C.c_int64(k),
+                                               _p(res), _p(idx), _p(n_out), _p(stats)))
+        out = []
+        for i in range(n):
+            g = int(n_out[i])
+            out.append((res[i, :g], idx[i, :g], dict(n_pairs=int(stats[i, 0]), l_hi=int(stats[i, 1]), l_lo=int(stats[i, 2]),
+                                                     n_corr=int(stats[i, 3]))))
+        return out
 
     def match_fetch(self, n_pairs):
         ph, pl = np.zeros(n_pairs, np.int32), np.zeros(n_pairs, np.int32)

@@ -73,6 +73,7 @@ enum { MAD_T_ORIENT = 0, MAD_T_DESCRIBE, MAD_T_CORRELATE, MAD_T_PAIRS, MAD_T_POS
        MAD_T_DENSITY, MAD_T_CCC, MAD_T_COUNT };
 
 #define MAD_T_RING 32
+#define MAD_LANES 4
 
 struct TimerGroup {
     hipEvent_t start[MAD_T_RING];
@@ -96,6 +97,7 @@ struct MatchState {            // the most recent mad_match_topk call
     int32_t n_hi_anchors = 0, n_lo_anchors = 0;
     int64_t cap_c = 0;         // capacity hints carried from call to call (elements of the int32 score matrix,
     int64_t cap_pairs = 0;     // number of pairs); the device raises a flag when one is too small
+    int lane = 0;              // scratch copy that holds this match's pairs and counts
 };
 
 struct mad_ctx {
@@ -111,10 +113,12 @@ struct mad_ctx {
     int mask_r = -1;
     int mask_n = 0;
     // named grow-only scratch buffers
-    DevBuf scratch[64];
+    DevBuf scratch[64 * MAD_LANES];   // MAD_LANES independent copies: matches in flight do not share scratch
+    int lane = 0;                    // the copy the current call works in
+    hipEvent_t lane_done[MAD_LANES]; // recorded behind the last operation enqueued in each lane
     // host pinned staging for small read-backs
-    int64_t *pinned = nullptr;     // 512 slots: [0..15] scratch read-backs, [16..] one per mad_set
-    int next_pinned = 16;
+    int64_t *pinned = nullptr;     // 1024 slots: [16 * lane ..] read-backs of the lane, [64..] two per mad_set
+    int next_pinned = 64;
     DensityDev dens;
     MatchState match;
     bool timing = false;
@@ -162,7 +166,8 @@ static_assert(S_N_SLOTS <= 64, "grow mad_ctx::scratch");
 int mad_fail(mad_ctx *ctx, int code, const char *fmt, ...);
 int mad_reserve(mad_ctx *ctx, DevBuf &b, size_t bytes);            // grow-only device buffer
 void mad_release(DevBuf &b);
-template <class T> static inline T *scratch(mad_ctx *ctx, int slot) { return (T *)ctx->scratch[slot].p; }
+static inline DevBuf &mad_sb(mad_ctx *ctx, int slot) { return ctx->scratch[ctx->lane * 64 + slot]; }
+template <class T> static inline T *scratch(mad_ctx *ctx, int slot) { return (T *)mad_sb(ctx, slot).p; }
 
 void mad_timer_begin(mad_ctx *ctx, int group);
 void mad_timer_end(mad_ctx *ctx, int group);

@@ -78,6 +78,7 @@ extern "C" int mad_init(int device, mad_ctx **out) {
             (void)hipEventCreate(&ctx->timers[g].start[i]);
             (void)hipEventCreate(&ctx->timers[g].stop[i]);
         }
+    for (int l = 0; l < MAD_LANES; l++) (void)hipEventCreateWithFlags(&ctx->lane_done[l], hipEventDisableTiming);
     *out = ctx;
     return MAD_OK;
 }
@@ -100,6 +101,7 @@ extern "C" void mad_destroy(mad_ctx *ctx) {
             (void)hipEventDestroy(ctx->timers[g].start[i]);
             (void)hipEventDestroy(ctx->timers[g].stop[i]);
         }
+    for (int l = 0; l < MAD_LANES; l++) (void)hipEventDestroy(ctx->lane_done[l]);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -393,7 +395,7 @@ int mad_scan_i32(mad_ctx *ctx, const int32_t *in, int32_t *out, int64_t n) {
         return MAD_OK;
     }
     const int64_t nb = mad_ceil_div(n, SCAN_CHUNK);
-    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_SCAN_TMP], (size_t)(nb + 1) * sizeof(int32_t)));
+    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_SCAN_TMP), (size_t)(nb + 1) * sizeof(int32_t)));
     int32_t *sums = scratch<int32_t>(ctx, S_SCAN_TMP);
     hipLaunchKernelGGL(k_scan_sums, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, ctx->stream, in, n, sums);
     hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, ctx->stream, sums, nb);

@@ -627,10 +627,10 @@ static int topk_device(mad_ctx *ctx, const int32_t *d_counts, int32_t *d_status,
     if (nbins > 16384) return mad_fail(ctx, MAD_EINVAL, "top-k: %d count bins", nbins);
     const int64_t max_chunks = mad_ceil_div(cap_pairs, TK_CHUNK) + 1;
     if (max_chunks > 65536) return mad_fail(ctx, MAD_EINVAL, "top-k: %lld pairs exceed the tie-ranking capacity", (long long)cap_pairs);
-    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_HIST], (size_t)(nbins + 16) * 4));
-    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_TIE_FLAG], (size_t)(max_chunks + 2) * 4));
-    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_TIE_OFF], (size_t)(max_chunks + 2) * 4));
-    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_SEL], (size_t)(k + 8) * 8));
+    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_HIST), (size_t)(nbins + 16) * 4));
+    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_TIE_FLAG), (size_t)(max_chunks + 2) * 4));
+    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_TIE_OFF), (size_t)(max_chunks + 2) * 4));
+    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_SEL), (size_t)(k + 8) * 8));
     int32_t *hist = scratch<int32_t>(ctx, S_HIST);
     int32_t *info = hist + nbins;            // 4 ints, then the chunk count
     int32_t *n_chunks = info + 4;
@@ -696,8 +696,8 @@ static int build_cells(mad_ctx *ctx, const double bb_min[3], const double bb_max
     MAD_TRY(mad_reserve(ctx, b_start, (ncell + 1) * 4));
     MAD_TRY(mad_reserve(ctx, b_pts, (size_t)(n > 0 ? n : 1) * 24));
     MAD_TRY(mad_reserve(ctx, b_ids, (size_t)(n > 0 ? n : 1) * 4));
-    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_TMP_C], (ncell + 1) * 4));
-    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_TMP_D], (size_t)(n > 0 ? n : 1) * 4));
+    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_TMP_C), (ncell + 1) * 4));
+    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_TMP_D), (size_t)(n > 0 ? n : 1) * 4));
     int32_t *cnt = scratch<int32_t>(ctx, S_TMP_C);
     int32_t *pt_cell = scratch<int32_t>(ctx, S_TMP_D);
     MAD_HIP(hipMemsetAsync(cnt, 0, (ncell + 1) * 4, ctx->stream));
@@ -753,12 +753,12 @@ static int correlate_device(mad_ctx *ctx, const Side &hi, const Side &lo, int D,
                             int64_t cap_pairs, uint8_t *d_used_hi, uint8_t *d_used_lo) {
     if (D % GEMM_BK) return mad_fail(ctx, MAD_EINVAL, "correlate: D = %d is not a multiple of %d", D, GEMM_BK);
     if (hi.cap_rows > 65000) return mad_fail(ctx, MAD_EINVAL, "correlate: %lld hi rows exceed the single-launch scan", (long long)hi.cap_rows);
-    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_CMAT], (size_t)cap_c * 4));
-    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_ROWCNT], (size_t)(hi.cap_rows + 2) * 4));
-    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_ROWOFF], (size_t)(hi.cap_rows + 2) * 4));
-    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_PAIR_HI], (size_t)cap_pairs * 4));
-    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_PAIR_LO], (size_t)cap_pairs * 4));
-    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_PAIR_SCORE], (size_t)cap_pairs * 8));
+    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_CMAT), (size_t)cap_c * 4));
+    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_ROWCNT), (size_t)(hi.cap_rows + 2) * 4));
+    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_ROWOFF), (size_t)(hi.cap_rows + 2) * 4));
+    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_PAIR_HI), (size_t)cap_pairs * 4));
+    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_PAIR_LO), (size_t)cap_pairs * 4));
+    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_PAIR_SCORE), (size_t)cap_pairs * 8));
     int32_t *C = scratch<int32_t>(ctx, S_CMAT);
     mad_timer_begin(ctx, MAD_T_CORRELATE);
     hipLaunchKernelGGL(k_corr_gemm, dim3(ctx->n_cu * 4), dim3(GEMM_THREADS), 0, ctx->stream, hi.dsc8, lo.dsc8, D, C, hi.n_rows,
@@ -782,7 +782,7 @@ static int correlate_device(mad_ctx *ctx, const Side &hi, const Side &lo, int D,
 static int pose_device(mad_ctx *ctx, const Side &hi, const Side &lo, int32_t *d_status, int64_t cap_pairs,
                        const double *d_hi_cloud, int l_hi_max, const double *d_cloud, int n_cloud, const uint8_t *d_cloud_used,
                        const double bb_min[3], const double bb_max[3], const CellGrid *fallback, double dist) {
-    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_COUNTS], (size_t)cap_pairs * 4));
+    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_COUNTS), (size_t)cap_pairs * 4));
     const double dd_lim = sqrt_limit(dist);
     const double reach = dist + 0.01;
     PoseGrid G;
@@ -800,8 +800,8 @@ static int pose_device(mad_ctx *ctx, const Side &hi, const Side &lo, int32_t *d_
     }
     const size_t lds = (size_t)(l_hi_max + n_cloud) * 24 + (size_t)(G.ncell + 1) * 2 + 16;
     if (!fallback && lds <= 150 * 1024 && n_cloud < 65535 && G.ncell <= 30000) {
-        MAD_TRY(mad_reserve(ctx, ctx->scratch[S_PG_START], (size_t)(G.ncell + 2) * 4));
-        MAD_TRY(mad_reserve(ctx, ctx->scratch[S_PG_PTS], (size_t)(n_cloud + 1) * 24));
+        MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_PG_START), (size_t)(G.ncell + 2) * 4));
+        MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_PG_PTS), (size_t)(n_cloud + 1) * 24));
         static bool attr_set = false;
         if (!attr_set) {
             MAD_HIP(hipFuncSetAttribute((const void *)k_pose_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -854,12 +854,12 @@ static int32_t *status_words(mad_ctx *ctx) {      // inside S_MISC
 static int stage_rows(mad_ctx *ctx, const int16_t *h_rows, int64_t n, int D, int slot16, int slot8, int slotn, int32_t *d_n,
                       int32_t *d_bad) {
     const int64_t n_pad = mad_ceil_div(n > 0 ? n : 1, GEMM_BM) * GEMM_BM;
-    MAD_TRY(mad_reserve(ctx, ctx->scratch[slot16], (size_t)n * D * 2));
-    MAD_TRY(mad_reserve(ctx, ctx->scratch[slot8], (size_t)n_pad * D));
-    MAD_TRY(mad_reserve(ctx, ctx->scratch[slotn], (size_t)n_pad * 8));
+    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, slot16), (size_t)n * D * 2));
+    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, slot8), (size_t)n_pad * D));
+    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, slotn), (size_t)n_pad * 8));
     const int32_t n32 = (int32_t)n;
     MAD_HIP(hipMemcpyAsync(d_n, &n32, 4, hipMemcpyHostToDevice, ctx->stream));
-    MAD_HIP(hipMemcpyAsync(ctx->scratch[slot16].p, h_rows, (size_t)n * D * 2, hipMemcpyHostToDevice, ctx->stream));
+    MAD_HIP(hipMemcpyAsync(mad_sb(ctx, slot16).p, h_rows, (size_t)n * D * 2, hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(k_pack_rows, dim3((unsigned)std::min<int64_t>(mad_ceil_div(n_pad, 4), 4096)), dim3(256), 0, ctx->stream,
                        scratch<int16_t>(ctx, slot16), d_n, D, scratch<int8_t>(ctx, slot8), scratch<double>(ctx, slotn), d_bad);
     MAD_HIP(hipGetLastError());
@@ -869,12 +869,13 @@ static int stage_rows(mad_ctx *ctx, const int16_t *h_rows, int64_t n, int D, int
 extern "C" int mad_correlate(mad_ctx *ctx, const int16_t *hi, int64_t n_hi, const int16_t *lo, int64_t n_lo, int D,
                              double cc, int32_t *pair_hi, int32_t *pair_lo, double *pair_score, int64_t *n_pairs,
                              int64_t cap) {
+    if (ctx) ctx->lane = 0;
     if (!ctx || !n_pairs) return MAD_EINVAL;
     *n_pairs = 0;
     if (n_hi <= 0 || n_lo <= 0) return MAD_OK;
     if (!hi || !lo) return mad_fail(ctx, MAD_EINVAL, "mad_correlate: NULL descriptors");
     if (n_hi * n_lo >= ((int64_t)1 << 31)) return mad_fail(ctx, MAD_EINVAL, "mad_correlate: %lld x %lld too large", (long long)n_hi, (long long)n_lo);
-    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_MISC], 4096));
+    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_MISC), 4096));
     int32_t *st = status_words(ctx);
     MAD_HIP(hipMemsetAsync(st, 0, ST_COUNT * 4, ctx->stream));
     MAD_TRY(stage_rows(ctx, hi, n_hi, D, S_HI16, S_HI8, S_HNORM, st + ST_NHI, st + ST_BAD));
@@ -898,9 +899,9 @@ extern "C" int mad_correlate(mad_ctx *ctx, const int16_t *hi, int64_t n_hi, cons
     const int64_t np = *n_pairs;
     if (np > cap) return mad_fail(ctx, MAD_ENOSPC, "mad_correlate: %lld pairs, capacity %lld", (long long)np, (long long)cap);
     if (np > 0) {
-        if (pair_hi) MAD_HIP(hipMemcpyAsync(pair_hi, ctx->scratch[S_PAIR_HI].p, np * 4, hipMemcpyDeviceToHost, ctx->stream));
-        if (pair_lo) MAD_HIP(hipMemcpyAsync(pair_lo, ctx->scratch[S_PAIR_LO].p, np * 4, hipMemcpyDeviceToHost, ctx->stream));
-        if (pair_score) MAD_HIP(hipMemcpyAsync(pair_score, ctx->scratch[S_PAIR_SCORE].p, np * 8, hipMemcpyDeviceToHost, ctx->stream));
+        if (pair_hi) MAD_HIP(hipMemcpyAsync(pair_hi, mad_sb(ctx, S_PAIR_HI).p, np * 4, hipMemcpyDeviceToHost, ctx->stream));
+        if (pair_lo) MAD_HIP(hipMemcpyAsync(pair_lo, mad_sb(ctx, S_PAIR_LO).p, np * 4, hipMemcpyDeviceToHost, ctx->stream));
+        if (pair_score) MAD_HIP(hipMemcpyAsync(pair_score, mad_sb(ctx, S_PAIR_SCORE).p, np * 8, hipMemcpyDeviceToHost, ctx->stream));
         MAD_HIP(hipStreamSynchronize(ctx->stream));
     }
     return MAD_OK;
@@ -911,6 +912,7 @@ extern "C" int mad_pose_score(mad_ctx *ctx, const int32_t *pair_hi, const int32_
                               const double *lo_p, const double *lo_R, const int32_t *lo_meta, int64_t n_lo,
                               const double *hi_cloud, int64_t l_hi, const double *lo_cloud, int64_t l_lo, double dist,
                               double *results, int32_t *counts) {
+    if (ctx) ctx->lane = 0;
     if (!ctx) return MAD_EINVAL;
     if (n_pairs <= 0) return MAD_OK;
     if (!pair_hi || !pair_lo || !pair_score || !hi_p || !hi_R || !hi_meta || !lo_p || !lo_R || !lo_meta || !hi_cloud || !lo_cloud)
@@ -925,11 +927,11 @@ extern "C" int mad_pose_score(mad_ctx *ctx, const int32_t *pair_hi, const int32_
         {S_HI_CLOUD, hi_cloud, (size_t)l_hi * 24}, {S_USED_LO, lo_cloud, (size_t)l_lo * 24},
     };
     for (const Up &u : ups) {
-        MAD_TRY(mad_reserve(ctx, ctx->scratch[u.slot], u.bytes));
-        MAD_HIP(hipMemcpyAsync(ctx->scratch[u.slot].p, u.src, u.bytes, hipMemcpyHostToDevice, ctx->stream));
+        MAD_TRY(mad_reserve(ctx, mad_sb(ctx, u.slot), u.bytes));
+        MAD_HIP(hipMemcpyAsync(mad_sb(ctx, u.slot).p, u.src, u.bytes, hipMemcpyHostToDevice, ctx->stream));
     }
-    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_TMP_A], (size_t)n_lo * 72));
-    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_MISC], 4096));
+    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_TMP_A), (size_t)n_lo * 72));
+    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_MISC), 4096));
     int32_t *st = status_words(ctx);
     int32_t hs[ST_COUNT] = {0};
     hs[ST_NPAIRS] = (int32_t)n_pairs; hs[ST_LHI] = (int32_t)l_hi; hs[ST_NHI] = (int32_t)n_hi; hs[ST_NLO] = (int32_t)n_lo;
@@ -953,8 +955,8 @@ extern "C" int mad_pose_score(mad_ctx *ctx, const int32_t *pair_hi, const int32_
     if (!fits) {      // global cell list (cell = dist) over the lo cloud
         double mn[3];
         int dim[3];
-        MAD_TRY(build_cells(ctx, bmn, bmx, scratch<double>(ctx, S_USED_LO), (int)l_lo, dist, ctx->scratch[S_CELL_START],
-                            ctx->scratch[S_CELL_PTS], ctx->scratch[S_CELL_IDS], mn, dim));
+        MAD_TRY(build_cells(ctx, bmn, bmx, scratch<double>(ctx, S_USED_LO), (int)l_lo, dist, mad_sb(ctx, S_CELL_START),
+                            mad_sb(ctx, S_CELL_PTS), mad_sb(ctx, S_CELL_IDS), mn, dim));
         G.start = scratch<int32_t>(ctx, S_CELL_START); G.pts = scratch<double>(ctx, S_CELL_PTS); G.ids = scratch<int32_t>(ctx, S_CELL_IDS);
         G.used = nullptr;
         for (int d = 0; d < 3; d++) { G.mn[d] = mn[d]; G.dim[d] = dim[d]; }
@@ -963,21 +965,22 @@ extern "C" int mad_pose_score(mad_ctx *ctx, const int32_t *pair_hi, const int32_
     MAD_TRY(pose_device(ctx, H, L, st, n_pairs, scratch<double>(ctx, S_HI_CLOUD), (int)l_hi, scratch<double>(ctx, S_USED_LO), (int)l_lo,
                         nullptr, bmn, bmx, fits ? nullptr : &G, dist));
     if (results) {
-        MAD_TRY(mad_reserve(ctx, ctx->scratch[S_RESULTS], (size_t)n_pairs * MAD_RESULT_COLS * 8));
+        MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_RESULTS), (size_t)n_pairs * MAD_RESULT_COLS * 8));
         hipLaunchKernelGGL(k_results, dim3((unsigned)std::min<int64_t>(mad_ceil_div(n_pairs, 256), 4096)), dim3(256), 0, ctx->stream,
                            (const int64_t *)nullptr, st + ST_NPAIRS, n_pairs, scratch<int32_t>(ctx, S_PAIR_HI),
                            scratch<int32_t>(ctx, S_PAIR_LO), scratch<double>(ctx, S_PAIR_SCORE), scratch<int32_t>(ctx, S_COUNTS), st,
                            H.p, H.R, H.meta, L.p, L.Rinv, L.meta, (const int32_t *)nullptr, (const int32_t *)nullptr,
                            scratch<double>(ctx, S_RESULTS));
         MAD_HIP(hipGetLastError());
-        MAD_HIP(hipMemcpyAsync(results, ctx->scratch[S_RESULTS].p, (size_t)n_pairs * MAD_RESULT_COLS * 8, hipMemcpyDeviceToHost, ctx->stream));
+        MAD_HIP(hipMemcpyAsync(results, mad_sb(ctx, S_RESULTS).p, (size_t)n_pairs * MAD_RESULT_COLS * 8, hipMemcpyDeviceToHost, ctx->stream));
     }
-    if (counts) MAD_HIP(hipMemcpyAsync(counts, ctx->scratch[S_COUNTS].p, (size_t)n_pairs * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (counts) MAD_HIP(hipMemcpyAsync(counts, mad_sb(ctx, S_COUNTS).p, (size_t)n_pairs * 4, hipMemcpyDeviceToHost, ctx->stream));
     MAD_HIP(hipStreamSynchronize(ctx->stream));
     return MAD_OK;
 }
 
 extern "C" int mad_topk(mad_ctx *ctx, const int32_t *counts, int64_t n, int64_t k, int64_t *order) {
+    if (ctx) ctx->lane = 0;
     if (!ctx) return MAD_EINVAL;
     if (n <= 0 || k <= 0) return MAD_OK;
     if (!counts || !order) return mad_fail(ctx, MAD_EINVAL, "mad_topk: NULL argument");
@@ -987,16 +990,16 @@ extern "C" int mad_topk(mad_ctx *ctx, const int32_t *counts, int64_t n, int64_t 
         if (counts[i] > maxc) maxc = counts[i];
     }
     if (k > n) k = n;
-    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_COUNTS], (size_t)n * 4));
-    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_SEL_OUT], (size_t)(k + 8) * 8));
-    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_MISC], 4096));
+    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_COUNTS), (size_t)n * 4));
+    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_SEL_OUT), (size_t)(k + 8) * 8));
+    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_MISC), 4096));
     int32_t *st = status_words(ctx);
     int32_t hs[ST_COUNT] = {0};
     hs[ST_NPAIRS] = (int32_t)n;
     MAD_HIP(hipMemcpyAsync(st, hs, sizeof(hs), hipMemcpyHostToDevice, ctx->stream));
-    MAD_HIP(hipMemcpyAsync(ctx->scratch[S_COUNTS].p, counts, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+    MAD_HIP(hipMemcpyAsync(mad_sb(ctx, S_COUNTS).p, counts, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
     MAD_TRY(topk_device(ctx, scratch<int32_t>(ctx, S_COUNTS), st, n, k, maxc, scratch<int64_t>(ctx, S_SEL_OUT)));
-    MAD_HIP(hipMemcpyAsync(order, ctx->scratch[S_SEL_OUT].p, (size_t)k * 8, hipMemcpyDeviceToHost, ctx->stream));
+    MAD_HIP(hipMemcpyAsync(order, mad_sb(ctx, S_SEL_OUT).p, (size_t)k * 8, hipMemcpyDeviceToHost, ctx->stream));
     MAD_HIP(hipStreamSynchronize(ctx->stream));
     return MAD_OK;
 }
@@ -1013,7 +1016,7 @@ extern "C" int mad_set_create(mad_ctx *ctx, mad_set **out) {
         return mad_fail(ctx, MAD_EHIP, "mad_set_create: event creation failed");
     }
     s->pinned_slot = ctx->next_pinned;
-    ctx->next_pinned = 16 + (ctx->next_pinned - 16 + 2) % 1000;      // two 8-byte slots per set
+    ctx->next_pinned = 64 + (ctx->next_pinned - 64 + 2) % 900;      // two 8-byte slots per set
     *out = s;
     return MAD_OK;
 }
@@ -1119,6 +1122,7 @@ static int set_finish_rows(mad_ctx *ctx, mad_set *s, bool check_range) {
 extern "C" int mad_set_build(mad_ctx *ctx, mad_set *s, const int *slot_of_octave, const int32_t *anc_coords,
                              const int32_t *anc_octave, const double *anc_subv, const int32_t *anc_index, int n, int r,
                              int lim_main, int lim_sec) {
+    if (ctx) ctx->lane = 0;
     if (!ctx || !s || !slot_of_octave) return MAD_EINVAL;
     if (n > 0 && (!anc_coords || !anc_octave || !anc_subv || !anc_index)) return mad_fail(ctx, MAD_EINVAL, "mad_set_build: NULL anchors");
     if (lim_main < 1 || lim_sec < 1 || lim_main * lim_sec > 64) return mad_fail(ctx, MAD_EINVAL, "mad_set_build: lim_main=%d lim_sec=%d", lim_main, lim_sec);
@@ -1156,6 +1160,7 @@ extern "C" int mad_set_build(mad_ctx *ctx, mad_set *s, const int *slot_of_octave
 extern "C" int mad_set_load(mad_ctx *ctx, mad_set *s, int64_t n_rows, const int32_t *row_anchor, const int32_t *row_main,
                             const double *row_R, const int16_t *dsc, int D, const double *anc_subv, const int32_t *anc_index,
                             const int32_t *anc_octave, int n_anchors) {
+    if (ctx) ctx->lane = 0;
     if (!ctx || !s) return MAD_EINVAL;
     if (n_rows > 0 && (!row_anchor || !row_main || !row_R || !dsc)) return mad_fail(ctx, MAD_EINVAL, "mad_set_load: NULL rows");
     if (n_anchors > 0 && (!anc_subv || !anc_index || !anc_octave)) return mad_fail(ctx, MAD_EINVAL, "mad_set_load: NULL anchors");
@@ -1211,124 +1216,208 @@ static Side side_of(const mad_set *s) {
     return x;
 }
 
-extern "C" int mad_match_topk(mad_ctx *ctx, const mad_set *hi, const mad_set *lo, double cc, double dist, int64_t k,
-                              double *results, int64_t *pair_index, int64_t *n_out, int64_t *stats) {
-    if (!ctx || !hi || !lo || !n_out) return MAD_EINVAL;
-    *n_out = 0;
-    const int64_t keep_c = ctx->match.cap_c, keep_p = ctx->match.cap_pairs;
-    ctx->match = MatchState();
-    ctx->match.cap_c = keep_c; ctx->match.cap_pairs = keep_p;
-    ctx->match.n_hi_anchors = hi->n_anchors;
-    ctx->match.n_lo_anchors = lo->n_anchors;
-    if (stats) { stats[0] = 0; stats[1] = 0; stats[2] = 0; stats[3] = 0; }
-    if (hi->cap_rows <= 0 || lo->cap_rows <= 0 || hi->n_anchors <= 0 || lo->n_anchors <= 0) return MAD_OK;
-    if (hi->D != lo->D) return mad_fail(ctx, MAD_EINVAL, "mad_match_topk: descriptor lengths %d vs %d", hi->D, lo->D);
-    if (!(dist > 0)) return mad_fail(ctx, MAD_EINVAL, "mad_match_topk: dist must be positive");
-    if (k < 1) k = 1;
-    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_MISC], 4096));
-    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_USED_HI], (size_t)hi->n_anchors + lo->n_anchors + 64));
-    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_HI_CLOUD], (size_t)hi->n_anchors * 24 + 24));
-    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_SEL_OUT], (size_t)(k + 8) * 8));
-    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_RESULTS], (size_t)(k + 1) * MAD_RESULT_COLS * 8));
+// capacity state of one match attempt
+struct MatchPlan {
+    int64_t cap_c, cap_pairs, k;
+    bool fits;
+    CellGrid G;
+};
+
+// enqueue a11 + a12 + top-k (+ the result rows) of one (hi, lo) pair in the CURRENT lane; no host round trip.
+static int match_enqueue(mad_ctx *ctx, const mad_set *hi, const mad_set *lo, double cc, double dist, const MatchPlan &P,
+                         double *results, int64_t *pair_index) {
     int32_t *st = status_words(ctx);
     uint8_t *used_hi = scratch<uint8_t>(ctx, S_USED_HI), *used_lo = used_hi + ((hi->n_anchors + 31) & ~31);
     const Side H = side_of(hi), L = side_of(lo);
+    MAD_HIP(hipMemsetAsync(st, 0, ST_COUNT * 4, ctx->stream));
+    MAD_HIP(hipMemsetAsync(used_hi, 0, (size_t)hi->n_anchors + lo->n_anchors + 64, ctx->stream));
+    MAD_HIP(hipMemcpyAsync(st + ST_NHI, hi->dev_n.p, 16, hipMemcpyDeviceToDevice, ctx->stream));
+    MAD_HIP(hipMemcpyAsync(st + ST_NLO, lo->dev_n.p, 16, hipMemcpyDeviceToDevice, ctx->stream));
+    MAD_TRY(correlate_device(ctx, H, L, hi->D, cc, st, P.cap_c, P.cap_pairs, used_hi, used_lo));
+    // clouds: anchors that take part in at least one pair (MaD.py:427-428)
+    hipLaunchKernelGGL(k_compact_cloud, dim3(1), dim3(1024), 0, ctx->stream, (const double *)hi->anc_subv.p, used_hi,
+                       hi->n_anchors, scratch<double>(ctx, S_HI_CLOUD), st + ST_LHI);
+    CellGrid G = P.G;
+    G.used = used_lo;
+    MAD_TRY(pose_device(ctx, H, L, st, P.cap_pairs, scratch<double>(ctx, S_HI_CLOUD), hi->n_anchors, (const double *)lo->anc_subv.p,
+                        lo->n_anchors, used_lo, lo->bb_min, lo->bb_max, P.fits ? nullptr : &G, dist));
+    MAD_TRY(topk_device(ctx, scratch<int32_t>(ctx, S_COUNTS), st, P.cap_pairs, P.k, hi->n_anchors, scratch<int64_t>(ctx, S_SEL_OUT)));
+    if (results) {
+        hipLaunchKernelGGL(k_results, dim3((unsigned)mad_ceil_div(P.k, 256)), dim3(256), 0, ctx->stream,
+                           scratch<int64_t>(ctx, S_SEL_OUT), st + ST_NKEYS, P.k, scratch<int32_t>(ctx, S_PAIR_HI),
+                           scratch<int32_t>(ctx, S_PAIR_LO), scratch<double>(ctx, S_PAIR_SCORE), scratch<int32_t>(ctx, S_COUNTS),
+                           st, H.p, H.R, H.meta, L.p, L.Rinv, L.meta, H.row_anchor, L.row_anchor, scratch<double>(ctx, S_RESULTS));
+        MAD_HIP(hipGetLastError());
+        MAD_HIP(hipMemcpyAsync(results, mad_sb(ctx, S_RESULTS).p, (size_t)P.k * MAD_RESULT_COLS * 8, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    if (pair_index) MAD_HIP(hipMemcpyAsync(pair_index, mad_sb(ctx, S_SEL_OUT).p, (size_t)P.k * 8, hipMemcpyDeviceToHost, ctx->stream));
+    MAD_HIP(hipMemcpyAsync(&ctx->pinned[16 * ctx->lane], st, ST_COUNT * 4, hipMemcpyDeviceToHost, ctx->stream));
+    MAD_HIP(hipEventRecord(ctx->lane_done[ctx->lane], ctx->stream));
+    return MAD_OK;
+}
+
+static int match_prepare(mad_ctx *ctx, const mad_set *hi, const mad_set *lo, double dist, int64_t k, MatchPlan *P) {
+    if (hi->D != lo->D) return mad_fail(ctx, MAD_EINVAL, "mad_match_topk: descriptor lengths %d vs %d", hi->D, lo->D);
+    if (!(dist > 0)) return mad_fail(ctx, MAD_EINVAL, "mad_match_topk: dist must be positive");
+    P->k = k < 1 ? 1 : k;
+    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_MISC), 4096));
+    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_USED_HI), (size_t)hi->n_anchors + lo->n_anchors + 64));
+    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_HI_CLOUD), (size_t)hi->n_anchors * 24 + 24));
+    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_SEL_OUT), (size_t)(P->k + 8) * 8));
+    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_RESULTS), (size_t)(P->k + 1) * MAD_RESULT_COLS * 8));
     // capacity hints: the score matrix for ~8 rows per anchor, pairs for 2 % of the matrix; both grow on demand
     const int64_t full_c = (mad_ceil_div(hi->cap_rows, 128) * 128) * (mad_ceil_div(lo->cap_rows, 128) * 128);
-    int64_t cap_c = std::max<int64_t>(ctx->match.cap_c, std::min<int64_t>((int64_t)(hi->n_anchors * 8 + 128) * (lo->n_anchors * 8 + 128), full_c));
-    int64_t cap_pairs = std::max<int64_t>(ctx->match.cap_pairs, std::max<int64_t>(cap_c / 50, 1 << 16));
+    P->cap_c = std::max<int64_t>(ctx->match.cap_c, std::min<int64_t>((int64_t)(hi->n_anchors * 8 + 128) * (lo->n_anchors * 8 + 128), full_c));
+    P->cap_pairs = std::max<int64_t>(ctx->match.cap_pairs, std::max<int64_t>(P->cap_c / 50, 1 << 16));
     // the global cell list is only needed when the clouds cannot live in LDS
-    const bool fits = clouds_fit_lds(hi->n_anchors, lo->n_anchors);
-    CellGrid G;
-    if (!fits) {
+    P->fits = clouds_fit_lds(hi->n_anchors, lo->n_anchors);
+    if (!P->fits) {
         if (!lo->cells_ready || lo->cell_size != dist) MAD_TRY(mad_build_cells(ctx, const_cast<mad_set *>(lo), dist));
-        G.start = (const int32_t *)lo->cell_start.p; G.pts = (const double *)lo->cell_pts.p; G.ids = (const int32_t *)lo->cell_ids.p;
-        G.used = used_lo;
-        for (int d = 0; d < 3; d++) { G.mn[d] = lo->cell_min[d]; G.dim[d] = lo->cell_dim[d]; }
-        G.cell = lo->cell_size;
+        P->G.start = (const int32_t *)lo->cell_start.p; P->G.pts = (const double *)lo->cell_pts.p; P->G.ids = (const int32_t *)lo->cell_ids.p;
+        P->G.used = nullptr;
+        for (int d = 0; d < 3; d++) { P->G.mn[d] = lo->cell_min[d]; P->G.dim[d] = lo->cell_dim[d]; }
+        P->G.cell = lo->cell_size;
     }
-    const int32_t *hs = (const int32_t *)&ctx->pinned[0];
-    for (int attempt = 0; attempt < 4; attempt++) {
-        if (cap_c >= ((int64_t)1 << 31)) return mad_fail(ctx, MAD_EINVAL, "mad_match_topk: score matrix of %lld entries", (long long)cap_c);
-        MAD_HIP(hipMemsetAsync(st, 0, ST_COUNT * 4, ctx->stream));
-        MAD_HIP(hipMemsetAsync(used_hi, 0, (size_t)hi->n_anchors + lo->n_anchors + 64, ctx->stream));
-        MAD_HIP(hipMemcpyAsync(st + ST_NHI, hi->dev_n.p, 16, hipMemcpyDeviceToDevice, ctx->stream));
-        MAD_HIP(hipMemcpyAsync(st + ST_NLO, lo->dev_n.p, 16, hipMemcpyDeviceToDevice, ctx->stream));
-        MAD_TRY(correlate_device(ctx, H, L, hi->D, cc, st, cap_c, cap_pairs, used_hi, used_lo));
-        // clouds: anchors that take part in at least one pair (MaD.py:427-428)
-        hipLaunchKernelGGL(k_compact_cloud, dim3(1), dim3(1024), 0, ctx->stream, (const double *)hi->anc_subv.p, used_hi,
-                           hi->n_anchors, scratch<double>(ctx, S_HI_CLOUD), st + ST_LHI);
-        MAD_TRY(pose_device(ctx, H, L, st, cap_pairs, scratch<double>(ctx, S_HI_CLOUD), hi->n_anchors, (const double *)lo->anc_subv.p,
-                            lo->n_anchors, used_lo, lo->bb_min, lo->bb_max, fits ? nullptr : &G, dist));
-        MAD_TRY(topk_device(ctx, scratch<int32_t>(ctx, S_COUNTS), st, cap_pairs, k, hi->n_anchors, scratch<int64_t>(ctx, S_SEL_OUT)));
-        if (results) {
-            hipLaunchKernelGGL(k_results, dim3((unsigned)mad_ceil_div(k, 256)), dim3(256), 0, ctx->stream,
-                               scratch<int64_t>(ctx, S_SEL_OUT), st + ST_NKEYS, k, scratch<int32_t>(ctx, S_PAIR_HI),
-                               scratch<int32_t>(ctx, S_PAIR_LO), scratch<double>(ctx, S_PAIR_SCORE), scratch<int32_t>(ctx, S_COUNTS),
-                               st, H.p, H.R, H.meta, L.p, L.Rinv, L.meta, H.row_anchor, L.row_anchor, scratch<double>(ctx, S_RESULTS));
-            MAD_HIP(hipGetLastError());
-            MAD_HIP(hipMemcpyAsync(results, ctx->scratch[S_RESULTS].p, (size_t)k * MAD_RESULT_COLS * 8, hipMemcpyDeviceToHost, ctx->stream));
-        }
-        if (pair_index) MAD_HIP(hipMemcpyAsync(pair_index, ctx->scratch[S_SEL_OUT].p, (size_t)k * 8, hipMemcpyDeviceToHost, ctx->stream));
-        MAD_HIP(hipMemcpyAsync(&ctx->pinned[0], st, ST_COUNT * 4, hipMemcpyDeviceToHost, ctx->stream));
-        MAD_HIP(hipStreamSynchronize(ctx->stream));      // the one host round trip of a match
-        if (hs[ST_NHI + 3] || hs[ST_NLO + 3]) {
-            // a set's describe launch had been sized from a stale hint: repair the set(s), then match again
-            int64_t dummy;
-            const_cast<mad_set *>(hi)->n_rows_host = -1;
-            const_cast<mad_set *>(lo)->n_rows_host = -1;
-            MAD_TRY(set_rows(ctx, hi, &dummy));
-            MAD_TRY(set_rows(ctx, lo, &dummy));
-            continue;
-        }
-        if (hs[ST_FLAG_C]) {
-            const int64_t hp = mad_ceil_div((int64_t)hs[ST_NHI], 128) * 128, lp = mad_ceil_div((int64_t)hs[ST_NLO], 128) * 128;
-            cap_c = hp * lp;
-            continue;
-        }
-        if (hs[ST_FLAG_PAIRS]) {
-            cap_pairs = (int64_t)hs[ST_NPAIRS] + hs[ST_NPAIRS] / 8 + 1024;
-            continue;
-        }
-        break;
+    return MAD_OK;
+}
+
+// read the status of the match that ran in `lane` (already complete).  Returns 1 when it has to be repeated with
+// larger capacities (updated in P), 0 when it is final (outputs filled), negative on error.
+static int match_finish(mad_ctx *ctx, int lane, const mad_set *hi, const mad_set *lo, MatchPlan *P, int64_t *n_out, int64_t *stats) {
+    const int32_t *hs = (const int32_t *)&ctx->pinned[16 * lane];
+    if (hs[ST_NHI + 3] || hs[ST_NLO + 3]) {
+        // a set's describe launch had been sized from a stale hint: repair the set(s), then match again
+        int64_t dummy;
+        const_cast<mad_set *>(hi)->n_rows_host = -1;
+        const_cast<mad_set *>(lo)->n_rows_host = -1;
+        MAD_TRY(set_rows(ctx, hi, &dummy));
+        MAD_TRY(set_rows(ctx, lo, &dummy));
+        return 1;
     }
-    if (hs[ST_FLAG_C] || hs[ST_FLAG_PAIRS]) return mad_fail(ctx, MAD_EHIP, "mad_match_topk: capacity negotiation did not converge");
-    ctx->match.cap_c = cap_c;
-    ctx->match.cap_pairs = cap_pairs;
+    if (hs[ST_FLAG_C]) {
+        const int64_t hp = mad_ceil_div((int64_t)hs[ST_NHI], 128) * 128, lp = mad_ceil_div((int64_t)hs[ST_NLO], 128) * 128;
+        P->cap_c = hp * lp;
+        if (P->cap_c >= ((int64_t)1 << 31)) return mad_fail(ctx, MAD_EINVAL, "mad_match_topk: score matrix of %lld entries", (long long)P->cap_c);
+        return 1;
+    }
+    if (hs[ST_FLAG_PAIRS]) {
+        P->cap_pairs = (int64_t)hs[ST_NPAIRS] + hs[ST_NPAIRS] / 8 + 1024;
+        return 1;
+    }
+    ctx->match.cap_c = std::max(ctx->match.cap_c, P->cap_c);
+    ctx->match.cap_pairs = std::max(ctx->match.cap_pairs, P->cap_pairs);
     ctx->match.n_pairs = hs[ST_NPAIRS];
     ctx->match.l_hi = hs[ST_LHI];
     ctx->match.l_lo = hs[ST_LLO];
+    ctx->match.lane = lane;
+    ctx->match.n_hi_anchors = hi->n_anchors;
+    ctx->match.n_lo_anchors = lo->n_anchors;
     const_cast<mad_set *>(hi)->n_rows_host = hs[ST_NHI];
     const_cast<mad_set *>(lo)->n_rows_host = hs[ST_NLO];
     const_cast<mad_set *>(hi)->rows_hint = hs[ST_NHI];
     const_cast<mad_set *>(lo)->rows_hint = hs[ST_NLO];
     if (stats) { stats[0] = hs[ST_NPAIRS]; stats[1] = hs[ST_LHI]; stats[2] = hs[ST_LLO]; stats[3] = (int64_t)hs[ST_NHI] * hs[ST_NLO]; }
     *n_out = hs[ST_NPAIRS] > 0 ? hs[ST_NKEYS] : 0;
-    return MAD_OK;
+    return 0;
+}
+
+static bool match_trivial(const mad_set *hi, const mad_set *lo) {
+    return hi->cap_rows <= 0 || lo->cap_rows <= 0 || hi->n_anchors <= 0 || lo->n_anchors <= 0;
+}
+
+extern "C" int mad_match_topk(mad_ctx *ctx, const mad_set *hi, const mad_set *lo, double cc, double dist, int64_t k,
+                              double *results, int64_t *pair_index, int64_t *n_out, int64_t *stats) {
+    if (!ctx || !hi || !lo || !n_out) return MAD_EINVAL;
+    *n_out = 0;
+    if (stats) { stats[0] = 0; stats[1] = 0; stats[2] = 0; stats[3] = 0; }
+    ctx->match.n_pairs = 0;
+    if (match_trivial(hi, lo)) return MAD_OK;
+    ctx->lane = 0;
+    MatchPlan P;
+    MAD_TRY(match_prepare(ctx, hi, lo, dist, k, &P));
+    for (int attempt = 0; attempt < 5; attempt++) {
+        MAD_TRY(match_enqueue(ctx, hi, lo, cc, dist, P, results, pair_index));
+        MAD_HIP(hipStreamSynchronize(ctx->stream));      // the one host round trip of a match
+        const int rc = match_finish(ctx, 0, hi, lo, &P, n_out, stats);
+        if (rc <= 0) return rc;
+    }
+    return mad_fail(ctx, MAD_EHIP, "mad_match_topk: capacity negotiation did not converge");
+}
+
+// Several subunits against one map.  Match i runs in scratch lane i % MAD_LANES, so up to MAD_LANES matches are in
+// flight before the host waits for the oldest: the GPU never idles on a result read-back.
+// results: n x k x 23, pair_index (nullable): n x k, n_out: n, stats (nullable): n x 4.
+extern "C" int mad_match_topk_many(mad_ctx *ctx, int n, const mad_set *const *hi, const mad_set *lo, double cc, double dist, int64_t k,
+                                   double *results, int64_t *pair_index, int64_t *n_out, int64_t *stats) {
+    if (!ctx || !hi || !lo || !n_out || n < 0) return MAD_EINVAL;
+    if (k < 1) k = 1;
+    MatchPlan plans[MAD_LANES];
+    int pending[MAD_LANES];
+    for (int l = 0; l < MAD_LANES; l++) pending[l] = -1;
+    int rc_all = MAD_OK;
+    auto retire = [&](int lane) -> int {
+        const int i = pending[lane];
+        if (i < 0) return MAD_OK;
+        pending[lane] = -1;
+        MAD_HIP(hipEventSynchronize(ctx->lane_done[lane]));
+        int rc = match_finish(ctx, lane, hi[i], lo, &plans[lane], &n_out[i], stats ? stats + 4 * i : nullptr);
+        for (int attempt = 0; rc == 1 && attempt < 5; attempt++) {      // rare: repeat this one synchronously
+            ctx->lane = lane;
+            MAD_TRY(match_enqueue(ctx, hi[i], lo, cc, dist, plans[lane], results ? results + (size_t)i * k * MAD_RESULT_COLS : nullptr,
+                                  pair_index ? pair_index + (size_t)i * k : nullptr));
+            MAD_HIP(hipStreamSynchronize(ctx->stream));
+            rc = match_finish(ctx, lane, hi[i], lo, &plans[lane], &n_out[i], stats ? stats + 4 * i : nullptr);
+        }
+        if (rc == 1) return mad_fail(ctx, MAD_EHIP, "mad_match_topk_many: capacity negotiation did not converge");
+        return rc;
+    };
+    for (int i = 0; i < n && rc_all == MAD_OK; i++) {
+        n_out[i] = 0;
+        if (stats) { stats[4 * i] = stats[4 * i + 1] = stats[4 * i + 2] = stats[4 * i + 3] = 0; }
+        if (!hi[i]) { rc_all = mad_fail(ctx, MAD_EINVAL, "mad_match_topk_many: set %d is NULL", i); break; }
+        if (match_trivial(hi[i], lo)) continue;
+        const int lane = i % MAD_LANES;
+        rc_all = retire(lane);
+        if (rc_all != MAD_OK) break;
+        ctx->lane = lane;
+        rc_all = match_prepare(ctx, hi[i], lo, dist, k, &plans[lane]);
+        if (rc_all != MAD_OK) break;
+        rc_all = match_enqueue(ctx, hi[i], lo, cc, dist, plans[lane], results ? results + (size_t)i * k * MAD_RESULT_COLS : nullptr,
+                               pair_index ? pair_index + (size_t)i * k : nullptr);
+        pending[lane] = i;
+    }
+    for (int l = 0; l < MAD_LANES; l++) {
+        const int rc = retire(l);
+        if (rc_all == MAD_OK) rc_all = rc;
+    }
+    ctx->lane = ctx->match.lane;
+    return rc_all;
 }
 
 extern "C" int mad_match_fetch(mad_ctx *ctx, int32_t *pair_hi, int32_t *pair_lo, double *pair_score, int32_t *counts,
                                int64_t cap) {
     if (!ctx) return MAD_EINVAL;
+    ctx->lane = ctx->match.lane;
     const int64_t np = ctx->match.n_pairs;
     if (np > cap) return mad_fail(ctx, MAD_ENOSPC, "mad_match_fetch: %lld pairs, capacity %lld", (long long)np, (long long)cap);
     if (np <= 0) return MAD_OK;
-    if (pair_hi) MAD_HIP(hipMemcpyAsync(pair_hi, ctx->scratch[S_PAIR_HI].p, np * 4, hipMemcpyDeviceToHost, ctx->stream));
-    if (pair_lo) MAD_HIP(hipMemcpyAsync(pair_lo, ctx->scratch[S_PAIR_LO].p, np * 4, hipMemcpyDeviceToHost, ctx->stream));
-    if (pair_score) MAD_HIP(hipMemcpyAsync(pair_score, ctx->scratch[S_PAIR_SCORE].p, np * 8, hipMemcpyDeviceToHost, ctx->stream));
-    if (counts) MAD_HIP(hipMemcpyAsync(counts, ctx->scratch[S_COUNTS].p, np * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (pair_hi) MAD_HIP(hipMemcpyAsync(pair_hi, mad_sb(ctx, S_PAIR_HI).p, np * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (pair_lo) MAD_HIP(hipMemcpyAsync(pair_lo, mad_sb(ctx, S_PAIR_LO).p, np * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (pair_score) MAD_HIP(hipMemcpyAsync(pair_score, mad_sb(ctx, S_PAIR_SCORE).p, np * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (counts) MAD_HIP(hipMemcpyAsync(counts, mad_sb(ctx, S_COUNTS).p, np * 4, hipMemcpyDeviceToHost, ctx->stream));
     MAD_HIP(hipStreamSynchronize(ctx->stream));
     return MAD_OK;
 }
 
 extern "C" int mad_match_results(mad_ctx *ctx, const mad_set *hi, const mad_set *lo, double *results, int64_t cap) {
     if (!ctx || !hi || !lo || !results) return MAD_EINVAL;
+    ctx->lane = ctx->match.lane;
     const int64_t np = ctx->match.n_pairs;
     if (np > cap) return mad_fail(ctx, MAD_ENOSPC, "mad_match_results: %lld pairs, capacity %lld", (long long)np, (long long)cap);
     if (np <= 0) return MAD_OK;
     if (hi->n_anchors != ctx->match.n_hi_anchors || lo->n_anchors != ctx->match.n_lo_anchors)
         return mad_fail(ctx, MAD_EINVAL, "mad_match_results: sets differ from the last mad_match_topk call");
-    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_RESULTS], (size_t)np * MAD_RESULT_COLS * 8));
+    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_RESULTS), (size_t)np * MAD_RESULT_COLS * 8));
     int32_t *st = status_words(ctx);
     const Side H = side_of(hi), L = side_of(lo);
     hipLaunchKernelGGL(k_results, dim3((unsigned)std::min<int64_t>(mad_ceil_div(np, 256), 4096)), dim3(256), 0, ctx->stream,
@@ -1336,7 +1425,7 @@ extern "C" int mad_match_results(mad_ctx *ctx, const mad_set *hi, const mad_set 
                        scratch<double>(ctx, S_PAIR_SCORE), scratch<int32_t>(ctx, S_COUNTS), st, H.p, H.R, H.meta, L.p, L.Rinv, L.meta,
                        H.row_anchor, L.row_anchor, scratch<double>(ctx, S_RESULTS));
     MAD_HIP(hipGetLastError());
-    MAD_HIP(hipMemcpyAsync(results, ctx->scratch[S_RESULTS].p, (size_t)np * MAD_RESULT_COLS * 8, hipMemcpyDeviceToHost, ctx->stream));
+    MAD_HIP(hipMemcpyAsync(results, mad_sb(ctx, S_RESULTS).p, (size_t)np * MAD_RESULT_COLS * 8, hipMemcpyDeviceToHost, ctx->stream));
     MAD_HIP(hipStreamSynchronize(ctx->stream));
     return MAD_OK;
 }
@@ -1345,6 +1434,7 @@ extern "C" int mad_match_used(mad_ctx *ctx, uint8_t *hi_used, int32_t n_hi_ancho
     if (!ctx) return MAD_EINVAL;
     if (n_hi_anchors != ctx->match.n_hi_anchors || n_lo_anchors != ctx->match.n_lo_anchors)
         return mad_fail(ctx, MAD_EINVAL, "mad_match_used: anchor counts do not match the last mad_match_topk call");
+    ctx->lane = ctx->match.lane;
     const uint8_t *d_hi = scratch<uint8_t>(ctx, S_USED_HI), *d_lo = d_hi + ((n_hi_anchors + 31) & ~31);
     if (hi_used && n_hi_anchors > 0) MAD_HIP(hipMemcpyAsync(hi_used, d_hi, n_hi_anchors, hipMemcpyDeviceToHost, ctx->stream));
     if (lo_used && n_lo_anchors > 0) MAD_HIP(hipMemcpyAsync(lo_used, d_lo, n_lo_anchors, hipMemcpyDeviceToHost, ctx->stream));

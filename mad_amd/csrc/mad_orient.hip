@@ -320,12 +320,12 @@ int mad_orient_device(mad_ctx *ctx, FieldDev f0, FieldDev f1, const int32_t *d_c
     const int Z = ctx->eq_host[0].Z;
     const int fan = lim_main * lim_sec;
     const bool want_hist = out.row_count != nullptr;
-    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_SLOT_CNT], (size_t)(n + 4) * 4));
-    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_SLOT_MAIN], (size_t)n * fan * 4));
-    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_SLOT_SEC], (size_t)n * fan * 4));
-    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_TMP_A], (size_t)n * fan * 4));
-    if (want_hist) MAD_TRY(mad_reserve(ctx, ctx->scratch[S_SLOT_HIST], (size_t)n * lim_main * Z * 4));
-    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_ROW_OFF], (size_t)(n + 2) * 4));
+    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_SLOT_CNT), (size_t)(n + 4) * 4));
+    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_SLOT_MAIN), (size_t)n * fan * 4));
+    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_SLOT_SEC), (size_t)n * fan * 4));
+    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_TMP_A), (size_t)n * fan * 4));
+    if (want_hist) MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_SLOT_HIST), (size_t)n * lim_main * Z * 4));
+    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_ROW_OFF), (size_t)(n + 2) * 4));
 
     OrientArgs A;
     A.f[0] = f0; A.f[1] = f1;
@@ -364,6 +364,7 @@ int mad_orient_device(mad_ctx *ctx, FieldDev f0, FieldDev f1, const int32_t *d_c
 extern "C" int mad_orient(mad_ctx *ctx, int slot, int octave, const int32_t *coords, int n, int r, int lim_main,
                           int lim_sec, int32_t *row_anchor, int32_t *row_main, int32_t *row_sec, double *row_R,
                           int32_t *row_count, int64_t *n_rows, int64_t cap, int32_t *n_reject) {
+    if (ctx) ctx->lane = 0;
     if (!ctx || !n_rows) return MAD_EINVAL;
     if (slot < 0 || slot >= MAD_MAX_FIELDS || !ctx->fields[slot].tex)
         return mad_fail(ctx, MAD_EINVAL, "mad_orient: field slot %d is empty", slot);
@@ -374,14 +375,14 @@ extern "C" int mad_orient(mad_ctx *ctx, int slot, int octave, const int32_t *coo
     if (lim_main < 1 || lim_sec < 1 || lim_main * lim_sec > ORI_MAX_FAN) return mad_fail(ctx, MAD_EINVAL, "mad_orient: lim_main=%d lim_sec=%d", lim_main, lim_sec);
     const int Z = ctx->eq_host[0].Z;
     const int64_t rows_cap = (int64_t)n * lim_main * lim_sec;
-    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_COORDS], (size_t)n * 12));
-    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_ROW_ANCHOR], (size_t)rows_cap * 4));
-    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_ROW_MAIN], (size_t)rows_cap * 4));
-    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_ROW_SEC], (size_t)rows_cap * 4));
-    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_ROW_R], (size_t)rows_cap * 72));
-    if (row_count) MAD_TRY(mad_reserve(ctx, ctx->scratch[S_ROW_COUNT], (size_t)rows_cap * Z * 4));
-    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_MISC], 256));
-    MAD_HIP(hipMemcpyAsync(ctx->scratch[S_COORDS].p, coords, (size_t)n * 12, hipMemcpyHostToDevice, ctx->stream));
+    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_COORDS), (size_t)n * 12));
+    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_ROW_ANCHOR), (size_t)rows_cap * 4));
+    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_ROW_MAIN), (size_t)rows_cap * 4));
+    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_ROW_SEC), (size_t)rows_cap * 4));
+    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_ROW_R), (size_t)rows_cap * 72));
+    if (row_count) MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_ROW_COUNT), (size_t)rows_cap * Z * 4));
+    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_MISC), 256));
+    MAD_HIP(hipMemcpyAsync(mad_sb(ctx, S_COORDS).p, coords, (size_t)n * 12, hipMemcpyHostToDevice, ctx->stream));
     OrientOut out;
     out.row_anchor = scratch<int32_t>(ctx, S_ROW_ANCHOR); out.row_main = scratch<int32_t>(ctx, S_ROW_MAIN);
     out.row_sec = scratch<int32_t>(ctx, S_ROW_SEC); out.row_R = scratch<double>(ctx, S_ROW_R);
@@ -617,6 +618,7 @@ int mad_describe_device(mad_ctx *ctx, FieldDev f0, FieldDev f1, const int32_t *d
 
 extern "C" int mad_describe(mad_ctx *ctx, int slot, int octave, const int32_t *coords, const double *R, int64_t n_rows,
                             int r, int16_t *dsc) {
+    if (ctx) ctx->lane = 0;
     if (!ctx) return MAD_EINVAL;
     if (slot < 0 || slot >= MAD_MAX_FIELDS || !ctx->fields[slot].tex)
         return mad_fail(ctx, MAD_EINVAL, "mad_describe: field slot %d is empty", slot);
@@ -624,19 +626,19 @@ extern "C" int mad_describe(mad_ctx *ctx, int slot, int octave, const int32_t *c
     if (n_rows <= 0) return MAD_OK;
     if (!coords || !R || !dsc) return mad_fail(ctx, MAD_EINVAL, "mad_describe: NULL argument");
     const int D = 64 * ctx->eq_host[1].Z;
-    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_ROW_COORDS], (size_t)n_rows * 12));
-    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_ROW_R], (size_t)n_rows * 72));
-    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_DSC], (size_t)n_rows * D * 2));
-    MAD_HIP(hipMemcpyAsync(ctx->scratch[S_ROW_COORDS].p, coords, (size_t)n_rows * 12, hipMemcpyHostToDevice, ctx->stream));
-    MAD_HIP(hipMemcpyAsync(ctx->scratch[S_ROW_R].p, R, (size_t)n_rows * 72, hipMemcpyHostToDevice, ctx->stream));
+    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_ROW_COORDS), (size_t)n_rows * 12));
+    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_ROW_R), (size_t)n_rows * 72));
+    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_DSC), (size_t)n_rows * D * 2));
+    MAD_HIP(hipMemcpyAsync(mad_sb(ctx, S_ROW_COORDS).p, coords, (size_t)n_rows * 12, hipMemcpyHostToDevice, ctx->stream));
+    MAD_HIP(hipMemcpyAsync(mad_sb(ctx, S_ROW_R).p, R, (size_t)n_rows * 72, hipMemcpyHostToDevice, ctx->stream));
     FieldDev f = ctx->fields[slot];
-    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_MISC], 256));
+    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_MISC), 256));
     int32_t *d_n = scratch<int32_t>(ctx, S_MISC) + 18;
     const int32_t n32 = (int32_t)n_rows;
     MAD_HIP(hipMemcpyAsync(d_n, &n32, 4, hipMemcpyHostToDevice, ctx->stream));
     MAD_TRY(mad_describe_device(ctx, f, f, scratch<int32_t>(ctx, S_ROW_COORDS), nullptr, octave, nullptr,
                                 scratch<double>(ctx, S_ROW_R), d_n, n_rows, d_n + 1, r, scratch<int16_t>(ctx, S_DSC)));
-    MAD_HIP(hipMemcpyAsync(dsc, ctx->scratch[S_DSC].p, (size_t)n_rows * D * 2, hipMemcpyDeviceToHost, ctx->stream));
+    MAD_HIP(hipMemcpyAsync(dsc, mad_sb(ctx, S_DSC).p, (size_t)n_rows * D * 2, hipMemcpyDeviceToHost, ctx->stream));
     MAD_HIP(hipStreamSynchronize(ctx->stream));
     return MAD_OK;
 }

@@ -278,17 +278,18 @@ __global__ __launch_bounds__(RF_THREADS) void k_refine(RefineArgs A) {
 
 extern "C" int mad_refine(mad_ctx *ctx, double *coords, int n_cand, int64_t n_atoms, int n_steps, double max_step,
                           double min_step, int32_t *converged, int32_t *last_step) {
+    if (ctx) ctx->lane = 0;
     if (!ctx) return MAD_EINVAL;
     if (!ctx->dens.grad) return mad_fail(ctx, MAD_EINVAL, "mad_refine: call mad_upload_density first");
     if (n_cand <= 0) return MAD_OK;
     if (!coords || !converged || !last_step || n_atoms <= 0 || n_steps < 0)
         return mad_fail(ctx, MAD_EINVAL, "mad_refine: bad argument");
     const size_t bytes = (size_t)n_cand * n_atoms * 24;
-    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_TMP_E], bytes));
-    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_TMP_F], bytes));
-    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_TMP_H], bytes));
-    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_MISC], 256 + (size_t)n_cand * 8));
-    MAD_HIP(hipMemcpyAsync(ctx->scratch[S_TMP_E].p, coords, bytes, hipMemcpyHostToDevice, ctx->stream));
+    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_TMP_E), bytes));
+    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_TMP_F), bytes));
+    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_TMP_H), bytes));
+    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_MISC), 256 + (size_t)n_cand * 8));
+    MAD_HIP(hipMemcpyAsync(mad_sb(ctx, S_TMP_E).p, coords, bytes, hipMemcpyHostToDevice, ctx->stream));
     const DensityDev &d = ctx->dens;
     RefineArgs A;
     A.grad = d.grad; A.nx = d.nx; A.ny = d.ny; A.nz = d.nz; A.vs = d.vs;
@@ -404,6 +405,7 @@ __global__ void k_norm_f32(float *__restrict__ g, size_t n, const unsigned *__re
 
 extern "C" int mad_structure_to_density(mad_ctx *ctx, const double *atoms, const double *mass, int64_t n, double resolution,
                                         double voxsp, double isovalue, int pad, int32_t dims[3], double origin[3], float *grid) {
+    if (ctx) ctx->lane = 0;
     if (!ctx || !atoms || !mass || !dims || !origin || n <= 0) return ctx ? mad_fail(ctx, MAD_EINVAL, "mad_structure_to_density: bad argument") : MAD_EINVAL;
     if (!(voxsp > 0) || !(resolution > 0) || pad < 0) return mad_fail(ctx, MAD_EINVAL, "mad_structure_to_density: resolution %g voxsp %g pad %d", resolution, voxsp, pad);
     // PDB.py:237-257 lattice-aligned bounding box
@@ -436,12 +438,12 @@ extern "C" int mad_structure_to_density(mad_ctx *ctx, const double *atoms, const
     double taps[129], ts = 0;
     for (int t = -r; t <= r; t++) { taps[t + r] = exp(-(double)(t * t) / (2.0 * sig * sig)); ts += taps[t + r]; }
     for (int t = 0; t <= 2 * r; t++) taps[t] /= ts;
-    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_TMP_E], (size_t)n * 24));
-    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_TMP_F], (size_t)n * 8));
-    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_TMP_H], no * 8));
-    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_TMP_I], no * 8));
-    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_TMP_J], no * 4));
-    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_MISC], 4096));
+    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_TMP_E), (size_t)n * 24));
+    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_TMP_F), (size_t)n * 8));
+    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_TMP_H), no * 8));
+    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_TMP_I), no * 8));
+    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_TMP_J), no * 4));
+    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_MISC), 4096));
     double *d_atoms = scratch<double>(ctx, S_TMP_E), *d_mass = scratch<double>(ctx, S_TMP_F);
     double *bufA = scratch<double>(ctx, S_TMP_H), *bufB = scratch<double>(ctx, S_TMP_I);
     float *d_out = scratch<float>(ctx, S_TMP_J);
@@ -504,12 +506,13 @@ static long py_round(double v) { return (long)nearbyint(v); }      // python rou
 
 extern "C" int mad_ccc(mad_ctx *ctx, float *grid1, const int32_t d1[3], const double o1[3], float *grid2,
                        const int32_t d2[3], const double o2[3], double voxsp, double isovalue, double *ccc) {
+    if (ctx) ctx->lane = 0;
     if (!ctx || !grid1 || !grid2 || !d1 || !d2 || !o1 || !o2 || !ccc) return ctx ? mad_fail(ctx, MAD_EINVAL, "mad_ccc: NULL argument") : MAD_EINVAL;
     *ccc = 0.0;
     const size_t n1 = (size_t)d1[0] * d1[1] * d1[2], n2 = (size_t)d2[0] * d2[1] * d2[2];
-    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_TMP_H], n1 * 4));
-    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_TMP_I], n2 * 4));
-    MAD_TRY(mad_reserve(ctx, ctx->scratch[S_MISC], 4096));
+    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_TMP_H), n1 * 4));
+    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_TMP_I), n2 * 4));
+    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_MISC), 4096));
     float *g1 = scratch<float>(ctx, S_TMP_H), *g2 = scratch<float>(ctx, S_TMP_I);
     double *acc = (double *)(scratch<char>(ctx, S_MISC) + 2048);
     MAD_HIP(hipMemcpyAsync(g1, grid1, n1 * 4, hipMemcpyHostToDevice, ctx->stream));

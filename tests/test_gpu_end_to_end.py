@@ -1,0 +1,60 @@
+"""The drop-in flow of run_MaD.py (`from mad import MaD`; add_map / add_subunit / run) on a synthetic dimer:
+both planted copies must be found, and the on-disk artefacts must have the reference's layout."""
+import csv
+import os
+
+import numpy as np
+import pytest
+
+from mad_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def test_run_mad_docks_a_synthetic_dimer(tmp_path, monkeypatch, lib):
+    from mad_amd import _lib
+    monkeypatch.setattr(_lib, "_default", lib)
+    lib._eq_loaded = {}
+    monkeypatch.chdir(tmp_path)
+    rng = np.random.default_rng(11)
+    coords, names, elems = synth.random_globule(1500, 16.0, seed=3)
+    synth.write_pdb("subunit.pdb", coords, names, elems)
+    truth = [synth.place(coords, synth.random_rotation(rng), t) for t in ([0, 0, 0], [39, 7, -5])]
+    synth.write_pdb("assembly.pdb", np.concatenate(truth), names * 2, elems * 2)
+
+    from mad import MaD      # the reference's import line (run_MaD.py:1)
+    mad = MaD.MaD()
+    mad.add_map("assembly.pdb", 10.0)      # a PDB as map: simulated at 1.2 A/voxel (MaD.py:329-335)
+    mad.add_subunit("subunit.pdb", n_copies=2)
+    mad.run()
+
+    out = mad.out_folder
+    assert out.startswith("results/assembly_subunitx2_res10.000_iso0.000")
+    assert os.path.isdir(os.path.join(out, "initial_files")) and os.path.isdir(os.path.join(out, "individual_solutions", "anchor_files"))
+    assert os.path.exists(os.path.join(out, "initial_files", "assembly_simulated_map.mrc"))
+    assert any(f.endswith((".npz", ".h5")) for f in os.listdir("dsc_db"))
+    table = os.path.join(out, "Solutions_refined_subunit.csv")
+    with open(table) as fh:
+        rows = list(csv.DictReader(fh))
+    assert list(rows[0].keys()) == ["ID", "Repeatability", "Weight", "mCC", "RWmCC"]
+    assert len(rows) >= 2
+    # the two best solutions are the two planted copies (CA RMSD < 3 A), each with a high cross-correlation
+    from mad_amd.PDB import PDB
+    found = []
+    for r in rows[:2]:
+        sol = PDB(os.path.join(out, "individual_solutions", "sol_subunit_%s.pdb" % r["ID"]))
+        d = [np.sqrt(((sol.coords - t) ** 2).sum(1).mean()) for t in truth]
+        found.append(int(np.argmin(d)))
+        assert min(d) < 3.0, d
+        assert float(r["mCC"]) > 0.8
+    assert sorted(found) == [0, 1]
+    assert mad.buildable_subunits["subunit"][0] == 2 and len(mad.buildable_subunits["subunit"][1]) >= 2
+    # a second run hits the descriptor cache and lands in a suffixed folder (MaD.py:304-309)
+    mad2 = MaD.MaD()
+    mad2.add_map("assembly.pdb", 10.0)
+    mad2.add_subunit("subunit.pdb", n_copies=2)
+    mad2.run()
+    assert mad2.out_folder == out + "_1"
+    with open(os.path.join(mad2.out_folder, "Solutions_refined_subunit.csv")) as fh:
+        rows2 = list(csv.DictReader(fh))
+    assert [r["Repeatability"] for r in rows2] == [r["Repeatability"] for r in rows]

@@ -229,3 +229,50 @@ def test_density_and_ccc_match_oracle(lib):
             assert abs(g - r) <= 1e-9 * max(1.0, abs(r))
         np.testing.assert_array_equal(a2, a1)      # clamped in place, like Dmap.py:160-161
         assert a2[2, 3, 4] == 0.0
+
+
+def test_set_pipeline_and_batched_match(lib, fields):
+    """The device-resident pipeline (set_build + match_topk / match_topk_many) equals the stage-by-stage oracle chain."""
+    sets, host = [], []
+    f = fields[1]
+    for seed, n in ((31, 50), (32, 18), (33, 22)):
+        coords = synth.interior_anchors(f["shape"], n, 10, seed)
+        subv = coords.astype(np.float64) * 1.5 + 0.37
+        sets.append(lib.set_build([-1, f["slot"]], coords, np.ones(n, np.int32), subv, np.arange(n)))
+        rows = O.orient(f["gx"], f["gy"], f["gz"], 1, coords, E112.sphere_eqsp, E112.p_centers_eqsp, want_counts=False)
+        dsc = O.describe(f["gx"], f["gy"], f["gz"], 1, coords[rows["anchor"]], rows["R"], E16.sphere_eqsp)
+        host.append(dict(rows=rows, dsc=dsc, subv=subv))
+        d = sets[-1].download()
+        np.testing.assert_array_equal(d["dsc"], dsc)
+        np.testing.assert_array_equal(d["anchor"], rows["anchor"])
+        np.testing.assert_array_equal(d["main"], rows["main"])
+        np.testing.assert_array_equal(d["sec"], rows["sec"])
+    lo, his = sets[0], sets[1:]
+    cc, k = 0.3, 40
+    batched = lib.match_topk_many(his, lo, cc, 4.0, k)
+    for hi, hh, (btop, bidx, bst) in zip(his, host[1:], batched):
+        top, idx, st = lib.match_topk(hi, lo, cc, 4.0, k)
+        np.testing.assert_array_equal(btop, top)
+        np.testing.assert_array_equal(bidx, idx)
+        assert bst == st
+        ph, pl, ps, _ = O.correlate(hh["dsc"], host[0]["dsc"], cc)
+        assert st["n_pairs"] == len(ph) > 100
+        hi_p, lo_p = hh["subv"][hh["rows"]["anchor"]], host[0]["subv"][host[0]["rows"]["anchor"]]
+        mh = np.stack([hh["rows"]["anchor"], np.ones_like(hh["rows"]["anchor"]), hh["rows"]["main"]], 1)
+        ml = np.stack([host[0]["rows"]["anchor"], np.ones_like(host[0]["rows"]["anchor"]), host[0]["rows"]["main"]], 1)
+        res, cnt = O.pose_score(ph, pl, ps, hi_p, hh["rows"]["R"], mh, lo_p, host[0]["rows"]["R"], ml,
+                                np.unique(hi_p[np.unique(ph)], axis=0), np.unique(lo_p[np.unique(pl)], axis=0), 4.0)
+        order = O.topk(cnt, k)
+        np.testing.assert_array_equal(idx, order)
+        np.testing.assert_allclose(top, res[order], rtol=1e-10, atol=1e-10)
+    # rebuilding a set in place (the describe launch is then sized from the previous row count) changes nothing,
+    # also when the new anchor list yields MORE rows than the hint
+    small = synth.interior_anchors(f["shape"], 6, 10, 77)
+    s2 = lib.set_build([-1, f["slot"]], small, np.ones(6, np.int32), small.astype(np.float64), np.arange(6))
+    n_small, _ = s2.size()
+    big = synth.interior_anchors(f["shape"], 60, 10, 78)
+    lib.set_build([-1, f["slot"]], big, np.ones(60, np.int32), big.astype(np.float64), np.arange(60), into=s2)
+    rows = O.orient(f["gx"], f["gy"], f["gz"], 1, big, E112.sphere_eqsp, E112.p_centers_eqsp, want_counts=False)
+    dsc = O.describe(f["gx"], f["gy"], f["gz"], 1, big[rows["anchor"]], rows["R"], E16.sphere_eqsp)
+    assert len(dsc) > n_small + n_small // 8 + 64
+    np.testing.assert_array_equal(s2.download()["dsc"], dsc)
