@@ -116,6 +116,8 @@ struct mad_ctx {
     DevBuf scratch[64 * MAD_LANES];   // MAD_LANES independent copies: matches in flight do not share scratch
     int lane = 0;                    // the copy the current call works in
     hipEvent_t lane_done[MAD_LANES]; // recorded behind the last operation enqueued in each lane
+    void *host_res[MAD_LANES] = {nullptr, nullptr, nullptr, nullptr};   // pinned staging of a match's results / indices / status
+    size_t host_res_cap[MAD_LANES] = {0, 0, 0, 0};
     // host pinned staging for small read-backs
     int64_t *pinned = nullptr;     // 1024 slots: [16 * lane ..] read-backs of the lane, [64..] two per mad_set
     int next_pinned = 64;
@@ -130,11 +132,16 @@ struct mad_set {
     int32_t n_anchors = 0;
     int64_t cap_rows = 0;        // capacity of the row buffers (rows are produced on the device; see dev_n)
     int D = 0;
-    // per anchor
+    // per anchor: views into anc_blob = [dev_n 64 B][subv n x 3 f64][coords n x 3 i32][octave n i32][index n i32], which one
+    // copy from the pinned staging buffer fills (a copy from pageable memory would block the host on the stream)
+    DevBuf anc_blob;
     DevBuf anc_coords, anc_octave, anc_subv, anc_index;
+    void *host_stage = nullptr;
+    size_t host_stage_cap = 0;
+    hipEvent_t uploaded = nullptr;      // recorded behind the staging copy: the buffer may be rewritten after it
     // per row
     DevBuf row_anchor, row_main, row_sec, row_R, row_Rinv, row_meta, dsc, dsc8, norm;
-    DevBuf dev_n;                // int32[4] on the device: [0] = number of rows
+    DevBuf dev_n;                // view: int32[4] on the device = {rows, rows out of int8 range, rejects, describe overflow}
     int64_t n_rows_host = -1;    // host copy of dev_n[0]; -1 until the asynchronous read-back has been waited for
     int64_t rows_hint = 0;       // row count of the previous build of this set (sizes the describe launch)
     // what mad_set_build needs to repeat the describe stage when the hint was too small
@@ -159,7 +166,7 @@ enum {
     S_PAIR_HI, S_PAIR_LO, S_PAIR_SCORE, S_COUNTS, S_USED_HI, S_USED_LO, S_HI_CLOUD, S_MISC,
     S_HIST, S_SEL, S_RESULTS, S_TMP_A, S_TMP_B, S_TMP_C, S_TMP_D, S_TMP_E, S_TMP_F, S_TMP_G,
     S_TIE_FLAG, S_TIE_OFF, S_SEL_OUT, S_TMP_H, S_TMP_I, S_TMP_J,
-    S_CELL_START, S_CELL_PTS, S_CELL_IDS, S_PG_START, S_PG_PTS, S_N_SLOTS
+    S_CELL_START, S_CELL_PTS, S_CELL_IDS, S_PG_START, S_PG_PTS, S_ZERO, S_N_SLOTS
 };
 static_assert(S_N_SLOTS <= 64, "grow mad_ctx::scratch");
 
@@ -176,13 +183,14 @@ void mad_timer_end(mad_ctx *ctx, int group);
 int mad_scan_i32(mad_ctx *ctx, const int32_t *in, int32_t *out, int64_t n);
 
 // single-launch exclusive scan for n <= 65536 with the length read on the device; out[*n] = total, also to *total_out
-void mad_scan_small(mad_ctx *ctx, const int32_t *in, int32_t *out, const int32_t *d_n, int32_t *total_out);
+void mad_scan_small(mad_ctx *ctx, const int32_t *in, int32_t *out, const int32_t *d_n, int32_t *total_out, int n_host = 0);
 
 // implemented in mad_orient.hip; used by the set API in mad_match.hip.  Both are fully asynchronous.
 struct OrientOut {
     int32_t *row_anchor, *row_main, *row_sec;
     double *row_R;
     int32_t *row_count;      // nullable: Z quantised counts per row
+    bool counters_zeroed = false;      // the caller has already enqueued the zeroing of d_n_rows / d_n_reject
     int32_t *d_n_rows;       // device: number of rows produced
     int32_t *d_n_reject;     // device, nullable: anchors refused at the border
 };

@@ -101,7 +101,10 @@ extern "C" void mad_destroy(mad_ctx *ctx) {
             (void)hipEventDestroy(ctx->timers[g].start[i]);
             (void)hipEventDestroy(ctx->timers[g].stop[i]);
         }
-    for (int l = 0; l < MAD_LANES; l++) (void)hipEventDestroy(ctx->lane_done[l]);
+    for (int l = 0; l < MAD_LANES; l++) {
+        (void)hipEventDestroy(ctx->lane_done[l]);
+        if (ctx->host_res[l]) (void)hipHostFree(ctx->host_res[l]);
+    }
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -406,10 +409,11 @@ int mad_scan_i32(mad_ctx *ctx, const int32_t *in, int32_t *out, int64_t n) {
 
 // one workgroup, length on the device: the launch-cheap form for the short scans of the pipeline
 __global__ __launch_bounds__(1024) void k_scan_small(const int32_t *__restrict__ in, int32_t *__restrict__ out,
-                                                     const int32_t *__restrict__ d_n, int32_t *__restrict__ total_out) {
+                                                     const int32_t *__restrict__ d_n, int32_t *__restrict__ total_out,
+                                                     int n_host) {
     __shared__ int wt[1024 / MAD_WAVE + 1];
     __shared__ int carry;
-    const int n = *d_n;
+    const int n = d_n ? *d_n : n_host;
     if (threadIdx.x == 0) carry = 0;
     __syncthreads();
     for (int base = 0; base < n; base += 1024) {
@@ -428,6 +432,6 @@ __global__ __launch_bounds__(1024) void k_scan_small(const int32_t *__restrict__
     }
 }
 
-void mad_scan_small(mad_ctx *ctx, const int32_t *in, int32_t *out, const int32_t *d_n, int32_t *total_out) {
-    hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(1024), 0, ctx->stream, in, out, d_n, total_out);
+void mad_scan_small(mad_ctx *ctx, const int32_t *in, int32_t *out, const int32_t *d_n, int32_t *total_out, int n_host) {
+    hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(1024), 0, ctx->stream, in, out, d_n, total_out, n_host);
 }

@@ -253,10 +253,14 @@ __global__ __launch_bounds__(256) void k_pair_emit(const int32_t *__restrict__ C
 
 // compact the used anchors' coordinates (order immaterial for the count)
 __global__ __launch_bounds__(1024) void k_compact_cloud(const double *__restrict__ subv, const uint8_t *__restrict__ used,
-                                                        int n, double *__restrict__ cloud, int32_t *__restrict__ count) {
+                                                        int n, double *__restrict__ cloud, int32_t *__restrict__ count,
+                                                        const int32_t *__restrict__ hi_words, const int32_t *__restrict__ lo_words,
+                                                        int32_t *__restrict__ status) {
     __shared__ int wt[17];
     __shared__ int s_base;
     if (threadIdx.x == 0) s_base = 0;
+    if (hi_words && threadIdx.x < 4) status[ST_NHI + threadIdx.x] = hi_words[threadIdx.x];      // for the host's read-back
+    if (lo_words && threadIdx.x >= 4 && threadIdx.x < 8) status[ST_NLO + threadIdx.x - 4] = lo_words[threadIdx.x - 4];
     __syncthreads();
     for (int b = 0; b < n; b += 1024) {
         const int i = b + threadIdx.x;
@@ -489,9 +493,9 @@ __global__ void k_results(const int64_t *__restrict__ sel, const int32_t *__rest
                           const int32_t *__restrict__ status, const double *__restrict__ hi_p, const double *__restrict__ hi_R,
                           const int32_t *__restrict__ hi_meta, const double *__restrict__ lo_p, const double *__restrict__ lo_Rinv,
                           const int32_t *__restrict__ lo_meta, const int32_t *__restrict__ hi_row_anchor,
-                          const int32_t *__restrict__ lo_row_anchor, double *__restrict__ out) {
-    if (status[ST_FLAG_C] || status[ST_FLAG_PAIRS]) return;
-    const int64_t n_sel = min((int64_t)*n_sel_ptr, n_sel_cap);
+                          const int32_t *__restrict__ lo_row_anchor, double *__restrict__ out, int tail) {
+    const bool failed = status[ST_FLAG_C] || status[ST_FLAG_PAIRS];
+    const int64_t n_sel = failed ? 0 : min((int64_t)*n_sel_ptr, n_sel_cap);
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n_sel; t += (int64_t)gridDim.x * blockDim.x) {
         const int64_t p = sel ? sel[t] : t;
         const int ih = pair_hi[p], il = pair_lo[p];
@@ -504,6 +508,11 @@ __global__ void k_results(const int64_t *__restrict__ sel, const int32_t *__rest
         o[8] = hi_p[3 * ah]; o[9] = hi_p[3 * ah + 1]; o[10] = hi_p[3 * ah + 2];
         o[11] = lo_p[3 * al]; o[12] = lo_p[3 * al + 1]; o[13] = lo_p[3 * al + 2];
         mat3_mul(lo_Rinv + 9 * il, hi_R + 9 * ih, o + 14);
+    }
+    if (tail) {      // [n_sel_cap x 23 rows][n_sel_cap int64 pair ranks][ST_COUNT int32 status]
+        int64_t *ti = (int64_t *)(out + MAD_RESULT_COLS * n_sel_cap);
+        for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n_sel; t += (int64_t)gridDim.x * blockDim.x) ti[t] = sel[t];
+        if (blockIdx.x == 0 && threadIdx.x < ST_COUNT) ((int32_t *)(ti + n_sel_cap))[threadIdx.x] = status[threadIdx.x];
     }
 }
 
@@ -620,7 +629,7 @@ __global__ __launch_bounds__(1024) void k_topk_sort(const unsigned long long *__
 // Selects the first k pairs of the (count desc, index asc) order into d_order (sorted); their number goes to
 // status[ST_NKEYS].  Everything is enqueued; nothing is read back.
 static int topk_device(mad_ctx *ctx, const int32_t *d_counts, int32_t *d_status, int64_t cap_pairs, int64_t k, int maxc,
-                       int64_t *d_order) {
+                       int64_t *d_order, int32_t *hist_zeroed = nullptr) {
     if (k > 8192) return mad_fail(ctx, MAD_EINVAL, "top-k: k = %lld exceeds 8192", (long long)k);
     if (cap_pairs >= ((int64_t)1 << 31)) return mad_fail(ctx, MAD_EINVAL, "top-k: %lld pairs", (long long)cap_pairs);
     const int nbins = maxc + 1;
@@ -631,10 +640,10 @@ static int topk_device(mad_ctx *ctx, const int32_t *d_counts, int32_t *d_status,
     MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_TIE_FLAG), (size_t)(max_chunks + 2) * 4));
     MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_TIE_OFF), (size_t)(max_chunks + 2) * 4));
     MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_SEL), (size_t)(k + 8) * 8));
-    int32_t *hist = scratch<int32_t>(ctx, S_HIST);
+    int32_t *hist = hist_zeroed ? hist_zeroed : scratch<int32_t>(ctx, S_HIST);      // nbins + 16 zeroed ints
     int32_t *info = hist + nbins;            // 4 ints, then the chunk count
     int32_t *n_chunks = info + 4;
-    MAD_HIP(hipMemsetAsync(hist, 0, (size_t)(nbins + 16) * 4, ctx->stream));
+    if (!hist_zeroed) MAD_HIP(hipMemsetAsync(hist, 0, (size_t)(nbins + 16) * 4, ctx->stream));
     mad_timer_begin(ctx, MAD_T_TOPK);
     const int gs = ctx->n_cu * 2;
     hipLaunchKernelGGL(k_count_hist, dim3(gs), dim3(256), (size_t)nbins * 4, ctx->stream, d_counts, d_status, cap_pairs, hist, nbins);
@@ -970,7 +979,7 @@ extern "C" int mad_pose_score(mad_ctx *ctx, const int32_t *pair_hi, const int32_
                            (const int64_t *)nullptr, st + ST_NPAIRS, n_pairs, scratch<int32_t>(ctx, S_PAIR_HI),
                            scratch<int32_t>(ctx, S_PAIR_LO), scratch<double>(ctx, S_PAIR_SCORE), scratch<int32_t>(ctx, S_COUNTS), st,
                            H.p, H.R, H.meta, L.p, L.Rinv, L.meta, (const int32_t *)nullptr, (const int32_t *)nullptr,
-                           scratch<double>(ctx, S_RESULTS));
+                           scratch<double>(ctx, S_RESULTS), 0);
         MAD_HIP(hipGetLastError());
         MAD_HIP(hipMemcpyAsync(results, mad_sb(ctx, S_RESULTS).p, (size_t)n_pairs * MAD_RESULT_COLS * 8, hipMemcpyDeviceToHost, ctx->stream));
     }
@@ -1011,7 +1020,9 @@ extern "C" int mad_topk(mad_ctx *ctx, const int32_t *counts, int64_t n, int64_t 
 extern "C" int mad_set_create(mad_ctx *ctx, mad_set **out) {
     if (!ctx || !out) return MAD_EINVAL;
     mad_set *s = new mad_set();
-    if (hipEventCreateWithFlags(&s->ready, hipEventDisableTiming) != hipSuccess) {
+    if (hipEventCreateWithFlags(&s->ready, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&s->uploaded, hipEventDisableTiming) != hipSuccess) {
+        if (s->ready) (void)hipEventDestroy(s->ready);
         delete s;
         return mad_fail(ctx, MAD_EHIP, "mad_set_create: event creation failed");
     }
@@ -1024,11 +1035,12 @@ extern "C" int mad_set_create(mad_ctx *ctx, mad_set **out) {
 extern "C" void mad_set_destroy(mad_ctx *ctx, mad_set *s) {
     if (!s) return;
     if (ctx) (void)hipStreamSynchronize(ctx->stream);
-    DevBuf *bufs[] = {&s->anc_coords, &s->anc_octave, &s->anc_subv, &s->anc_index, &s->row_anchor, &s->row_main, &s->row_sec,
-                      &s->row_R, &s->row_Rinv, &s->row_meta, &s->dsc, &s->dsc8, &s->norm, &s->dev_n, &s->cell_start, &s->cell_pts,
-                      &s->cell_ids};
+    DevBuf *bufs[] = {&s->anc_blob, &s->row_anchor, &s->row_main, &s->row_sec, &s->row_R, &s->row_Rinv, &s->row_meta, &s->dsc,
+                      &s->dsc8, &s->norm, &s->cell_start, &s->cell_pts, &s->cell_ids};      // anc_* and dev_n are views
     for (DevBuf *b : bufs) mad_release(*b);
+    if (s->host_stage) (void)hipHostFree(s->host_stage);
     if (s->ready) (void)hipEventDestroy(s->ready);
+    if (s->uploaded) (void)hipEventDestroy(s->uploaded);
     delete s;
 }
 
@@ -1058,26 +1070,43 @@ static int set_rows(mad_ctx *ctx, const mad_set *cs, int64_t *n_rows) {
 }
 
 static int set_upload_anchors(mad_ctx *ctx, mad_set *s, const int32_t *anc_coords, const int32_t *anc_octave,
-                              const double *anc_subv, const int32_t *anc_index, int n) {
+                              const double *anc_subv, const int32_t *anc_index, int n, int32_t rows0 = 0) {
     s->n_anchors = n;
     const size_t m = (size_t)(n > 0 ? n : 1);
-    MAD_TRY(mad_reserve(ctx, s->anc_coords, m * 12));
-    MAD_TRY(mad_reserve(ctx, s->anc_octave, m * 4));
-    MAD_TRY(mad_reserve(ctx, s->anc_subv, m * 24));
-    MAD_TRY(mad_reserve(ctx, s->anc_index, m * 4));
-    MAD_TRY(mad_reserve(ctx, s->dev_n, 64));
-    MAD_HIP(hipMemsetAsync(s->dev_n.p, 0, 64, ctx->stream));
-    if (n > 0) {
-        if (anc_coords) MAD_HIP(hipMemcpyAsync(s->anc_coords.p, anc_coords, (size_t)n * 12, hipMemcpyHostToDevice, ctx->stream));
-        MAD_HIP(hipMemcpyAsync(s->anc_octave.p, anc_octave, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
-        MAD_HIP(hipMemcpyAsync(s->anc_subv.p, anc_subv, (size_t)n * 24, hipMemcpyHostToDevice, ctx->stream));
-        MAD_HIP(hipMemcpyAsync(s->anc_index.p, anc_index, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+    const size_t o_subv = 64, o_coords = o_subv + m * 24, o_oct = o_coords + m * 12, o_idx = o_oct + m * 4, total = o_idx + m * 4;
+    if (s->host_stage_cap < total) {
+        if (s->host_stage) {
+            MAD_HIP(hipEventSynchronize(s->uploaded));
+            (void)hipHostFree(s->host_stage);
+            s->host_stage = nullptr;
+            s->host_stage_cap = 0;
+        }
+        const size_t want = total + total / 2;
+        if (hipHostMalloc(&s->host_stage, want) != hipSuccess) return mad_fail(ctx, MAD_ENOMEM, "pinned anchor staging of %zu bytes", want);
+        s->host_stage_cap = want;
+    } else {
+        MAD_HIP(hipEventSynchronize(s->uploaded));      // the previous copy out of the staging buffer has finished
     }
+    MAD_TRY(mad_reserve(ctx, s->anc_blob, total));
+    char *h = (char *)s->host_stage, *d = (char *)s->anc_blob.p;
+    s->dev_n.p = d;
+    s->anc_subv.p = d + o_subv; s->anc_coords.p = d + o_coords; s->anc_octave.p = d + o_oct; s->anc_index.p = d + o_idx;
+    memset(h, 0, 64);      // the device counters start from zero
+    ((int32_t *)h)[0] = rows0;
+    if (n > 0) {
+        memcpy(h + o_subv, anc_subv, (size_t)n * 24);
+        if (anc_coords) memcpy(h + o_coords, anc_coords, (size_t)n * 12);
+        else memset(h + o_coords, 0, (size_t)n * 12);
+        memcpy(h + o_oct, anc_octave, (size_t)n * 4);
+        memcpy(h + o_idx, anc_index, (size_t)n * 4);
+    }
+    MAD_HIP(hipMemcpyAsync(d, h, n > 0 ? total : 64, hipMemcpyHostToDevice, ctx->stream));
+    MAD_HIP(hipEventRecord(s->uploaded, ctx->stream));
     for (int i = 0; i < n; i++)
-        for (int d = 0; d < 3; d++) {
-            const double v = anc_subv[3 * i + d];
-            if (i == 0 || v < s->bb_min[d]) s->bb_min[d] = v;
-            if (i == 0 || v > s->bb_max[d]) s->bb_max[d] = v;
+        for (int d3 = 0; d3 < 3; d3++) {
+            const double v = anc_subv[3 * i + d3];
+            if (i == 0 || v < s->bb_min[d3]) s->bb_min[d3] = v;
+            if (i == 0 || v > s->bb_max[d3]) s->bb_max[d3] = v;
         }
     s->cells_ready = false;
     s->n_rows_host = -1;
@@ -1102,8 +1131,7 @@ static int set_reserve_rows(mad_ctx *ctx, mad_set *s, int64_t cap) {
 // int8 rows + norms, inverse rotations, result meta; then the asynchronous read-back of the row count
 static int set_finish_rows(mad_ctx *ctx, mad_set *s, bool check_range) {
     int32_t *d_n = (int32_t *)s->dev_n.p;
-    int32_t *bad = d_n + 1;
-    MAD_HIP(hipMemsetAsync(bad, 0, 4, ctx->stream));
+    int32_t *bad = d_n + 1;      // zeroed with the other counters by the anchor upload
     const int64_t cap_pad = mad_ceil_div(s->cap_rows > 0 ? s->cap_rows : 1, GEMM_BM) * GEMM_BM;
     hipLaunchKernelGGL(k_pack_rows, dim3((unsigned)std::min<int64_t>(mad_ceil_div(cap_pad, 4), (int64_t)ctx->n_cu * 8)), dim3(256), 0,
                        ctx->stream, (const int16_t *)s->dsc.p, d_n, s->D, (int8_t *)s->dsc8.p, (double *)s->norm.p,
@@ -1145,11 +1173,11 @@ extern "C" int mad_set_build(mad_ctx *ctx, mad_set *s, const int *slot_of_octave
     out.row_anchor = (int32_t *)s->row_anchor.p; out.row_main = (int32_t *)s->row_main.p; out.row_sec = (int32_t *)s->row_sec.p;
     out.row_R = (double *)s->row_R.p; out.row_count = nullptr;
     out.d_n_rows = (int32_t *)s->dev_n.p; out.d_n_reject = (int32_t *)s->dev_n.p + 2;
+    out.counters_zeroed = true;
     MAD_TRY(mad_orient_device(ctx, f[0], f[1], (const int32_t *)s->anc_coords.p, (const int32_t *)s->anc_octave.p, 0, n, r,
                               lim_main, lim_sec, out));
     // the describe launch is sized from the row count of this set's previous build when there is one
     const int64_t grid_rows = s->rows_hint > 0 ? std::min<int64_t>(s->cap_rows, s->rows_hint + s->rows_hint / 8 + 64) : s->cap_rows;
-    MAD_HIP(hipMemsetAsync((int32_t *)s->dev_n.p + 3, 0, 4, ctx->stream));
     MAD_TRY(mad_describe_device(ctx, f[0], f[1], (const int32_t *)s->anc_coords.p, (const int32_t *)s->anc_octave.p, 0,
                                 (const int32_t *)s->row_anchor.p, (const double *)s->row_R.p, (const int32_t *)s->dev_n.p,
                                 grid_rows, (int32_t *)s->dev_n.p + 3, r, (int16_t *)s->dsc.p));
@@ -1166,11 +1194,9 @@ extern "C" int mad_set_load(mad_ctx *ctx, mad_set *s, int64_t n_rows, const int3
     if (n_anchors > 0 && (!anc_subv || !anc_index || !anc_octave)) return mad_fail(ctx, MAD_EINVAL, "mad_set_load: NULL anchors");
     for (int64_t i = 0; i < n_rows; i++)
         if (row_anchor[i] < 0 || row_anchor[i] >= n_anchors) return mad_fail(ctx, MAD_EINVAL, "mad_set_load: row %lld -> anchor %d", (long long)i, row_anchor[i]);
-    MAD_TRY(set_upload_anchors(ctx, s, nullptr, anc_octave, anc_subv, anc_index, n_anchors));
+    MAD_TRY(set_upload_anchors(ctx, s, nullptr, anc_octave, anc_subv, anc_index, n_anchors, (int32_t)n_rows));
     s->D = D;
     MAD_TRY(set_reserve_rows(ctx, s, n_rows));
-    const int32_t n32 = (int32_t)n_rows;
-    MAD_HIP(hipMemcpyAsync(s->dev_n.p, &n32, 4, hipMemcpyHostToDevice, ctx->stream));
     if (n_rows > 0) {
         MAD_HIP(hipMemcpyAsync(s->row_anchor.p, row_anchor, n_rows * 4, hipMemcpyHostToDevice, ctx->stream));
         MAD_HIP(hipMemcpyAsync(s->row_main.p, row_main, n_rows * 4, hipMemcpyHostToDevice, ctx->stream));
@@ -1224,34 +1250,36 @@ struct MatchPlan {
 };
 
 // enqueue a11 + a12 + top-k (+ the result rows) of one (hi, lo) pair in the CURRENT lane; no host round trip.
-static int match_enqueue(mad_ctx *ctx, const mad_set *hi, const mad_set *lo, double cc, double dist, const MatchPlan &P,
-                         double *results, int64_t *pair_index) {
-    int32_t *st = status_words(ctx);
-    uint8_t *used_hi = scratch<uint8_t>(ctx, S_USED_HI), *used_lo = used_hi + ((hi->n_anchors + 31) & ~31);
+// layout of the zero region of a match: [status ST_COUNT int32][hist (n_hi_anchors + 17) int32][used flags]
+static int32_t *zero_status(mad_ctx *ctx) { return scratch<int32_t>(ctx, S_ZERO); }
+static size_t zero_bytes(const mad_set *hi, const mad_set *lo) {
+    return (size_t)(ST_COUNT + hi->n_anchors + 17) * 4 + (size_t)hi->n_anchors + lo->n_anchors + 64;
+}
+static size_t tail_bytes(int64_t k) { return (size_t)k * (MAD_RESULT_COLS * 8 + 8) + ST_COUNT * 4; }
+
+static int match_enqueue(mad_ctx *ctx, const mad_set *hi, const mad_set *lo, double cc, double dist, const MatchPlan &P) {
+    int32_t *st = zero_status(ctx);
+    int32_t *hist = st + ST_COUNT;
+    uint8_t *used_hi = (uint8_t *)(hist + hi->n_anchors + 17), *used_lo = used_hi + ((hi->n_anchors + 31) & ~31);
     const Side H = side_of(hi), L = side_of(lo);
-    MAD_HIP(hipMemsetAsync(st, 0, ST_COUNT * 4, ctx->stream));
-    MAD_HIP(hipMemsetAsync(used_hi, 0, (size_t)hi->n_anchors + lo->n_anchors + 64, ctx->stream));
-    MAD_HIP(hipMemcpyAsync(st + ST_NHI, hi->dev_n.p, 16, hipMemcpyDeviceToDevice, ctx->stream));
-    MAD_HIP(hipMemcpyAsync(st + ST_NLO, lo->dev_n.p, 16, hipMemcpyDeviceToDevice, ctx->stream));
+    MAD_HIP(hipMemsetAsync(st, 0, zero_bytes(hi, lo), ctx->stream));      // status, histogram and flags in one go
     MAD_TRY(correlate_device(ctx, H, L, hi->D, cc, st, P.cap_c, P.cap_pairs, used_hi, used_lo));
     // clouds: anchors that take part in at least one pair (MaD.py:427-428)
     hipLaunchKernelGGL(k_compact_cloud, dim3(1), dim3(1024), 0, ctx->stream, (const double *)hi->anc_subv.p, used_hi,
-                       hi->n_anchors, scratch<double>(ctx, S_HI_CLOUD), st + ST_LHI);
+                       hi->n_anchors, scratch<double>(ctx, S_HI_CLOUD), st + ST_LHI, (const int32_t *)hi->dev_n.p,
+                       (const int32_t *)lo->dev_n.p, st);
     CellGrid G = P.G;
     G.used = used_lo;
     MAD_TRY(pose_device(ctx, H, L, st, P.cap_pairs, scratch<double>(ctx, S_HI_CLOUD), hi->n_anchors, (const double *)lo->anc_subv.p,
                         lo->n_anchors, used_lo, lo->bb_min, lo->bb_max, P.fits ? nullptr : &G, dist));
-    MAD_TRY(topk_device(ctx, scratch<int32_t>(ctx, S_COUNTS), st, P.cap_pairs, P.k, hi->n_anchors, scratch<int64_t>(ctx, S_SEL_OUT)));
-    if (results) {
-        hipLaunchKernelGGL(k_results, dim3((unsigned)mad_ceil_div(P.k, 256)), dim3(256), 0, ctx->stream,
-                           scratch<int64_t>(ctx, S_SEL_OUT), st + ST_NKEYS, P.k, scratch<int32_t>(ctx, S_PAIR_HI),
-                           scratch<int32_t>(ctx, S_PAIR_LO), scratch<double>(ctx, S_PAIR_SCORE), scratch<int32_t>(ctx, S_COUNTS),
-                           st, H.p, H.R, H.meta, L.p, L.Rinv, L.meta, H.row_anchor, L.row_anchor, scratch<double>(ctx, S_RESULTS));
-        MAD_HIP(hipGetLastError());
-        MAD_HIP(hipMemcpyAsync(results, mad_sb(ctx, S_RESULTS).p, (size_t)P.k * MAD_RESULT_COLS * 8, hipMemcpyDeviceToHost, ctx->stream));
-    }
-    if (pair_index) MAD_HIP(hipMemcpyAsync(pair_index, mad_sb(ctx, S_SEL_OUT).p, (size_t)P.k * 8, hipMemcpyDeviceToHost, ctx->stream));
-    MAD_HIP(hipMemcpyAsync(&ctx->pinned[16 * ctx->lane], st, ST_COUNT * 4, hipMemcpyDeviceToHost, ctx->stream));
+    MAD_TRY(topk_device(ctx, scratch<int32_t>(ctx, S_COUNTS), st, P.cap_pairs, P.k, hi->n_anchors, scratch<int64_t>(ctx, S_SEL_OUT), hist));
+    hipLaunchKernelGGL(k_results, dim3((unsigned)mad_ceil_div(P.k, 256)), dim3(256), 0, ctx->stream,
+                       scratch<int64_t>(ctx, S_SEL_OUT), st + ST_NKEYS, P.k, scratch<int32_t>(ctx, S_PAIR_HI),
+                       scratch<int32_t>(ctx, S_PAIR_LO), scratch<double>(ctx, S_PAIR_SCORE), scratch<int32_t>(ctx, S_COUNTS),
+                       st, H.p, H.R, H.meta, L.p, L.Rinv, L.meta, H.row_anchor, L.row_anchor, scratch<double>(ctx, S_RESULTS), 1);
+    MAD_HIP(hipGetLastError());
+    // rows, pair ranks and status come back in ONE copy into pinned memory: the host is never blocked by it
+    MAD_HIP(hipMemcpyAsync(ctx->host_res[ctx->lane], mad_sb(ctx, S_RESULTS).p, tail_bytes(P.k), hipMemcpyDeviceToHost, ctx->stream));
     MAD_HIP(hipEventRecord(ctx->lane_done[ctx->lane], ctx->stream));
     return MAD_OK;
 }
@@ -1260,11 +1288,20 @@ static int match_prepare(mad_ctx *ctx, const mad_set *hi, const mad_set *lo, dou
     if (hi->D != lo->D) return mad_fail(ctx, MAD_EINVAL, "mad_match_topk: descriptor lengths %d vs %d", hi->D, lo->D);
     if (!(dist > 0)) return mad_fail(ctx, MAD_EINVAL, "mad_match_topk: dist must be positive");
     P->k = k < 1 ? 1 : k;
-    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_MISC), 4096));
-    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_USED_HI), (size_t)hi->n_anchors + lo->n_anchors + 64));
+    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_ZERO), zero_bytes(hi, lo)));
     MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_HI_CLOUD), (size_t)hi->n_anchors * 24 + 24));
     MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_SEL_OUT), (size_t)(P->k + 8) * 8));
-    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_RESULTS), (size_t)(P->k + 1) * MAD_RESULT_COLS * 8));
+    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_RESULTS), tail_bytes(P->k) + 64));
+    if (ctx->host_res_cap[ctx->lane] < tail_bytes(P->k)) {
+        if (ctx->host_res[ctx->lane]) {
+            MAD_HIP(hipStreamSynchronize(ctx->stream));
+            (void)hipHostFree(ctx->host_res[ctx->lane]);
+            ctx->host_res[ctx->lane] = nullptr;
+        }
+        const size_t want = tail_bytes(P->k) * 2;
+        if (hipHostMalloc(&ctx->host_res[ctx->lane], want) != hipSuccess) return mad_fail(ctx, MAD_ENOMEM, "pinned result staging of %zu bytes", want);
+        ctx->host_res_cap[ctx->lane] = want;
+    }
     // capacity hints: the score matrix for ~8 rows per anchor, pairs for 2 % of the matrix; both grow on demand
     const int64_t full_c = (mad_ceil_div(hi->cap_rows, 128) * 128) * (mad_ceil_div(lo->cap_rows, 128) * 128);
     P->cap_c = std::max<int64_t>(ctx->match.cap_c, std::min<int64_t>((int64_t)(hi->n_anchors * 8 + 128) * (lo->n_anchors * 8 + 128), full_c));
@@ -1283,8 +1320,11 @@ static int match_prepare(mad_ctx *ctx, const mad_set *hi, const mad_set *lo, dou
 
 // read the status of the match that ran in `lane` (already complete).  Returns 1 when it has to be repeated with
 // larger capacities (updated in P), 0 when it is final (outputs filled), negative on error.
-static int match_finish(mad_ctx *ctx, int lane, const mad_set *hi, const mad_set *lo, MatchPlan *P, int64_t *n_out, int64_t *stats) {
-    const int32_t *hs = (const int32_t *)&ctx->pinned[16 * lane];
+static int match_finish(mad_ctx *ctx, int lane, const mad_set *hi, const mad_set *lo, MatchPlan *P, double *results,
+                        int64_t *pair_index, int64_t *n_out, int64_t *stats) {
+    const char *base = (const char *)ctx->host_res[lane];
+    const int64_t *h_idx = (const int64_t *)(base + (size_t)P->k * MAD_RESULT_COLS * 8);
+    const int32_t *hs = (const int32_t *)(h_idx + P->k);
     if (hs[ST_NHI + 3] || hs[ST_NLO + 3]) {
         // a set's describe launch had been sized from a stale hint: repair the set(s), then match again
         int64_t dummy;
@@ -1317,7 +1357,10 @@ static int match_finish(mad_ctx *ctx, int lane, const mad_set *hi, const mad_set
     const_cast<mad_set *>(hi)->rows_hint = hs[ST_NHI];
     const_cast<mad_set *>(lo)->rows_hint = hs[ST_NLO];
     if (stats) { stats[0] = hs[ST_NPAIRS]; stats[1] = hs[ST_LHI]; stats[2] = hs[ST_LLO]; stats[3] = (int64_t)hs[ST_NHI] * hs[ST_NLO]; }
-    *n_out = hs[ST_NPAIRS] > 0 ? hs[ST_NKEYS] : 0;
+    const int64_t got = hs[ST_NPAIRS] > 0 ? hs[ST_NKEYS] : 0;
+    if (results && got > 0) memcpy(results, base, (size_t)got * MAD_RESULT_COLS * 8);
+    if (pair_index && got > 0) memcpy(pair_index, h_idx, (size_t)got * 8);
+    *n_out = got;
     return 0;
 }
 
@@ -1336,9 +1379,9 @@ extern "C" int mad_match_topk(mad_ctx *ctx, const mad_set *hi, const mad_set *lo
     MatchPlan P;
     MAD_TRY(match_prepare(ctx, hi, lo, dist, k, &P));
     for (int attempt = 0; attempt < 5; attempt++) {
-        MAD_TRY(match_enqueue(ctx, hi, lo, cc, dist, P, results, pair_index));
+        MAD_TRY(match_enqueue(ctx, hi, lo, cc, dist, P));
         MAD_HIP(hipStreamSynchronize(ctx->stream));      // the one host round trip of a match
-        const int rc = match_finish(ctx, 0, hi, lo, &P, n_out, stats);
+        const int rc = match_finish(ctx, 0, hi, lo, &P, results, pair_index, n_out, stats);
         if (rc <= 0) return rc;
     }
     return mad_fail(ctx, MAD_EHIP, "mad_match_topk: capacity negotiation did not converge");
@@ -1360,13 +1403,14 @@ extern "C" int mad_match_topk_many(mad_ctx *ctx, int n, const mad_set *const *hi
         if (i < 0) return MAD_OK;
         pending[lane] = -1;
         MAD_HIP(hipEventSynchronize(ctx->lane_done[lane]));
-        int rc = match_finish(ctx, lane, hi[i], lo, &plans[lane], &n_out[i], stats ? stats + 4 * i : nullptr);
+        double *res_i = results ? results + (size_t)i * k * MAD_RESULT_COLS : nullptr;
+        int64_t *idx_i = pair_index ? pair_index + (size_t)i * k : nullptr;
+        int rc = match_finish(ctx, lane, hi[i], lo, &plans[lane], res_i, idx_i, &n_out[i], stats ? stats + 4 * i : nullptr);
         for (int attempt = 0; rc == 1 && attempt < 5; attempt++) {      // rare: repeat this one synchronously
             ctx->lane = lane;
-            MAD_TRY(match_enqueue(ctx, hi[i], lo, cc, dist, plans[lane], results ? results + (size_t)i * k * MAD_RESULT_COLS : nullptr,
-                                  pair_index ? pair_index + (size_t)i * k : nullptr));
+            MAD_TRY(match_enqueue(ctx, hi[i], lo, cc, dist, plans[lane]));
             MAD_HIP(hipStreamSynchronize(ctx->stream));
-            rc = match_finish(ctx, lane, hi[i], lo, &plans[lane], &n_out[i], stats ? stats + 4 * i : nullptr);
+            rc = match_finish(ctx, lane, hi[i], lo, &plans[lane], res_i, idx_i, &n_out[i], stats ? stats + 4 * i : nullptr);
         }
         if (rc == 1) return mad_fail(ctx, MAD_EHIP, "mad_match_topk_many: capacity negotiation did not converge");
         return rc;
@@ -1382,8 +1426,7 @@ extern "C" int mad_match_topk_many(mad_ctx *ctx, int n, const mad_set *const *hi
         ctx->lane = lane;
         rc_all = match_prepare(ctx, hi[i], lo, dist, k, &plans[lane]);
         if (rc_all != MAD_OK) break;
-        rc_all = match_enqueue(ctx, hi[i], lo, cc, dist, plans[lane], results ? results + (size_t)i * k * MAD_RESULT_COLS : nullptr,
-                               pair_index ? pair_index + (size_t)i * k : nullptr);
+        rc_all = match_enqueue(ctx, hi[i], lo, cc, dist, plans[lane]);
         pending[lane] = i;
     }
     for (int l = 0; l < MAD_LANES; l++) {
@@ -1418,12 +1461,12 @@ extern "C" int mad_match_results(mad_ctx *ctx, const mad_set *hi, const mad_set 
     if (hi->n_anchors != ctx->match.n_hi_anchors || lo->n_anchors != ctx->match.n_lo_anchors)
         return mad_fail(ctx, MAD_EINVAL, "mad_match_results: sets differ from the last mad_match_topk call");
     MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_RESULTS), (size_t)np * MAD_RESULT_COLS * 8));
-    int32_t *st = status_words(ctx);
+    int32_t *st = zero_status(ctx);
     const Side H = side_of(hi), L = side_of(lo);
     hipLaunchKernelGGL(k_results, dim3((unsigned)std::min<int64_t>(mad_ceil_div(np, 256), 4096)), dim3(256), 0, ctx->stream,
                        (const int64_t *)nullptr, st + ST_NPAIRS, np, scratch<int32_t>(ctx, S_PAIR_HI), scratch<int32_t>(ctx, S_PAIR_LO),
                        scratch<double>(ctx, S_PAIR_SCORE), scratch<int32_t>(ctx, S_COUNTS), st, H.p, H.R, H.meta, L.p, L.Rinv, L.meta,
-                       H.row_anchor, L.row_anchor, scratch<double>(ctx, S_RESULTS));
+                       H.row_anchor, L.row_anchor, scratch<double>(ctx, S_RESULTS), 0);
     MAD_HIP(hipGetLastError());
     MAD_HIP(hipMemcpyAsync(results, mad_sb(ctx, S_RESULTS).p, (size_t)np * MAD_RESULT_COLS * 8, hipMemcpyDeviceToHost, ctx->stream));
     MAD_HIP(hipStreamSynchronize(ctx->stream));
@@ -1435,7 +1478,7 @@ extern "C" int mad_match_used(mad_ctx *ctx, uint8_t *hi_used, int32_t n_hi_ancho
     if (n_hi_anchors != ctx->match.n_hi_anchors || n_lo_anchors != ctx->match.n_lo_anchors)
         return mad_fail(ctx, MAD_EINVAL, "mad_match_used: anchor counts do not match the last mad_match_topk call");
     ctx->lane = ctx->match.lane;
-    const uint8_t *d_hi = scratch<uint8_t>(ctx, S_USED_HI), *d_lo = d_hi + ((n_hi_anchors + 31) & ~31);
+    const uint8_t *d_hi = (const uint8_t *)(zero_status(ctx) + ST_COUNT + n_hi_anchors + 17), *d_lo = d_hi + ((n_hi_anchors + 31) & ~31);
     if (hi_used && n_hi_anchors > 0) MAD_HIP(hipMemcpyAsync(hi_used, d_hi, n_hi_anchors, hipMemcpyDeviceToHost, ctx->stream));
     if (lo_used && n_lo_anchors > 0) MAD_HIP(hipMemcpyAsync(lo_used, d_lo, n_lo_anchors, hipMemcpyDeviceToHost, ctx->stream));
     MAD_HIP(hipStreamSynchronize(ctx->stream));

@@ -12,7 +12,7 @@
 // 16 independent 16-byte loads; the 64 x 16 histogram lives in LDS.
 #include "mad_common.h"
 
-#define ORI_THREADS 256
+#define ORI_THREADS 512
 #define ORI_MAX_FAN 64          // lim_main * lim_sec must not exceed this
 #define ORI_MAX_MAIN 8
 
@@ -312,6 +312,7 @@ int mad_orient_device(mad_ctx *ctx, FieldDev f0, FieldDev f1, const int32_t *d_c
     if (lim_main < 1 || lim_main > ORI_MAX_MAIN || lim_sec < 1 || lim_main * lim_sec > ORI_MAX_FAN)
         return mad_fail(ctx, MAD_EINVAL, "mad_orient: lim_main=%d lim_sec=%d unsupported", lim_main, lim_sec);
     if (n <= 0) {
+        if (out.counters_zeroed) return MAD_OK;
         MAD_HIP(hipMemsetAsync(out.d_n_rows, 0, 4, ctx->stream));
         if (out.d_n_reject) MAD_HIP(hipMemsetAsync(out.d_n_reject, 0, 4, ctx->stream));
         return MAD_OK;
@@ -338,9 +339,7 @@ int mad_orient_device(mad_ctx *ctx, FieldDev f0, FieldDev f1, const int32_t *d_c
     A.slot_sec = scratch<int32_t>(ctx, S_SLOT_SEC);
     A.slot_hist = want_hist ? scratch<int32_t>(ctx, S_SLOT_HIST) : nullptr;
     A.slot_hidx = scratch<int32_t>(ctx, S_TMP_A);
-    int32_t *d_n = A.slot_cnt + n;      // the anchor count, for the device-length scan
-    MAD_HIP(hipMemcpyAsync(d_n, &n, 4, hipMemcpyHostToDevice, ctx->stream));
-    if (out.d_n_reject) MAD_HIP(hipMemsetAsync(out.d_n_reject, 0, 4, ctx->stream));
+    if (out.d_n_reject && !out.counters_zeroed) MAD_HIP(hipMemsetAsync(out.d_n_reject, 0, 4, ctx->stream));
 
     mad_timer_begin(ctx, MAD_T_ORIENT);
     const size_t lds = (size_t)ctx->mask_n * 4 * sizeof(float);      // unit gradients (SoA) + the undecided-voxel queue
@@ -348,7 +347,7 @@ int mad_orient_device(mad_ctx *ctx, FieldDev f0, FieldDev f1, const int32_t *d_c
     mad_timer_end(ctx, MAD_T_ORIENT);
     int32_t *row_off = scratch<int32_t>(ctx, S_ROW_OFF);
     if (n <= 65536) {
-        mad_scan_small(ctx, A.slot_cnt, row_off, d_n, out.d_n_rows);
+        mad_scan_small(ctx, A.slot_cnt, row_off, nullptr, out.d_n_rows, n);
     } else {
         MAD_TRY(mad_scan_i32(ctx, A.slot_cnt, row_off, n));
         MAD_HIP(hipMemcpyAsync(out.d_n_rows, row_off + n, 4, hipMemcpyDeviceToDevice, ctx->stream));
