@@ -330,22 +330,27 @@ def main():
 
     def exchange(tops):
         """The path's one exchange: every rank receives every rank's per-subunit top-k poses
-        (one fused RCCL all-gather of world x n_sub x k x 23 float64, mad_amd/dist.py)."""
+        (one fused RCCL all-gather of world x n_sub x k x 23 float64, mad_amd/dist.py).  It is started
+        asynchronously and collected one step later, so it overlaps the next step's kernels."""
         from mad_amd import dist as mdist
-        return mdist.all_gather_topk(tops, k, world * W["n_sub"], rank, world)
+        return mdist.TopkExchange(tops, k, world * W["n_sub"], rank, world)
 
     sets = [_lib.DeviceSet(lib) for _ in range(1 + len(subs))]
     for _ in range(args.warmup):
         corr, tops, stats = hot_path_step(lib, the_map, subs, cc, dist_thr, k, sets)
-        exchange(tops)
+        exchange(tops).finish()
     lib.timing_enable(True)
     lib.timing_reset()
     HOST_T.clear()
     barrier()
     t0 = time.perf_counter()
+    pending = None
     for _ in range(args.steps):
         corr, tops, stats = hot_path_step(lib, the_map, subs, cc, dist_thr, k, sets)
-        gathered = exchange(tops)
+        if pending is not None:
+            gathered = pending.finish()
+        pending = exchange(tops)
+    gathered = pending.finish()      # every step's exchange completes inside the timed region
     barrier()
     dt = time.perf_counter() - t0
     lib.timing_enable(False)

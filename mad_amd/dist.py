@@ -38,30 +38,51 @@ def pack_topk(tops, k):
     return block, valid
 
 
+class TopkExchange(object):
+    """One in-flight all-gather of top-k rows: the constructor enqueues it (asynchronously for world > 1, on
+    the collective library's own stream, so it overlaps the kernels of the next step); `finish` waits and
+    unpacks."""
+
+    def __init__(self, tops, k, n_items_total, rank, world, group=None, device=None):
+        import torch
+        import torch.distributed as dist
+        self.k, self.n_items, self.world = k, n_items_total, world
+        self.per_rank = (n_items_total + world - 1) // world
+        mine = list(tops) + [np.zeros((0, RESULT_COLS))] * (self.per_rank - len(tops))
+        block, valid = pack_topk(mine, k)
+        self.work = None
+        if world == 1:
+            self.local = (block, valid)
+            return
+        dev = device if device is not None else ("cuda" if dist.get_backend(group) == "nccl" else "cpu")
+        self.payload = torch.from_numpy(np.concatenate([block.reshape(-1), valid.astype(np.float64)])).to(dev)
+        self.out = torch.empty(world * self.payload.numel(), dtype=torch.float64, device=dev)
+        # flat output: accepted by gloo and by RCCL
+        self.work = dist.all_gather_into_tensor(self.out, self.payload, group=group, async_op=True)
+
+    def finish(self):
+        """-> list of n_items_total arrays (item order), identical on every rank."""
+        k, per_rank = self.k, self.per_rank
+        if self.world == 1:
+            block, valid = self.local
+            return [block[i, :valid[i]] for i in range(self.n_items)]
+        self.work.wait()
+        out = self.out.view(self.world, self.payload.numel()).cpu().numpy()
+        res = []
+        for item in range(self.n_items):
+            r, slot = owner_of(item, self.world), item // self.world
+            blk = out[r, :per_rank * k * RESULT_COLS].reshape(per_rank, k, RESULT_COLS)
+            nv = int(out[r, per_rank * k * RESULT_COLS + slot])
+            res.append(blk[slot, :nv].copy())
+        return res
+
+
 def all_gather_topk(tops, k, n_items_total, rank, world, group=None, device=None):
     """Every rank contributes the top-k rows of ITS items (round-robin owner) and receives all.
 
     tops: list of (<=k, 23) arrays for shard_round_robin(range(n_items_total), rank, world), in that order.
     Returns a list of n_items_total arrays (item order), identical on every rank."""
-    import torch
-    import torch.distributed as dist
-    per_rank = (n_items_total + world - 1) // world
-    mine = list(tops) + [np.zeros((0, RESULT_COLS))] * (per_rank - len(tops))
-    block, valid = pack_topk(mine, k)
-    if world == 1:
-        return [block[i, :valid[i]] for i in range(n_items_total)]
-    dev = device if device is not None else ("cuda" if dist.get_backend(group) == "nccl" else "cpu")
-    payload = torch.from_numpy(np.concatenate([block.reshape(-1), valid.astype(np.float64)])).to(dev)
-    out = torch.empty(world * payload.numel(), dtype=torch.float64, device=dev)
-    dist.all_gather_into_tensor(out, payload, group=group)      # flat output: accepted by gloo and by RCCL
-    out = out.view(world, payload.numel()).cpu().numpy()
-    res = []
-    for item in range(n_items_total):
-        r, slot = owner_of(item, world), item // world
-        blk = out[r, :per_rank * k * RESULT_COLS].reshape(per_rank, k, RESULT_COLS)
-        nv = int(out[r, per_rank * k * RESULT_COLS + slot])
-        res.append(blk[slot, :nv].copy())
-    return res
+    return TopkExchange(tops, k, n_items_total, rank, world, group, device).finish()
 
 
 def merge_topk(shard_rows, shard_counts, shard_pair_rank, k):
