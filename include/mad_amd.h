@@ -236,6 +236,60 @@ int mad_ccc(mad_ctx *ctx, float *grid1, const int32_t dims1[3], const double ori
             float *grid2, const int32_t dims2[3], const double origin2[3],
             double voxsp, double isovalue, double *ccc);
 
+/* ---- next to the path, upstream: MapSpace.build_space (MapSpace.py:116-189) and the
+ *      dense half of Detector.find_anchors (Detector.py:28-29) ------------------------ */
+
+typedef struct mad_space mad_space;
+
+int mad_space_create(mad_ctx *ctx, mad_space **out);
+void mad_space_destroy(mad_ctx *ctx, mad_space *s);
+
+/*
+ * Builds the scale space of one density grid on the device.
+ *   grid      host, [x][y][z] z fastest, float32 (is_f64 = 0; PDB / MRC input) or float64
+ *             (is_f64 = 1; Situs input, MapSpace.py:93-96); padded with `pad` zero voxels
+ *             per face (MapSpace.py:117-118).
+ *   oct_mode  1 = base, 2 = upsampled, 3 = both (MapSpace.py:147-163).  List entry 0 is the
+ *             upsampled octave when it exists, as in the reference.
+ *   g0, g2    order-0 and order-2 Gaussian kernels of sigma_init, 2*radius+1 taps each, as
+ *             scipy.ndimage computes them (the host passes numpy's values so that the
+ *             weights are identical); sig2 = sigma_init^2 (MapSpace.py:171).
+ *   pre       order-0 kernel of the pre-smoothing sigma (MapSpace.py:144), pre_radius = 0
+ *             to skip it.
+ *   lu, ev_w, ev_i   per axis a (padded length n_a): banded LU factors [5][n_a] of the
+ *             not-a-knot cubic collocation matrix, and for the 2 n_a - 1 half-integer
+ *             sites the 4 basis weights + first coefficient index (interp1d(kind="cubic"),
+ *             MapSpace.py:206-214).  Only read when the upsampled octave is built.
+ *   slot_up, slot_base   field slots that receive the gradient texels of np.gradient(
+ *             gaussian_filter(grid, sigma_init)) (MapSpace.py:182-187); -1 = do not fill.
+ * Filter passes reproduce scipy.ndimage's summation order and per-pass rounding; the
+ * spline agrees with scipy to ~4e-16 relative (see mad_space.hip).
+ */
+int mad_space_build(mad_ctx *ctx, mad_space *s, const void *grid, int is_f64, int nx, int ny, int nz, int pad,
+                    int oct_mode, const double *g0, const double *g2, int radius, double sig2,
+                    const double *pre, int pre_radius, const double *const *lu, const double *const *ev_w,
+                    const int32_t *const *ev_i, int slot_up, int slot_base);
+
+/* n_octaves list entries; dims6 = [entry][3]; kind2[entry] = 0 upsampled / 1 base; is_f64_2[entry]. */
+int mad_space_info(mad_ctx *ctx, const mad_space *s, int *n_octaves, int32_t *dims6, int32_t *kind2, int32_t *is_f64_2);
+
+/* what: 0 = grid_list[entry], 1 = map_space[entry] (LoG), 2 = gauss_list[entry]; storage type of the entry. */
+int mad_space_download(mad_ctx *ctx, const mad_space *s, int entry, int what, void *out);
+
+/*
+ * skimage.feature.peak_local_max(map_space[entry], exclude_border=border, threshold_abs=
+ * threshold) as Detector.py:29 calls it: voxels equal to the maximum of their zero-extended
+ * 3x3x3 neighbourhood and strictly above the threshold.  Returns linear indices
+ * ((x*ny + y)*nz + z) and values in NO particular order; the host sorts (row-major, then by
+ * descending value).  MAD_ENOSPC with *n_out = required capacity if cap is too small.
+ */
+int mad_space_peaks(mad_ctx *ctx, const mad_space *s, int entry, double threshold, int border, int64_t *lin_index,
+                    double *value, int64_t cap, int64_t *n_out);
+
+/* (2r+1)^3 LoG neighbourhoods of n voxels (zero outside), storage type of the entry: the input of
+ * Detector.check_localize (Detector.py:53-123), which stays on the host. */
+int mad_space_patches(mad_ctx *ctx, const mad_space *s, int entry, const int32_t *coords, int n, int r, void *out);
+
 #ifdef __cplusplus
 }
 #endif

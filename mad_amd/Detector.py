@@ -1,39 +1,40 @@
 """Anchor detection (upstream of the hot path).
 
-Mirror of the reference's `Detector` (mad/Detector.py:18-128): anchors are local
-maxima of the LoG volumes, refined to sub-voxel precision with a quadratic fit and
-rejected when the fit wanders or the Hessian has a positive eigenvalue.
+Mirror of the reference's `Detector` (mad/Detector.py:18-128): anchors are local maxima of the LoG volumes,
+refined to sub-voxel precision with a quadratic fit and rejected when the fit wanders or the Hessian has a
+positive eigenvalue.
 
-PARITY UNPINNED for the peak search: the reference calls
-`skimage.feature.peak_local_max(grid, exclude_border=12, threshold_abs=5e-2)`
-(scikit-image 0.17.2, requirements.txt:5), which is not vendored and not installed
-here.  `peak_local_max` below restates that version's published behaviour
-(3x3x3 maximum filter, strict threshold, border exclusion, peaks ordered by
-descending intensity).  Everything from `check_localize` on is pinned by fixtures.
+The dense half -- the 3x3x3 local-maximum mask over the whole LoG volume (Detector.py:29) -- runs on the
+device where the volume already is (`mad_space_peaks`); only the peak list (a few thousand voxels) and their
+13^3 neighbourhoods (`mad_space_patches`) come back, and `check_localize` runs on those with the reference's
+own numpy expressions.
+
+PARITY UNPINNED for the peak search: the reference calls `skimage.feature.peak_local_max(grid,
+exclude_border=12, threshold_abs=5e-2)` (scikit-image 0.17.2, requirements.txt:5), which is not vendored and
+not installed here.  The device kernel follows that version's published behaviour (3x3x3 maximum filter with
+zero extension, strict threshold, border exclusion, peaks ordered by descending intensity).  Everything from
+`check_localize` on is pinned by fixtures.
 """
 import os
 
 import numpy as np
-from scipy import ndimage as ndi
 
 from .DensityFeature import DensityFeature
 
+WALK = 6      # check_localize moves at most 5 voxels per axis and reads one voxel further
 
-def peak_local_max(image, exclude_border=12, threshold_abs=5e-2, min_distance=1):
-    size = 2 * min_distance + 1
-    is_max = ndi.maximum_filter(image, size=size, mode="constant") == image
-    is_max &= image > threshold_abs
-    if exclude_border:
-        b = int(exclude_border)
-        for ax in range(image.ndim):
-            sl = [slice(None)] * image.ndim
-            sl[ax] = slice(None, b)
-            is_max[tuple(sl)] = False
-            sl[ax] = slice(-b, None)
-            is_max[tuple(sl)] = False
-    coords = np.transpose(np.nonzero(is_max))
-    order = np.argsort(-image[tuple(coords.T)], kind="stable")
-    return coords[order]
+
+class PatchGrid(object):
+    """A LoG volume seen through the neighbourhood of one peak: indexable like `grid[x, y, z]` with the
+    volume's own coordinates, which is all `check_localize` needs."""
+
+    def __init__(self, patch, centre, shape):
+        self.patch, self.shape = patch, shape
+        self.off = (int(centre[0]) - WALK, int(centre[1]) - WALK, int(centre[2]) - WALK)
+
+    def __getitem__(self, xyz):
+        x, y, z = xyz
+        return self.patch[x - self.off[0], y - self.off[1], z - self.off[2]]
 
 
 class Detector(object):
@@ -48,17 +49,19 @@ class Detector(object):
     def find_anchors(self, ms, outname=""):
         print("MaD> Finding anchors in %s... " % ms.name)
         df_list = []
-        for o, grid in enumerate(ms.map_space):
-            for peak in peak_local_max(grid, exclude_border=12, threshold_abs=5e-2):
-                ok, coord, subcoord = self.check_localize(grid, peak)
+        for o in range(len(ms.space.shapes)):
+            peaks, vals = ms.space.peaks(o, threshold=5e-2, border=12)
+            patches = ms.space.patches(o, peaks, WALK)
+            vs = ms.voxelsp_list[o]
+            for peak, val, patch in zip(peaks, vals, patches):
+                ok, coord, subcoord = self.check_localize(PatchGrid(patch, peak, ms.space.shapes[o]), peak)
                 if not ok:
                     continue
                 df = DensityFeature()
-                vs = ms.voxelsp_list[o]
                 df.set_detector_info(len(df_list), o, [coord[0], coord[1], coord[2]],
                                      self.get_coord_in_ref_map(coord[0], coord[1], coord[2], ms.xi, ms.yi, ms.zi, vs),
                                      self.get_coord_in_ref_map(subcoord[0], subcoord[1], subcoord[2], ms.xi, ms.yi, ms.zi, vs),
-                                     grid[tuple(peak)])
+                                     patch.dtype.type(val))
                 df_list.append(df)
         if outname and os.path.exists(os.path.split(outname)[0]):
             self.write_df_to_pdb(df_list, outname + ".pdb")

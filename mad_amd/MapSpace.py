@@ -1,25 +1,24 @@
 """Scale-space preparation: the producer of the hot path's input fields.
 
-Mirror of the reference's `MapSpace` (mad/MapSpace.py:12-214): load or simulate the
-density grid, pad it by 9 voxels, build the 2x cubic-spline upsampled octave (pre-
-smoothed with sigma 1), the scale-normalised LoG volumes the detector searches and the
-Gaussian(sigma)-smoothed gradient fields `grad_list` that orientation and description
-sample.  Attributes kept: `grad_list, rgi_space, map_space, gauss_list, grid_list,
+Mirror of the reference's `MapSpace` (mad/MapSpace.py:12-214): load or simulate the density grid, pad it by
+9 voxels, build the 2x cubic-spline upsampled octave (pre-smoothed with sigma 1), the scale-normalised LoG
+volumes the detector searches and the Gaussian(sigma)-smoothed gradient fields that orientation and
+description sample.  Attributes kept: `grad_list, rgi_space, map_space, gauss_list, grid_list,
 voxelsp_list, xi, yi, zi, name`.
 
-This stage is SURVEY.md section 8(f) rank 2 ("next"): it runs on the host with the same
-scipy calls as the reference and its gradient fields are uploaded once per structure
-(`device_slots`).  `rgi_space[o]` is kept for API compatibility only (a nearest-
-neighbour lookup object); the HIP descriptor kernel gathers from the uploaded field.
+SURVEY.md section 8(f) rank 2.  The numerical body runs on the device (`mad_space_build`,
+mad_amd/csrc/mad_space.hip): the volumes stay in HBM, the gradient texels are written straight into the
+field slots the orientation / descriptor kernels sample (`device_slots`), and the peak search of the detector
+reads the LoG volumes where they are (`space`).  The list attributes of the reference are materialised on the
+host only when somebody reads them.  There is no CPU fallback; the scipy restatement used to check this
+module lives in oracle/scale_space.py (test infrastructure).
 """
 import os
 import sys
 
 import numpy as np
-from scipy.interpolate import interp1d
-from scipy.ndimage import gaussian_filter, gaussian_laplace
 
-from . import mapio
+from . import _lib, mapio
 from .PDB import PDB
 
 
@@ -76,6 +75,8 @@ class MapSpace(object):
             print(self.ext)
             sys.exit(1)
         self._slots = None
+        self.space = None
+        self._cache = {}
 
     def _load_grid(self):
         if self.PDB_mode:
@@ -95,59 +96,65 @@ class MapSpace(object):
         grid, xi, yi, zi = self._load_grid()
         self.build_from_grid(grid, xi, yi, zi)
 
-    def build_from_grid(self, grid, xi, yi, zi):
-        """Everything after the file has become a grid (MapSpace.py:116-189)."""
+    def build_from_grid(self, grid, xi, yi, zi, lib=None):
+        """Everything after the file has become a grid (MapSpace.py:116-189), on the device."""
+        lib = lib if lib is not None else _lib.get_lib()
+        self.release_device()
         if self.map_padding:
-            grid = np.pad(grid, self.map_padding, mode="constant")
             xi -= self.map_padding * self.voxelsp
             yi -= self.map_padding * self.voxelsp
             zi -= self.map_padding * self.voxelsp
         self.xi, self.yi, self.zi = xi, yi, zi
-        xb, yb, zb = grid.shape
+        grid = np.asarray(grid)
+        if grid.dtype not in (np.float32, np.float64):
+            grid = grid.astype(np.float32)
+        slot_up = lib.new_slot() if self.oct_mode in ("up", "both") else -1
+        slot_base = lib.new_slot() if self.oct_mode in ("base", "both") else -1
+        self.space = _lib.DeviceSpace(lib).build(grid, pad=self.map_padding, oct_mode=self.oct_mode, sig_init=self.sig_init,
+                                                 sig_presmooth=self.sig_presmooth, slot_up=slot_up, slot_base=slot_base)
+        # list index == DensityFeature.oct_scale when oct_mode is "both": 0 = upsampled, 1 = base
+        slots = [slot_up if k == 0 else slot_base for k in self.space.kinds]
+        while len(slots) < 2:
+            slots.append(-1)
+        self._slots = (lib, slots)
+        self.voxelsp_list = [self.voxelsp / 2 if k == 0 else self.voxelsp for k in self.space.kinds]
+        self._cache = {}
 
-        octaves = []
-        if self.oct_mode in ("up", "both"):
-            # 2x upsampling by successive 1-D cubic splines, then a light pre-smoothing (MapSpace.py:137-146)
-            up = grid
-            for axis, n in enumerate((xb, yb, zb)):
-                up = interp1d(np.arange(0, n, 1), up, axis=axis, kind="cubic")(np.arange(0, n - 0.5, 0.5))
-            if self.sig_presmooth:
-                up = gaussian_filter(up, sigma=self.sig_presmooth)
-            octaves.append((up.astype(np.float32), self.voxelsp / 2))
-        if self.oct_mode in ("base", "both"):
-            octaves.append((grid, self.voxelsp))
-        self.grid_list = [g for g, _ in octaves]
-        self.voxelsp_list = [v for _, v in octaves]
+    # -- the reference's list attributes, fetched from the device on first use ----------------------------
+    def _volumes(self, what, key):
+        if key not in self._cache:
+            self._cache[key] = [self.space.download(o, what) for o in range(len(self.space.shapes))]
+        return self._cache[key]
 
-        # scale-normalised LoG for the detector (MapSpace.py:169-173)
-        self.map_space = []
-        for g in self.grid_list:
-            log_g = -1 * gaussian_laplace(g, sigma=self.sig_init) * self.sig_init ** 2
-            log_g[log_g < 0] = 0.0
-            self.map_space.append(log_g)
+    @property
+    def grid_list(self):
+        return self._volumes(_lib.DeviceSpace.GRID, "grid")
 
-        # Gaussian-smoothed gradient fields (MapSpace.py:178-189)
-        self.gauss_list, self.grad_list, self.rgi_space = [], [], []
-        for g in self.grid_list:
-            self.gauss_list.append(gaussian_filter(g, self.sig_init))
-            self.grad_list.append(np.moveaxis(np.array(np.gradient(self.gauss_list[-1])), 0, -1))
-            self.rgi_space.append(NearestGradient(self.grad_list[-1]))
-        self._slots = None
+    @property
+    def map_space(self):
+        return self._volumes(_lib.DeviceSpace.LOG, "log")
+
+    @property
+    def gauss_list(self):
+        return self._volumes(_lib.DeviceSpace.GAUSS, "gauss")
+
+    @property
+    def grad_list(self):
+        if "grad" not in self._cache:      # MapSpace.py:187 on the downloaded smoothed volumes
+            self._cache["grad"] = [np.moveaxis(np.array(np.gradient(g)), 0, -1) for g in self.gauss_list]
+        return self._cache["grad"]
+
+    @property
+    def rgi_space(self):
+        if "rgi" not in self._cache:
+            self._cache["rgi"] = [NearestGradient(g) for g in self.grad_list]
+        return self._cache["rgi"]
 
     # -- device residency ---------------------------------------------------------------
     def device_slots(self, lib):
-        """Upload grad_list once; returns [slot of list entry 0, slot of list entry 1] (-1 if absent).
-
-        List index == DensityFeature.oct_scale (0 = upsampled, 1 = base) when oct_mode is "both"."""
+        """[field slot of list entry 0, of list entry 1] (-1 if absent), filled by build_from_grid."""
         if self._slots is None or self._slots[0] is not lib:
-            slots = []
-            for g in self.grad_list:
-                s = lib.new_slot()
-                lib.upload_field(s, g)
-                slots.append(s)
-            while len(slots) < 2:
-                slots.append(-1)
-            self._slots = (lib, slots)
+            raise _lib.MadBackendError("MaD> this MapSpace was not built on the requested device context")
         return self._slots[1]
 
     def release_device(self):
@@ -157,3 +164,6 @@ class MapSpace(object):
                 if s >= 0 and lib.ctx:
                     lib.free_field(s)
         self._slots = None
+        if getattr(self, "space", None) is not None:
+            self.space.close()
+        self.space = None

@@ -24,6 +24,8 @@ SYMBOLS = [
     "mad_set_create", "mad_set_destroy", "mad_set_build", "mad_set_load", "mad_set_size", "mad_set_download",
     "mad_match_topk", "mad_match_topk_many", "mad_match_fetch", "mad_match_results", "mad_match_used",
     "mad_upload_density", "mad_refine", "mad_structure_to_density", "mad_ccc",
+    "mad_space_create", "mad_space_destroy", "mad_space_build", "mad_space_info", "mad_space_download",
+    "mad_space_peaks", "mad_space_patches",
 ]
 
 
@@ -54,6 +56,7 @@ def load_library():
         _dll.mad_last_ms.argtypes = [C.c_void_p, C.c_char_p]
         _dll.mad_destroy.restype = None
         _dll.mad_set_destroy.restype = None
+        _dll.mad_space_destroy.restype = None
     return _dll
 
 
@@ -100,6 +103,98 @@ class DeviceSet(object):
             pass
 
 
+class DeviceSpace(object):
+    """Device-resident scale space of one structure (mad_space): the volumes of MapSpace.build_space."""
+
+    GRID, LOG, GAUSS = 0, 1, 2
+
+    def __init__(self, lib):
+        self.lib = lib
+        self.h = C.c_void_p()
+        lib._chk(lib.dll.mad_space_create(lib.ctx, C.byref(self.h)))
+        self.shapes, self.kinds, self.dtypes = [], [], []
+
+    def build(self, grid, pad=9, oct_mode="both", sig_init=2, sig_presmooth=1, slot_up=-1, slot_base=-1):
+        """grid: float32 or float64 (X, Y, Z).  Fills the field slots with the gradient texels."""
+        from . import scale_tables as st
+        g = np.asarray(grid)
+        if g.ndim != 3 or g.dtype not in (np.float32, np.float64):
+            raise ValueError("density grid must be a 3-D float32 or float64 array")
+        g = np.ascontiguousarray(g)
+        mode = {"base": 1, "up": 2, "both": 3}[oct_mode]
+        R = st.kernel_radius(sig_init)
+        g0 = np.ascontiguousarray(st.gaussian_kernel1d(sig_init, 0, R)[::-1])
+        g2 = np.ascontiguousarray(st.gaussian_kernel1d(sig_init, 2, R)[::-1])
+        pre_R = st.kernel_radius(sig_presmooth) if (sig_presmooth and mode & 2) else 0
+        pre = np.ascontiguousarray(st.gaussian_kernel1d(sig_presmooth, 0, pre_R)[::-1]) if pre_R else None
+        P3, I3 = C.c_void_p * 3, C.c_void_p * 3
+        lu = ev_w = ev_i = None
+        keep = []
+        if mode & 2:
+            tabs = [st.spline_tables(int(n) + 2 * pad) for n in g.shape]
+            keep = tabs
+            lu = P3(*[t[0].ctypes.data for t in tabs])
+            ev_w = P3(*[t[1].ctypes.data for t in tabs])
+            ev_i = I3(*[t[2].ctypes.data for t in tabs])
+        self.lib._chk(self.lib.dll.mad_space_build(
+            self.lib.ctx, self.h, _p(g), C.c_int(1 if g.dtype == np.float64 else 0), C.c_int(g.shape[0]), C.c_int(g.shape[1]),
+            C.c_int(g.shape[2]), C.c_int(pad), C.c_int(mode), _p(g0), _p(g2), C.c_int(R), C.c_double(float(sig_init) ** 2),
+            _p(pre), C.c_int(pre_R), lu, ev_w, ev_i, C.c_int(slot_up), C.c_int(slot_base)))
+        del keep
+        n = C.c_int(0)
+        dims, kind, f64 = np.zeros(6, np.int32), np.zeros(2, np.int32), np.zeros(2, np.int32)
+        self.lib._chk(self.lib.dll.mad_space_info(self.lib.ctx, self.h, C.byref(n), _p(dims), _p(kind), _p(f64)))
+        self.shapes = [tuple(int(v) for v in dims[3 * o:3 * o + 3]) for o in range(n.value)]
+        self.kinds = [int(kind[o]) for o in range(n.value)]
+        self.dtypes = [np.float64 if f64[o] else np.float32 for o in range(n.value)]
+        return self
+
+    def download(self, entry, what):
+        out = np.empty(self.shapes[entry], self.dtypes[entry])
+        self.lib._chk(self.lib.dll.mad_space_download(self.lib.ctx, self.h, C.c_int(entry), C.c_int(what), _p(out)))
+        return out
+
+    def peaks(self, entry, threshold=5e-2, border=12):
+        """-> (coords int (n, 3), values float64 (n,)) in skimage's order: descending value, row-major among equals."""
+        cap = 1 << 16
+        while True:
+            idx, val = np.zeros(cap, np.int64), np.zeros(cap, np.float64)
+            n = C.c_int64(0)
+            rc = self.lib.dll.mad_space_peaks(self.lib.ctx, self.h, C.c_int(entry), C.c_double(threshold), C.c_int(border), _p(idx), _p(val),
+                                              C.c_int64(cap), C.byref(n))
+            if rc == -28 and n.value > cap:      # MAD_ENOSPC: n holds the required capacity
+                cap = int(n.value) + 1024
+                continue
+            self.lib._chk(rc)
+            break
+        idx, val = idx[:n.value], val[:n.value]
+        order = np.argsort(idx, kind="stable")              # row-major, like np.nonzero
+        idx, val = idx[order], val[order]
+        order = np.argsort(-val, kind="stable")
+        idx, val = idx[order], val[order]
+        _, ny, nz = self.shapes[entry]
+        coords = np.stack([idx // (ny * nz), (idx // nz) % ny, idx % nz], 1).astype(np.int64)
+        return coords, val
+
+    def patches(self, entry, coords, r):
+        coords = _c(coords, np.int32).reshape(-1, 3)
+        side = 2 * r + 1
+        out = np.zeros((len(coords), side, side, side), self.dtypes[entry])
+        self.lib._chk(self.lib.dll.mad_space_patches(self.lib.ctx, self.h, C.c_int(entry), _p(coords), C.c_int(len(coords)), C.c_int(r), _p(out)))
+        return out
+
+    def close(self):
+        if self.h and self.lib.ctx:
+            self.lib.dll.mad_space_destroy(self.lib.ctx, self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Lib(object):
     """One mad_ctx on one GPU."""
 
@@ -115,6 +210,7 @@ class Lib(object):
         self.device = device
         self._fields = {}      # id(array) -> slot bookkeeping is done by the callers
         self._next_slot = 0
+        self._free_slots = []
         self._eq_loaded = {}
 
     # -- plumbing -----------------------------------------------------------------
@@ -154,6 +250,8 @@ class Lib(object):
         self._chk(self.dll.mad_set_eqsp(self.ctx, C.c_int(which), C.c_int(len(bounds)), _p(bounds), _p(to_dom), _p(adj_sec)))
 
     def new_slot(self):
+        if self._free_slots:
+            return self._free_slots.pop()
         s = self._next_slot
         self._next_slot += 1
         if s >= 64:
@@ -179,6 +277,8 @@ class Lib(object):
 
     def free_field(self, slot):
         self._chk(self.dll.mad_free_field(self.ctx, C.c_int(slot)))
+        if slot not in self._free_slots:
+            self._free_slots.append(slot)
 
     # -- stage API --------------------------------------------------------------------
     def orient(self, slot, octave, coords, r=8, lim_main=6, lim_sec=6, want_counts=True, Z=112):

@@ -173,6 +173,7 @@ static_assert(S_N_SLOTS <= 64, "grow mad_ctx::scratch");
 int mad_fail(mad_ctx *ctx, int code, const char *fmt, ...);
 int mad_reserve(mad_ctx *ctx, DevBuf &b, size_t bytes);            // grow-only device buffer
 void mad_release(DevBuf &b);
+int mad_field_alloc(mad_ctx *ctx, int slot, int nx, int ny, int nz, size_t *n_texels);      // (re)allocates the texels of a field slot
 static inline DevBuf &mad_sb(mad_ctx *ctx, int slot) { return ctx->scratch[ctx->lane * 64 + slot]; }
 template <class T> static inline T *scratch(mad_ctx *ctx, int slot) { return (T *)mad_sb(ctx, slot).p; }
 

@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256) void k_pack_field(const float *__restrict__ gx
     }
 }
 
-static int field_alloc(mad_ctx *ctx, int slot, int nx, int ny, int nz, size_t *n_out) {
+int mad_field_alloc(mad_ctx *ctx, int slot, int nx, int ny, int nz, size_t *n_out) {
     if (slot < 0 || slot >= MAD_MAX_FIELDS) return mad_fail(ctx, MAD_EINVAL, "field slot %d out of range", slot);
     if (nx < 2 || ny < 2 || nz < 2) return mad_fail(ctx, MAD_EINVAL, "field dims %dx%dx%d", nx, ny, nz);
     const size_t n = (size_t)nx * ny * nz;
@@ -287,7 +287,7 @@ static int field_alloc(mad_ctx *ctx, int slot, int nx, int ny, int nz, size_t *n
 extern "C" int mad_upload_field_device(mad_ctx *ctx, int slot, const float *g3, int nx, int ny, int nz) {
     if (!ctx || !g3) return MAD_EINVAL;
     size_t n = 0;
-    MAD_TRY(field_alloc(ctx, slot, nx, ny, nz, &n));
+    MAD_TRY(mad_field_alloc(ctx, slot, nx, ny, nz, &n));
     const int blocks = (int)std::min<size_t>(mad_ceil_div((int64_t)n, 256), (size_t)ctx->n_cu * 16);
     hipLaunchKernelGGL(k_pack_field, dim3(blocks), dim3(256), 0, ctx->stream, g3, g3 + n, g3 + 2 * n,
                        (float4 *)ctx->field_mem[slot], n);

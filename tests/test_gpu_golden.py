@@ -40,8 +40,13 @@ class _FakeSpace(object):
         self.name = "golden"
 
     def device_slots(self, lib):
-        from mad_amd.MapSpace import MapSpace
-        return MapSpace.device_slots(self, lib)
+        if self._slots is None:
+            slots = []
+            for g in self.grad_list:
+                slots.append(lib.new_slot())
+                lib.upload_field(slots[-1], g)
+            self._slots = slots
+        return self._slots
 
 
 def _anchors(coords, octave):

@@ -91,33 +91,45 @@ def test_math_utils_against_reference():
     np.testing.assert_allclose(T, g["kabsch_T"], atol=1e-12)
 
 
-def test_mapspace_and_detector_against_reference(tmp_path):
-    from mad_amd.Detector import Detector
-    from mad_amd.MapSpace import MapSpace
+def test_scale_space_checker_against_reference():
+    """oracle/scale_space.py (the scipy restatement that checks the device MapSpace) vs the reference's own output."""
+    from oracle import scale_space as OS
     g = load("g_mapspace.npz")
-    sit = str(tmp_path / "map.sit")
-    open(sit, "w").write("x")      # only the extension is inspected before build_from_grid
-    ms = MapSpace(sit, sig_init=2.0, sig_presmooth=1)
-    ms.voxelsp = float(g["vs"])
     grid = g["map_grid"].astype(np.float64)
     grid = grid / np.amax(grid).astype(np.float32)      # what MapSpace.py:96 does to a situs map
-    ms.build_from_grid(grid, *[float(v) for v in g["map_origin"]])
-    np.testing.assert_allclose([ms.xi, ms.yi, ms.zi], g["origin"], atol=1e-12)
+    vol = OS.build_volumes(grid, pad=9, oct_mode="both", sig_init=2.0, sig_presmooth=1)
     for o in (0, 1):
         idx = g["grad_idx_%d" % o]
-        assert tuple(g["grad_shape_%d" % o]) == ms.grad_list[o].shape
+        assert tuple(g["grad_shape_%d" % o]) == vol["grad_list"][o].shape
         # the fixture's map went through a 6-decimal situs text file; this one did not
-        np.testing.assert_allclose(ms.grad_list[o][idx[:, 0], idx[:, 1], idx[:, 2]], g["grad_val_%d" % o], rtol=0, atol=2e-6)
-        np.testing.assert_allclose(ms.map_space[o][idx[:, 0], idx[:, 1], idx[:, 2]], g["log_val_%d" % o], rtol=0, atol=2e-6)
-    anchors = Detector().find_anchors(ms)
-    # same anchors as at fixture time up to the text round-off of the map: same count, same voxels
-    assert abs(len(anchors) - len(g["anchor_coords"])) <= 2
-    got = {(a.oct_scale,) + tuple(a.coords) for a in anchors}
-    ref = {(int(o),) + tuple(int(v) for v in c) for o, c in zip(g["anchor_oct"], g["anchor_coords"])}
-    assert len(got & ref) >= len(ref) - 2
-    # nearest-gradient lookup object: tie rule and bounds of the reference's interpolator
-    rgi = ms.rgi_space[1]
-    np.testing.assert_array_equal(rgi(np.array([[3.5, 4.5, 5.5], [3.51, 4.0, 5.0]])), ms.grad_list[1][[3, 4], [4, 4], [5, 5]])
+        np.testing.assert_allclose(vol["grad_list"][o][idx[:, 0], idx[:, 1], idx[:, 2]], g["grad_val_%d" % o], rtol=0, atol=2e-6)
+        np.testing.assert_allclose(vol["map_space"][o][idx[:, 0], idx[:, 1], idx[:, 2]], g["log_val_%d" % o], rtol=0, atol=2e-6)
+
+
+def test_scale_tables_are_scipys():
+    """The weights / spline operator handed to mad_space_build are the ones scipy uses."""
+    from scipy.interpolate import interp1d
+    from scipy.ndimage import _filters
+    from mad_amd import scale_tables as st
+    for sig in (1, 2, 2.0, 1.5, 3):
+        r = st.kernel_radius(sig)
+        for order in (0, 2):
+            np.testing.assert_array_equal(st.gaussian_kernel1d(sig, order, r), _filters._gaussian_kernel1d(sig, order, r))
+    rng = np.random.default_rng(5)
+    for n in (4, 5, 7, 27, 83):
+        y = rng.random((n, 3))
+        ref = interp1d(np.arange(n), y, axis=0, kind="cubic")(np.arange(0, n - 0.5, 0.5))
+        np.testing.assert_allclose(st.spline_apply(y, 0), ref, rtol=0, atol=2e-15)
+    with pytest.raises(ValueError):
+        st.spline_tables(3)
+
+
+def test_nearest_gradient_lookup():
+    """The stand-in for RegularGridInterpolator(method="nearest"): tie rule and bounds of the reference's interpolator."""
+    from mad_amd.MapSpace import NearestGradient
+    vals = np.random.default_rng(2).random((8, 9, 10, 3))
+    rgi = NearestGradient(vals)
+    np.testing.assert_array_equal(rgi(np.array([[3.5, 4.5, 5.5], [3.51, 4.0, 5.0]])), vals[[3, 4], [4, 4], [5, 5]])
     with pytest.raises(ValueError):
         rgi(np.array([[-0.1, 1, 1]]))
 
