@@ -15,9 +15,9 @@ the path, the all-gather of the per-subunit top-k poses (RCCL over xGMI), is ins
 timed region.  value = correlations of all ranks / max-over-ranks time.
 
 Inputs are synthetic (seeded pseudo-atom assemblies).  The density grids
-come from this library's own GPU density simulation; the scale-space preparation
-(upsampling, smoothing, LoG peaks -- MapSpace/Detector, upstream of the hot path) is done
-with torch ops on the device as untimed setup.
+come from this library's own GPU density simulation, the scale space and the anchors from
+its device MapSpace / Detector (upstream of the hot path, untimed setup, times reported
+in config.setup_detail_s).
 
 The JSON line also carries `roofline` (dominant kernel, HIP-event timed on the library's
 stream inside the timed region) and `cpu_baseline` (the CPU oracle timed on a bounded
@@ -47,73 +47,19 @@ DESCRIBE_BYTES = 51200     # 4096 x 12 B gathered + 2048 B written per row
 
 
 # --------------------------------------------------------------------------------------------
-# untimed setup: synthetic structures and their scale-space fields (torch = plumbing)
+# untimed setup: synthetic structures, their scale space and anchors (the library's own upstream stages)
 # --------------------------------------------------------------------------------------------
 
-def gaussian_blur(t, sigma):
-    """Separable Gaussian (reflect boundary, truncated at 4 sigma) by shifted adds."""
-    import torch
-    import torch.nn.functional as F
-    r = int(4.0 * sigma + 0.5)
-    x = torch.arange(-r, r + 1, device=t.device, dtype=torch.float32)
-    w = torch.exp(-0.5 * (x / sigma) ** 2)
-    w = (w / w.sum()).tolist()
-    for ax in range(3):
-        pad = [0, 0, 0, 0, 0, 0]
-        pad[2 * (2 - ax)] = r
-        pad[2 * (2 - ax) + 1] = r
-        p = F.pad(t[None, None], pad, mode="reflect")[0, 0]
-        acc = torch.zeros_like(t)
-        n = t.shape[ax]
-        for k in range(2 * r + 1):
-            acc += w[k] * p.narrow(ax, k, n)
-        t = acc
-        del p
-    return t
-
-
-def scale_space(grid, pad=9, sig=2.0, presmooth=1.0):
-    """-> per octave (0 = upsampled, 1 = base): gradient field [3,X,Y,Z] f32 and LoG volume."""
-    import torch
-    import torch.nn.functional as F
-    g = F.pad(grid, (pad,) * 6)
-    up = F.interpolate(g[None, None], size=tuple(2 * s - 1 for s in g.shape), mode="trilinear", align_corners=True)[0, 0]
-    up = gaussian_blur(up, presmooth)
-    out = []
-    for vol in (up, g):
-        sm = gaussian_blur(vol, sig)
-        lap = -6.0 * sm
-        for ax in range(3):
-            lap = lap + torch.roll(sm, 1, ax) + torch.roll(sm, -1, ax)
-        log = torch.clamp(-lap * sig * sig, min=0.0)
-        grad = torch.stack(torch.gradient(sm))
-        out.append((grad.contiguous(), log))
-        del sm, lap
-    return out
-
-
-def find_anchors(log, border=12, thresh=5e-2):
-    """3x3x3 local maxima of the LoG above the threshold, strongest first (Detector.py:28-29)."""
-    import torch
-    import torch.nn.functional as F
-    mx = F.max_pool3d(log[None, None], 3, 1, 1)[0, 0]
-    ok = (log == mx) & (log > thresh)
-    ok[:border] = False
-    ok[-border:] = False
-    ok[:, :border] = False
-    ok[:, -border:] = False
-    ok[:, :, :border] = False
-    ok[:, :, -border:] = False
-    idx = torch.nonzero(ok)
-    vals = log[idx[:, 0], idx[:, 1], idx[:, 2]]
-    order = torch.argsort(vals, descending=True, stable=True)
-    return idx[order].to(torch.int32).cpu().numpy()
+SETUP_T = {}
 
 
 class Structure(object):
-    """Device-resident fields + anchors of one structure."""
+    """Device-resident fields + anchors of one structure: density simulation (a14-a15), MapSpace and Detector
+     all through the library; nothing of it is inside the timed region."""
 
-    def __init__(self, lib, torch, atoms, mass, res, vs, N=None):
+    def __init__(self, lib, atoms, mass, res, vs, N=None, tag="sub"):
+        from mad_amd.Detector import Detector
+        from mad_amd.MapSpace import MapSpace
         grid, x0, y0, z0 = lib.structure_to_density(atoms, mass, res, vs)
         origin = np.array([x0, y0, z0])
         if N is not None:      # centre the simulated density in an exactly N^3 box
@@ -125,31 +71,31 @@ class Structure(object):
             grid = big
         self.shape = grid.shape
         self.grid, self.origin, self.atoms, self.mass = grid, origin, atoms, mass
-        dev = torch.device("cuda", lib.device)
-        octs = scale_space(torch.from_numpy(grid).to(dev))
-        torch.cuda.synchronize()
-        self.slots, coords, octave, subv = [], [], [], []
-        self.field_host = {}
-        pad_origin = origin - 9 * vs
-        for o, (grad, log) in enumerate(octs):
-            s = lib.new_slot()
-            lib.upload_field_device(s, grad.data_ptr(), *grad.shape[1:])
-            self.slots.append(s)
-            a = find_anchors(log)
-            coords.append(a)
-            octave.append(np.full(len(a), o, np.int32))
-            subv.append(a.astype(np.float64) * (vs / 2 if o == 0 else vs) + pad_origin)
-            if o == 1:
-                self.field_host[1] = grad.cpu().numpy()      # base octave, for the CPU baseline sample
-        del octs
-        torch.cuda.empty_cache()
-        self.coords = np.concatenate(coords).astype(np.int32)
-        self.octave = np.concatenate(octave)
-        self.subv = np.concatenate(subv)
-        self.index = np.arange(len(self.coords), dtype=np.int32)
+        ms = MapSpace(tag + ".pdb", resolution=res, voxelsp=vs)
+        lib.synchronize()
+        t0 = time.perf_counter()
+        ms.build_from_grid(grid, float(origin[0]), float(origin[1]), float(origin[2]), lib=lib)
+        lib.synchronize()
+        SETUP_T[tag + "_mapspace_s"] = SETUP_T.get(tag + "_mapspace_s", 0.0) + time.perf_counter() - t0
+        t0 = time.perf_counter()
+        import contextlib
+        import io
+        with contextlib.redirect_stdout(io.StringIO()):
+            anchors = Detector().find_anchors(ms)
+        SETUP_T[tag + "_detector_s"] = SETUP_T.get(tag + "_detector_s", 0.0) + time.perf_counter() - t0
+        self.ms = ms
+        self.slots = ms.device_slots(lib)
+        self.coords = np.array([a.coords for a in anchors], np.int32).reshape(-1, 3)
+        self.octave = np.array([a.oct_scale for a in anchors], np.int32)
+        self.subv = np.array([a.subv_map_coords for a in anchors], np.float64).reshape(-1, 3)
+        self.index = np.arange(len(anchors), dtype=np.int32)
+
+    def base_gradient(self):
+        """(3, X, Y, Z) float32 gradient of the base octave on the host, for the CPU baseline sample."""
+        return np.ascontiguousarray(np.moveaxis(self.ms.grad_list[1], -1, 0), dtype=np.float32)
 
 
-def build_inputs(lib, torch, W, rank):
+def build_inputs(lib, W, rank):
     from mad_amd import synth
     rng = np.random.default_rng(1234)
     subs, placed, placed_mass = [], [], []
@@ -168,8 +114,8 @@ def build_inputs(lib, torch, W, rank):
             subs.append((a2, synth.masses(e2)))
     mass_all = np.concatenate(placed_mass)
     t0 = time.time()
-    the_map = Structure(lib, torch, np.concatenate(placed), mass_all, W["res"], W["vs"], N=W["N"])
-    sub_structs = [Structure(lib, torch, a, m, W["res"], W["vs"]) for a, m in subs]
+    the_map = Structure(lib, np.concatenate(placed), mass_all, W["res"], W["vs"], N=W["N"], tag="map")
+    sub_structs = [Structure(lib, a, m, W["res"], W["vs"]) for a, m in subs]
     return the_map, sub_structs, time.time() - t0
 
 
@@ -240,7 +186,7 @@ def cpu_baseline(the_map, sub, cc, dist, k, lib, n_lo_anchor=800, n_hi_anchor=25
 
     def sample(st, n):
         sel = np.flatnonzero(st.octave == 1)[:n]
-        g = st.field_host[1]
+        g = st.base_gradient()
         return g[0], g[1], g[2], st.coords[sel], st.subv[sel], sel
 
     out = {}
@@ -320,7 +266,7 @@ def main():
 
     W = WORKLOADS[args.workload]
     cc, dist_thr, k = 0.6, 4.0, 60
-    the_map, subs, t_setup = build_inputs(lib, torch, W, rank)
+    the_map, subs, t_setup = build_inputs(lib, W, rank)
 
     def barrier():
         torch.cuda.synchronize()
@@ -435,7 +381,8 @@ def main():
                        "subunit_anchors": anchors_hi, "subunit_rows": rows_hi, "pairs_over_cc": pairs,
                        "cc_threshold": cc, "top_k": k, "correlations_per_step_per_gpu": corr,
                        "parallelism": "1 process per GPU, subunits sharded, RCCL all-gather of top-k" if world > 1 else "single GPU",
-                       "topk_agrees_with_cpu_oracle": agree, "setup_s": t_setup},
+                       "topk_agrees_with_cpu_oracle": agree, "setup_s": t_setup,
+                       "setup_detail_s": {k_: round(v, 4) for k_, v in SETUP_T.items()}},
             "roofline": roof,
             "cpu_baseline": cpu,
             "refine_ccc": refine_line,
