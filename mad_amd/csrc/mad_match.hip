@@ -401,12 +401,15 @@ __global__ __launch_bounds__(POSE_LDS_THREADS) void k_pose_lds(const int32_t *__
                 s[1] = cs[c01 + zz0]; e[1] = (yb != ya) ? cs[c01 + zz1] : s[1];
                 s[2] = cs[c10 + zz0]; e[2] = (xb != xa) ? cs[c10 + zz1] : s[2];
                 s[3] = cs[c11 + zz0]; e[3] = (xb != xa && yb != ya) ? cs[c11 + zz1] : s[3];
-#pragma unroll
-                for (int c = 0; c < 4; c++)
-                    for (int q = s[c]; q < e[c] && !hit; q++) {
-                        const double e0 = lp[3 * q] - x, e1 = lp[3 * q + 1] - y, e2 = lp[3 * q + 2] - z;
-                        hit = (e0 * e0 + e1 * e1 + e2 * e2) < dd_lim;      // MaD.py:447-448
-                    }
+                // one loop over the concatenation of the four runs: the wave then iterates max-over-lanes of the
+                // TOTAL candidate count instead of the sum over runs of the per-run maxima
+                const int n0 = e[0] - s[0], n1 = n0 + (e[1] - s[1]), n2 = n1 + (e[2] - s[2]), n3 = n2 + (e[3] - s[3]);
+                const int b1 = s[1] - n0, b2 = s[2] - n1, b3 = s[3] - n2;
+                for (int t = 0; t < n3 && !hit; t++) {
+                    const int q = t + (t < n0 ? s[0] : (t < n1 ? b1 : (t < n2 ? b2 : b3)));
+                    const double e0 = lp[3 * q] - x, e1 = lp[3 * q + 1] - y, e2 = lp[3 * q + 2] - z;
+                    hit = (e0 * e0 + e1 * e1 + e2 * e2) < dd_lim;      // MaD.py:447-448
+                }
             }
             cnt += hit ? 1 : 0;
         }
