@@ -102,10 +102,17 @@ __global__ void k_row_aux(const double *__restrict__ row_R, const int32_t *__res
 typedef int v4i __attribute__((ext_vector_type(4)));
 
 // persistent over 128 x 128 tiles; the row counts (hence the tile grid and ldc) are read on the device
+//
+// Epilogue: besides the int32 dot products, every tile leaves one bit per correlation in `mask` ([row][ldc / 32]
+// words): set when the score MAY exceed cc.  The test is a float32 product with a relative margin of 4e-6
+// (dot > cc |h| |l| (1 - margin)), i.e. a superset of the reference's float64 `dot / (|h| |l|) > cc`; the pair
+// kernels apply the exact expression to the flagged entries only (~0.1 % of the matrix) instead of dividing
+// and comparing N_hi x N_lo times, and never read the rest of C.
 __global__ __launch_bounds__(GEMM_THREADS) void k_corr_gemm(const int8_t *__restrict__ A, const int8_t *__restrict__ B,
                                                             int K, int32_t *__restrict__ C, const int32_t *__restrict__ n_hi_ptr,
                                                             const int32_t *__restrict__ n_lo_ptr, int64_t cap_c,
-                                                            int32_t *__restrict__ status) {
+                                                            int32_t *__restrict__ status, const double *__restrict__ hn,
+                                                            const double *__restrict__ ln, double cc, uint32_t *__restrict__ mask) {
     __shared__ __align__(16) int8_t sA[GEMM_BM * GEMM_LDA];
     __shared__ __align__(16) int8_t sB[GEMM_BN * GEMM_LDA];
     const int64_t hp = ((int64_t)*n_hi_ptr + GEMM_BM - 1) / GEMM_BM * GEMM_BM;
@@ -160,16 +167,38 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_corr_gemm(const int8_t *__rest
             }
         }
         // C/D layout of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg
+        const int64_t ldm = lp / 32;
+        float tl[4];      // cc |l| of this lane's four columns (zero rows count as norm 1, MaD.py:416)
+#pragma unroll
+        for (int n = 0; n < 4; n++) {
+            const double v = ln[col0 + wn * 64 + n * 16 + (lane & 15)];
+            tl[n] = (float)(cc * (v > 0 ? v : 1.0));
+        }
 #pragma unroll
         for (int m = 0; m < 4; m++)
 #pragma unroll
-            for (int n = 0; n < 4; n++)
+            for (int j = 0; j < 4; j++) {
+                const int64_t r = row0 + wm * 64 + m * 16 + (lane >> 4) * 4 + j;
+                const double hv = hn[r];
+                const float th = (float)(hv > 0 ? hv : 1.0);
+                unsigned long long bal[4];
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const int64_t r = row0 + wm * 64 + m * 16 + (lane >> 4) * 4 + j;
+                for (int n = 0; n < 4; n++) {
                     const int64_t c = col0 + wn * 64 + n * 16 + (lane & 15);
-                    C[r * lp + c] = acc[m][n][j];
+                    const int d = acc[m][n][j];
+                    C[r * lp + c] = d;
+                    const float t = th * tl[n];
+                    bal[n] = __ballot((float)d > t - fabsf(t) * 4e-6f);
                 }
+                // bits 16 g .. 16 g + 15 of a ballot = row group g (= lane >> 4), columns n * 16 ..: lanes 0..7 write
+                // the two 32-bit words of the four rows (lane & 3 = row group, lane >> 2 = word)
+                if (lane < 8) {
+                    const int g = lane & 3, h = lane >> 2;
+                    const unsigned lo16 = (unsigned)(bal[2 * h] >> (16 * g)) & 0xffffu, hi16 = (unsigned)(bal[2 * h + 1] >> (16 * g)) & 0xffffu;
+                    const int64_t rr = row0 + wm * 64 + m * 16 + g * 4 + j;
+                    mask[rr * ldm + (col0 + wn * 64) / 32 + h] = lo16 | (hi16 << 16);
+                }
+            }
         __syncthreads();
     }
 }
@@ -183,18 +212,30 @@ __device__ __forceinline__ double corr_score(int dot, double nh, double nl) {
     return (double)dot / ((nh > 0 ? nh : 1.0) * (nl > 0 ? nl : 1.0));
 }
 
-__global__ __launch_bounds__(256) void k_pair_count(const int32_t *__restrict__ C, const int32_t *__restrict__ n_hi_ptr,
-                                                    const int32_t *__restrict__ n_lo_ptr, const double *__restrict__ hn,
-                                                    const double *__restrict__ ln, double cc, int32_t *__restrict__ row_cnt,
-                                                    const int32_t *__restrict__ status) {
+// Exact test of the entries the GEMM flagged; the mask word is rewritten with the exact bits, so that the
+// emit pass only has to place them.  One workgroup per hi row (persistent), one thread per 32 columns.
+__global__ __launch_bounds__(256) void k_pair_count(const int32_t *__restrict__ C, uint32_t *__restrict__ mask,
+                                                    const int32_t *__restrict__ n_hi_ptr, const int32_t *__restrict__ n_lo_ptr,
+                                                    const double *__restrict__ hn, const double *__restrict__ ln, double cc,
+                                                    int32_t *__restrict__ row_cnt, const int32_t *__restrict__ status) {
     __shared__ int wt[4];
     if (status[ST_FLAG_C]) return;
     const int64_t n_hi = *n_hi_ptr, n_lo = *n_lo_ptr;
-    const int64_t ldc = (n_lo + GEMM_BN - 1) / GEMM_BN * GEMM_BN;
+    const int64_t ldc = (n_lo + GEMM_BN - 1) / GEMM_BN * GEMM_BN, ldm = ldc / 32;
     for (int64_t i = blockIdx.x; i < n_hi; i += gridDim.x) {
         const double nh = hn[i];
         int c = 0;
-        for (int64_t j = threadIdx.x; j < n_lo; j += 256) c += corr_score(C[i * ldc + j], nh, ln[j]) > cc ? 1 : 0;
+        for (int64_t w = threadIdx.x; w < ldm; w += 256) {
+            unsigned m = mask[i * ldm + w], exact = 0;
+            while (m) {
+                const int b = __ffs(m) - 1;
+                m &= m - 1;
+                const int64_t j = w * 32 + b;
+                if (j < n_lo && corr_score(C[i * ldc + j], nh, ln[j]) > cc) exact |= 1u << b;
+            }
+            mask[i * ldm + w] = exact;
+            c += __popc(exact);
+        }
         c = wave_sum_i32(c);
         __syncthreads();
         if (lane_id() == 0) wt[threadIdx.x >> 6] = c;
@@ -203,17 +244,18 @@ __global__ __launch_bounds__(256) void k_pair_count(const int32_t *__restrict__ 
     }
 }
 
-__global__ __launch_bounds__(256) void k_pair_emit(const int32_t *__restrict__ C, const int32_t *__restrict__ n_hi_ptr,
-                                                   const int32_t *__restrict__ n_lo_ptr, const double *__restrict__ hn,
-                                                   const double *__restrict__ ln, double cc, const int32_t *__restrict__ row_off,
-                                                   int64_t cap_pairs, int32_t *__restrict__ pair_hi, int32_t *__restrict__ pair_lo,
+__global__ __launch_bounds__(256) void k_pair_emit(const int32_t *__restrict__ C, const uint32_t *__restrict__ mask,
+                                                   const int32_t *__restrict__ n_hi_ptr, const int32_t *__restrict__ n_lo_ptr,
+                                                   const double *__restrict__ hn, const double *__restrict__ ln,
+                                                   const int32_t *__restrict__ row_off, int64_t cap_pairs,
+                                                   int32_t *__restrict__ pair_hi, int32_t *__restrict__ pair_lo,
                                                    double *__restrict__ pair_score, const int32_t *__restrict__ hi_row_anchor,
                                                    const int32_t *__restrict__ lo_row_anchor, uint8_t *__restrict__ used_hi,
                                                    uint8_t *__restrict__ used_lo, int32_t *__restrict__ status) {
     __shared__ int wt[5];
     if (status[ST_FLAG_C]) return;
     const int64_t n_hi = *n_hi_ptr, n_lo = *n_lo_ptr;
-    const int64_t ldc = (n_lo + GEMM_BN - 1) / GEMM_BN * GEMM_BN;
+    const int64_t ldc = (n_lo + GEMM_BN - 1) / GEMM_BN * GEMM_BN, ldm = ldc / 32;
     if (row_off[n_hi] > cap_pairs) {
         if (blockIdx.x == 0 && threadIdx.x == 0) status[ST_FLAG_PAIRS] = 1;
         return;
@@ -222,28 +264,24 @@ __global__ __launch_bounds__(256) void k_pair_emit(const int32_t *__restrict__ C
         const double nh = hn[i];
         int64_t base = row_off[i];
         if (row_off[i + 1] == base) continue;
-        bool any = false;
-        for (int64_t j0 = 0; j0 < n_lo; j0 += 256) {
-            const int64_t j = j0 + threadIdx.x;
-            double s = 0;
-            bool p = false;
-            if (j < n_lo) {
-                s = corr_score(C[i * ldc + j], nh, ln[j]);
-                p = s > cc;
-            }
+        for (int64_t w0 = 0; w0 < ldm; w0 += 256) {
+            const int64_t w = w0 + threadIdx.x;
+            unsigned m = w < ldm ? mask[i * ldm + w] : 0;
             int tot;
-            const int pos = block_excl_scan(p ? 1 : 0, wt, &tot);
-            if (p) {
-                const int64_t o = base + pos;
+            int64_t o = base + block_excl_scan(__popc(m), wt, &tot);
+            while (m) {      // ascending columns: the row-major order of np.where (MaD.py:423)
+                const int b = __ffs(m) - 1;
+                m &= m - 1;
+                const int64_t j = w * 32 + b;
                 pair_hi[o] = (int32_t)i;
                 pair_lo[o] = (int32_t)j;
-                pair_score[o] = s;
+                pair_score[o] = corr_score(C[i * ldc + j], nh, ln[j]);
                 if (used_lo) used_lo[lo_row_anchor ? lo_row_anchor[j] : j] = 1;
-                any = true;
+                o++;
             }
             base += tot;
         }
-        if (any && used_hi) used_hi[hi_row_anchor ? hi_row_anchor[i] : i] = 1;
+        if (threadIdx.x == 0 && used_hi) used_hi[hi_row_anchor ? hi_row_anchor[i] : i] = 1;
     }
 }
 
@@ -771,16 +809,18 @@ static int correlate_device(mad_ctx *ctx, const Side &hi, const Side &lo, int D,
     MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_PAIR_HI), (size_t)cap_pairs * 4));
     MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_PAIR_LO), (size_t)cap_pairs * 4));
     MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_PAIR_SCORE), (size_t)cap_pairs * 8));
+    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_CMASK), (size_t)cap_c / 8 + 64));
     int32_t *C = scratch<int32_t>(ctx, S_CMAT);
+    uint32_t *mask = scratch<uint32_t>(ctx, S_CMASK);
     mad_timer_begin(ctx, MAD_T_CORRELATE);
     hipLaunchKernelGGL(k_corr_gemm, dim3(ctx->n_cu * 4), dim3(GEMM_THREADS), 0, ctx->stream, hi.dsc8, lo.dsc8, D, C, hi.n_rows,
-                       lo.n_rows, cap_c, d_status);
+                       lo.n_rows, cap_c, d_status, hi.norm, lo.norm, cc, mask);
     mad_timer_end(ctx, MAD_T_CORRELATE);
     mad_timer_begin(ctx, MAD_T_PAIRS);
-    hipLaunchKernelGGL(k_pair_count, dim3(ctx->n_cu * 8), dim3(256), 0, ctx->stream, C, hi.n_rows, lo.n_rows, hi.norm, lo.norm, cc,
+    hipLaunchKernelGGL(k_pair_count, dim3(ctx->n_cu * 8), dim3(256), 0, ctx->stream, C, mask, hi.n_rows, lo.n_rows, hi.norm, lo.norm, cc,
                        scratch<int32_t>(ctx, S_ROWCNT), d_status);
     mad_scan_small(ctx, scratch<int32_t>(ctx, S_ROWCNT), scratch<int32_t>(ctx, S_ROWOFF), hi.n_rows, d_status + ST_NPAIRS);
-    hipLaunchKernelGGL(k_pair_emit, dim3(ctx->n_cu * 8), dim3(256), 0, ctx->stream, C, hi.n_rows, lo.n_rows, hi.norm, lo.norm, cc,
+    hipLaunchKernelGGL(k_pair_emit, dim3(ctx->n_cu * 8), dim3(256), 0, ctx->stream, C, mask, hi.n_rows, lo.n_rows, hi.norm, lo.norm,
                        scratch<int32_t>(ctx, S_ROWOFF), cap_pairs, scratch<int32_t>(ctx, S_PAIR_HI), scratch<int32_t>(ctx, S_PAIR_LO),
                        scratch<double>(ctx, S_PAIR_SCORE), hi.row_anchor, lo.row_anchor, d_used_hi, d_used_lo, d_status);
     mad_timer_end(ctx, MAD_T_PAIRS);
