@@ -143,6 +143,7 @@ struct mad_set {
     DevBuf row_anchor, row_main, row_sec, row_R, row_Rinv, row_meta, dsc, dsc8, norm;
     DevBuf dev_n;                // view: int32[4] on the device = {rows, rows out of int8 range, rejects, describe overflow}
     int64_t n_rows_host = -1;    // host copy of dev_n[0]; -1 until the asynchronous read-back has been waited for
+    bool range_bad = false;      // a loaded row held a count outside the int8 range
     int64_t rows_hint = 0;       // row count of the previous build of this set (sizes the describe launch)
     // what mad_set_build needs to repeat the describe stage when the hint was too small
     FieldDev last_f[2];
@@ -191,6 +192,10 @@ struct OrientOut {
     int32_t *row_anchor, *row_main, *row_sec;
     double *row_R;
     int32_t *row_count;      // nullable: Z quantised counts per row
+    // nullable extras of the set pipeline, written with the rows: inv(Rfinal) and {anchor index, octave, main bin}
+    double *row_Rinv = nullptr;
+    int32_t *row_meta = nullptr;
+    const int32_t *anc_index = nullptr, *anc_octave = nullptr;
     bool counters_zeroed = false;      // the caller has already enqueued the zeroing of d_n_rows / d_n_reject
     int32_t *d_n_rows;       // device: number of rows produced
     int32_t *d_n_reject;     // device, nullable: anchors refused at the border
@@ -199,7 +204,10 @@ int mad_orient_device(mad_ctx *ctx, FieldDev f0, FieldDev f1, const int32_t *d_c
                       int uniform_octave, int n, int r, int lim_main, int lim_sec, OrientOut out);
 int mad_describe_device(mad_ctx *ctx, FieldDev f0, FieldDev f1, const int32_t *d_anc_coords, const int32_t *d_anc_octave,
                         int uniform_octave, const int32_t *d_row_anchor, const double *d_row_R, const int32_t *d_n_rows,
-                        int64_t grid_rows, int32_t *d_overflow, int r, int16_t *d_dsc);
+                        int64_t grid_rows, int32_t *d_overflow, int r, int16_t *d_dsc, int8_t *d_dsc8 = nullptr,
+                        double *d_norm = nullptr);
+void mad_zero_words(mad_ctx *ctx, void *p, size_t bytes);              // one-launch zero fill (bytes rounded up to 16)
+void mad_copy_words(mad_ctx *ctx, void *dst, const void *src, size_t bytes);      // kernel copy, e.g. out of pinned host memory
 int mad_build_cells(mad_ctx *ctx, mad_set *set, double cell);
 
 #define MAD_HIP(call)                                                                            \
@@ -291,6 +299,17 @@ __device__ __forceinline__ void eqsp_classify(const EqspDev *t, double th, doubl
 }
 
 #define MAD_TWO_PI 6.283185307179586476925286766559
+
+__device__ __forceinline__ void mad_mat3_inv(const double *m, double *o) {      // cofactors (np.linalg.inv, MaD.py:438)
+    const double c00 = m[4] * m[8] - m[5] * m[7];
+    const double c01 = m[5] * m[6] - m[3] * m[8];
+    const double c02 = m[3] * m[7] - m[4] * m[6];
+    const double det = m[0] * c00 + m[1] * c01 + m[2] * c02;
+    const double id = 1.0 / det;
+    o[0] = c00 * id; o[1] = (m[2] * m[7] - m[1] * m[8]) * id; o[2] = (m[1] * m[5] - m[2] * m[4]) * id;
+    o[3] = c01 * id; o[4] = (m[0] * m[8] - m[2] * m[6]) * id; o[5] = (m[2] * m[3] - m[0] * m[5]) * id;
+    o[6] = c02 * id; o[7] = (m[1] * m[6] - m[0] * m[7]) * id; o[8] = (m[0] * m[4] - m[1] * m[3]) * id;
+}
 
 // Tables the fast classifier reads per lane, staged in LDS by the kernels.
 struct EqspFastLds {

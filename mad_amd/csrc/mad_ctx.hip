@@ -326,6 +326,29 @@ extern "C" int mad_free_field(mad_ctx *ctx, int slot) {
 }
 
 // ---------------------------------------------------------------------------
+// small fills and copies as ordinary kernels: one launch each, in stream order, no copy-engine hand-over
+// ---------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void k_zero_words(uint4 *__restrict__ p, size_t n16) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) p[i] = make_uint4(0, 0, 0, 0);
+}
+
+__global__ __launch_bounds__(256) void k_copy_words(uint4 *__restrict__ dst, const uint4 *__restrict__ src, size_t n16) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
+void mad_zero_words(mad_ctx *ctx, void *p, size_t bytes) {
+    const size_t n16 = (bytes + 15) / 16;
+    hipLaunchKernelGGL(k_zero_words, dim3((unsigned)std::min<size_t>((n16 + 255) / 256, 1024)), dim3(256), 0, ctx->stream, (uint4 *)p, n16);
+}
+
+void mad_copy_words(mad_ctx *ctx, void *dst, const void *src, size_t bytes) {
+    const size_t n16 = (bytes + 15) / 16;
+    hipLaunchKernelGGL(k_copy_words, dim3((unsigned)std::min<size_t>((n16 + 255) / 256, 1024)), dim3(256), 0, ctx->stream, (uint4 *)dst,
+                       (const uint4 *)src, n16);
+}
+
+// ---------------------------------------------------------------------------
 // exclusive prefix sum (three launches: chunk sums, scan of sums, apply)
 // ---------------------------------------------------------------------------
 

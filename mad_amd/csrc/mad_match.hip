@@ -56,16 +56,7 @@ __global__ __launch_bounds__(256) void k_pack_rows(const int16_t *__restrict__ s
     }
 }
 
-__device__ __forceinline__ void mat3_inv(const double *m, double *o) {      // cofactors (np.linalg.inv, MaD.py:438)
-    const double c00 = m[4] * m[8] - m[5] * m[7];
-    const double c01 = m[5] * m[6] - m[3] * m[8];
-    const double c02 = m[3] * m[7] - m[4] * m[6];
-    const double det = m[0] * c00 + m[1] * c01 + m[2] * c02;
-    const double id = 1.0 / det;
-    o[0] = c00 * id; o[1] = (m[2] * m[7] - m[1] * m[8]) * id; o[2] = (m[1] * m[5] - m[2] * m[4]) * id;
-    o[3] = c01 * id; o[4] = (m[0] * m[8] - m[2] * m[6]) * id; o[5] = (m[2] * m[3] - m[0] * m[5]) * id;
-    o[6] = c02 * id; o[7] = (m[1] * m[6] - m[0] * m[7]) * id; o[8] = (m[0] * m[4] - m[1] * m[3]) * id;
-}
+__device__ __forceinline__ void mat3_inv(const double *m, double *o) { mad_mat3_inv(m, o); }
 
 __device__ __forceinline__ void mat3_mul(const double *a, const double *b, double *o) {
 #pragma unroll
@@ -1087,26 +1078,27 @@ extern "C" void mad_set_destroy(mad_ctx *ctx, mad_set *s) {
     delete s;
 }
 
-static int set_finish_rows(mad_ctx *ctx, mad_set *s, bool check_range);
-
-// waits for the asynchronous read-back once; repeats the describe stage if its launch had been sized too small
+// the row count of a set on the host: read back on demand (the pipeline itself never needs it); repeats the
+// describe stage if its launch had been sized too small
 static int set_rows(mad_ctx *ctx, const mad_set *cs, int64_t *n_rows) {
     mad_set *s = const_cast<mad_set *>(cs);
     if (s->n_rows_host < 0) {
-        MAD_HIP(hipEventSynchronize(s->ready));
         const int32_t *h = (const int32_t *)&ctx->pinned[s->pinned_slot];
-        s->n_rows_host = h[0];
-        s->rows_hint = h[0];
+        MAD_HIP(hipMemcpyAsync(&ctx->pinned[s->pinned_slot], s->dev_n.p, 16, hipMemcpyDeviceToHost, ctx->stream));
+        MAD_HIP(hipStreamSynchronize(ctx->stream));
         if (h[3] && s->last_r > 0) {
             MAD_HIP(hipMemsetAsync((int32_t *)s->dev_n.p + 3, 0, 4, ctx->stream));
             MAD_TRY(mad_describe_device(ctx, s->last_f[0], s->last_f[1], (const int32_t *)s->anc_coords.p,
                                         (const int32_t *)s->anc_octave.p, 0, (const int32_t *)s->row_anchor.p,
                                         (const double *)s->row_R.p, (const int32_t *)s->dev_n.p, s->cap_rows,
-                                        (int32_t *)s->dev_n.p + 3, s->last_r, (int16_t *)s->dsc.p));
-            MAD_TRY(set_finish_rows(ctx, s, false));
-            MAD_HIP(hipEventSynchronize(s->ready));
-            s->n_rows_host = h[0];
+                                        (int32_t *)s->dev_n.p + 3, s->last_r, (int16_t *)s->dsc.p, (int8_t *)s->dsc8.p,
+                                        (double *)s->norm.p));
+            MAD_HIP(hipMemcpyAsync(&ctx->pinned[s->pinned_slot], s->dev_n.p, 16, hipMemcpyDeviceToHost, ctx->stream));
+            MAD_HIP(hipStreamSynchronize(ctx->stream));
         }
+        s->n_rows_host = h[0];
+        s->rows_hint = h[0];
+        s->range_bad = h[1] != 0;
     }
     *n_rows = s->n_rows_host;
     return MAD_OK;
@@ -1116,7 +1108,8 @@ static int set_upload_anchors(mad_ctx *ctx, mad_set *s, const int32_t *anc_coord
                               const double *anc_subv, const int32_t *anc_index, int n, int32_t rows0 = 0) {
     s->n_anchors = n;
     const size_t m = (size_t)(n > 0 ? n : 1);
-    const size_t o_subv = 64, o_coords = o_subv + m * 24, o_oct = o_coords + m * 12, o_idx = o_oct + m * 4, total = o_idx + m * 4;
+    const size_t o_subv = 64, o_coords = o_subv + m * 24, o_oct = o_coords + m * 12, o_idx = o_oct + m * 4,
+                 total = (o_idx + m * 4 + 15) / 16 * 16;
     if (s->host_stage_cap < total) {
         if (s->host_stage) {
             MAD_HIP(hipEventSynchronize(s->uploaded));
@@ -1143,7 +1136,9 @@ static int set_upload_anchors(mad_ctx *ctx, mad_set *s, const int32_t *anc_coord
         memcpy(h + o_oct, anc_octave, (size_t)n * 4);
         memcpy(h + o_idx, anc_index, (size_t)n * 4);
     }
-    MAD_HIP(hipMemcpyAsync(d, h, n > 0 ? total : 64, hipMemcpyHostToDevice, ctx->stream));
+    // a kernel reads the pinned buffer directly: in stream order, without the copy engine's start-up latency
+    mad_copy_words(ctx, d, h, n > 0 ? total : 64);
+    MAD_HIP(hipGetLastError());
     MAD_HIP(hipEventRecord(s->uploaded, ctx->stream));
     for (int i = 0; i < n; i++)
         for (int d3 = 0; d3 < 3; d3++) {
@@ -1171,21 +1166,19 @@ static int set_reserve_rows(mad_ctx *ctx, mad_set *s, int64_t cap) {
     return MAD_OK;
 }
 
-// int8 rows + norms, inverse rotations, result meta; then the asynchronous read-back of the row count
-static int set_finish_rows(mad_ctx *ctx, mad_set *s, bool check_range) {
+// for rows that came from the host (mad_set_load): int8 rows + norms with the range check, inverse rotations,
+// result meta.  Rows built on the device get all of that from k_orient_rows / k_describe directly.
+static int set_finish_rows(mad_ctx *ctx, mad_set *s) {
     int32_t *d_n = (int32_t *)s->dev_n.p;
     int32_t *bad = d_n + 1;      // zeroed with the other counters by the anchor upload
     const int64_t cap_pad = mad_ceil_div(s->cap_rows > 0 ? s->cap_rows : 1, GEMM_BM) * GEMM_BM;
     hipLaunchKernelGGL(k_pack_rows, dim3((unsigned)std::min<int64_t>(mad_ceil_div(cap_pad, 4), (int64_t)ctx->n_cu * 8)), dim3(256), 0,
-                       ctx->stream, (const int16_t *)s->dsc.p, d_n, s->D, (int8_t *)s->dsc8.p, (double *)s->norm.p,
-                       check_range ? bad : (int32_t *)nullptr);
+                       ctx->stream, (const int16_t *)s->dsc.p, d_n, s->D, (int8_t *)s->dsc8.p, (double *)s->norm.p, bad);
     hipLaunchKernelGGL(k_row_aux, dim3((unsigned)std::min<int64_t>(mad_ceil_div(cap_pad, 256), 1024)), dim3(256), 0, ctx->stream,
                        (const double *)s->row_R.p, d_n, (double *)s->row_Rinv.p, (const int32_t *)s->row_anchor.p,
                        (const int32_t *)s->row_main.p, (const int32_t *)s->anc_index.p, (const int32_t *)s->anc_octave.p,
                        (int32_t *)s->row_meta.p);
     MAD_HIP(hipGetLastError());
-    MAD_HIP(hipMemcpyAsync(&ctx->pinned[s->pinned_slot], d_n, 16, hipMemcpyDeviceToHost, ctx->stream));
-    MAD_HIP(hipEventRecord(s->ready, ctx->stream));
     s->n_rows_host = -1;
     return MAD_OK;
 }
@@ -1216,6 +1209,8 @@ extern "C" int mad_set_build(mad_ctx *ctx, mad_set *s, const int *slot_of_octave
     out.row_anchor = (int32_t *)s->row_anchor.p; out.row_main = (int32_t *)s->row_main.p; out.row_sec = (int32_t *)s->row_sec.p;
     out.row_R = (double *)s->row_R.p; out.row_count = nullptr;
     out.d_n_rows = (int32_t *)s->dev_n.p; out.d_n_reject = (int32_t *)s->dev_n.p + 2;
+    out.row_Rinv = (double *)s->row_Rinv.p; out.row_meta = (int32_t *)s->row_meta.p;
+    out.anc_index = (const int32_t *)s->anc_index.p; out.anc_octave = (const int32_t *)s->anc_octave.p;
     out.counters_zeroed = true;
     MAD_TRY(mad_orient_device(ctx, f[0], f[1], (const int32_t *)s->anc_coords.p, (const int32_t *)s->anc_octave.p, 0, n, r,
                               lim_main, lim_sec, out));
@@ -1223,9 +1218,11 @@ extern "C" int mad_set_build(mad_ctx *ctx, mad_set *s, const int *slot_of_octave
     const int64_t grid_rows = s->rows_hint > 0 ? std::min<int64_t>(s->cap_rows, s->rows_hint + s->rows_hint / 8 + 64) : s->cap_rows;
     MAD_TRY(mad_describe_device(ctx, f[0], f[1], (const int32_t *)s->anc_coords.p, (const int32_t *)s->anc_octave.p, 0,
                                 (const int32_t *)s->row_anchor.p, (const double *)s->row_R.p, (const int32_t *)s->dev_n.p,
-                                grid_rows, (int32_t *)s->dev_n.p + 3, r, (int16_t *)s->dsc.p));
+                                grid_rows, (int32_t *)s->dev_n.p + 3, r, (int16_t *)s->dsc.p, (int8_t *)s->dsc8.p,
+                                (double *)s->norm.p));      // int8 copy + norms included: counts are <= 64 by construction
     s->last_f[0] = f[0]; s->last_f[1] = f[1]; s->last_r = r;
-    return set_finish_rows(ctx, s, false);      // counts come from k_describe: <= 64 by construction
+    s->n_rows_host = -1;
+    return MAD_OK;
 }
 
 extern "C" int mad_set_load(mad_ctx *ctx, mad_set *s, int64_t n_rows, const int32_t *row_anchor, const int32_t *row_main,
@@ -1247,9 +1244,10 @@ extern "C" int mad_set_load(mad_ctx *ctx, mad_set *s, int64_t n_rows, const int3
         MAD_HIP(hipMemcpyAsync(s->row_R.p, row_R, n_rows * 72, hipMemcpyHostToDevice, ctx->stream));
         MAD_HIP(hipMemcpyAsync(s->dsc.p, dsc, (size_t)n_rows * D * 2, hipMemcpyHostToDevice, ctx->stream));
     }
-    MAD_TRY(set_finish_rows(ctx, s, true));
-    MAD_HIP(hipStreamSynchronize(ctx->stream));      // the host arrays may go away; also fetch the range check
-    if (((const int32_t *)&ctx->pinned[s->pinned_slot])[1]) return mad_fail(ctx, MAD_EDOM, "descriptor count outside the int8 range");
+    MAD_TRY(set_finish_rows(ctx, s));
+    int64_t n_dev = 0;
+    MAD_TRY(set_rows(ctx, s, &n_dev));      // synchronises (the host arrays may go away) and fetches the range check
+    if (s->range_bad) return mad_fail(ctx, MAD_EDOM, "descriptor count outside the int8 range");
     return MAD_OK;
 }
 
@@ -1296,7 +1294,7 @@ struct MatchPlan {
 // layout of the zero region of a match: [status ST_COUNT int32][hist (n_hi_anchors + 17) int32][used flags]
 static int32_t *zero_status(mad_ctx *ctx) { return scratch<int32_t>(ctx, S_ZERO); }
 static size_t zero_bytes(const mad_set *hi, const mad_set *lo) {
-    return (size_t)(ST_COUNT + hi->n_anchors + 17) * 4 + (size_t)hi->n_anchors + lo->n_anchors + 64;
+    return ((size_t)(ST_COUNT + hi->n_anchors + 17) * 4 + (size_t)hi->n_anchors + lo->n_anchors + 64 + 15) / 16 * 16;
 }
 static size_t tail_bytes(int64_t k) { return (size_t)k * (MAD_RESULT_COLS * 8 + 8) + ST_COUNT * 4; }
 
@@ -1305,7 +1303,7 @@ static int match_enqueue(mad_ctx *ctx, const mad_set *hi, const mad_set *lo, dou
     int32_t *hist = st + ST_COUNT;
     uint8_t *used_hi = (uint8_t *)(hist + hi->n_anchors + 17), *used_lo = used_hi + ((hi->n_anchors + 31) & ~31);
     const Side H = side_of(hi), L = side_of(lo);
-    MAD_HIP(hipMemsetAsync(st, 0, zero_bytes(hi, lo), ctx->stream));      // status, histogram and flags in one go
+    mad_zero_words(ctx, st, zero_bytes(hi, lo));      // status, histogram and flags in one launch
     MAD_TRY(correlate_device(ctx, H, L, hi->D, cc, st, P.cap_c, P.cap_pairs, used_hi, used_lo));
     // clouds: anchors that take part in at least one pair (MaD.py:427-428)
     hipLaunchKernelGGL(k_compact_cloud, dim3(1), dim3(1024), 0, ctx->stream, (const double *)hi->anc_subv.p, used_hi,

@@ -281,7 +281,8 @@ __global__ __launch_bounds__(ORI_THREADS) void k_orient(OrientArgs A) {
 __global__ void k_orient_rows(const int32_t *slot_cnt, const int32_t *slot_main, const int32_t *slot_sec,
                               const int32_t *slot_hist, const int32_t *slot_hidx, const int32_t *row_off, int n, int fan,
                               int lim_main, const EqspDev *eq, int32_t *row_anchor, int32_t *row_main, int32_t *row_sec,
-                              double *row_R, int32_t *row_count) {
+                              double *row_R, int32_t *row_count, double *row_Rinv, int32_t *row_meta,
+                              const int32_t *anc_index, const int32_t *anc_octave) {
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int a = (int)(gid / fan), s = (int)(gid % fan);
     if (a >= n) return;
@@ -301,6 +302,8 @@ __global__ void k_orient_rows(const int32_t *slot_cnt, const int32_t *slot_main,
         const int32_t *h = slot_hist + ((size_t)a * lim_main + slot_hidx[(size_t)a * fan + s]) * Z;
         for (int i = 0; i < Z; i++) row_count[row * Z + i] = h[i];
     }
+    if (row_Rinv) mad_mat3_inv(o, row_Rinv + 9 * row);      // inv(lo.Rfinal) of MaD.py:438, once per row
+    if (row_meta) { row_meta[3 * row] = anc_index[a]; row_meta[3 * row + 1] = anc_octave[a]; row_meta[3 * row + 2] = mb; }
 }
 
 // Runs a1-a8 for n anchors whose coordinates (and octaves) are already on the device and writes the rows to
@@ -355,7 +358,8 @@ int mad_orient_device(mad_ctx *ctx, FieldDev f0, FieldDev f1, const int32_t *d_c
     const int64_t total = (int64_t)n * fan;
     hipLaunchKernelGGL(k_orient_rows, dim3((unsigned)mad_ceil_div(total, 256)), dim3(256), 0, ctx->stream, A.slot_cnt,
                        A.slot_main, A.slot_sec, A.slot_hist, A.slot_hidx, row_off, n, fan, lim_main, ctx->eq[0],
-                       out.row_anchor, out.row_main, out.row_sec, out.row_R, out.row_count);
+                       out.row_anchor, out.row_main, out.row_sec, out.row_R, out.row_count, out.row_Rinv, out.row_meta,
+                       out.anc_index, out.anc_octave);
     MAD_HIP(hipGetLastError());
     return MAD_OK;
 }
@@ -425,6 +429,8 @@ struct DescribeArgs {
     int r;
     const EqspDev *eq;
     int16_t *dsc;                  // n_rows x 64*Z
+    int8_t *dsc8;                  // nullable: the same rows as int8, zero-padded to a multiple of 128 rows (GEMM operand)
+    double *norm;                  // with dsc8: |row|_2 (MaD.py:416)
 };
 
 // The reference's arithmetic for one sample (Descriptor.py:153-187): float32 normalisation, float64
@@ -460,6 +466,14 @@ __global__ __launch_bounds__(DSC_THREADS) void k_describe(DescribeArgs A) {
     if (8 * chunk > (int64_t)gridDim.x) {      // the launch was sized from a stale hint: tell the host
         if (blockIdx.x == 0 && tid == 0) *A.overflow = 1;
         return;
+    }
+    if (A.dsc8) {      // zero rows up to the next multiple of 128: the GEMM reads whole tiles
+        const int64_t n_pad = (n_rows + 127) / 128 * 128;
+        const int Dp = 64 * A.eq->Z;
+        for (int64_t r = n_rows + blockIdx.x; r < n_pad; r += gridDim.x) {
+            for (int i = tid; i < Dp / 4; i += DSC_THREADS) ((int32_t *)(A.dsc8 + r * Dp))[i] = 0;
+            if (tid == 0) A.norm[r] = 0.0;
+        }
     }
     const int64_t row = (int64_t)(blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
     if ((int64_t)(blockIdx.x >> 3) >= chunk || row >= n_rows) return;
@@ -545,6 +559,10 @@ __global__ __launch_bounds__(DSC_THREADS) void k_describe(DescribeArgs A) {
     __syncthreads();
     if (s_oob) {      // Descriptor.py:142-149: the whole descriptor is zero
         for (int i = tid; i < D; i += DSC_THREADS) A.dsc[row * D + i] = 0;
+        if (A.dsc8) {
+            for (int i = tid; i < D; i += DSC_THREADS) A.dsc8[row * D + i] = 0;
+            if (tid == 0) A.norm[row] = 0.0;
+        }
         return;
     }
     if (active) {
@@ -581,12 +599,29 @@ __global__ __launch_bounds__(DSC_THREADS) void k_describe(DescribeArgs A) {
         for (int qi = tid; qi < nq; qi += DSC_THREADS) atomicAdd(&hist[qsub[qi] * Z + describe_exact(A.eq, qv[qi], sR)], 1);
     }
     __syncthreads();
-    for (int i = tid; i < D; i += DSC_THREADS) A.dsc[row * D + i] = (int16_t)hist[i];
+    int ss = 0;      // counts <= 64, 1024 of them: the sum of squares is exact in int32
+    for (int i = tid; i < D; i += DSC_THREADS) {
+        const int v = hist[i];
+        A.dsc[row * D + i] = (int16_t)v;
+        if (A.dsc8) A.dsc8[row * D + i] = (int8_t)v;
+        ss += v * v;
+    }
+    if (A.dsc8) {
+        ss = wave_sum_i32(ss);
+        __syncthreads();
+        if (lane_id() == 0) hist[tid >> 6] = ss;
+        __syncthreads();
+        if (tid == 0) {
+            int tot = 0;
+            for (int w = 0; w < DSC_THREADS / MAD_WAVE; w++) tot += hist[w];
+            A.norm[row] = sqrt((double)tot);
+        }
+    }
 }
 
 int mad_describe_device(mad_ctx *ctx, FieldDev f0, FieldDev f1, const int32_t *d_anc_coords, const int32_t *d_anc_octave,
                         int uniform_octave, const int32_t *d_row_anchor, const double *d_row_R, const int32_t *d_n_rows,
-                        int64_t grid_rows, int32_t *d_overflow, int r, int16_t *d_dsc) {
+                        int64_t grid_rows, int32_t *d_overflow, int r, int16_t *d_dsc, int8_t *d_dsc8, double *d_norm) {
     const int64_t cap_rows = grid_rows;
     if (!ctx->eq_set[1]) return mad_fail(ctx, MAD_EINVAL, "mad_describe: descriptor EQSP table not set");
     if (ctx->eq_host[1].Z != 16) return mad_fail(ctx, MAD_EINVAL, "mad_describe: kernel is built for 16 descriptor zones");
@@ -600,7 +635,7 @@ int mad_describe_device(mad_ctx *ctx, FieldDev f0, FieldDev f1, const int32_t *d
     DescribeArgs A;
     A.f[0] = f0; A.f[1] = f1;
     A.anc_coords = d_anc_coords; A.anc_octave = d_anc_octave; A.uniform_octave = uniform_octave;
-    A.row_anchor = d_row_anchor; A.row_R = d_row_R; A.n_rows = d_n_rows; A.overflow = d_overflow; A.r = r; A.eq = ctx->eq[1]; A.dsc = d_dsc;
+    A.row_anchor = d_row_anchor; A.row_R = d_row_R; A.n_rows = d_n_rows; A.overflow = d_overflow; A.r = r; A.eq = ctx->eq[1]; A.dsc = d_dsc; A.dsc8 = d_dsc8; A.norm = d_norm;
     mad_timer_begin(ctx, MAD_T_DESCRIBE);
     // enough workgroups to fill the chip a few times over, never more than one per possible row
     const unsigned nblk = (unsigned)(((cap_rows + 7) / 8) * 8 + 8);      // one workgroup per possible row
