@@ -570,33 +570,43 @@ __global__ __launch_bounds__(256) void k_count_hist(const int32_t *__restrict__ 
         if (h[b]) atomicAdd(&hist[b], h[b]);
 }
 
-// info[0] = threshold count c*, info[1] = pairs with count > c*, info[2] = ties to take at c*, info[3] = min(k, n)
-__global__ void k_topk_threshold(const int32_t *__restrict__ hist, int nbins, int64_t k, const int32_t *__restrict__ status,
-                                 int64_t cap_pairs, int32_t *__restrict__ info) {
-    if (threadIdx.x || blockIdx.x) return;
-    const int64_t n = (status[ST_FLAG_C] || status[ST_FLAG_PAIRS]) ? 0 : min((int64_t)status[ST_NPAIRS], cap_pairs);
-    if (k > n) k = n;
-    info[3] = (int32_t)k;
-    if (k <= 0) { info[0] = nbins; info[1] = 0; info[2] = 0; return; }
-    int64_t above = 0;
-    int c = nbins - 1;
-    for (; c >= 0; c--) {
-        if (above + hist[c] >= k) break;
-        above += hist[c];
+// Threshold count c* from the histogram: the bin, walking down from the top, where the running total reaches k.
+// Every workgroup computes it for itself (a few hundred bins) -- cheaper than a launch of its own.
+// -> c* (nbins when k <= 0, -1 when fewer than k pairs exist), *need = ties to take at c*
+__device__ __forceinline__ int topk_threshold(const int32_t *__restrict__ hist, int nbins, int64_t k, int *wt, int *sh, int *need) {
+    // sh: 3 ints of shared memory {c*, need, carry}
+    if (threadIdx.x == 0) { sh[0] = k <= 0 ? nbins : -1; sh[1] = 0; sh[2] = 0; }
+    __syncthreads();
+    if (k > 0) {
+        for (int base = nbins - 1; base >= 0; base -= (int)blockDim.x) {
+            const int b = base - (int)threadIdx.x;
+            const int v = b >= 0 ? hist[b] : 0;
+            int tot;
+            const int ex = sh[2] + block_excl_scan(v, wt, &tot);
+            if (b >= 0 && ex < k && (int64_t)ex + v >= k) { sh[0] = b; sh[1] = (int)(k - ex); }
+            __syncthreads();
+            if (threadIdx.x == 0) sh[2] += tot;
+            __syncthreads();
+            if (sh[0] >= 0) break;
+        }
     }
-    if (c < 0) { info[0] = -1; info[1] = (int32_t)above; info[2] = 0; return; }
-    info[0] = c; info[1] = (int32_t)above; info[2] = (int32_t)(k - above);
+    *need = sh[1];
+    return sh[0];
 }
 
-// ties per chunk of TK_CHUNK consecutive pairs
+// ties per chunk of TK_CHUNK consecutive pairs; info[0] = c*, info[2] = ties to take at c*, info[3] = min(k, n)
 __global__ __launch_bounds__(256) void k_tie_chunks(const int32_t *__restrict__ counts, const int32_t *__restrict__ status,
-                                                    int64_t cap_pairs, const int32_t *__restrict__ info,
-                                                    int32_t *__restrict__ chunk_cnt, int32_t *__restrict__ n_chunks) {
-    __shared__ int wt[4];
+                                                    int64_t cap_pairs, const int32_t *__restrict__ hist, int nbins, int64_t k,
+                                                    int32_t *__restrict__ info, int32_t *__restrict__ chunk_cnt,
+                                                    int32_t *__restrict__ n_chunks) {
+    __shared__ int wt[5];
+    __shared__ int sh[3];
     const int64_t n = (status[ST_FLAG_C] || status[ST_FLAG_PAIRS]) ? 0 : min((int64_t)status[ST_NPAIRS], cap_pairs);
     const int64_t nch = (n + TK_CHUNK - 1) / TK_CHUNK;
-    if (blockIdx.x == 0 && threadIdx.x == 0) *n_chunks = (int32_t)nch;
-    const int cstar = info[0];
+    if (k > n) k = n;
+    int need;
+    const int cstar = topk_threshold(hist, nbins, k, wt, sh, &need);
+    if (blockIdx.x == 0 && threadIdx.x == 0) { *n_chunks = (int32_t)nch; info[0] = cstar; info[2] = need; info[3] = (int32_t)k; }
     for (int64_t ch = blockIdx.x; ch < nch; ch += gridDim.x) {
         int c = 0;
         for (int t = threadIdx.x; t < TK_CHUNK; t += 256) {
@@ -611,31 +621,39 @@ __global__ __launch_bounds__(256) void k_tie_chunks(const int32_t *__restrict__ 
     }
 }
 
-// keys = ((maxc - count) << 40) | pair index; survivors appended in any order, sorted afterwards.
-// A tie is taken when its rank among the ties (in pair order) is below info[2].
+// keys = ((maxc - count) << 40) | pair index; survivors appended in any order.  A tie is taken when its rank among
+// the ties (in pair order) is below info[2]; a chunk's first rank is the sum of the tie counts of the chunks before it.
 __global__ __launch_bounds__(TK_CHUNK) void k_topk_select(const int32_t *__restrict__ counts, const int32_t *__restrict__ status,
                                                           int64_t cap_pairs, const int32_t *__restrict__ info,
-                                                          const int32_t *__restrict__ chunk_off, int maxc,
+                                                          const int32_t *__restrict__ chunk_cnt, int maxc,
                                                           unsigned long long *__restrict__ keys, int32_t *__restrict__ n_keys) {
     __shared__ int wt[TK_CHUNK / MAD_WAVE + 1];
     const int64_t n = (status[ST_FLAG_C] || status[ST_FLAG_PAIRS]) ? 0 : min((int64_t)status[ST_NPAIRS], cap_pairs);
     const int64_t nch = (n + TK_CHUNK - 1) / TK_CHUNK;
     const int cstar = info[0], need = info[2];
     for (int64_t ch = blockIdx.x; ch < nch; ch += gridDim.x) {
+        int before = 0;
+        for (int64_t q = threadIdx.x; q < ch; q += TK_CHUNK) before += chunk_cnt[q];
+        int off;
+        (void)block_excl_scan(before, wt, &off);
+        __syncthreads();
         const int64_t i = ch * TK_CHUNK + threadIdx.x;
         const int c = i < n ? counts[i] : -1;
         const bool tie = i < n && c == cstar;
         int tot;
-        const int rank = chunk_off[ch] + block_excl_scan(tie ? 1 : 0, wt, &tot);
+        const int rank = off + block_excl_scan(tie ? 1 : 0, wt, &tot);
         const bool take = i < n && (c > cstar || (tie && rank < need));
         if (take) {
             const int o = atomicAdd(n_keys, 1);
             keys[o] = ((unsigned long long)(maxc - c) << 40) | (unsigned long long)i;
         }
+        __syncthreads();
     }
 }
 
-// one workgroup: bitonic sort of up to `cap` (power of two) 64-bit keys in LDS, emit pair indices
+// one workgroup: bitonic sort of up to `cap` (power of two) 64-bit keys in LDS, emit pair indices.  (Sorting from
+// the last workgroup of k_topk_select to finish was tried: the agent-scope fences it needs write back the whole
+// L2 of every XCD and cost 60 us.)
 __global__ __launch_bounds__(1024) void k_topk_sort(const unsigned long long *__restrict__ keys,
                                                     const int32_t *__restrict__ n_keys, int cap, int64_t *__restrict__ order) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -667,28 +685,24 @@ static int topk_device(mad_ctx *ctx, const int32_t *d_counts, int32_t *d_status,
     const int nbins = maxc + 1;
     if (nbins > 16384) return mad_fail(ctx, MAD_EINVAL, "top-k: %d count bins", nbins);
     const int64_t max_chunks = mad_ceil_div(cap_pairs, TK_CHUNK) + 1;
-    if (max_chunks > 65536) return mad_fail(ctx, MAD_EINVAL, "top-k: %lld pairs exceed the tie-ranking capacity", (long long)cap_pairs);
     MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_HIST), (size_t)(nbins + 16) * 4));
     MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_TIE_FLAG), (size_t)(max_chunks + 2) * 4));
-    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_TIE_OFF), (size_t)(max_chunks + 2) * 4));
     MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_SEL), (size_t)(k + 8) * 8));
     int32_t *hist = hist_zeroed ? hist_zeroed : scratch<int32_t>(ctx, S_HIST);      // nbins + 16 zeroed ints
     int32_t *info = hist + nbins;            // 4 ints, then the chunk count
     int32_t *n_chunks = info + 4;
     if (!hist_zeroed) MAD_HIP(hipMemsetAsync(hist, 0, (size_t)(nbins + 16) * 4, ctx->stream));
+    int cap = 1;
+    while (cap < k) cap <<= 1;
     mad_timer_begin(ctx, MAD_T_TOPK);
     const int gs = ctx->n_cu * 2;
     hipLaunchKernelGGL(k_count_hist, dim3(gs), dim3(256), (size_t)nbins * 4, ctx->stream, d_counts, d_status, cap_pairs, hist, nbins);
-    hipLaunchKernelGGL(k_topk_threshold, dim3(1), dim3(64), 0, ctx->stream, hist, nbins, k, d_status, cap_pairs, info);
-    hipLaunchKernelGGL(k_tie_chunks, dim3(gs), dim3(256), 0, ctx->stream, d_counts, d_status, cap_pairs, info,
+    hipLaunchKernelGGL(k_tie_chunks, dim3(gs), dim3(256), 0, ctx->stream, d_counts, d_status, cap_pairs, hist, nbins, k, info,
                        scratch<int32_t>(ctx, S_TIE_FLAG), n_chunks);
-    mad_scan_small(ctx, scratch<int32_t>(ctx, S_TIE_FLAG), scratch<int32_t>(ctx, S_TIE_OFF), n_chunks, nullptr);
-    hipLaunchKernelGGL(k_topk_select, dim3(gs), dim3(TK_CHUNK), 0, ctx->stream, d_counts, d_status, cap_pairs, info,
-                       scratch<int32_t>(ctx, S_TIE_OFF), maxc, scratch<unsigned long long>(ctx, S_SEL), d_status + ST_NKEYS);
-    int cap = 1;
-    while (cap < k) cap <<= 1;
-    hipLaunchKernelGGL(k_topk_sort, dim3(1), dim3(1024), (size_t)cap * 8, ctx->stream,
-                       scratch<unsigned long long>(ctx, S_SEL), d_status + ST_NKEYS, cap, d_order);
+    hipLaunchKernelGGL(k_topk_select, dim3(ctx->n_cu), dim3(TK_CHUNK), 0, ctx->stream, d_counts, d_status, cap_pairs, info,
+                       scratch<int32_t>(ctx, S_TIE_FLAG), maxc, scratch<unsigned long long>(ctx, S_SEL), d_status + ST_NKEYS);
+    hipLaunchKernelGGL(k_topk_sort, dim3(1), dim3(1024), (size_t)cap * 8, ctx->stream, scratch<unsigned long long>(ctx, S_SEL),
+                       d_status + ST_NKEYS, cap, d_order);
     mad_timer_end(ctx, MAD_T_TOPK);
     MAD_HIP(hipGetLastError());
     return MAD_OK;

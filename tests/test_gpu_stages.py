@@ -166,6 +166,15 @@ def test_topk_order(lib):
         np.testing.assert_array_equal(ref, py)
 
 
+def test_topk_large_lists(lib):
+    """> 2^20 pairs, many chunks per workgroup and heavy ties: the order is python's stable sort."""
+    rng = np.random.default_rng(1)
+    for n, k, hi in ((1 << 20, 60, 300), ((1 << 20) + 12345, 840, 7), (1500000, 3000, 2)):
+        counts = rng.integers(0, hi, n).astype(np.int32)
+        ref = np.lexsort((np.arange(n), -counts.astype(np.int64)))[:k]
+        np.testing.assert_array_equal(lib.topk(counts, k), ref)
+
+
 def _refine_case(seed, n_atoms=400):
     coords, names, elems = synth.random_globule(n_atoms, 14.0, seed)
     m = synth.masses(elems)
