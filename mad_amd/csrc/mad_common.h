@@ -317,6 +317,10 @@ struct EqspFastLds {
     float z_in_lo[MAD_MAX_BELT], z_in_hi[MAD_MAX_BELT], belt_lo0[MAD_MAX_BELT], belt_inv_w[MAD_MAX_BELT];
     int belt_first[MAD_MAX_BELT], belt_count[MAD_MAX_BELT];
     unsigned char zlut[MAD_ZLUT];
+    // the exact float64 bounds as well: the fallback walks them serially, and an LDS read is several times
+    // closer than the L1/L2 path of a global table
+    double th_lo[MAD_MAX_Z], th_hi[MAD_MAX_Z], ph_lo[MAD_MAX_BELT], ph_hi[MAD_MAX_BELT];
+    int nbelt;
 };
 
 __device__ __forceinline__ void eqsp_fast_stage(const EqspDev *t, EqspFastLds *l) {
@@ -329,6 +333,25 @@ __device__ __forceinline__ void eqsp_fast_stage(const EqspDev *t, EqspFastLds *l
         l->belt_first[i] = t->belt_first32[i]; l->belt_count[i] = t->belt_count32[i];
     }
     for (int i = threadIdx.x; i < MAD_ZLUT; i += blockDim.x) l->zlut[i] = t->zlut[i];
+    for (int i = threadIdx.x; i < t->Z; i += blockDim.x) { l->th_lo[i] = t->th_lo[i]; l->th_hi[i] = t->th_hi[i]; }
+    for (int i = threadIdx.x; i < MAD_MAX_BELT; i += blockDim.x) { l->ph_lo[i] = t->ph_lo[i]; l->ph_hi[i] = t->ph_hi[i]; }
+    if (threadIdx.x == 0) l->nbelt = t->nbelt;
+}
+
+// eqsp_classify on the LDS copy of the table
+template <class F>
+__device__ __forceinline__ void eqsp_classify_lds(const EqspFastLds *t, double th, double sth, double ph, F &&f) {
+    const int nb = t->nbelt;
+    for (int b = 0; b < nb; b++) {
+        if (ph < t->ph_hi[b] && ph > t->ph_lo[b]) {
+            const int a0 = t->belt_first[b], a1 = a0 + t->belt_count[b];
+            for (int a = a0; a < a1; a++) {
+                const double lo = t->th_lo[a], hi = t->th_hi[a];
+                if ((th < hi && th > lo) || (sth < hi && sth > lo)) f(a);
+            }
+            break;
+        }
+    }
 }
 
 // atan2 in [0, 2pi) to ~2e-6 rad (odd minimax polynomial on [0, 1] + octant unfolding): a GUESS only

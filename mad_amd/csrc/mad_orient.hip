@@ -84,13 +84,13 @@ __device__ __forceinline__ int quantise_wave0(const int *hist, int *q, int Z) {
 
 // exact zone test of one rotated direction in float64 (the reference's arithmetic); f(zone) per match
 template <class F>
-__device__ __forceinline__ void classify_exact64(const EqspDev *eq, double rx, double ry, double rz, F &&f) {
+__device__ __forceinline__ void classify_exact64(const EqspFastLds *eq, double rx, double ry, double rz, F &&f) {
     double th = atan2(ry, rx);
     if (th < 0) th += MAD_TWO_PI;
     const double sth = th + MAD_TWO_PI;
     rz = rz > 1.0 ? 1.0 : (rz < -1.0 ? -1.0 : rz);
     const double ph = acos(rz);
-    eqsp_classify(eq, th, sth, ph, f);
+    eqsp_classify_lds(eq, th, sth, ph, f);
 }
 
 __global__ __launch_bounds__(ORI_THREADS) void k_orient(OrientArgs A) {
@@ -138,7 +138,8 @@ __global__ __launch_bounds__(ORI_THREADS) void k_orient(OrientArgs A) {
     // step01: fetch, normalise (float32, Orientator.py:139-147), keep weighted voxels only
     const float cutoff = 1e-5f;
     for (int m = tid; m < A.nmask; m += ORI_THREADS) {
-        const int dx = A.mask_off[4 * m], dy = A.mask_off[4 * m + 1], dz = A.mask_off[4 * m + 2];
+        const int packed = ((const int *)A.mask_off)[m];      // {dx, dy, dz, 0} as one load
+        const int dx = (int)(int8_t)(packed & 0xff), dy = (int)(int8_t)((packed >> 8) & 0xff), dz = (int)(int8_t)((packed >> 16) & 0xff);
         const size_t src = ((size_t)(x + dx * stride) * F.ny + (size_t)(y + dy * stride)) * F.nz + (size_t)(z + dz * stride);
         const float4 t = F.tex[src];
         if (!(t.w < cutoff)) {
@@ -170,7 +171,7 @@ __global__ __launch_bounds__(ORI_THREADS) void k_orient(OrientArgs A) {
             double cz = (double)vz[v];
             cz = cz > 1.0 ? 1.0 : (cz < -1.0 ? -1.0 : cz);
             const float ph = (float)acos(cz);
-            eqsp_classify(A.eq, (double)th, (double)sth, (double)ph, [&](int zn) { atomicAdd(&hist[0][zn], 1); });
+            eqsp_classify_lds(&fast, (double)th, (double)sth, (double)ph, [&](int zn) { atomicAdd(&hist[0][zn], 1); });
         }
     }
     __syncthreads();
@@ -215,7 +216,7 @@ __global__ __launch_bounds__(ORI_THREADS) void k_orient(OrientArgs A) {
             // queue full (only if nearly every direction sat on a bound): exact test in place
             const double *dd = s_dom[c];
             const double e0 = g0, e1 = g1, e2 = g2;
-            classify_exact64(A.eq, e0 * dd[0] + e1 * dd[1] + e2 * dd[2], e0 * dd[3] + e1 * dd[4] + e2 * dd[5],
+            classify_exact64(&fast, e0 * dd[0] + e1 * dd[1] + e2 * dd[2], e0 * dd[3] + e1 * dd[4] + e2 * dd[5],
                              e0 * dd[6] + e1 * dd[7] + e2 * dd[8], [&](int z2) { atomicAdd(&hist[1 + c][z2], 1); });
         }
     }
@@ -229,7 +230,7 @@ __global__ __launch_bounds__(ORI_THREADS) void k_orient(OrientArgs A) {
             const double rx = g0 * d[0] + g1 * d[1] + g2 * d[2];
             const double ry = g0 * d[3] + g1 * d[4] + g2 * d[5];
             const double rz = g0 * d[6] + g1 * d[7] + g2 * d[8];
-            classify_exact64(A.eq, rx, ry, rz, [&](int zn) { atomicAdd(&hist[1 + c][zn], 1); });
+            classify_exact64(&fast, rx, ry, rz, [&](int zn) { atomicAdd(&hist[1 + c][zn], 1); });
         }
     }
     __syncthreads();
@@ -435,7 +436,7 @@ struct DescribeArgs {
 
 // The reference's arithmetic for one sample (Descriptor.py:153-187): float32 normalisation, float64
 // rotation by Rfinal, atan2 / arccos against the table; default zone 0, the last matching zone wins.
-__device__ __forceinline__ int describe_exact(const EqspDev *eq, float4 t, const double *R) {
+__device__ __forceinline__ int describe_exact(const EqspFastLds *eq, float4 t, const double *R) {
     float gx = t.x, gy = t.y, gz = t.z;
     if (t.w > 1e-12f) { gx = __fdiv_rn(gx, t.w); gy = __fdiv_rn(gy, t.w); gz = __fdiv_rn(gz, t.w); }
     const double g0 = gx, g1 = gy, g2 = gz;
@@ -588,7 +589,7 @@ __global__ __launch_bounds__(DSC_THREADS) void k_describe(DescribeArgs A) {
                     qv[slot] = t[i]; qsub[slot] = sub;
                     continue;
                 }
-                zone = describe_exact(A.eq, t[i], sR);      // queue full (not seen in practice)
+                zone = describe_exact(&fast, t[i], sR);      // queue full (not seen in practice)
             }
             atomicAdd(&hist[sub * Z + zone], 1);
         }
@@ -596,7 +597,7 @@ __global__ __launch_bounds__(DSC_THREADS) void k_describe(DescribeArgs A) {
     __syncthreads();
     {
         const int nq = min(s_nq, DSC_QUEUE);
-        for (int qi = tid; qi < nq; qi += DSC_THREADS) atomicAdd(&hist[qsub[qi] * Z + describe_exact(A.eq, qv[qi], sR)], 1);
+        for (int qi = tid; qi < nq; qi += DSC_THREADS) atomicAdd(&hist[qsub[qi] * Z + describe_exact(&fast, qv[qi], sR)], 1);
     }
     __syncthreads();
     int ss = 0;      // counts <= 64, 1024 of them: the sum of squares is exact in int32
