@@ -321,7 +321,7 @@ def main():
         pairs = sum(s["n_pairs"] for s in stats)
         # one roofline entry per kernel group; `roofline` = the group with the largest share of device time
         traffic = {}
-        prof = os.path.join(ROOT, "profiles", "r01_b_bench_c3_summary.json")
+        prof = os.path.join(ROOT, "profiles", "r01_c_bench_c3_summary.json")
         if args.workload == "c3" and os.path.exists(prof):      # PMC passes of this same command (profiles/README.md)
             with open(prof) as fh:
                 pj = json.load(fh)
