@@ -52,8 +52,16 @@ int mad_init(int device, mad_ctx **out);
 void mad_destroy(mad_ctx *ctx);
 const char *mad_last_error(const mad_ctx *ctx);   /* ctx may be NULL: last init error */
 int mad_synchronize(mad_ctx *ctx);
-/* HIP stream (hipStream_t) every kernel of this ctx is launched on, for callers that time with events. */
+/*
+ * A ctx owns 4 "lanes" (a HIP stream + its scratch buffers each).  Independent work -- the builds of different
+ * mad_sets, the matches of one mad_match_topk_many call -- is enqueued on different lanes and overlaps on the
+ * device; every entry point still returns only results that are complete.  mad_stream returns the stream of
+ * lane 0 (the one the stage API uses), for callers that time with events.
+ * mad_set_overlap(ctx, 0) makes every lane enqueue on that one stream, so kernels run one at a time: the mode in
+ * which the duration of a launch is a property of the kernel alone (profiling, per-kernel rooflines).
+ */
 void *mad_stream(mad_ctx *ctx);
+int mad_set_overlap(mad_ctx *ctx, int on);
 /*
  * Per-kernel-group timing with HIP events recorded on the ctx stream around each launch.
  * Groups: "orient", "describe", "correlate", "pairs", "pose", "topk", "refine", "density", "ccc".

@@ -17,7 +17,7 @@ ERRORS = {-22: "EINVAL", -12: "ENOMEM", -28: "ENOSPC", -19: "ENODEV", -33: "EDOM
 
 # every symbol include/mad_amd.h declares (tests check the library exports all of them)
 SYMBOLS = [
-    "mad_init", "mad_destroy", "mad_last_error", "mad_synchronize", "mad_stream",
+    "mad_init", "mad_destroy", "mad_last_error", "mad_synchronize", "mad_stream", "mad_set_overlap",
     "mad_timing_enable", "mad_timing_reset", "mad_timing_get", "mad_last_ms",
     "mad_set_eqsp", "mad_upload_field", "mad_upload_field_device", "mad_free_field",
     "mad_orient", "mad_describe", "mad_correlate", "mad_pose_score", "mad_topk",
@@ -229,6 +229,10 @@ class Lib(object):
 
     def stream(self):
         return self.dll.mad_stream(self.ctx)
+
+    def set_overlap(self, on=True):
+        """False: kernels of all lanes run one at a time (per-kernel timing); True (default): lanes overlap."""
+        self._chk(self.dll.mad_set_overlap(self.ctx, C.c_int(1 if on else 0)))
 
     def timing_enable(self, on=True):
         self._chk(self.dll.mad_timing_enable(self.ctx, C.c_int(1 if on else 0)))

@@ -102,7 +102,10 @@ struct MatchState {            // the most recent mad_match_topk call
 
 struct mad_ctx {
     int device = -1;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;            // the stream of the current lane (lane_stream[lane])
+    hipStream_t lane_stream[MAD_LANES] = {nullptr, nullptr, nullptr, nullptr};      // [0] is the stream mad_stream() reports
+    int next_set_lane = 0;
+    bool overlap = true;                      // false: every lane enqueues on lane_stream[0] (kernels run one at a time)
     char err[512] = {0};
     FieldDev fields[MAD_MAX_FIELDS];
     void *field_mem[MAD_MAX_FIELDS];
@@ -139,6 +142,8 @@ struct mad_set {
     void *host_stage = nullptr;
     size_t host_stage_cap = 0;
     hipEvent_t uploaded = nullptr;      // recorded behind the staging copy: the buffer may be rewritten after it
+    int lane = 0;                       // the lane (stream + scratch) this set is built on
+    hipEvent_t built = nullptr;         // recorded behind the last kernel of a build / load: consumers on other lanes wait for it
     // per row
     DevBuf row_anchor, row_main, row_sec, row_R, row_Rinv, row_meta, dsc, dsc8, norm;
     DevBuf dev_n;                // view: int32[4] on the device = {rows, rows out of int8 range, rejects, describe overflow}
@@ -176,6 +181,9 @@ int mad_reserve(mad_ctx *ctx, DevBuf &b, size_t bytes);            // grow-only 
 void mad_release(DevBuf &b);
 int mad_field_alloc(mad_ctx *ctx, int slot, int nx, int ny, int nz, size_t *n_texels);      // (re)allocates the texels of a field slot
 static inline DevBuf &mad_sb(mad_ctx *ctx, int slot) { return ctx->scratch[ctx->lane * 64 + slot]; }
+// A lane = one HIP stream + one set of scratch buffers.  Independent pieces of work (the builds of different
+// sets, the matches of one mad_match_topk_many call) go to different lanes and overlap on the device.
+static inline void mad_use_lane(mad_ctx *ctx, int lane) { ctx->lane = lane; ctx->stream = ctx->lane_stream[ctx->overlap ? lane : 0]; }
 template <class T> static inline T *scratch(mad_ctx *ctx, int slot) { return (T *)mad_sb(ctx, slot).p; }
 
 void mad_timer_begin(mad_ctx *ctx, int group);

@@ -65,7 +65,10 @@ extern "C" int mad_init(int device, mad_ctx **out) {
         ctx->fields[i] = FieldDev{nullptr, 0, 0, 0};
         ctx->field_mem[i] = nullptr;
     }
-    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+    bool streams_ok = true;
+    for (int l = 0; l < MAD_LANES; l++) streams_ok &= hipStreamCreateWithFlags(&ctx->lane_stream[l], hipStreamNonBlocking) == hipSuccess;
+    ctx->stream = ctx->lane_stream[0];
+    if (!streams_ok ||
         hipMalloc((void **)&ctx->eq[0], sizeof(EqspDev)) != hipSuccess ||
         hipMalloc((void **)&ctx->eq[1], sizeof(EqspDev)) != hipSuccess ||
         hipHostMalloc((void **)&ctx->pinned, 8192) != hipSuccess) {
@@ -86,7 +89,7 @@ extern "C" int mad_init(int device, mad_ctx **out) {
 extern "C" void mad_destroy(mad_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    (void)hipStreamSynchronize(ctx->stream);
+    for (int l = 0; l < MAD_LANES; l++) (void)hipStreamSynchronize(ctx->lane_stream[l]);
     for (int i = 0; i < MAD_MAX_FIELDS; i++)
         if (ctx->field_mem[i]) (void)hipFree(ctx->field_mem[i]);
     for (auto &b : ctx->scratch) mad_release(b);
@@ -105,17 +108,26 @@ extern "C" void mad_destroy(mad_ctx *ctx) {
         (void)hipEventDestroy(ctx->lane_done[l]);
         if (ctx->host_res[l]) (void)hipHostFree(ctx->host_res[l]);
     }
-    (void)hipStreamDestroy(ctx->stream);
+    for (int l = 0; l < MAD_LANES; l++)
+        if (ctx->lane_stream[l]) (void)hipStreamDestroy(ctx->lane_stream[l]);
     delete ctx;
 }
 
 extern "C" int mad_synchronize(mad_ctx *ctx) {
     if (!ctx) return MAD_EINVAL;
-    MAD_HIP(hipStreamSynchronize(ctx->stream));
+    for (int l = 0; l < MAD_LANES; l++) MAD_HIP(hipStreamSynchronize(ctx->lane_stream[l]));
     return MAD_OK;
 }
 
-extern "C" void *mad_stream(mad_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+extern "C" int mad_set_overlap(mad_ctx *ctx, int on) {
+    if (!ctx) return MAD_EINVAL;
+    MAD_TRY(mad_synchronize(ctx));
+    ctx->overlap = on != 0;
+    mad_use_lane(ctx, 0);
+    return MAD_OK;
+}
+
+extern "C" void *mad_stream(mad_ctx *ctx) { return ctx ? (void *)ctx->lane_stream[0] : nullptr; }
 
 // ---------------------------------------------------------------------------
 // timing: HIP events on the ctx stream around each kernel group

@@ -926,7 +926,7 @@ static int stage_rows(mad_ctx *ctx, const int16_t *h_rows, int64_t n, int D, int
 extern "C" int mad_correlate(mad_ctx *ctx, const int16_t *hi, int64_t n_hi, const int16_t *lo, int64_t n_lo, int D,
                              double cc, int32_t *pair_hi, int32_t *pair_lo, double *pair_score, int64_t *n_pairs,
                              int64_t cap) {
-    if (ctx) ctx->lane = 0;
+    if (ctx) mad_use_lane(ctx, 0);
     if (!ctx || !n_pairs) return MAD_EINVAL;
     *n_pairs = 0;
     if (n_hi <= 0 || n_lo <= 0) return MAD_OK;
@@ -969,7 +969,7 @@ extern "C" int mad_pose_score(mad_ctx *ctx, const int32_t *pair_hi, const int32_
                               const double *lo_p, const double *lo_R, const int32_t *lo_meta, int64_t n_lo,
                               const double *hi_cloud, int64_t l_hi, const double *lo_cloud, int64_t l_lo, double dist,
                               double *results, int32_t *counts) {
-    if (ctx) ctx->lane = 0;
+    if (ctx) mad_use_lane(ctx, 0);
     if (!ctx) return MAD_EINVAL;
     if (n_pairs <= 0) return MAD_OK;
     if (!pair_hi || !pair_lo || !pair_score || !hi_p || !hi_R || !hi_meta || !lo_p || !lo_R || !lo_meta || !hi_cloud || !lo_cloud)
@@ -1037,7 +1037,7 @@ extern "C" int mad_pose_score(mad_ctx *ctx, const int32_t *pair_hi, const int32_
 }
 
 extern "C" int mad_topk(mad_ctx *ctx, const int32_t *counts, int64_t n, int64_t k, int64_t *order) {
-    if (ctx) ctx->lane = 0;
+    if (ctx) mad_use_lane(ctx, 0);
     if (!ctx) return MAD_EINVAL;
     if (n <= 0 || k <= 0) return MAD_OK;
     if (!counts || !order) return mad_fail(ctx, MAD_EINVAL, "mad_topk: NULL argument");
@@ -1069,11 +1069,16 @@ extern "C" int mad_set_create(mad_ctx *ctx, mad_set **out) {
     if (!ctx || !out) return MAD_EINVAL;
     mad_set *s = new mad_set();
     if (hipEventCreateWithFlags(&s->ready, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&s->uploaded, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&s->uploaded, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&s->built, hipEventDisableTiming) != hipSuccess) {
         if (s->ready) (void)hipEventDestroy(s->ready);
+        if (s->uploaded) (void)hipEventDestroy(s->uploaded);
+    if (s->built) (void)hipEventDestroy(s->built);
         delete s;
         return mad_fail(ctx, MAD_EHIP, "mad_set_create: event creation failed");
     }
+    s->lane = ctx->next_set_lane;      // sets take turns on the lanes, so that their builds overlap
+    ctx->next_set_lane = (ctx->next_set_lane + 1) % MAD_LANES;
     s->pinned_slot = ctx->next_pinned;
     ctx->next_pinned = 64 + (ctx->next_pinned - 64 + 2) % 900;      // two 8-byte slots per set
     *out = s;
@@ -1082,13 +1087,14 @@ extern "C" int mad_set_create(mad_ctx *ctx, mad_set **out) {
 
 extern "C" void mad_set_destroy(mad_ctx *ctx, mad_set *s) {
     if (!s) return;
-    if (ctx) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx) (void)mad_synchronize(ctx);
     DevBuf *bufs[] = {&s->anc_blob, &s->row_anchor, &s->row_main, &s->row_sec, &s->row_R, &s->row_Rinv, &s->row_meta, &s->dsc,
                       &s->dsc8, &s->norm, &s->cell_start, &s->cell_pts, &s->cell_ids};      // anc_* and dev_n are views
     for (DevBuf *b : bufs) mad_release(*b);
     if (s->host_stage) (void)hipHostFree(s->host_stage);
     if (s->ready) (void)hipEventDestroy(s->ready);
     if (s->uploaded) (void)hipEventDestroy(s->uploaded);
+    if (s->built) (void)hipEventDestroy(s->built);
     delete s;
 }
 
@@ -1097,6 +1103,9 @@ extern "C" void mad_set_destroy(mad_ctx *ctx, mad_set *s) {
 static int set_rows(mad_ctx *ctx, const mad_set *cs, int64_t *n_rows) {
     mad_set *s = const_cast<mad_set *>(cs);
     if (s->n_rows_host < 0) {
+        const int lane_before = ctx->lane;
+        mad_use_lane(ctx, s->lane);
+        struct Back { mad_ctx *c; int l; ~Back() { mad_use_lane(c, l); } } back{ctx, lane_before};
         const int32_t *h = (const int32_t *)&ctx->pinned[s->pinned_slot];
         MAD_HIP(hipMemcpyAsync(&ctx->pinned[s->pinned_slot], s->dev_n.p, 16, hipMemcpyDeviceToHost, ctx->stream));
         MAD_HIP(hipStreamSynchronize(ctx->stream));
@@ -1107,6 +1116,7 @@ static int set_rows(mad_ctx *ctx, const mad_set *cs, int64_t *n_rows) {
                                         (const double *)s->row_R.p, (const int32_t *)s->dev_n.p, s->cap_rows,
                                         (int32_t *)s->dev_n.p + 3, s->last_r, (int16_t *)s->dsc.p, (int8_t *)s->dsc8.p,
                                         (double *)s->norm.p));
+            MAD_HIP(hipEventRecord(s->built, ctx->stream));
             MAD_HIP(hipMemcpyAsync(&ctx->pinned[s->pinned_slot], s->dev_n.p, 16, hipMemcpyDeviceToHost, ctx->stream));
             MAD_HIP(hipStreamSynchronize(ctx->stream));
         }
@@ -1200,8 +1210,8 @@ static int set_finish_rows(mad_ctx *ctx, mad_set *s) {
 extern "C" int mad_set_build(mad_ctx *ctx, mad_set *s, const int *slot_of_octave, const int32_t *anc_coords,
                              const int32_t *anc_octave, const double *anc_subv, const int32_t *anc_index, int n, int r,
                              int lim_main, int lim_sec) {
-    if (ctx) ctx->lane = 0;
     if (!ctx || !s || !slot_of_octave) return MAD_EINVAL;
+    mad_use_lane(ctx, s->lane);
     if (n > 0 && (!anc_coords || !anc_octave || !anc_subv || !anc_index)) return mad_fail(ctx, MAD_EINVAL, "mad_set_build: NULL anchors");
     if (lim_main < 1 || lim_sec < 1 || lim_main * lim_sec > 64) return mad_fail(ctx, MAD_EINVAL, "mad_set_build: lim_main=%d lim_sec=%d", lim_main, lim_sec);
     FieldDev f[2] = {FieldDev{nullptr, 0, 0, 0}, FieldDev{nullptr, 0, 0, 0}};
@@ -1236,14 +1246,15 @@ extern "C" int mad_set_build(mad_ctx *ctx, mad_set *s, const int *slot_of_octave
                                 (double *)s->norm.p));      // int8 copy + norms included: counts are <= 64 by construction
     s->last_f[0] = f[0]; s->last_f[1] = f[1]; s->last_r = r;
     s->n_rows_host = -1;
+    MAD_HIP(hipEventRecord(s->built, ctx->stream));
     return MAD_OK;
 }
 
 extern "C" int mad_set_load(mad_ctx *ctx, mad_set *s, int64_t n_rows, const int32_t *row_anchor, const int32_t *row_main,
                             const double *row_R, const int16_t *dsc, int D, const double *anc_subv, const int32_t *anc_index,
                             const int32_t *anc_octave, int n_anchors) {
-    if (ctx) ctx->lane = 0;
     if (!ctx || !s) return MAD_EINVAL;
+    mad_use_lane(ctx, s->lane);
     if (n_rows > 0 && (!row_anchor || !row_main || !row_R || !dsc)) return mad_fail(ctx, MAD_EINVAL, "mad_set_load: NULL rows");
     if (n_anchors > 0 && (!anc_subv || !anc_index || !anc_octave)) return mad_fail(ctx, MAD_EINVAL, "mad_set_load: NULL anchors");
     for (int64_t i = 0; i < n_rows; i++)
@@ -1259,6 +1270,7 @@ extern "C" int mad_set_load(mad_ctx *ctx, mad_set *s, int64_t n_rows, const int3
         MAD_HIP(hipMemcpyAsync(s->dsc.p, dsc, (size_t)n_rows * D * 2, hipMemcpyHostToDevice, ctx->stream));
     }
     MAD_TRY(set_finish_rows(ctx, s));
+    MAD_HIP(hipEventRecord(s->built, ctx->stream));
     int64_t n_dev = 0;
     MAD_TRY(set_rows(ctx, s, &n_dev));      // synchronises (the host arrays may go away) and fetches the range check
     if (s->range_bad) return mad_fail(ctx, MAD_EDOM, "descriptor count outside the int8 range");
@@ -1277,6 +1289,7 @@ extern "C" int mad_set_size(mad_ctx *ctx, const mad_set *s, int64_t *n_rows, int
 extern "C" int mad_set_download(mad_ctx *ctx, const mad_set *s, int32_t *row_anchor, int32_t *row_main, int32_t *row_sec,
                                 double *row_R, int16_t *dsc) {
     if (!ctx || !s) return MAD_EINVAL;
+    mad_use_lane(ctx, s->lane);
     int64_t n = 0;
     MAD_TRY(set_rows(ctx, s, &n));
     if (n <= 0) return MAD_OK;
@@ -1317,6 +1330,9 @@ static int match_enqueue(mad_ctx *ctx, const mad_set *hi, const mad_set *lo, dou
     int32_t *hist = st + ST_COUNT;
     uint8_t *used_hi = (uint8_t *)(hist + hi->n_anchors + 17), *used_lo = used_hi + ((hi->n_anchors + 31) & ~31);
     const Side H = side_of(hi), L = side_of(lo);
+    // the sets may have been built on other lanes
+    MAD_HIP(hipStreamWaitEvent(ctx->stream, hi->built, 0));
+    MAD_HIP(hipStreamWaitEvent(ctx->stream, lo->built, 0));
     mad_zero_words(ctx, st, zero_bytes(hi, lo));      // status, histogram and flags in one launch
     MAD_TRY(correlate_device(ctx, H, L, hi->D, cc, st, P.cap_c, P.cap_pairs, used_hi, used_lo));
     // clouds: anchors that take part in at least one pair (MaD.py:427-428)
@@ -1364,7 +1380,11 @@ static int match_prepare(mad_ctx *ctx, const mad_set *hi, const mad_set *lo, dou
     // the global cell list is only needed when the clouds cannot live in LDS
     P->fits = clouds_fit_lds(hi->n_anchors, lo->n_anchors);
     if (!P->fits) {
-        if (!lo->cells_ready || lo->cell_size != dist) MAD_TRY(mad_build_cells(ctx, const_cast<mad_set *>(lo), dist));
+        if (!lo->cells_ready || lo->cell_size != dist) {      // shared by every lane afterwards: finish it here
+            MAD_HIP(hipStreamWaitEvent(ctx->stream, lo->built, 0));
+            MAD_TRY(mad_build_cells(ctx, const_cast<mad_set *>(lo), dist));
+            MAD_HIP(hipStreamSynchronize(ctx->stream));
+        }
         P->G.start = (const int32_t *)lo->cell_start.p; P->G.pts = (const double *)lo->cell_pts.p; P->G.ids = (const int32_t *)lo->cell_ids.p;
         P->G.used = nullptr;
         for (int d = 0; d < 3; d++) { P->G.mn[d] = lo->cell_min[d]; P->G.dim[d] = lo->cell_dim[d]; }
@@ -1430,7 +1450,7 @@ extern "C" int mad_match_topk(mad_ctx *ctx, const mad_set *hi, const mad_set *lo
     if (stats) { stats[0] = 0; stats[1] = 0; stats[2] = 0; stats[3] = 0; }
     ctx->match.n_pairs = 0;
     if (match_trivial(hi, lo)) return MAD_OK;
-    ctx->lane = 0;
+    mad_use_lane(ctx, 0);
     MatchPlan P;
     MAD_TRY(match_prepare(ctx, hi, lo, dist, k, &P));
     for (int attempt = 0; attempt < 5; attempt++) {
@@ -1462,7 +1482,7 @@ extern "C" int mad_match_topk_many(mad_ctx *ctx, int n, const mad_set *const *hi
         int64_t *idx_i = pair_index ? pair_index + (size_t)i * k : nullptr;
         int rc = match_finish(ctx, lane, hi[i], lo, &plans[lane], res_i, idx_i, &n_out[i], stats ? stats + 4 * i : nullptr);
         for (int attempt = 0; rc == 1 && attempt < 5; attempt++) {      // rare: repeat this one synchronously
-            ctx->lane = lane;
+            mad_use_lane(ctx, lane);
             MAD_TRY(match_enqueue(ctx, hi[i], lo, cc, dist, plans[lane]));
             MAD_HIP(hipStreamSynchronize(ctx->stream));
             rc = match_finish(ctx, lane, hi[i], lo, &plans[lane], res_i, idx_i, &n_out[i], stats ? stats + 4 * i : nullptr);
@@ -1478,7 +1498,7 @@ extern "C" int mad_match_topk_many(mad_ctx *ctx, int n, const mad_set *const *hi
         const int lane = i % MAD_LANES;
         rc_all = retire(lane);
         if (rc_all != MAD_OK) break;
-        ctx->lane = lane;
+        mad_use_lane(ctx, lane);
         rc_all = match_prepare(ctx, hi[i], lo, dist, k, &plans[lane]);
         if (rc_all != MAD_OK) break;
         rc_all = match_enqueue(ctx, hi[i], lo, cc, dist, plans[lane]);
@@ -1488,14 +1508,14 @@ extern "C" int mad_match_topk_many(mad_ctx *ctx, int n, const mad_set *const *hi
         const int rc = retire(l);
         if (rc_all == MAD_OK) rc_all = rc;
     }
-    ctx->lane = ctx->match.lane;
+    mad_use_lane(ctx, ctx->match.lane);
     return rc_all;
 }
 
 extern "C" int mad_match_fetch(mad_ctx *ctx, int32_t *pair_hi, int32_t *pair_lo, double *pair_score, int32_t *counts,
                                int64_t cap) {
     if (!ctx) return MAD_EINVAL;
-    ctx->lane = ctx->match.lane;
+    mad_use_lane(ctx, ctx->match.lane);
     const int64_t np = ctx->match.n_pairs;
     if (np > cap) return mad_fail(ctx, MAD_ENOSPC, "mad_match_fetch: %lld pairs, capacity %lld", (long long)np, (long long)cap);
     if (np <= 0) return MAD_OK;
@@ -1509,7 +1529,7 @@ extern "C" int mad_match_fetch(mad_ctx *ctx, int32_t *pair_hi, int32_t *pair_lo,
 
 extern "C" int mad_match_results(mad_ctx *ctx, const mad_set *hi, const mad_set *lo, double *results, int64_t cap) {
     if (!ctx || !hi || !lo || !results) return MAD_EINVAL;
-    ctx->lane = ctx->match.lane;
+    mad_use_lane(ctx, ctx->match.lane);
     const int64_t np = ctx->match.n_pairs;
     if (np > cap) return mad_fail(ctx, MAD_ENOSPC, "mad_match_results: %lld pairs, capacity %lld", (long long)np, (long long)cap);
     if (np <= 0) return MAD_OK;
@@ -1532,7 +1552,7 @@ extern "C" int mad_match_used(mad_ctx *ctx, uint8_t *hi_used, int32_t n_hi_ancho
     if (!ctx) return MAD_EINVAL;
     if (n_hi_anchors != ctx->match.n_hi_anchors || n_lo_anchors != ctx->match.n_lo_anchors)
         return mad_fail(ctx, MAD_EINVAL, "mad_match_used: anchor counts do not match the last mad_match_topk call");
-    ctx->lane = ctx->match.lane;
+    mad_use_lane(ctx, ctx->match.lane);
     const uint8_t *d_hi = (const uint8_t *)(zero_status(ctx) + ST_COUNT + n_hi_anchors + 17), *d_lo = d_hi + ((n_hi_anchors + 31) & ~31);
     if (hi_used && n_hi_anchors > 0) MAD_HIP(hipMemcpyAsync(hi_used, d_hi, n_hi_anchors, hipMemcpyDeviceToHost, ctx->stream));
     if (lo_used && n_lo_anchors > 0) MAD_HIP(hipMemcpyAsync(lo_used, d_lo, n_lo_anchors, hipMemcpyDeviceToHost, ctx->stream));

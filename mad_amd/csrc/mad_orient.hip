@@ -33,7 +33,7 @@ static int ensure_mask(mad_ctx *ctx, int r) {
                     n++;
                 }
     if (ctx->mask_off) {
-        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipDeviceSynchronize();
         (void)hipFree(ctx->mask_off);
         ctx->mask_off = nullptr;
     }
@@ -368,7 +368,7 @@ int mad_orient_device(mad_ctx *ctx, FieldDev f0, FieldDev f1, const int32_t *d_c
 extern "C" int mad_orient(mad_ctx *ctx, int slot, int octave, const int32_t *coords, int n, int r, int lim_main,
                           int lim_sec, int32_t *row_anchor, int32_t *row_main, int32_t *row_sec, double *row_R,
                           int32_t *row_count, int64_t *n_rows, int64_t cap, int32_t *n_reject) {
-    if (ctx) ctx->lane = 0;
+    if (ctx) mad_use_lane(ctx, 0);
     if (!ctx || !n_rows) return MAD_EINVAL;
     if (slot < 0 || slot >= MAD_MAX_FIELDS || !ctx->fields[slot].tex)
         return mad_fail(ctx, MAD_EINVAL, "mad_orient: field slot %d is empty", slot);
@@ -653,7 +653,7 @@ int mad_describe_device(mad_ctx *ctx, FieldDev f0, FieldDev f1, const int32_t *d
 
 extern "C" int mad_describe(mad_ctx *ctx, int slot, int octave, const int32_t *coords, const double *R, int64_t n_rows,
                             int r, int16_t *dsc) {
-    if (ctx) ctx->lane = 0;
+    if (ctx) mad_use_lane(ctx, 0);
     if (!ctx) return MAD_EINVAL;
     if (slot < 0 || slot >= MAD_MAX_FIELDS || !ctx->fields[slot].tex)
         return mad_fail(ctx, MAD_EINVAL, "mad_describe: field slot %d is empty", slot);

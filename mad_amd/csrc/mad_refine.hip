@@ -278,7 +278,7 @@ __global__ __launch_bounds__(RF_THREADS) void k_refine(RefineArgs A) {
 
 extern "C" int mad_refine(mad_ctx *ctx, double *coords, int n_cand, int64_t n_atoms, int n_steps, double max_step,
                           double min_step, int32_t *converged, int32_t *last_step) {
-    if (ctx) ctx->lane = 0;
+    if (ctx) mad_use_lane(ctx, 0);
     if (!ctx) return MAD_EINVAL;
     if (!ctx->dens.grad) return mad_fail(ctx, MAD_EINVAL, "mad_refine: call mad_upload_density first");
     if (n_cand <= 0) return MAD_OK;
@@ -405,7 +405,7 @@ __global__ void k_norm_f32(float *__restrict__ g, size_t n, const unsigned *__re
 
 extern "C" int mad_structure_to_density(mad_ctx *ctx, const double *atoms, const double *mass, int64_t n, double resolution,
                                         double voxsp, double isovalue, int pad, int32_t dims[3], double origin[3], float *grid) {
-    if (ctx) ctx->lane = 0;
+    if (ctx) mad_use_lane(ctx, 0);
     if (!ctx || !atoms || !mass || !dims || !origin || n <= 0) return ctx ? mad_fail(ctx, MAD_EINVAL, "mad_structure_to_density: bad argument") : MAD_EINVAL;
     if (!(voxsp > 0) || !(resolution > 0) || pad < 0) return mad_fail(ctx, MAD_EINVAL, "mad_structure_to_density: resolution %g voxsp %g pad %d", resolution, voxsp, pad);
     // PDB.py:237-257 lattice-aligned bounding box
@@ -506,7 +506,7 @@ static long py_round(double v) { return (long)nearbyint(v); }      // python rou
 
 extern "C" int mad_ccc(mad_ctx *ctx, float *grid1, const int32_t d1[3], const double o1[3], float *grid2,
                        const int32_t d2[3], const double o2[3], double voxsp, double isovalue, double *ccc) {
-    if (ctx) ctx->lane = 0;
+    if (ctx) mad_use_lane(ctx, 0);
     if (!ctx || !grid1 || !grid2 || !d1 || !d2 || !o1 || !o2 || !ccc) return ctx ? mad_fail(ctx, MAD_EINVAL, "mad_ccc: NULL argument") : MAD_EINVAL;
     *ccc = 0.0;
     const size_t n1 = (size_t)d1[0] * d1[1] * d1[2], n2 = (size_t)d2[0] * d2[1] * d2[2];

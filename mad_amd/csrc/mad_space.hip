@@ -441,7 +441,7 @@ extern "C" int mad_space_download(mad_ctx *ctx, const mad_space *s, int entry, i
 extern "C" int mad_space_peaks(mad_ctx *ctx, const mad_space *s, int entry, double threshold, int border, int64_t *lin_index,
                                double *value, int64_t cap, int64_t *n_out) {
     if (!ctx || !s || !n_out) return MAD_EINVAL;
-    ctx->lane = 0;
+    mad_use_lane(ctx, 0);
     if (entry < 0 || entry >= s->n_oct) return mad_fail(ctx, MAD_EINVAL, "mad_space_peaks: entry %d of %d", entry, s->n_oct);
     if (border < 0 || cap < 0 || cap >= ((int64_t)1 << 31)) return mad_fail(ctx, MAD_EINVAL, "mad_space_peaks: border %d cap %lld", border, (long long)cap);
     const Octave &O = s->oct[entry];
@@ -467,7 +467,7 @@ extern "C" int mad_space_peaks(mad_ctx *ctx, const mad_space *s, int entry, doub
 
 extern "C" int mad_space_patches(mad_ctx *ctx, const mad_space *s, int entry, const int32_t *coords, int n, int r, void *out) {
     if (!ctx || !s || (n > 0 && (!coords || !out))) return MAD_EINVAL;
-    ctx->lane = 0;
+    mad_use_lane(ctx, 0);
     if (entry < 0 || entry >= s->n_oct) return mad_fail(ctx, MAD_EINVAL, "mad_space_patches: entry %d of %d", entry, s->n_oct);
     if (n <= 0) return MAD_OK;
     if (r < 1 || r > 16) return mad_fail(ctx, MAD_EINVAL, "mad_space_patches: radius %d", r);
