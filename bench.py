@@ -298,7 +298,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     # Per-kernel durations for the rooflines: in the timed region the builds of the five sets and the four matches
-    # overlap on the device (4 lanes), so a launch's elapsed time there depends on what ran beside it.  The same
+    # overlap on the device (one lane per structure), so a launch's elapsed time there depends on what ran beside it.  The same
     # steps are therefore repeated with the lanes serialised onto one stream, HIP events around every launch.
     n_serial = min(args.steps, 5)
     lib.set_overlap(False)
@@ -362,7 +362,7 @@ def main():
         roof = dict(roofs[dom_name])
         roof["kernel_ms_per_step"] = {g: groups[g]["ms_total"] / n_serial for g in groups}
         roof["timing"] = ("HIP events around every launch over %d steps with the lanes serialised onto one stream (%.3f ms/step); "
-                          "the timed region overlaps 4 lanes (%.3f ms/step)" % (n_serial, 1e3 * dt_serial / n_serial, 1e3 * t_max / args.steps))
+                          "the timed region overlaps the lanes (%.3f ms/step)" % (n_serial, 1e3 * dt_serial / n_serial, 1e3 * t_max / args.steps))
         roof["host_ms_per_step"] = {k_: 1e3 * v / n_serial for k_, v in HOST_T.items()}
         if dom_name == "pose":
             # what actually bounds it: ~18 flop per transformed point + ~8 per candidate lo anchor, float64

@@ -53,7 +53,7 @@ void mad_destroy(mad_ctx *ctx);
 const char *mad_last_error(const mad_ctx *ctx);   /* ctx may be NULL: last init error */
 int mad_synchronize(mad_ctx *ctx);
 /*
- * A ctx owns 4 "lanes" (a HIP stream + its scratch buffers each).  Independent work -- the builds of different
+ * A ctx owns 8 "lanes" (a HIP stream + its scratch buffers each).  Independent work -- the builds of different
  * mad_sets, the matches of one mad_match_topk_many call -- is enqueued on different lanes and overlaps on the
  * device; every entry point still returns only results that are complete.  mad_stream returns the stream of
  * lane 0 (the one the stage API uses), for callers that time with events.

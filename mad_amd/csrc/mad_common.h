@@ -73,7 +73,7 @@ enum { MAD_T_ORIENT = 0, MAD_T_DESCRIBE, MAD_T_CORRELATE, MAD_T_PAIRS, MAD_T_POS
        MAD_T_DENSITY, MAD_T_CCC, MAD_T_COUNT };
 
 #define MAD_T_RING 32
-#define MAD_LANES 4
+#define MAD_LANES 8
 
 struct TimerGroup {
     hipEvent_t start[MAD_T_RING];
@@ -103,7 +103,7 @@ struct MatchState {            // the most recent mad_match_topk call
 struct mad_ctx {
     int device = -1;
     hipStream_t stream = nullptr;            // the stream of the current lane (lane_stream[lane])
-    hipStream_t lane_stream[MAD_LANES] = {nullptr, nullptr, nullptr, nullptr};      // [0] is the stream mad_stream() reports
+    hipStream_t lane_stream[MAD_LANES] = {};      // [0] is the stream mad_stream() reports
     int next_set_lane = 0;
     bool overlap = true;                      // false: every lane enqueues on lane_stream[0] (kernels run one at a time)
     char err[512] = {0};
@@ -119,8 +119,8 @@ struct mad_ctx {
     DevBuf scratch[64 * MAD_LANES];   // MAD_LANES independent copies: matches in flight do not share scratch
     int lane = 0;                    // the copy the current call works in
     hipEvent_t lane_done[MAD_LANES]; // recorded behind the last operation enqueued in each lane
-    void *host_res[MAD_LANES] = {nullptr, nullptr, nullptr, nullptr};   // pinned staging of a match's results / indices / status
-    size_t host_res_cap[MAD_LANES] = {0, 0, 0, 0};
+    void *host_res[MAD_LANES] = {};   // pinned staging of a match's results / indices / status
+    size_t host_res_cap[MAD_LANES] = {};
     // host pinned staging for small read-backs
     int64_t *pinned = nullptr;     // 1024 slots: [16 * lane ..] read-backs of the lane, [64..] two per mad_set
     int next_pinned = 64;

@@ -1462,7 +1462,7 @@ extern "C" int mad_match_topk(mad_ctx *ctx, const mad_set *hi, const mad_set *lo
     return mad_fail(ctx, MAD_EHIP, "mad_match_topk: capacity negotiation did not converge");
 }
 
-// Several subunits against one map.  Match i runs in scratch lane i % MAD_LANES, so up to MAD_LANES matches are in
+// Several subunits against one map.  Match i runs in the lane of its hi set, so up to MAD_LANES matches are in
 // flight before the host waits for the oldest: the GPU never idles on a result read-back.
 // results: n x k x 23, pair_index (nullable): n x k, n_out: n, stats (nullable): n x 4.
 extern "C" int mad_match_topk_many(mad_ctx *ctx, int n, const mad_set *const *hi, const mad_set *lo, double cc, double dist, int64_t k,
@@ -1495,7 +1495,7 @@ extern "C" int mad_match_topk_many(mad_ctx *ctx, int n, const mad_set *const *hi
         if (stats) { stats[4 * i] = stats[4 * i + 1] = stats[4 * i + 2] = stats[4 * i + 3] = 0; }
         if (!hi[i]) { rc_all = mad_fail(ctx, MAD_EINVAL, "mad_match_topk_many: set %d is NULL", i); break; }
         if (match_trivial(hi[i], lo)) continue;
-        const int lane = i % MAD_LANES;
+        const int lane = hi[i]->lane;      // where its hi set was built: no cross-lane wait for it, and the matches spread like the sets
         rc_all = retire(lane);
         if (rc_all != MAD_OK) break;
         mad_use_lane(ctx, lane);
