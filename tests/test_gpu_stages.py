@@ -285,3 +285,45 @@ def test_set_pipeline_and_batched_match(lib, fields):
     dsc = O.describe(f["gx"], f["gy"], f["gz"], 1, big[rows["anchor"]], rows["R"], E16.sphere_eqsp)
     assert len(dsc) > n_small + n_small // 8 + 64
     np.testing.assert_array_equal(s2.download()["dsc"], dsc)
+
+
+def test_lanes_overlap_and_serial_give_identical_results(lib):
+    """Builds and matches of several structures spread over the lanes (streams); serialising the lanes with
+    mad_set_overlap(0) must not change a bit of the output."""
+    from mad_amd._lib import DeviceSet
+    from mad_amd.eqsp import EQSP_Sphere
+    from mad_amd.orient_tables import orientation_matrices
+    e112, e16 = EQSP_Sphere(112), EQSP_Sphere(16)
+    dom, adj = orientation_matrices(e112)
+    lib.set_eqsp(0, e112.sphere_eqsp, dom, adj)
+    lib.set_eqsp(1, e16.sphere_eqsp)
+    rng = np.random.default_rng(11)
+    vol = synth.blob_volume((72, 70, 68), n_blobs=60, seed=5, sigma=(1.5, 3.5))
+    slot = lib.new_slot()
+    lib.upload_field(slot, synth.gradient_field(vol))
+    structs = []
+    for s_ in range(4):
+        n = 50 + 10 * s_
+        coords = np.stack([rng.integers(12, d - 12, n) for d in vol.shape], 1).astype(np.int32)
+        structs.append((coords, np.ones(n, np.int32), coords.astype(np.float64) * 1.5 + rng.normal(scale=0.2, size=(n, 3)), np.arange(n, dtype=np.int32)))
+    outs = []
+    for overlap in (True, False, True):
+        lib.set_overlap(overlap)
+        sets = [lib.set_build([-1, slot], *st) for st in structs]
+        res = lib.match_topk_many(sets[1:], sets[0], 0.5, 4.0, 25)
+        outs.append([(top.copy(), idx.copy(), dict(st)) for top, idx, st in res])
+        rows = [s_.download() for s_ in sets]
+        outs[-1].append(rows)
+        for s_ in sets:
+            s_.close()
+    lib.set_overlap(True)
+    lib.free_field(slot)
+    for other in outs[1:]:
+        for a, b in zip(outs[0][:-1], other[:-1]):
+            np.testing.assert_array_equal(a[0], b[0])
+            np.testing.assert_array_equal(a[1], b[1])
+            assert a[2] == b[2]
+        for ra, rb in zip(outs[0][-1], other[-1]):
+            for key in ("anchor", "main", "sec", "R", "dsc"):
+                np.testing.assert_array_equal(ra[key], rb[key])
+    assert any(len(o[0]) for o in outs[0][:-1])
