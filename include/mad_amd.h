@@ -244,6 +244,16 @@ int mad_ccc(mad_ctx *ctx, float *grid1, const int32_t dims1[3], const double ori
             float *grid2, const int32_t dims2[3], const double origin2[3],
             double voxsp, double isovalue, double *ccc);
 
+/*
+ * a14-a16 for a batch of placed copies of one structure, on the device end to end: candidate c's atoms
+ * (atoms + c*n*3, float64) -> simulated density at the voxel spacing of the map uploaded with
+ * mad_upload_density (PDB.structure_to_density(resolution, voxsp, isovalue = density_isovalue)) ->
+ * ccc[c] = Dmap.get_CCC_with_grid(grid, x0, y0, z0, isovalue = ccc_isovalue) against that map.  The uploaded
+ * map is clamped on the fly, not modified.  One read-back at the end (MaD.py:613-616 per solution).
+ */
+int mad_density_ccc(mad_ctx *ctx, const double *atoms, const double *mass, int n_cand, int64_t n,
+                    double resolution, double density_isovalue, double ccc_isovalue, double *ccc);
+
 /* ---- next to the path, upstream: MapSpace.build_space (MapSpace.py:116-189) and the
  *      dense half of Detector.find_anchors (Detector.py:28-29) ------------------------ */
 

@@ -23,7 +23,7 @@ SYMBOLS = [
     "mad_orient", "mad_describe", "mad_correlate", "mad_pose_score", "mad_topk",
     "mad_set_create", "mad_set_destroy", "mad_set_build", "mad_set_load", "mad_set_size", "mad_set_download",
     "mad_match_topk", "mad_match_topk_many", "mad_match_fetch", "mad_match_results", "mad_match_used",
-    "mad_upload_density", "mad_refine", "mad_structure_to_density", "mad_ccc",
+    "mad_upload_density", "mad_refine", "mad_structure_to_density", "mad_ccc", "mad_density_ccc",
     "mad_space_create", "mad_space_destroy", "mad_space_build", "mad_space_info", "mad_space_download",
     "mad_space_peaks", "mad_space_patches",
 ]
@@ -458,6 +458,19 @@ class Lib(object):
         grid = np.zeros(tuple(int(d) for d in dims), np.float32)
         self._chk(self.dll.mad_structure_to_density(*args, _p(grid)))
         return grid, float(org[0]), float(org[1]), float(org[2])
+
+    def density_ccc(self, coords, mass, resolution, density_isovalue=0.0, ccc_isovalue=0.0):
+        """coords: (n_cand, n_atoms, 3) placed copies of one structure -> CCC of each copy's simulated density with the
+        map given to upload_density (PDB.structure_to_density + Dmap.get_CCC_with_grid, on the device end to end)."""
+        c = _c(coords, np.float64)
+        if c.ndim == 2:
+            c = c[None]
+        n_cand, n_atoms, _ = c.shape
+        mass = _c(mass, np.float64)
+        out = np.zeros(n_cand, np.float64)
+        self._chk(self.dll.mad_density_ccc(self.ctx, _p(c), _p(mass), C.c_int(n_cand), C.c_int64(n_atoms), C.c_double(resolution),
+                                           C.c_double(density_isovalue), C.c_double(ccc_isovalue), _p(out)))
+        return out
 
     def ccc(self, g1, o1, g2, o2, voxsp, isovalue=0.0):
         """Both grids must be C-contiguous float32; they are clamped in place like the reference."""

@@ -10,6 +10,8 @@
 //  density : float64 atomic splat, three separable float64 blur passes (the reference's
 //            Gaussian is a product of 1-D Gaussians), float32 normalise + threshold.
 //  ccc     : three float64 dot products over the overlap box.
+#include <vector>
+
 #include "mad_common.h"
 
 #define RF_THREADS 1024
@@ -390,7 +392,14 @@ __global__ void k_to_f32(const double *__restrict__ in, size_t n, float *__restr
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, MAD_WAVE));
-    if (lane_id() == 0) atomicMax(maxbits, __float_as_uint(m));
+    // one atomic per workgroup: thousands of waves hitting one address serialise in the L2
+    __shared__ float wm[16];
+    if (lane_id() == 0) wm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (unsigned w = 1; w < blockDim.x / MAD_WAVE; w++) m = fmaxf(m, wm[w]);
+        atomicMax(maxbits, __float_as_uint(m));
+    }
 }
 
 // PDB.py:162-163: / max (float32), then zero below the isovalue
@@ -403,12 +412,17 @@ __global__ void k_norm_f32(float *__restrict__ g, size_t n, const unsigned *__re
     }
 }
 
-extern "C" int mad_structure_to_density(mad_ctx *ctx, const double *atoms, const double *mass, int64_t n, double resolution,
-                                        double voxsp, double isovalue, int pad, int32_t dims[3], double origin[3], float *grid) {
-    if (ctx) mad_use_lane(ctx, 0);
-    if (!ctx || !atoms || !mass || !dims || !origin || n <= 0) return ctx ? mad_fail(ctx, MAD_EINVAL, "mad_structure_to_density: bad argument") : MAD_EINVAL;
-    if (!(voxsp > 0) || !(resolution > 0) || pad < 0) return mad_fail(ctx, MAD_EINVAL, "mad_structure_to_density: resolution %g voxsp %g pad %d", resolution, voxsp, pad);
-    // PDB.py:237-257 lattice-aligned bounding box
+// geometry of the simulated density of one structure (PDB.py:144-145, 157-159, 237-257)
+struct DensityPlan {
+    double mn[3];        // lattice-aligned minimum of the atoms
+    int p[3];            // splat grid
+    int dims[3];         // blurred grid
+    double origin[3];
+    int r, margin;
+    double sig;
+};
+
+static int density_plan(mad_ctx *ctx, const double *atoms, int64_t n, double resolution, double voxsp, int pad, DensityPlan *P) {
     double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (int64_t i = 0; i < n; i++)
         for (int d = 0; d < 3; d++) {
@@ -417,27 +431,62 @@ extern "C" int mad_structure_to_density(mad_ctx *ctx, const double *atoms, const
             mn[d] = v < mn[d] ? v : mn[d];
             mx[d] = v > mx[d] ? v : mx[d];
         }
-    const int margin = 2 + pad;
-    int p[3];
+    P->margin = 2 + pad;
     for (int d = 0; d < 3; d++) {
-        mn[d] = voxsp * floor(mn[d] / voxsp);
+        P->mn[d] = voxsp * floor(mn[d] / voxsp);
         mx[d] = voxsp * ceil(mx[d] / voxsp);
-        p[d] = (int)ceil((mx[d] - mn[d]) / voxsp) + 2 * margin + 1;
+        P->p[d] = (int)ceil((mx[d] - P->mn[d]) / voxsp) + 2 * P->margin + 1;
     }
-    // PDB.py:144-145 kernel size
-    const double sig = resolution / (M_PI * sqrt(2.0)) / voxsp;
-    const int r = (int)ceil(3.0 * sig);
+    P->sig = resolution / (M_PI * sqrt(2.0)) / voxsp;
+    P->r = (int)ceil(3.0 * P->sig);
     for (int d = 0; d < 3; d++) {
-        dims[d] = p[d] + 2 * r;
-        origin[d] = mn[d] - (r + margin) * voxsp;      // PDB.py:157-159
+        P->dims[d] = P->p[d] + 2 * P->r;
+        P->origin[d] = P->mn[d] - (P->r + P->margin) * voxsp;
     }
+    if (P->r > 64) return mad_fail(ctx, MAD_EINVAL, "mad_structure_to_density: kernel radius %d", P->r);
+    return MAD_OK;
+}
+
+// 1-D taps; the 3-D kernel of PDB.py:148-150 is their outer product over the cube of their sum
+static void density_taps(const DensityPlan &P, double *taps) {
+    double ts = 0;
+    for (int t = -P.r; t <= P.r; t++) { taps[t + P.r] = exp(-(double)(t * t) / (2.0 * P.sig * P.sig)); ts += taps[t + P.r]; }
+    for (int t = 0; t <= 2 * P.r; t++) taps[t] /= ts;
+}
+
+// splat + blur + float32 + normalise + isovalue of atoms already on the device; d_max (2 doubles) and d_maxf zeroed by the caller
+static void density_enqueue(mad_ctx *ctx, const DensityPlan &P, const double *d_atoms, const double *d_mass, int64_t n, double voxsp,
+                            double isovalue, const double *d_taps, double *d_max, unsigned *d_maxf, double *bufA, double *bufB, float *d_out) {
+    const size_t np_ = (size_t)P.p[0] * P.p[1] * P.p[2], no = (size_t)P.dims[0] * P.dims[1] * P.dims[2];
+    const int r = P.r;
+    mad_zero_words(ctx, bufA, np_ * 8);
+    hipLaunchKernelGGL(k_splat, dim3((unsigned)mad_ceil_div(n, 256)), dim3(256), 0, ctx->stream, d_atoms, d_mass, n, P.mn[0], P.mn[1],
+                       P.mn[2], voxsp, P.margin, P.p[0], P.p[1], P.p[2], bufA);
+    const int rb = (int)std::min<size_t>(mad_ceil_div((int64_t)np_, 256), (size_t)ctx->n_cu * 2);
+    hipLaunchKernelGGL(k_max_f64, dim3(rb), dim3(256), 0, ctx->stream, bufA, np_, d_max);
+    const int gb = ctx->n_cu * 8;
+    hipLaunchKernelGGL(k_blur_axis, dim3(gb), dim3(256), 0, ctx->stream, bufA, P.p[0], P.p[1], P.p[2], 0, r, d_taps, d_max, bufB);
+    hipLaunchKernelGGL(k_blur_axis, dim3(gb), dim3(256), 0, ctx->stream, bufB, P.p[0] + 2 * r, P.p[1], P.p[2], 1, r, d_taps,
+                       (const double *)nullptr, bufA);
+    hipLaunchKernelGGL(k_blur_axis, dim3(gb), dim3(256), 0, ctx->stream, bufA, P.p[0] + 2 * r, P.p[1] + 2 * r, P.p[2], 2, r, d_taps,
+                       (const double *)nullptr, bufB);
+    hipLaunchKernelGGL(k_to_f32, dim3((unsigned)std::min<size_t>(mad_ceil_div((int64_t)no, 256), (size_t)ctx->n_cu * 2)), dim3(256), 0,
+                       ctx->stream, bufB, no, d_out, d_maxf);
+    hipLaunchKernelGGL(k_norm_f32, dim3(gb), dim3(256), 0, ctx->stream, d_out, no, d_maxf, (float)isovalue);
+}
+
+extern "C" int mad_structure_to_density(mad_ctx *ctx, const double *atoms, const double *mass, int64_t n, double resolution,
+                                        double voxsp, double isovalue, int pad, int32_t dims[3], double origin[3], float *grid) {
+    if (ctx) mad_use_lane(ctx, 0);
+    if (!ctx || !atoms || !mass || !dims || !origin || n <= 0) return ctx ? mad_fail(ctx, MAD_EINVAL, "mad_structure_to_density: bad argument") : MAD_EINVAL;
+    if (!(voxsp > 0) || !(resolution > 0) || pad < 0) return mad_fail(ctx, MAD_EINVAL, "mad_structure_to_density: resolution %g voxsp %g pad %d", resolution, voxsp, pad);
+    DensityPlan P;
+    MAD_TRY(density_plan(ctx, atoms, n, resolution, voxsp, pad, &P));
+    for (int d = 0; d < 3; d++) { dims[d] = P.dims[d]; origin[d] = P.origin[d]; }
     if (!grid) return MAD_OK;
-    if (r > 64) return mad_fail(ctx, MAD_EINVAL, "mad_structure_to_density: kernel radius %d", r);
-    const size_t np_ = (size_t)p[0] * p[1] * p[2], no = (size_t)dims[0] * dims[1] * dims[2];
-    // 1-D taps; the 3-D kernel of PDB.py:148-150 is their outer product over the cube of their sum
-    double taps[129], ts = 0;
-    for (int t = -r; t <= r; t++) { taps[t + r] = exp(-(double)(t * t) / (2.0 * sig * sig)); ts += taps[t + r]; }
-    for (int t = 0; t <= 2 * r; t++) taps[t] /= ts;
+    const size_t no = (size_t)dims[0] * dims[1] * dims[2];
+    double taps[129];
+    density_taps(P, taps);
     MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_TMP_E), (size_t)n * 24));
     MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_TMP_F), (size_t)n * 8));
     MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_TMP_H), no * 8));
@@ -452,32 +501,16 @@ extern "C" int mad_structure_to_density(mad_ctx *ctx, const double *atoms, const
     unsigned *d_maxf = (unsigned *)(scratch<char>(ctx, S_MISC) + 520);
     MAD_HIP(hipMemcpyAsync(d_atoms, atoms, (size_t)n * 24, hipMemcpyHostToDevice, ctx->stream));
     MAD_HIP(hipMemcpyAsync(d_mass, mass, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
-    MAD_HIP(hipMemcpyAsync(d_taps, taps, sizeof(double) * (2 * r + 1), hipMemcpyHostToDevice, ctx->stream));
+    MAD_HIP(hipMemcpyAsync(d_taps, taps, sizeof(double) * (2 * P.r + 1), hipMemcpyHostToDevice, ctx->stream));
     MAD_HIP(hipMemsetAsync(d_max, 0, 16, ctx->stream));
-    MAD_HIP(hipMemsetAsync(bufA, 0, np_ * 8, ctx->stream));
     mad_timer_begin(ctx, MAD_T_DENSITY);
-    hipLaunchKernelGGL(k_splat, dim3((unsigned)mad_ceil_div(n, 256)), dim3(256), 0, ctx->stream, d_atoms, d_mass, n, mn[0], mn[1],
-                       mn[2], voxsp, margin, p[0], p[1], p[2], bufA);
-    const int rb = (int)std::min<size_t>(mad_ceil_div((int64_t)np_, 256), (size_t)ctx->n_cu * 8);
-    hipLaunchKernelGGL(k_max_f64, dim3(rb), dim3(256), 0, ctx->stream, bufA, np_, d_max);
-    const int gb = ctx->n_cu * 8;
-    hipLaunchKernelGGL(k_blur_axis, dim3(gb), dim3(256), 0, ctx->stream, bufA, p[0], p[1], p[2], 0, r, d_taps, d_max, bufB);
-    hipLaunchKernelGGL(k_blur_axis, dim3(gb), dim3(256), 0, ctx->stream, bufB, p[0] + 2 * r, p[1], p[2], 1, r, d_taps,
-                       (const double *)nullptr, bufA);
-    hipLaunchKernelGGL(k_blur_axis, dim3(gb), dim3(256), 0, ctx->stream, bufA, p[0] + 2 * r, p[1] + 2 * r, p[2], 2, r, d_taps,
-                       (const double *)nullptr, bufB);
-    hipLaunchKernelGGL(k_to_f32, dim3(gb), dim3(256), 0, ctx->stream, bufB, no, d_out, d_maxf);
-    hipLaunchKernelGGL(k_norm_f32, dim3(gb), dim3(256), 0, ctx->stream, d_out, no, d_maxf, (float)isovalue);
+    density_enqueue(ctx, P, d_atoms, d_mass, n, voxsp, isovalue, d_taps, d_max, d_maxf, bufA, bufB, d_out);
     mad_timer_end(ctx, MAD_T_DENSITY);
     MAD_HIP(hipGetLastError());
     MAD_HIP(hipMemcpyAsync(grid, d_out, no * 4, hipMemcpyDeviceToHost, ctx->stream));
     MAD_HIP(hipStreamSynchronize(ctx->stream));
     return MAD_OK;
 }
-
-// ---------------------------------------------------------------------------
-// cross-correlation
-// ---------------------------------------------------------------------------
 
 __global__ void k_clamp_f32(float *__restrict__ g, size_t n, float iso) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
@@ -486,13 +519,14 @@ __global__ void k_clamp_f32(float *__restrict__ g, size_t n, float iso) {
 
 __global__ __launch_bounds__(256) void k_ccc(const float *__restrict__ g1, int a1, int a2, int s10, int s11, int s12,
                                              const float *__restrict__ g2, int b1, int b2, int s20, int s21, int s22, int e0,
-                                             int e1, int e2, double *__restrict__ acc) {
+                                             int e1, int e2, double *__restrict__ acc, float iso1) {
     __shared__ double wt[4][3];
     const size_t n = (size_t)e0 * e1 * e2;
     double o = 0, na = 0, nb = 0;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         const int z = (int)(i % e2), y = (int)((i / e2) % e1), x = (int)(i / ((size_t)e2 * e1));
-        const double a = g1[((size_t)(s10 + x) * a1 + (s11 + y)) * a2 + (s12 + z)];
+        const float a_raw = g1[((size_t)(s10 + x) * a1 + (s11 + y)) * a2 + (s12 + z)];
+        const double a = a_raw < iso1 ? 0.f : a_raw;      // grid 1 clamped on the fly (-inf: already clamped)
         const double b = g2[((size_t)(s20 + x) * b1 + (s21 + y)) * b2 + (s22 + z)];
         o += a * b; na += a * a; nb += b * b;
     }
@@ -503,6 +537,34 @@ __global__ __launch_bounds__(256) void k_ccc(const float *__restrict__ g1, int a
 }
 
 static long py_round(double v) { return (long)nearbyint(v); }      // python round(): half to even
+
+// Dmap.py:163-230: overlap box of two grids in voxel units.  Returns false when the boxes do not overlap
+// (Dmap.py:232-234); e[] may still hold a zero extent (0/0 -> NaN, as the reference).
+static bool ccc_overlap(const int32_t d1[3], const double o1[3], const int32_t d2[3], const double o2[3], double voxsp, long mn1[3],
+                        long mn2[3], long e[3]) {
+    long mx1[3], mx2[3];
+    bool empty = false;
+    for (int d = 0; d < 3; d++) {
+        const double a = o1[d] / voxsp, b = o2[d] / voxsp;
+        if (a > b) { mn1[d] = 0; mn2[d] = py_round(a - b); }
+        else if (a < b) { mn1[d] = py_round(b - a); mn2[d] = 0; }
+        else { mn1[d] = 0; mn2[d] = 0; }
+        if (a + d1[d] > b + d2[d]) { mx1[d] = py_round(b + d2[d] - a); mx2[d] = d2[d]; }
+        else if (a + d1[d] < b + d2[d]) { mx1[d] = d1[d]; mx2[d] = py_round(a + d1[d] - b); }
+        else { mx1[d] = d1[d]; mx2[d] = d2[d]; }
+        if (mx1[d] - mn1[d] < 0) empty = true;      // Dmap.py:232-234
+    }
+    e[0] = e[1] = e[2] = 0;
+    if (empty) return false;
+    for (int d = 0; d < 3; d++) {      // python slice semantics
+        const long a0 = mn1[d] < 0 ? 0 : mn1[d], a1 = mx1[d] > d1[d] ? d1[d] : mx1[d];
+        const long b0 = mn2[d] < 0 ? 0 : mn2[d], b1 = mx2[d] > d2[d] ? d2[d] : mx2[d];
+        const long ea = a1 - a0 > 0 ? a1 - a0 : 0, eb = b1 - b0 > 0 ? b1 - b0 : 0;
+        e[d] = ea < eb ? ea : eb;
+        mn1[d] = a0; mn2[d] = b0;
+    }
+    return true;
+}
 
 extern "C" int mad_ccc(mad_ctx *ctx, float *grid1, const int32_t d1[3], const double o1[3], float *grid2,
                        const int32_t d2[3], const double o2[3], double voxsp, double isovalue, double *ccc) {
@@ -523,32 +585,11 @@ extern "C" int mad_ccc(mad_ctx *ctx, float *grid1, const int32_t d1[3], const do
     // Dmap.py:160-161: both grids are clamped in place
     hipLaunchKernelGGL(k_clamp_f32, dim3(gb), dim3(256), 0, ctx->stream, g1, n1, (float)isovalue);
     hipLaunchKernelGGL(k_clamp_f32, dim3(gb), dim3(256), 0, ctx->stream, g2, n2, (float)isovalue);
-    // Dmap.py:163-230 overlap box in voxel units
-    long mn1[3], mn2[3], mx1[3], mx2[3];
-    bool empty = false;
-    for (int d = 0; d < 3; d++) {
-        const double a = o1[d] / voxsp, b = o2[d] / voxsp;
-        if (a > b) { mn1[d] = 0; mn2[d] = py_round(a - b); }
-        else if (a < b) { mn1[d] = py_round(b - a); mn2[d] = 0; }
-        else { mn1[d] = 0; mn2[d] = 0; }
-        if (a + d1[d] > b + d2[d]) { mx1[d] = py_round(b + d2[d] - a); mx2[d] = d2[d]; }
-        else if (a + d1[d] < b + d2[d]) { mx1[d] = d1[d]; mx2[d] = py_round(a + d1[d] - b); }
-        else { mx1[d] = d1[d]; mx2[d] = d2[d]; }
-        if (mx1[d] - mn1[d] < 0) empty = true;      // Dmap.py:232-234
-    }
-    long e[3] = {0, 0, 0};
-    if (!empty) {
-        for (int d = 0; d < 3; d++) {      // python slice semantics
-            const long a0 = mn1[d] < 0 ? 0 : mn1[d], a1 = mx1[d] > d1[d] ? d1[d] : mx1[d];
-            const long b0 = mn2[d] < 0 ? 0 : mn2[d], b1 = mx2[d] > d2[d] ? d2[d] : mx2[d];
-            const long ea = a1 - a0 > 0 ? a1 - a0 : 0, eb = b1 - b0 > 0 ? b1 - b0 : 0;
-            e[d] = ea < eb ? ea : eb;
-            mn1[d] = a0; mn2[d] = b0;
-        }
-        if (e[0] > 0 && e[1] > 0 && e[2] > 0)
-            hipLaunchKernelGGL(k_ccc, dim3(gb), dim3(256), 0, ctx->stream, g1, d1[1], d1[2], (int)mn1[0], (int)mn1[1], (int)mn1[2],
-                               g2, d2[1], d2[2], (int)mn2[0], (int)mn2[1], (int)mn2[2], (int)e[0], (int)e[1], (int)e[2], acc);
-    }
+    long mn1[3], mn2[3], e[3];
+    const bool empty = !ccc_overlap(d1, o1, d2, o2, voxsp, mn1, mn2, e);
+    if (!empty && e[0] > 0 && e[1] > 0 && e[2] > 0)
+        hipLaunchKernelGGL(k_ccc, dim3(gb), dim3(256), 0, ctx->stream, g1, d1[1], d1[2], (int)mn1[0], (int)mn1[1], (int)mn1[2],
+                           g2, d2[1], d2[2], (int)mn2[0], (int)mn2[1], (int)mn2[2], (int)e[0], (int)e[1], (int)e[2], acc, -INFINITY);
     mad_timer_end(ctx, MAD_T_CCC);
     MAD_HIP(hipGetLastError());
     double h[3] = {0, 0, 0};
@@ -558,5 +599,75 @@ extern "C" int mad_ccc(mad_ctx *ctx, float *grid1, const int32_t d1[3], const do
     MAD_HIP(hipStreamSynchronize(ctx->stream));
     if (empty) { *ccc = 0.0; return MAD_OK; }
     *ccc = h[0] / sqrt(h[1] * h[2]);      // 0/0 -> NaN for an empty but non-inverted box, as the reference
+    return MAD_OK;
+}
+
+// a14-a16 for a batch of placed copies of one structure, without leaving the device: each candidate's atoms are
+// turned into a simulated density (PDB.structure_to_density, PDB.py:131-208) and scored against the map uploaded with
+// mad_upload_density (Dmap.get_CCC_with_grid, Dmap.py:153-258: both grids clamped at ccc_isovalue -- the map on the
+// fly, so the uploaded copy stays as it was).  One read-back of 3 sums per candidate at the end.
+extern "C" int mad_density_ccc(mad_ctx *ctx, const double *atoms, const double *mass, int n_cand, int64_t n, double resolution,
+                               double density_isovalue, double ccc_isovalue, double *ccc) {
+    if (ctx) mad_use_lane(ctx, 0);
+    if (!ctx || !atoms || !mass || !ccc || n_cand < 0 || n <= 0) return ctx ? mad_fail(ctx, MAD_EINVAL, "mad_density_ccc: bad argument") : MAD_EINVAL;
+    if (!ctx->dens.grid) return mad_fail(ctx, MAD_EINVAL, "mad_density_ccc: call mad_upload_density first");
+    if (!(resolution > 0)) return mad_fail(ctx, MAD_EINVAL, "mad_density_ccc: resolution %g", resolution);
+    if (n_cand == 0) return MAD_OK;
+    if (n_cand > 4096) return mad_fail(ctx, MAD_EINVAL, "mad_density_ccc: %d candidates in one call", n_cand);
+    const DensityDev &M = ctx->dens;
+    const double voxsp = M.vs;
+    std::vector<DensityPlan> plans(n_cand);
+    size_t no_max = 0;
+    for (int c = 0; c < n_cand; c++) {
+        MAD_TRY(density_plan(ctx, atoms + (size_t)c * n * 3, n, resolution, voxsp, 0, &plans[c]));
+        no_max = std::max(no_max, (size_t)plans[c].dims[0] * plans[c].dims[1] * plans[c].dims[2]);
+    }
+    double taps[129];
+    density_taps(plans[0], taps);      // sigma and radius do not depend on the candidate
+    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_TMP_E), (size_t)n_cand * n * 24));
+    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_TMP_F), (size_t)n * 8));
+    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_TMP_H), no_max * 8));
+    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_TMP_I), no_max * 8));
+    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_TMP_J), no_max * 4));
+    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_TMP_G), (size_t)n_cand * 64 + 2048));
+    double *d_atoms = scratch<double>(ctx, S_TMP_E), *d_mass = scratch<double>(ctx, S_TMP_F);
+    double *bufA = scratch<double>(ctx, S_TMP_H), *bufB = scratch<double>(ctx, S_TMP_I);
+    float *d_out = scratch<float>(ctx, S_TMP_J);
+    // per candidate 64 bytes: {max of the splat (double), pad, max of the float32 grid (uint), pad, 3 sums}; then the taps
+    char *blk = scratch<char>(ctx, S_TMP_G);
+    double *d_taps = (double *)(blk + (size_t)n_cand * 64);
+    MAD_HIP(hipMemcpyAsync(d_atoms, atoms, (size_t)n_cand * n * 24, hipMemcpyHostToDevice, ctx->stream));
+    MAD_HIP(hipMemcpyAsync(d_mass, mass, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+    MAD_HIP(hipMemcpyAsync(d_taps, taps, sizeof(double) * (2 * plans[0].r + 1), hipMemcpyHostToDevice, ctx->stream));
+    mad_zero_words(ctx, blk, (size_t)n_cand * 64);
+    const int gb = ctx->n_cu * 8;
+    const int32_t d1[3] = {M.nx, M.ny, M.nz};
+    std::vector<char> is_empty(n_cand, 0);
+    for (int c = 0; c < n_cand; c++) {
+        const DensityPlan &P = plans[c];
+        double *d_max = (double *)(blk + (size_t)c * 64);
+        unsigned *d_maxf = (unsigned *)(blk + (size_t)c * 64 + 16);
+        double *acc = (double *)(blk + (size_t)c * 64 + 32);
+        mad_timer_begin(ctx, MAD_T_DENSITY);
+        density_enqueue(ctx, P, d_atoms + (size_t)c * n * 3, d_mass, n, voxsp, density_isovalue, d_taps, d_max, d_maxf, bufA, bufB, d_out);
+        mad_timer_end(ctx, MAD_T_DENSITY);
+        const size_t no = (size_t)P.dims[0] * P.dims[1] * P.dims[2];
+        const int32_t d2[3] = {P.dims[0], P.dims[1], P.dims[2]};
+        long mn1[3], mn2[3], e[3];
+        const bool empty = !ccc_overlap(d1, M.o, d2, P.origin, voxsp, mn1, mn2, e);
+        is_empty[c] = empty ? 1 : 0;
+        mad_timer_begin(ctx, MAD_T_CCC);
+        hipLaunchKernelGGL(k_clamp_f32, dim3(gb), dim3(256), 0, ctx->stream, d_out, no, (float)ccc_isovalue);
+        if (!empty && e[0] > 0 && e[1] > 0 && e[2] > 0)
+            hipLaunchKernelGGL(k_ccc, dim3(gb), dim3(256), 0, ctx->stream, (const float *)M.grid, d1[1], d1[2], (int)mn1[0], (int)mn1[1],
+                               (int)mn1[2], (const float *)d_out, d2[1], d2[2], (int)mn2[0], (int)mn2[1], (int)mn2[2], (int)e[0], (int)e[1],
+                               (int)e[2], acc, (float)ccc_isovalue);
+        mad_timer_end(ctx, MAD_T_CCC);
+    }
+    MAD_HIP(hipGetLastError());
+    std::vector<double> h((size_t)n_cand * 8);
+    MAD_HIP(hipMemcpyAsync(h.data(), blk, (size_t)n_cand * 64, hipMemcpyDeviceToHost, ctx->stream));
+    MAD_HIP(hipStreamSynchronize(ctx->stream));
+    for (int c = 0; c < n_cand; c++) ccc[c] = is_empty[c] ? 0.0 : h[(size_t)c * 8 + 4] / sqrt(h[(size_t)c * 8 + 5] * h[(size_t)c * 8 + 6]);
     return MAD_OK;
 }

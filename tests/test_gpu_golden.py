@@ -184,6 +184,27 @@ def test_density_ccc_against_reference(lib):
         assert abs(got - ref) <= 1e-5 * max(abs(ref), 1e-3)      # north_star tolerance: 1e-5 relative
 
 
+def test_density_ccc_batch_on_device(lib):
+    """mad_density_ccc (density simulation + CCC of a batch of placed copies without leaving the device) against the
+    reference's CCC values (atoms shifted by whole voxels = the reference's shifted origin) and against the
+    stage-by-stage path."""
+    g = load("g7_density_ccc.npz")
+    vs = float(g["map_vs"])
+    assert vs == float(g["vs"])
+    m = synth.masses([str(e) for e in g["elements"]])
+    shifts = g["ccc_shifts"]
+    assert np.allclose(shifts[:3] / vs, np.round(shifts[:3] / vs)) and g["ccc"][3] == 0      # the last one leaves the map
+    lib.upload_density(g["map_grid"], g["map_origin"], vs)
+    cands = np.stack([g["atoms"] + sh for sh in shifts] + [g["atoms"] + np.array([0.37, -0.81, 1.13])])
+    got = lib.density_ccc(cands, m, float(g["res"]))
+    for v, ref in zip(got[:len(shifts)], g["ccc"]):
+        assert abs(v - ref) <= 1e-5 * max(abs(ref), 1e-3)      # north_star tolerance: 1e-5 relative
+    for c, v in zip(cands, got):
+        dens, x0, y0, z0 = lib.structure_to_density(c, m, float(g["res"]), vs)
+        ref = lib.ccc(g["map_grid"].copy(), g["map_origin"], dens, np.array([x0, y0, z0]), vs)
+        assert abs(v - ref) <= 1e-12 * max(abs(ref), 1.0)
+
+
 def test_pdb_and_dmap_classes(default_lib, tmp_path):
     from mad_amd.Dmap import Dmap
     from mad_amd.PDB import PDB
