@@ -30,7 +30,7 @@ from .MapSpace import MapSpace
 from .math_utils import get_rototrans_SVD
 from .Orientator import Orientator
 from .PDB import PDB
-from .structure_utils import move_copy_structure, refine_many
+from .structure_utils import ccc_many, move_copy_structure, refine_many
 
 try:      # optional: the reference's cache format
     import h5py
@@ -385,7 +385,9 @@ class MaD(object):
                 sol.set_coords(xyz)
                 refined.append([sol, moved[dist < dmap.voxsp * 2], repeat, weight, clustered])
         final = []
-        for sol, corresp, repeat, weight, clustered in refined:
+        # density simulation + CCC of every surviving placement in one device-resident batch (MaD.py:613-616)
+        cccs = ccc_many(dmap, np.stack([r[0].coords for r in refined]), hi_pdb.atom_masses(), self.resolution) if refined else []
+        for (sol, corresp, repeat, weight, clustered), ccc in zip(refined, cccs):
             if final:
                 rmsds = [sol.get_rmsdCA_with(f[0]) for f in final]
                 if np.min(rmsds) < 6:      # a clone of an earlier solution: merge (MaD.py:609-612)
@@ -393,9 +395,7 @@ class MaD(object):
                     final[j][3] += weight
                     final[j][5].extend(clustered)
                     continue
-            grid, sx, sy, sz = sol.structure_to_density(self.resolution, dmap.voxsp)
-            ccc = dmap.get_CCC_with_grid(grid, sx, sy, sz)
-            final.append([sol, corresp, repeat, weight, ccc, clustered])
+            final.append([sol, corresp, repeat, weight, float(ccc), clustered])
         for sol in final:
             sol.append(sol[2] * sol[3] * sol[4])
         return sorted(final, key=itemgetter(-1), reverse=True)

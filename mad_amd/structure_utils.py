@@ -52,6 +52,18 @@ def refine_many(dmap, start_coords, n_steps=500, max_step_size=0.5, min_step_siz
     return lib.refine(np.asarray(start_coords, dtype=np.float64), n_steps=n_steps, max_step=max_step_size, min_step=min_step_size)
 
 
+def ccc_many(dmap, coords, masses, resolution, isovalue=0):
+    """CCC of the simulated densities of several placements of one structure with `dmap`: what
+    `pdb.structure_to_density(resolution, dmap.voxsp)` + `dmap.get_CCC_with_grid(grid, x0, y0, z0, isovalue)` give
+    one placement at a time (MaD.py:613-616), in one device-resident batch (`mad_density_ccc`).  Like the
+    reference's get_CCC_with_grid, the map is left clamped at the isovalue (Dmap.py:160)."""
+    lib = _lib.get_lib()
+    _ensure_density(lib, dmap)
+    out = lib.density_ccc(np.asarray(coords, dtype=np.float64), masses, resolution, 0.0, isovalue)
+    dmap.grid3d[dmap.grid3d < isovalue] = 0
+    return out
+
+
 def move_structure(original_struct, t=None, a=0.375, b=1.735, c=2.452, suffix=""):
     moved = original_struct.replace(".pdb", "_moved%s.pdb" % suffix)
     pdb = PDB(original_struct)
