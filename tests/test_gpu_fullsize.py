@@ -1,0 +1,69 @@
+"""The hot path at BASELINE.json's full sizes (configs[1] = 128^3, configs[2] = 256^3), checked through properties
+that do not need the CPU oracle to finish: descriptor invariants, pair-list order, top-k = stable sort of the match
+counts, determinism, and recovery of the planted poses (the best pose of every subunit, turned into a simulated
+density, correlates with the map).  Inputs come from bench.py's generator, i.e. the benchmark's own workload."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("workload", ["c2", "c3"])
+def test_full_size_properties(lib, workload):
+    import bench
+    from mad_amd import _lib
+    from mad_amd.eqsp import EQSP_Sphere
+    from mad_amd.orient_tables import orientation_matrices
+    e112, e16 = EQSP_Sphere(112), EQSP_Sphere(16)
+    dom, adj = orientation_matrices(e112)
+    lib.set_eqsp(0, e112.sphere_eqsp, dom, adj)
+    lib.set_eqsp(1, e16.sphere_eqsp)
+    W = bench.WORKLOADS[workload]
+    cc, dist, k = 0.6, 4.0, 60
+    the_map, subs, _ = bench.build_inputs(lib, W, 0)
+    assert the_map.shape == (W["N"],) * 3
+    sets = [_lib.DeviceSet(lib) for _ in range(1 + len(subs))]
+    try:
+        corr, tops, stats = bench.hot_path_step(lib, the_map, subs, cc, dist, k, sets)
+        corr2, tops2, _ = bench.hot_path_step(lib, the_map, subs, cc, dist, k, sets)
+        assert corr == corr2 and corr == sum(s["n_hi"] * s["n_lo"] for s in stats)
+        for a, b in zip(tops, tops2):      # determinism: atomics only ever feed order-independent sums
+            np.testing.assert_array_equal(a, b)
+        # descriptor invariants (Descriptor.py:193-198): counts of <= 64 samples per sub-cube, <= 4096 per row
+        for s in sets:
+            rows = s.download()
+            d = rows["dsc"].astype(np.int64)
+            assert d.min() >= 0 and d.max() <= 64 and d.sum(1).max() <= 4096
+            assert np.all(np.diff(rows["anchor"]) >= 0)      # rows in anchor order (Orientator.py:80-108)
+            Rt = rows["R"] @ np.swapaxes(rows["R"], 1, 2)
+            np.testing.assert_allclose(Rt, np.broadcast_to(np.eye(3), Rt.shape), atol=1e-12)
+        # one match in detail: pair list, counts, top-k
+        hi, lo = sets[1], sets[0]
+        top, idx, st = lib.match_topk(hi, lo, cc, dist, k)
+        np.testing.assert_array_equal(top, tops[0])
+        ph, pl, ps, cnt = lib.match_fetch(st["n_pairs"])
+        key = ph.astype(np.int64) * (lo.size()[0] + 1) + pl
+        assert np.all(np.diff(key) > 0)                      # row-major, no duplicates (np.where, MaD.py:423)
+        assert ps.min() > cc and ps.max() <= 1.0 + 1e-12
+        assert cnt.min() >= 0 and cnt.max() <= st["l_hi"]
+        order = np.lexsort((np.arange(len(cnt)), -cnt.astype(np.int64)))[:k]      # python's stable sort, MaD.py:480
+        np.testing.assert_array_equal(idx, order)
+        np.testing.assert_allclose(top[:, 1], 100.0 * cnt[order] / st["l_hi"], rtol=0, atol=1e-12)
+        np.testing.assert_array_equal(top[:, 0], ps[order])
+        # the planted poses come back: best pose of every subunit -> simulated density -> CCC with the map
+        lib.upload_density(the_map.grid, the_map.origin, W["vs"])
+        for sub, t in zip(subs, tops):
+            R = t[0, 14:23].reshape(3, 3)
+            placed = (sub.atoms - t[0, 8:11]) @ R.T + t[0, 11:14]
+            assert lib.density_ccc(placed[None], sub.mass, W["res"])[0] > 0.85
+    finally:
+        for s in sets:
+            s.close()
+        for st_ in [the_map] + subs:
+            st_.ms.release_device()
