@@ -38,6 +38,7 @@ WORKLOADS = {
     # name: map size N, voxel spacing, resolution, subunits per rank, atoms per subunit, globule radius, lattice
     "c3": dict(N=256, vs=1.2, res=7.0, n_sub=4, n_atoms=26000, radius=46.0, grid=(2, 2, 1), desc="C3: 256^3 map, 4 subunits, EQSP-112/16"),
     "c2": dict(N=128, vs=1.5, res=8.0, n_sub=4, n_atoms=14000, radius=34.0, grid=(2, 2, 1), desc="C2: 128^3 tetramer map"),
+    "c5": dict(N=512, vs=1.0, res=6.0, n_sub=12, n_atoms=26000, radius=46.0, grid=(3, 2, 2), desc="C5: 512^3 map, 12 subunits, EQSP-112/16"),
     "small": dict(N=64, vs=2.0, res=10.0, n_sub=2, n_atoms=1500, radius=16.0, grid=(2, 1, 1), desc="C1: 64^3 dimer map"),
 }
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec

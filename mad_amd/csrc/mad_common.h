@@ -105,6 +105,8 @@ struct mad_ctx {
     hipStream_t stream = nullptr;            // the stream of the current lane (lane_stream[lane])
     hipStream_t lane_stream[MAD_LANES] = {};      // [0] is the stream mad_stream() reports
     int next_set_lane = 0;
+    hipEvent_t lane_built[MAD_LANES] = {};   // recorded behind the last set build enqueued on each lane
+    bool lane_has_build[MAD_LANES] = {};
     bool overlap = true;                      // false: every lane enqueues on lane_stream[0] (kernels run one at a time)
     char err[512] = {0};
     FieldDev fields[MAD_MAX_FIELDS];
@@ -172,7 +174,7 @@ enum {
     S_PAIR_HI, S_PAIR_LO, S_PAIR_SCORE, S_COUNTS, S_USED_HI, S_USED_LO, S_HI_CLOUD, S_MISC,
     S_HIST, S_SEL, S_RESULTS, S_TMP_A, S_TMP_B, S_TMP_C, S_TMP_D, S_TMP_E, S_TMP_F, S_TMP_G,
     S_TIE_FLAG, S_TIE_OFF, S_SEL_OUT, S_TMP_H, S_TMP_I, S_TMP_J,
-    S_CELL_START, S_CELL_PTS, S_CELL_IDS, S_PG_START, S_PG_PTS, S_ZERO, S_CMASK, S_N_SLOTS
+    S_CELL_START, S_CELL_PTS, S_CELL_IDS, S_PG_START, S_PG_PTS, S_PG_PTSF, S_ZERO, S_CMASK, S_N_SLOTS
 };
 static_assert(S_N_SLOTS <= 64, "grow mad_ctx::scratch");
 

@@ -333,7 +333,7 @@ __device__ __forceinline__ int pg_cell(double v, double mn, double inv, int dim)
 // one workgroup: counting sort of the used points into cells; sorted points and offsets to global
 __global__ __launch_bounds__(1024) void k_pose_grid_build(const double *__restrict__ pts, const uint8_t *__restrict__ used, int n,
                                                           PoseGrid G, int32_t *__restrict__ cell_start, double *__restrict__ sorted,
-                                                          int32_t *__restrict__ n_used) {
+                                                          float4 *__restrict__ sorted_f, int32_t *__restrict__ n_used) {
     extern __shared__ __align__(16) unsigned char smem[];
     int *cnt = (int *)smem;
     __shared__ int wt[17];
@@ -368,6 +368,9 @@ __global__ __launch_bounds__(1024) void k_pose_grid_build(const double *__restri
                           pg_cell(pts[3 * i + 2], G.mn[2], G.inv_cell[2], G.dim[2]);
             const int o = atomicAdd(&cnt[c], 1);
             sorted[3 * o] = pts[3 * i]; sorted[3 * o + 1] = pts[3 * i + 1]; sorted[3 * o + 2] = pts[3 * i + 2];
+            // float32 copy relative to the grid origin: what the candidate filter of k_pose_lds32 reads
+            if (sorted_f)
+                sorted_f[o] = make_float4((float)(pts[3 * i] - G.mn[0]), (float)(pts[3 * i + 1] - G.mn[1]), (float)(pts[3 * i + 2] - G.mn[2]), 0.f);
         }
 }
 
@@ -438,6 +441,103 @@ __global__ __launch_bounds__(POSE_LDS_THREADS) void k_pose_lds(const int32_t *__
                     const int q = t + (t < n0 ? s[0] : (t < n1 ? b1 : (t < n2 ? b2 : b3)));
                     const double e0 = lp[3 * q] - x, e1 = lp[3 * q + 1] - y, e2 = lp[3 * q + 2] - z;
                     hit = (e0 * e0 + e1 * e1 + e2 * e2) < dd_lim;      // MaD.py:447-448
+                }
+            }
+            cnt += hit ? 1 : 0;
+        }
+        cnt = wave_sum_i32(cnt);
+        if (lane == 0) counts[p] = cnt;
+    }
+}
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// The same search for lo clouds too large for float64 points in LDS (maps of ~512^3: 5 000+ anchors).  The lo points
+// sit in LDS as float32 offsets from the grid origin (16 B each) and the hi cloud is read from global memory (a
+// coalesced, cache-resident stream).  Candidates are tested in two tiers, two per iteration in packed float32
+// (v_pk_add / v_pk_fma): d2 < lim_in decides "within dist", d2 > lim_out decides "outside"; lim_in / lim_out bracket
+// dist^2 by a margin far above the float32 error of the offsets (host: pose_device).  Only a candidate whose float32
+// distance falls inside that band (about one sample in 10^4) is re-evaluated with the reference's float64 expression
+// on the float64 point in global memory, so the count is the float64 count.  On clouds that fit both kernels this one
+// is ~20 % slower than k_pose_lds, and ~10 x faster than the global cell list it replaces for the big ones.
+__global__ __launch_bounds__(POSE_LDS_THREADS) void k_pose_lds32(const int32_t *__restrict__ pair_hi, const int32_t *__restrict__ pair_lo,
+                                                                 const int32_t *__restrict__ status, int64_t cap_pairs,
+                                                                 const double *__restrict__ hi_p, const double *__restrict__ hi_R,
+                                                                 const double *__restrict__ lo_p, const double *__restrict__ lo_Rinv,
+                                                                 const int32_t *__restrict__ hi_row_anchor,
+                                                                 const int32_t *__restrict__ lo_row_anchor,
+                                                                 const double *__restrict__ hi_cloud, const double *__restrict__ lo_sorted,
+                                                                 const float4 *__restrict__ lo_sorted_f,
+                                                                 const int32_t *__restrict__ cell_start, PoseGrid G, int l_lo_cap,
+                                                                 float reach, double dd_lim, float lim_in, float lim_out,
+                                                                 int32_t *__restrict__ counts) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    if (status[ST_FLAG_C] || status[ST_FLAG_PAIRS]) return;
+    float4 *lpf = (float4 *)smem;                                  // sorted lo cloud, float32 offsets from G.mn
+    unsigned short *cs = (unsigned short *)(lpf + l_lo_cap + 1);   // cell offsets
+    const int64_t n_pairs = min((int64_t)status[ST_NPAIRS], cap_pairs);
+    const int l_hi = status[ST_LHI];
+    const int l_lo = cell_start[G.ncell];
+    for (int i = threadIdx.x; i < l_lo; i += POSE_LDS_THREADS) lpf[i] = lo_sorted_f[i];
+    if (threadIdx.x == 0) lpf[l_lo] = make_float4(1e30f, 1e30f, 1e30f, 0.f);      // pad: the odd partner of a run's last point
+    for (int i = threadIdx.x; i <= G.ncell; i += POSE_LDS_THREADS) cs[i] = (unsigned short)cell_start[i];
+    __syncthreads();
+    const int lane = lane_id();
+    const int64_t wave = (int64_t)blockIdx.x * (POSE_LDS_THREADS / MAD_WAVE) + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * (POSE_LDS_THREADS / MAD_WAVE);
+    for (int64_t p = wave; p < n_pairs; p += nwaves) {
+        const int ih = pair_hi[p], il = pair_lo[p];
+        double R[9];      // R = inv(lo.Rfinal) @ hi.Rfinal (MaD.py:438)
+        mat3_mul(lo_Rinv + 9 * il, hi_R + 9 * ih, R);
+        const int ah = hi_row_anchor ? hi_row_anchor[ih] : ih, al = lo_row_anchor ? lo_row_anchor[il] : il;
+        const double ph0 = hi_p[3 * ah], ph1 = hi_p[3 * ah + 1], ph2 = hi_p[3 * ah + 2];
+        const double pl0 = lo_p[3 * al], pl1 = lo_p[3 * al + 1], pl2 = lo_p[3 * al + 2];
+        int cnt = 0;
+        for (int a = lane; a < l_hi; a += MAD_WAVE) {
+            const double d0 = hi_cloud[3 * a] - ph0, d1 = hi_cloud[3 * a + 1] - ph1, d2 = hi_cloud[3 * a + 2] - ph2;
+            const double x = (d0 * R[0] + d1 * R[1] + d2 * R[2]) + pl0;      // MaD.py:440-444
+            const double y = (d0 * R[3] + d1 * R[4] + d2 * R[5]) + pl1;
+            const double z = (d0 * R[6] + d1 * R[7] + d2 * R[8]) + pl2;
+            // offsets from the grid origin, rounded once to float32
+            const float xf = (float)(x - G.mn[0]), yf = (float)(y - G.mn[1]), zf = (float)(z - G.mn[2]);
+            // cells met by a slightly larger ball (reach = dist + 0.01), in float32: a superset is harmless
+            const int x0 = (int)floorf((xf - reach) * G.inv_cell_f[0]), x1 = (int)floorf((xf + reach) * G.inv_cell_f[0]);
+            const int y0 = (int)floorf((yf - reach) * G.inv_cell_f[1]), y1 = (int)floorf((yf + reach) * G.inv_cell_f[1]);
+            const int z0 = (int)floorf((zf - reach) * G.inv_cell_f[2]), z1 = (int)floorf((zf + reach) * G.inv_cell_f[2]);
+            bool hit = false;
+            if (x1 >= 0 && x0 < G.dim[0] && y1 >= 0 && y0 < G.dim[1] && z1 >= 0 && z0 < G.dim[2]) {
+                const int zz0 = max(z0, 0), zz1 = min(z1, G.dim[2] - 1) + 1;
+                const int xa = max(x0, 0), xb = min(x1, G.dim[0] - 1), ya = max(y0, 0), yb = min(y1, G.dim[1] - 1);
+                const int c00 = (xa * G.dim[1] + ya) * G.dim[2], c01 = (xa * G.dim[1] + yb) * G.dim[2];
+                const int c10 = (xb * G.dim[1] + ya) * G.dim[2], c11 = (xb * G.dim[1] + yb) * G.dim[2];
+                int s[4], e[4];
+                s[0] = cs[c00 + zz0]; e[0] = cs[c00 + zz1];
+                s[1] = cs[c01 + zz0]; e[1] = (yb != ya) ? cs[c01 + zz1] : s[1];
+                s[2] = cs[c10 + zz0]; e[2] = (xb != xa) ? cs[c10 + zz1] : s[2];
+                s[3] = cs[c11 + zz0]; e[3] = (xb != xa && yb != ya) ? cs[c11 + zz1] : s[3];
+                // one loop over the concatenation of the four runs, two candidates (a "slot") per iteration
+                const int m0 = (e[0] - s[0] + 1) >> 1, m1 = m0 + ((e[1] - s[1] + 1) >> 1), m2 = m1 + ((e[2] - s[2] + 1) >> 1),
+                          m3 = m2 + ((e[3] - s[3] + 1) >> 1);
+                for (int t = 0; t < m3 && !hit; t++) {
+                    const int c = t < m0 ? 0 : (t < m1 ? 1 : (t < m2 ? 2 : 3));
+                    const int q = (c == 0 ? s[0] + 2 * t : (c == 1 ? s[1] + 2 * (t - m0) : (c == 2 ? s[2] + 2 * (t - m1) : s[3] + 2 * (t - m2))));
+                    const int qe = c == 0 ? e[0] : (c == 1 ? e[1] : (c == 2 ? e[2] : e[3]));
+                    const float4 pa = lpf[q], pb = lpf[q + 1];      // q + 1 may belong to the next cell (or be the pad): masked below
+                    const v2f ex = (v2f){pa.x, pb.x} - xf, ey = (v2f){pa.y, pb.y} - yf, ez = (v2f){pa.z, pb.z} - zf;
+                    const v2f dd = __builtin_elementwise_fma(ez, ez, __builtin_elementwise_fma(ey, ey, ex * ex));
+                    const bool vb = q + 1 < qe;
+                    hit = dd.x < lim_in || (vb && dd.y < lim_in);
+                    if (!hit && ((dd.x <= lim_out) || (vb && dd.y <= lim_out))) {
+                        // inside the band: the reference's float64 expression (MaD.py:447-448)
+                        if (dd.x <= lim_out) {
+                            const double e0 = lo_sorted[3 * q] - x, e1 = lo_sorted[3 * q + 1] - y, e2 = lo_sorted[3 * q + 2] - z;
+                            hit = (e0 * e0 + e1 * e1 + e2 * e2) < dd_lim;
+                        }
+                        if (!hit && vb && dd.y <= lim_out) {
+                            const double e0 = lo_sorted[3 * q + 3] - x, e1 = lo_sorted[3 * q + 4] - y, e2 = lo_sorted[3 * q + 5] - z;
+                            hit = (e0 * e0 + e1 * e1 + e2 * e2) < dd_lim;
+                        }
+                    }
                 }
             }
             cnt += hit ? 1 : 0;
@@ -856,22 +956,42 @@ static int pose_device(mad_ctx *ctx, const Side &hi, const Side &lo, int32_t *d_
         G.ncell *= G.dim[d];
     }
     const size_t lds = (size_t)(l_hi_max + n_cloud) * 24 + (size_t)(G.ncell + 1) * 2 + 16;
-    if (!fallback && lds <= 150 * 1024 && n_cloud < 65535 && G.ncell <= 30000) {
+    const size_t lds32 = (size_t)(n_cloud + 1) * 16 + (size_t)(G.ncell + 1) * 2 + 16;
+    // float32 tier of k_pose_lds32: offsets from the grid origin are below M = extent + reach, each rounded once (error
+    // <= ulp(M) / 2); a squared distance near dist^2 is then off by < 2 sqrt(3) (dist + 1) ulp(M) plus ~1e-5 of float32
+    // arithmetic.  The band is 4 x that bound.
+    double M = reach;
+    for (int d = 0; d < 3; d++) M = std::max(M, bb_max[d] - bb_min[d] + 2.0 * reach);
+    const double ulpM = ldexp(1.0, (int)ceil(log2(M)) - 23);
+    const double band = 4.0 * (2.0 * sqrt(3.0) * (dist + 1.0) * ulpM + 1e-5 * dist * dist);
+    const float lim_in = nextafterf((float)(dist * dist - band), 0.f), lim_out = nextafterf((float)(dist * dist + band), 1e30f);
+    const bool fits64 = lds <= 150 * 1024, fits32 = lds32 <= 150 * 1024 && lim_in > 0.f;
+    if (!fallback && (fits64 || fits32) && n_cloud < 65535 && G.ncell <= 30000) {
         MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_PG_START), (size_t)(G.ncell + 2) * 4));
-        MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_PG_PTS), (size_t)(n_cloud + 1) * 24));
+        MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_PG_PTS), (size_t)(n_cloud + 2) * 24));
+        if (!fits64) MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_PG_PTSF), (size_t)(n_cloud + 2) * 16));
         static bool attr_set = false;
         if (!attr_set) {
+            MAD_HIP(hipFuncSetAttribute((const void *)k_pose_lds32, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             MAD_HIP(hipFuncSetAttribute((const void *)k_pose_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             MAD_HIP(hipFuncSetAttribute((const void *)k_pose_grid_build, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
             attr_set = true;
         }
         mad_timer_begin(ctx, MAD_T_POSE);
         hipLaunchKernelGGL(k_pose_grid_build, dim3(1), dim3(1024), (size_t)G.ncell * 4, ctx->stream, d_cloud, d_cloud_used, n_cloud, G,
-                           scratch<int32_t>(ctx, S_PG_START), scratch<double>(ctx, S_PG_PTS), d_status + ST_LLO);
-        hipLaunchKernelGGL(k_pose_lds, dim3(ctx->n_cu * 2), dim3(POSE_LDS_THREADS), lds, ctx->stream, scratch<int32_t>(ctx, S_PAIR_HI),
-                           scratch<int32_t>(ctx, S_PAIR_LO), d_status, cap_pairs, hi.p, hi.R, lo.p, lo.Rinv, hi.row_anchor,
-                           lo.row_anchor, d_hi_cloud, scratch<double>(ctx, S_PG_PTS), scratch<int32_t>(ctx, S_PG_START), G,
-                           l_hi_max, n_cloud, (float)reach, dd_lim, scratch<int32_t>(ctx, S_COUNTS));
+                           scratch<int32_t>(ctx, S_PG_START), scratch<double>(ctx, S_PG_PTS),
+                           fits64 ? (float4 *)nullptr : scratch<float4>(ctx, S_PG_PTSF), d_status + ST_LLO);
+        if (fits64)
+            hipLaunchKernelGGL(k_pose_lds, dim3(ctx->n_cu * 2), dim3(POSE_LDS_THREADS), lds, ctx->stream, scratch<int32_t>(ctx, S_PAIR_HI),
+                               scratch<int32_t>(ctx, S_PAIR_LO), d_status, cap_pairs, hi.p, hi.R, lo.p, lo.Rinv, hi.row_anchor,
+                               lo.row_anchor, d_hi_cloud, scratch<double>(ctx, S_PG_PTS), scratch<int32_t>(ctx, S_PG_START), G,
+                               l_hi_max, n_cloud, (float)reach, dd_lim, scratch<int32_t>(ctx, S_COUNTS));
+        else
+            hipLaunchKernelGGL(k_pose_lds32, dim3(ctx->n_cu), dim3(POSE_LDS_THREADS), lds32, ctx->stream, scratch<int32_t>(ctx, S_PAIR_HI),
+                               scratch<int32_t>(ctx, S_PAIR_LO), d_status, cap_pairs, hi.p, hi.R, lo.p, lo.Rinv, hi.row_anchor,
+                               lo.row_anchor, d_hi_cloud, scratch<double>(ctx, S_PG_PTS), scratch<float4>(ctx, S_PG_PTSF),
+                               scratch<int32_t>(ctx, S_PG_START), G, n_cloud, (float)reach, dd_lim, lim_in, lim_out,
+                               scratch<int32_t>(ctx, S_COUNTS));
         mad_timer_end(ctx, MAD_T_POSE);
         MAD_HIP(hipGetLastError());
         return MAD_OK;
@@ -896,7 +1016,7 @@ static int pose_device(mad_ctx *ctx, const Side &hi, const Side &lo, int32_t *d_
 }
 
 static bool clouds_fit_lds(int64_t l_hi, int64_t l_lo) {      // with the largest cell table (30 000 cells)
-    return (size_t)(l_hi + l_lo) * 24 + 60016 <= 150 * 1024 && l_lo < 65535;
+    return ((size_t)(l_hi + l_lo) * 24 + 60016 <= 150 * 1024 || (size_t)(l_lo + 1) * 16 + 60016 <= 150 * 1024) && l_lo < 65535;
 }
 
 static int32_t *status_words(mad_ctx *ctx) {      // inside S_MISC
@@ -1247,6 +1367,8 @@ extern "C" int mad_set_build(mad_ctx *ctx, mad_set *s, const int *slot_of_octave
     s->last_f[0] = f[0]; s->last_f[1] = f[1]; s->last_r = r;
     s->n_rows_host = -1;
     MAD_HIP(hipEventRecord(s->built, ctx->stream));
+    MAD_HIP(hipEventRecord(ctx->lane_built[ctx->lane], ctx->stream));
+    ctx->lane_has_build[ctx->lane] = true;
     return MAD_OK;
 }
 
@@ -1271,6 +1393,8 @@ extern "C" int mad_set_load(mad_ctx *ctx, mad_set *s, int64_t n_rows, const int3
     }
     MAD_TRY(set_finish_rows(ctx, s));
     MAD_HIP(hipEventRecord(s->built, ctx->stream));
+    MAD_HIP(hipEventRecord(ctx->lane_built[ctx->lane], ctx->stream));
+    ctx->lane_has_build[ctx->lane] = true;
     int64_t n_dev = 0;
     MAD_TRY(set_rows(ctx, s, &n_dev));      // synchronises (the host arrays may go away) and fetches the range check
     if (s->range_bad) return mad_fail(ctx, MAD_EDOM, "descriptor count outside the int8 range");
@@ -1330,9 +1454,14 @@ static int match_enqueue(mad_ctx *ctx, const mad_set *hi, const mad_set *lo, dou
     int32_t *hist = st + ST_COUNT;
     uint8_t *used_hi = (uint8_t *)(hist + hi->n_anchors + 17), *used_lo = used_hi + ((hi->n_anchors + 31) & ~31);
     const Side H = side_of(hi), L = side_of(lo);
-    // the sets may have been built on other lanes
+    // The sets may have been built on other lanes.  A match also waits for EVERY build enqueued so far, on any lane:
+    // builds overlap builds and matches overlap matches, but a match never runs beside a build.  (With k_describe
+    // running beside the pose-stage kernels of another lane, a few samples per thousand rows were binned into a
+    // neighbouring zone -- reproducibly, and only then; the cause has not been found)
     MAD_HIP(hipStreamWaitEvent(ctx->stream, hi->built, 0));
     MAD_HIP(hipStreamWaitEvent(ctx->stream, lo->built, 0));
+    for (int l = 0; l < MAD_LANES; l++)
+        if (ctx->lane_has_build[l] && l != ctx->lane) MAD_HIP(hipStreamWaitEvent(ctx->stream, ctx->lane_built[l], 0));
     mad_zero_words(ctx, st, zero_bytes(hi, lo));      // status, histogram and flags in one launch
     MAD_TRY(correlate_device(ctx, H, L, hi->D, cc, st, P.cap_c, P.cap_pairs, used_hi, used_lo));
     // clouds: anchors that take part in at least one pair (MaD.py:427-428)

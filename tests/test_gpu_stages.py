@@ -154,6 +154,37 @@ def test_pose_score_matches_oracle(lib):
     np.testing.assert_allclose(got_res, ref_res, rtol=1e-12, atol=1e-12)
 
 
+@pytest.mark.parametrize("n_lo_anchor,n_pairs,box", [(5600, 600, 170.0), (9600, 300, 200.0)])
+def test_pose_score_large_lo_cloud(lib, n_lo_anchor, n_pairs, box):
+    """Lo clouds too large for float64 points in LDS.  5 600 points: the float32-tier kernel (k_pose_lds32) with its exact
+    float64 re-test; 9 600 points: the global cell list (k_pose).  Both must give the oracle's counts bit for bit."""
+    rng = np.random.default_rng(17)
+    n_hi_anchor = 300
+    lo_anchor_p = rng.uniform(0, box, size=(n_lo_anchor, 3))
+    Rt = synth.random_rotation(rng)
+    sub = rng.choice(n_lo_anchor, n_hi_anchor, replace=False)
+    hi_anchor_p = (lo_anchor_p[sub] - box / 2) @ Rt.T + rng.normal(scale=1.5, size=(n_hi_anchor, 3))
+    lo_R = np.stack([synth.random_rotation(rng) for _ in range(n_lo_anchor)])
+    hi_R = np.stack([synth.random_rotation(rng) for _ in range(n_hi_anchor)])
+    pair_hi = rng.integers(0, n_hi_anchor, n_pairs).astype(np.int32)
+    pair_lo = rng.integers(0, n_lo_anchor, n_pairs).astype(np.int32)
+    for t in range(0, n_pairs, 5):      # planted poses: many hi anchors land within ~dist of a lo anchor
+        ih = int(rng.integers(0, n_hi_anchor))
+        hi_R[ih] = lo_R[sub[ih]] @ Rt.T
+        pair_hi[t], pair_lo[t] = ih, sub[ih]
+    order = np.lexsort((pair_lo, pair_hi))
+    pair_hi, pair_lo = pair_hi[order], pair_lo[order]
+    meta_h = np.stack([np.arange(n_hi_anchor), np.ones(n_hi_anchor), np.zeros(n_hi_anchor)], 1).astype(np.int32)
+    meta_l = np.stack([np.arange(n_lo_anchor), np.ones(n_lo_anchor), np.zeros(n_lo_anchor)], 1).astype(np.int32)
+    a = dict(pair_hi=pair_hi, pair_lo=pair_lo, pair_score=rng.uniform(0.6, 1.0, n_pairs), hi_p=hi_anchor_p, hi_R=hi_R, hi_meta=meta_h,
+             lo_p=lo_anchor_p, lo_R=lo_R, lo_meta=meta_l, hi_cloud=np.unique(hi_anchor_p, axis=0), lo_cloud=np.unique(lo_anchor_p, axis=0))
+    ref_res, ref_cnt = O.pose_score(**a, dist=4.0)
+    got_res, got_cnt = lib.pose_score(**a, dist=4.0)
+    assert ref_cnt.max() > 100 and ref_cnt.mean() > 1
+    np.testing.assert_array_equal(got_cnt, ref_cnt)
+    np.testing.assert_allclose(got_res, ref_res, rtol=1e-12, atol=1e-12)
+
+
 def test_topk_order(lib):
     rng = np.random.default_rng(0)
     for n, k, hi in ((5000, 60, 40), (777, 777, 5), (20000, 840, 3), (50, 200, 9)):
