@@ -105,8 +105,6 @@ struct mad_ctx {
     hipStream_t stream = nullptr;            // the stream of the current lane (lane_stream[lane])
     hipStream_t lane_stream[MAD_LANES] = {};      // [0] is the stream mad_stream() reports
     int next_set_lane = 0;
-    hipEvent_t lane_built[MAD_LANES] = {};   // recorded behind the last set build enqueued on each lane
-    bool lane_has_build[MAD_LANES] = {};
     bool overlap = true;                      // false: every lane enqueues on lane_stream[0] (kernels run one at a time)
     char err[512] = {0};
     FieldDev fields[MAD_MAX_FIELDS];

@@ -81,10 +81,7 @@ extern "C" int mad_init(int device, mad_ctx **out) {
             (void)hipEventCreate(&ctx->timers[g].start[i]);
             (void)hipEventCreate(&ctx->timers[g].stop[i]);
         }
-    for (int l = 0; l < MAD_LANES; l++) {
-        (void)hipEventCreateWithFlags(&ctx->lane_done[l], hipEventDisableTiming);
-        (void)hipEventCreateWithFlags(&ctx->lane_built[l], hipEventDisableTiming);
-    }
+    for (int l = 0; l < MAD_LANES; l++) (void)hipEventCreateWithFlags(&ctx->lane_done[l], hipEventDisableTiming);
     *out = ctx;
     return MAD_OK;
 }
@@ -109,7 +106,6 @@ extern "C" void mad_destroy(mad_ctx *ctx) {
         }
     for (int l = 0; l < MAD_LANES; l++) {
         (void)hipEventDestroy(ctx->lane_done[l]);
-        if (ctx->lane_built[l]) (void)hipEventDestroy(ctx->lane_built[l]);
         if (ctx->host_res[l]) (void)hipHostFree(ctx->host_res[l]);
     }
     for (int l = 0; l < MAD_LANES; l++)

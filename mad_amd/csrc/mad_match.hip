@@ -450,12 +450,11 @@ __global__ __launch_bounds__(POSE_LDS_THREADS) void k_pose_lds(const int32_t *__
     }
 }
 
-typedef float v2f __attribute__((ext_vector_type(2)));
 
 // The same search for lo clouds too large for float64 points in LDS (maps of ~512^3: 5 000+ anchors).  The lo points
 // sit in LDS as float32 offsets from the grid origin (16 B each) and the hi cloud is read from global memory (a
-// coalesced, cache-resident stream).  Candidates are tested in two tiers, two per iteration in packed float32
-// (v_pk_add / v_pk_fma): d2 < lim_in decides "within dist", d2 > lim_out decides "outside"; lim_in / lim_out bracket
+// coalesced, cache-resident stream).  Candidates are tested in two tiers, two per iteration in float32:
+// d2 < lim_in decides "within dist", d2 > lim_out decides "outside"; lim_in / lim_out bracket
 // dist^2 by a margin far above the float32 error of the offsets (host: pose_device).  Only a candidate whose float32
 // distance falls inside that band (about one sample in 10^4) is re-evaluated with the reference's float64 expression
 // on the float64 point in global memory, so the count is the float64 count.  On clouds that fit both kernels this one
@@ -523,17 +522,18 @@ __global__ __launch_bounds__(POSE_LDS_THREADS) void k_pose_lds32(const int32_t *
                     const int q = (c == 0 ? s[0] + 2 * t : (c == 1 ? s[1] + 2 * (t - m0) : (c == 2 ? s[2] + 2 * (t - m1) : s[3] + 2 * (t - m2))));
                     const int qe = c == 0 ? e[0] : (c == 1 ? e[1] : (c == 2 ? e[2] : e[3]));
                     const float4 pa = lpf[q], pb = lpf[q + 1];      // q + 1 may belong to the next cell (or be the pad): masked below
-                    const v2f ex = (v2f){pa.x, pb.x} - xf, ey = (v2f){pa.y, pb.y} - yf, ez = (v2f){pa.z, pb.z} - zf;
-                    const v2f dd = __builtin_elementwise_fma(ez, ez, __builtin_elementwise_fma(ey, ey, ex * ex));
+                    // plain float32 on purpose: packed float32 VALU instructions are banned in this library (Makefile)
+                    const float ax = pa.x - xf, ay = pa.y - yf, az = pa.z - zf, bx = pb.x - xf, by = pb.y - yf, bz = pb.z - zf;
+                    const float dda = fmaf(az, az, fmaf(ay, ay, ax * ax)), ddb = fmaf(bz, bz, fmaf(by, by, bx * bx));
                     const bool vb = q + 1 < qe;
-                    hit = dd.x < lim_in || (vb && dd.y < lim_in);
-                    if (!hit && ((dd.x <= lim_out) || (vb && dd.y <= lim_out))) {
+                    hit = dda < lim_in || (vb && ddb < lim_in);
+                    if (!hit && ((dda <= lim_out) || (vb && ddb <= lim_out))) {
                         // inside the band: the reference's float64 expression (MaD.py:447-448)
-                        if (dd.x <= lim_out) {
+                        if (dda <= lim_out) {
                             const double e0 = lo_sorted[3 * q] - x, e1 = lo_sorted[3 * q + 1] - y, e2 = lo_sorted[3 * q + 2] - z;
                             hit = (e0 * e0 + e1 * e1 + e2 * e2) < dd_lim;
                         }
-                        if (!hit && vb && dd.y <= lim_out) {
+                        if (!hit && vb && ddb <= lim_out) {
                             const double e0 = lo_sorted[3 * q + 3] - x, e1 = lo_sorted[3 * q + 4] - y, e2 = lo_sorted[3 * q + 5] - z;
                             hit = (e0 * e0 + e1 * e1 + e2 * e2) < dd_lim;
                         }
@@ -1367,8 +1367,6 @@ extern "C" int mad_set_build(mad_ctx *ctx, mad_set *s, const int *slot_of_octave
     s->last_f[0] = f[0]; s->last_f[1] = f[1]; s->last_r = r;
     s->n_rows_host = -1;
     MAD_HIP(hipEventRecord(s->built, ctx->stream));
-    MAD_HIP(hipEventRecord(ctx->lane_built[ctx->lane], ctx->stream));
-    ctx->lane_has_build[ctx->lane] = true;
     return MAD_OK;
 }
 
@@ -1393,8 +1391,6 @@ extern "C" int mad_set_load(mad_ctx *ctx, mad_set *s, int64_t n_rows, const int3
     }
     MAD_TRY(set_finish_rows(ctx, s));
     MAD_HIP(hipEventRecord(s->built, ctx->stream));
-    MAD_HIP(hipEventRecord(ctx->lane_built[ctx->lane], ctx->stream));
-    ctx->lane_has_build[ctx->lane] = true;
     int64_t n_dev = 0;
     MAD_TRY(set_rows(ctx, s, &n_dev));      // synchronises (the host arrays may go away) and fetches the range check
     if (s->range_bad) return mad_fail(ctx, MAD_EDOM, "descriptor count outside the int8 range");
@@ -1454,14 +1450,9 @@ static int match_enqueue(mad_ctx *ctx, const mad_set *hi, const mad_set *lo, dou
     int32_t *hist = st + ST_COUNT;
     uint8_t *used_hi = (uint8_t *)(hist + hi->n_anchors + 17), *used_lo = used_hi + ((hi->n_anchors + 31) & ~31);
     const Side H = side_of(hi), L = side_of(lo);
-    // The sets may have been built on other lanes.  A match also waits for EVERY build enqueued so far, on any lane:
-    // builds overlap builds and matches overlap matches, but a match never runs beside a build.  (With k_describe
-    // running beside the pose-stage kernels of another lane, a few samples per thousand rows were binned into a
-    // neighbouring zone -- reproducibly, and only then; the cause has not been found)
+    // the sets may have been built on other lanes
     MAD_HIP(hipStreamWaitEvent(ctx->stream, hi->built, 0));
     MAD_HIP(hipStreamWaitEvent(ctx->stream, lo->built, 0));
-    for (int l = 0; l < MAD_LANES; l++)
-        if (ctx->lane_has_build[l] && l != ctx->lane) MAD_HIP(hipStreamWaitEvent(ctx->stream, ctx->lane_built[l], 0));
     mad_zero_words(ctx, st, zero_bytes(hi, lo));      // status, histogram and flags in one launch
     MAD_TRY(correlate_device(ctx, H, L, hi->D, cc, st, P.cap_c, P.cap_pairs, used_hi, used_lo));
     // clouds: anchors that take part in at least one pair (MaD.py:427-428)
