@@ -238,6 +238,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--serial", action="store_true", help="lanes serialised for the whole run: the mode the rocprofv3 summaries in profiles/ are "
+                    "taken in, so that a kernel's average duration there is the one the roofline pass measures")
     args = ap.parse_args()
 
     import torch
@@ -288,6 +290,8 @@ def main():
         return mdist.TopkExchange(tops, k, world * W["n_sub"], rank, world)
 
     sets = [_lib.DeviceSet(lib) for _ in range(1 + len(subs))]
+    if args.serial:
+        lib.set_overlap(False)
     for _ in range(args.warmup):
         corr, tops, stats = hot_path_step(lib, the_map, subs, cc, dist_thr, k, sets)
         exchange(tops).finish()
@@ -317,7 +321,7 @@ def main():
     lib.synchronize()
     dt_serial = time.perf_counter() - t1
     lib.timing_enable(False)
-    lib.set_overlap(True)
+    lib.set_overlap(not args.serial)
 
     red_dev = "cuda" if (world == 1 or backend == "nccl") else "cpu"
     t_all = torch.tensor([dt], dtype=torch.float64, device=red_dev)
@@ -339,7 +343,7 @@ def main():
         pairs = sum(s["n_pairs"] for s in stats)
         # one roofline entry per kernel group; `roofline` = the group with the largest share of device time
         traffic = {}
-        prof = os.path.join(ROOT, "profiles", "r01_c_bench_c3_summary.json")
+        prof = os.path.join(ROOT, "profiles", "r01_d_bench_c3_serial_summary.json")
         if args.workload == "c3" and os.path.exists(prof):      # PMC passes of this same command (profiles/README.md)
             with open(prof) as fh:
                 pj = json.load(fh)
