@@ -184,8 +184,9 @@ def refine_ccc_leg(lib, the_map, subs, tops, W, n_cand=8):
                 note="mad_refine + mad_density_ccc (one host round trip each per batch); not part of the headline metric")
 
 
-def cpu_baseline(the_map, sub, cc, dist, k, lib, n_lo_anchor=800, n_hi_anchor=250):
-    """The CPU oracle on a bounded sample of the same workload: base-octave anchors only."""
+def cpu_baseline(the_map, sub, cc, dist, k, lib, n_lo_anchor=800, n_hi_anchor=250, threads=1):
+    """The CPU oracle on a bounded sample of the same workload: base-octave anchors only.  threads > 1: the same
+    scalar C functions on contiguous chunks of the work in that many host threads (oracle.py, *_mt)."""
     from mad_amd.eqsp import EQSP_Sphere
     from oracle import oracle as O
     e112, e16 = EQSP_Sphere(112), EQSP_Sphere(16)
@@ -200,11 +201,11 @@ def cpu_baseline(the_map, sub, cc, dist, k, lib, n_lo_anchor=800, n_hi_anchor=25
     sets = []
     for st, n in ((the_map, n_lo_anchor), (sub, n_hi_anchor)):
         gx, gy, gz, coords, subv, sel = sample(st, n)
-        rows = O.orient(gx, gy, gz, 1, coords, e112.sphere_eqsp, e112.p_centers_eqsp, want_counts=False)
-        dsc = O.describe(gx, gy, gz, 1, coords[rows["anchor"]], rows["R"], e16.sphere_eqsp)
+        rows = O.orient_mt(gx, gy, gz, 1, coords, e112.sphere_eqsp, e112.p_centers_eqsp, threads, want_counts=False)
+        dsc = O.describe_mt(gx, gy, gz, 1, coords[rows["anchor"]], rows["R"], e16.sphere_eqsp, threads)
         sets.append(dict(rows=rows, dsc=dsc, subv=subv, coords=coords, sel=sel))
     lo_s, hi_s = sets
-    ph, pl, ps, _ = O.correlate(hi_s["dsc"], lo_s["dsc"], cc)
+    ph, pl, ps, _ = O.correlate_mt(hi_s["dsc"], lo_s["dsc"], cc, threads)
     hi_p, lo_p = hi_s["subv"][hi_s["rows"]["anchor"]], lo_s["subv"][lo_s["rows"]["anchor"]]
     order = np.zeros(0, np.int64)
     if len(ph):
@@ -212,7 +213,7 @@ def cpu_baseline(the_map, sub, cc, dist, k, lib, n_lo_anchor=800, n_hi_anchor=25
         lo_cloud = np.unique(lo_p[np.unique(pl)], axis=0)
         meta_h = np.stack([hi_s["rows"]["anchor"], np.ones_like(hi_s["rows"]["anchor"]), hi_s["rows"]["main"]], 1)
         meta_l = np.stack([lo_s["rows"]["anchor"], np.ones_like(lo_s["rows"]["anchor"]), lo_s["rows"]["main"]], 1)
-        res, cnt = O.pose_score(ph, pl, ps, hi_p, hi_s["rows"]["R"], meta_h, lo_p, lo_s["rows"]["R"], meta_l, hi_cloud, lo_cloud, dist)
+        res, cnt = O.pose_score_mt(ph, pl, ps, hi_p, hi_s["rows"]["R"], meta_h, lo_p, lo_s["rows"]["R"], meta_l, hi_cloud, lo_cloud, dist, threads)
         order = O.topk(cnt, k)
     dt = time.perf_counter() - t0
     n_corr = len(hi_s["dsc"]) * len(lo_s["dsc"])
@@ -225,9 +226,10 @@ def cpu_baseline(the_map, sub, cc, dist, k, lib, n_lo_anchor=800, n_hi_anchor=25
         agree = bool(st["n_pairs"] == len(ph) and np.array_equal(idx, order) and np.array_equal(top[:, 1], res[order][:, 1]))
         lo_d.close()
         hi_d.close()
-    out = dict(value=n_corr / dt, unit="correlations/s", cores=1, kind="port",
-               sample="CPU oracle (scalar C, 1 thread) on %d map x %d subunit base-octave anchors of the same workload: "
-                      "%d x %d rows, %d pairs, %.1f s" % (len(lo_s["coords"]), len(hi_s["coords"]), len(hi_s["dsc"]), len(lo_s["dsc"]), len(ph), dt))
+    out = dict(value=n_corr / dt, unit="correlations/s", cores=threads, kind="port",
+               sample="CPU oracle (scalar C, %d thread%s) on %d map x %d subunit base-octave anchors of the same workload: "
+                      "%d x %d rows, %d pairs, %.1f s" % (threads, "" if threads == 1 else "s", len(lo_s["coords"]), len(hi_s["coords"]),
+                                                        len(hi_s["dsc"]), len(lo_s["dsc"]), len(ph), dt))
     return out, agree
 
 
@@ -382,9 +384,14 @@ def main():
                             " algorithmic 12 B/pair" % (flops / (groups["pose"]["ms_total"] / n_serial * 1e-3) / 1e12))
         roof["others"] = {g: roofs[g] for g in roofs if g != dom_name}
 
-        cpu, agree = (None, None)
+        cpu, agree, cpu_all = (None, None, None)
         if world == 1 and not args.no_cpu_baseline:
             cpu, agree = cpu_baseline(the_map, subs[0], cc, dist_thr, k, lib)
+            n_host = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            n_host = min(n_host, 16)      # a one-GPU box's CPU share
+            if n_host > 1:      # the same sample on the host cores of this box's share
+                cpu_all, agree_all = cpu_baseline(the_map, subs[0], cc, dist_thr, k, lib, threads=n_host)
+                agree = bool(agree and agree_all)
         refine_line = None
         if world == 1:
             lib.timing_enable(True)
@@ -409,6 +416,7 @@ def main():
                        "setup_detail_s": {k_: round(v, 4) for k_, v in SETUP_T.items()}},
             "roofline": roof,
             "cpu_baseline": cpu,
+            "cpu_baseline_all_cores": cpu_all,
             "refine_ccc": refine_line,
         }
         print(json.dumps(line))

@@ -193,3 +193,62 @@ def ccc(g1, o1, g2, o2, vs, isovalue=0.0):
     d1, d2 = np.array(g1.shape, np.int32), np.array(g2.shape, np.int32)
     o1, o2 = _c(o1, np.float64), _c(o2, np.float64)
     return lib().orc_ccc(_opt(g1), _opt(d1), _opt(o1), _opt(g2), _opt(d2), _opt(o2), C.c_double(vs), C.c_double(isovalue))
+
+
+# ---------------------------------------------------------------------------------------------
+# The same four stages on several host cores: the independent units (anchors, rows, hi rows, pairs) are
+# cut into contiguous chunks, every chunk goes through the scalar C function above in its own thread
+# (ctypes releases the GIL for the call) and the pieces are joined in order -- results are identical to the
+# single-threaded functions.  Used by bench.py's all-cores CPU baseline only.
+# ---------------------------------------------------------------------------------------------
+
+def _chunks(n, parts):
+    parts = max(1, min(parts, n))
+    edges = [n * i // parts for i in range(parts + 1)]
+    return [(a, b) for a, b in zip(edges[:-1], edges[1:]) if b > a]
+
+
+def _pool_map(fn, items, threads):
+    if threads <= 1 or len(items) <= 1:
+        return [fn(it) for it in items]
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=threads) as ex:
+        return list(ex.map(fn, items))
+
+
+def orient_mt(gx, gy, gz, octave, coords, bounds, centers, threads, **kw):
+    coords = _c(coords, np.int32).reshape(-1, 3)
+    parts = _pool_map(lambda ab: orient(gx, gy, gz, octave, coords[ab[0]:ab[1]], bounds, centers, **kw), _chunks(len(coords), 4 * threads), threads)
+    spans = _chunks(len(coords), 4 * threads)
+    out = dict(anchor=np.concatenate([p["anchor"] + a for p, (a, _) in zip(parts, spans)]) if parts else np.zeros(0, np.int32),
+               n_reject=sum(p["n_reject"] for p in parts))
+    for key in ("main", "sec", "R"):
+        out[key] = np.concatenate([p[key] for p in parts]) if parts else np.zeros(0)
+    out["counts"] = None if not parts or parts[0]["counts"] is None else np.concatenate([p["counts"] for p in parts])
+    return out
+
+
+def describe_mt(gx, gy, gz, octave, coords, R, bounds, threads, **kw):
+    coords = _c(coords, np.int32).reshape(-1, 3)
+    R = _c(R, np.float64).reshape(-1, 3, 3)
+    parts = _pool_map(lambda ab: describe(gx, gy, gz, octave, coords[ab[0]:ab[1]], R[ab[0]:ab[1]], bounds, **kw), _chunks(len(coords), 4 * threads), threads)
+    return np.concatenate(parts) if parts else np.zeros((0, 64 * len(bounds)), np.int16)
+
+
+def correlate_mt(hi, lo, cc, threads):
+    hi, lo = _c(hi, np.int16), _c(lo, np.int16)
+    spans = _chunks(len(hi), 4 * threads)
+    parts = _pool_map(lambda ab: correlate(hi[ab[0]:ab[1]], lo, cc), spans, threads)
+    if not parts:
+        return np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(0), None
+    return (np.concatenate([p[0] + a for p, (a, _) in zip(parts, spans)]).astype(np.int32), np.concatenate([p[1] for p in parts]),
+            np.concatenate([p[2] for p in parts]), None)
+
+
+def pose_score_mt(pair_hi, pair_lo, pair_score, hi_p, hi_R, hi_meta, lo_p, lo_R, lo_meta, hi_cloud, lo_cloud, dist, threads):
+    spans = _chunks(len(pair_hi), 4 * threads)
+    parts = _pool_map(lambda ab: pose_score(pair_hi[ab[0]:ab[1]], pair_lo[ab[0]:ab[1]], pair_score[ab[0]:ab[1]], hi_p, hi_R, hi_meta,
+                                            lo_p, lo_R, lo_meta, hi_cloud, lo_cloud, dist), spans, threads)
+    if not parts:
+        return np.zeros((0, 23)), np.zeros(0, np.int32)
+    return np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts])
