@@ -244,6 +244,27 @@ int mad_ccc(mad_ctx *ctx, float *grid1, const int32_t dims1[3], const double ori
             float *grid2, const int32_t dims2[3], const double origin2[3],
             double voxsp, double isovalue, double *ccc);
 
+/* ---- one subunit's pair grid sharded over GPUs by blocks of map rows (the exchange steps are the caller's:
+ *      OR of the flag vectors, all-gather of the per-shard top-k; mad_amd/dist.py::sharded_match) -------------- */
+
+/*
+ * Stage B of a sharded match: correlate hi against the lo rows [lo_begin, lo_end) (MaD.py:416-424 on that block of
+ * `preds`), keep the pairs on the device, return this shard's flags "anchor takes part in a pair" (one byte per
+ * anchor of hi / of lo).  The OR of the flags over all shards defines the global clouds of MaD.py:427-428.
+ */
+int mad_match_shard_pairs(mad_ctx *ctx, const mad_set *hi, const mad_set *lo, int64_t lo_begin, int64_t lo_end, double cc,
+                          uint8_t *used_hi, uint8_t *used_lo, int64_t *n_pairs);
+
+/*
+ * Stage C: score the shard's pairs against the global clouds (MaD.py:433-451) and return its k best in the order of
+ * MaD.py:480 restricted to the shard: result rows [k][23], match counts, and pair_rank = hi_row * N_lo + lo_row, the
+ * position of the pair in the unsharded row-major list.  *l_hi = size of the global hi cloud.  Must follow
+ * mad_match_shard_pairs for the same sets on the same ctx.
+ */
+int mad_match_shard_topk(mad_ctx *ctx, const mad_set *hi, const mad_set *lo, const uint8_t *used_hi_all,
+                         const uint8_t *used_lo_all, double dist, int64_t k, double *results, int64_t *pair_rank,
+                         int32_t *counts, int64_t *n_out, int64_t *l_hi);
+
 /*
  * a14-a16 for a batch of placed copies of one structure, on the device end to end: candidate c's atoms
  * (atoms + c*n*3, float64) -> simulated density at the voxel spacing of the map uploaded with

@@ -23,6 +23,7 @@ SYMBOLS = [
     "mad_orient", "mad_describe", "mad_correlate", "mad_pose_score", "mad_topk",
     "mad_set_create", "mad_set_destroy", "mad_set_build", "mad_set_load", "mad_set_size", "mad_set_download",
     "mad_match_topk", "mad_match_topk_many", "mad_match_fetch", "mad_match_results", "mad_match_used",
+    "mad_match_shard_pairs", "mad_match_shard_topk",
     "mad_upload_density", "mad_refine", "mad_structure_to_density", "mad_ccc", "mad_density_ccc",
     "mad_space_create", "mad_space_destroy", "mad_space_build", "mad_space_info", "mad_space_download",
     "mad_space_peaks", "mad_space_patches",
@@ -410,6 +411,26 @@ class Lib(object):
             out.append((res[i, :g], idx[i, :g], dict(n_pairs=int(stats[i, 0]), l_hi=int(stats[i, 1]), l_lo=int(stats[i, 2]),
                                                      n_corr=int(stats[i, 3]))))
         return out
+
+    def match_shard_pairs(self, hi, lo, lo_begin, lo_end, cc):
+        """Stage B of a sharded match -> (used_hi flags, used_lo flags, n_pairs) of the lo-row block [lo_begin, lo_end)."""
+        used_hi, used_lo = np.zeros(max(hi.n_anchors, 1), np.uint8), np.zeros(max(lo.n_anchors, 1), np.uint8)
+        n = C.c_int64(0)
+        self._chk(self.dll.mad_match_shard_pairs(self.ctx, hi.h, lo.h, C.c_int64(lo_begin), C.c_int64(lo_end), C.c_double(cc),
+                                                 _p(used_hi), _p(used_lo), C.byref(n)))
+        return used_hi[:hi.n_anchors], used_lo[:lo.n_anchors], n.value
+
+    def match_shard_topk(self, hi, lo, used_hi_all, used_lo_all, dist, k):
+        """Stage C -> (rows (m, 23), counts (m,), global pair ranks (m,), l_hi) with m <= k."""
+        uh, ul = _c(used_hi_all, np.uint8), _c(used_lo_all, np.uint8)
+        assert len(uh) == hi.n_anchors and len(ul) == lo.n_anchors
+        res = np.zeros((k, RESULT_COLS))
+        rank, cnt = np.zeros(k, np.int64), np.zeros(k, np.int32)
+        n, l_hi = C.c_int64(0), C.c_int64(0)
+        self._chk(self.dll.mad_match_shard_topk(self.ctx, hi.h, lo.h, _p(uh), _p(ul), C.c_double(dist), C.c_int64(k), _p(res), _p(rank),
+                                                _p(cnt), C.byref(n), C.byref(l_hi)))
+        m = n.value
+        return res[:m].copy(), cnt[:m].copy(), rank[:m].copy(), l_hi.value
 
     def match_fetch(self, n_pairs):
         ph, pl = np.zeros(n_pairs, np.int32), np.zeros(n_pairs, np.int32)

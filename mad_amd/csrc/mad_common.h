@@ -98,6 +98,9 @@ struct MatchState {            // the most recent mad_match_topk call
     int64_t cap_c = 0;         // capacity hints carried from call to call (elements of the int32 score matrix,
     int64_t cap_pairs = 0;     // number of pairs); the device raises a flag when one is too small
     int lane = 0;              // scratch copy that holds this match's pairs and counts
+    // the shard left in lane 0 by mad_match_shard_pairs, consumed by mad_match_shard_topk
+    const void *shard_hi = nullptr, *shard_lo = nullptr;
+    int64_t shard_begin = 0, shard_end = 0, shard_pairs = 0, shard_cap_pairs = 0;
 };
 
 struct mad_ctx {

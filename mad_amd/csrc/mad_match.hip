@@ -16,6 +16,8 @@
 // sizes stay on the device (kernels read them through pointers and are persistent / grid-
 // stride), buffers are sized from capacity hints, and the device raises a flag when a hint
 // was too small -- the host then grows the buffer and re-runs (only ever on a first call).
+#include <vector>
+
 #include "mad_common.h"
 
 // status words of one match, on the device (int32)
@@ -1630,6 +1632,148 @@ extern "C" int mad_match_topk_many(mad_ctx *ctx, int n, const mad_set *const *hi
     }
     mad_use_lane(ctx, ctx->match.lane);
     return rc_all;
+}
+
+// ---------------------------------------------------------------------------
+// one subunit's pair grid sharded over ranks by blocks of lo rows (stages B and C)
+// ---------------------------------------------------------------------------
+
+static Side side_block(const mad_set *s, int64_t begin, const int32_t *d_n_rows, int64_t n) {
+    Side x = side_of(s);
+    x.dsc8 += begin * s->D; x.norm += begin; x.R += 9 * begin; x.Rinv += 9 * begin; x.meta += 3 * begin; x.row_anchor += begin;
+    x.n_rows = d_n_rows; x.cap_rows = n;
+    return x;
+}
+
+// Stage B: correlate hi against the lo rows [lo_begin, lo_end) and list the pairs above cc (kept on the device for
+// mad_match_shard_topk).  used_hi / used_lo (one byte per anchor of hi / lo) receive this shard's "anchor takes part
+// in a pair" flags: the caller ORs them over all shards (Exchange 1) -- the clouds and the repeatability denominator
+// of MaD.py:427-428,448 are global.
+extern "C" int mad_match_shard_pairs(mad_ctx *ctx, const mad_set *hi, const mad_set *lo, int64_t lo_begin, int64_t lo_end, double cc,
+                                     uint8_t *used_hi, uint8_t *used_lo, int64_t *n_pairs) {
+    if (!ctx || !hi || !lo || !used_hi || !used_lo || !n_pairs) return MAD_EINVAL;
+    mad_use_lane(ctx, 0);
+    *n_pairs = 0;
+    ctx->match.shard_hi = nullptr;
+    int64_t n_hi = 0, n_lo = 0;
+    MAD_TRY(set_rows(ctx, hi, &n_hi));
+    MAD_TRY(set_rows(ctx, lo, &n_lo));
+    if (hi->D != lo->D) return mad_fail(ctx, MAD_EINVAL, "mad_match_shard_pairs: descriptor lengths %d vs %d", hi->D, lo->D);
+    if (lo_begin < 0 || lo_end < lo_begin || lo_end > n_lo) return mad_fail(ctx, MAD_EINVAL, "mad_match_shard_pairs: lo rows [%lld, %lld) of %lld", (long long)lo_begin, (long long)lo_end, (long long)n_lo);
+    memset(used_hi, 0, (size_t)hi->n_anchors);
+    memset(used_lo, 0, (size_t)lo->n_anchors);
+    const int64_t nb = lo_end - lo_begin;
+    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_ZERO), zero_bytes(hi, lo)));
+    int32_t *st = zero_status(ctx);
+    int32_t *hist = st + ST_COUNT;
+    uint8_t *d_used_hi = (uint8_t *)(hist + hi->n_anchors + 17), *d_used_lo = d_used_hi + ((hi->n_anchors + 31) & ~31);
+    MAD_HIP(hipStreamWaitEvent(ctx->stream, hi->built, 0));
+    MAD_HIP(hipStreamWaitEvent(ctx->stream, lo->built, 0));
+    int64_t cap_pairs = std::max<int64_t>(ctx->match.cap_pairs, 1 << 16);
+    const int64_t cap_c = (mad_ceil_div(std::max<int64_t>(n_hi, 1), 128) * 128) * (mad_ceil_div(std::max<int64_t>(nb, 1), 128) * 128);
+    if (cap_c >= ((int64_t)1 << 31)) return mad_fail(ctx, MAD_EINVAL, "mad_match_shard_pairs: score matrix of %lld entries", (long long)cap_c);
+    const int32_t *hs = (const int32_t *)&ctx->pinned[0];
+    for (int attempt = 0; attempt < 4 && n_hi > 0 && nb > 0; attempt++) {
+        mad_zero_words(ctx, st, zero_bytes(hi, lo));
+        const int32_t nb32 = (int32_t)nb;
+        MAD_HIP(hipMemcpyAsync(st + ST_NLO, &nb32, 4, hipMemcpyHostToDevice, ctx->stream));
+        const Side H = side_of(hi), L = side_block(lo, lo_begin, st + ST_NLO, nb);
+        MAD_TRY(correlate_device(ctx, H, L, hi->D, cc, st, cap_c, cap_pairs, d_used_hi, d_used_lo));
+        MAD_HIP(hipMemcpyAsync(&ctx->pinned[0], st, ST_COUNT * 4, hipMemcpyDeviceToHost, ctx->stream));
+        MAD_HIP(hipStreamSynchronize(ctx->stream));
+        if (hs[ST_FLAG_C]) return mad_fail(ctx, MAD_EHIP, "mad_match_shard_pairs: score matrix capacity");
+        if (!hs[ST_FLAG_PAIRS]) break;
+        cap_pairs = (int64_t)hs[ST_NPAIRS] + 1024;
+        if (attempt == 3) return mad_fail(ctx, MAD_EHIP, "mad_match_shard_pairs: pair capacity did not converge");
+    }
+    const int64_t np = (n_hi > 0 && nb > 0) ? hs[ST_NPAIRS] : 0;
+    if (np > 0) {
+        MAD_HIP(hipMemcpyAsync(used_hi, d_used_hi, (size_t)hi->n_anchors, hipMemcpyDeviceToHost, ctx->stream));
+        MAD_HIP(hipMemcpyAsync(used_lo, d_used_lo, (size_t)lo->n_anchors, hipMemcpyDeviceToHost, ctx->stream));
+        MAD_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    ctx->match.cap_pairs = std::max(ctx->match.cap_pairs, cap_pairs);
+    ctx->match.shard_hi = hi; ctx->match.shard_lo = lo;
+    ctx->match.shard_begin = lo_begin; ctx->match.shard_end = lo_end; ctx->match.shard_pairs = np; ctx->match.shard_cap_pairs = cap_pairs;
+    *n_pairs = np;
+    return MAD_OK;
+}
+
+// Stage C: score this shard's pairs against the GLOBAL clouds (used_*_all = OR over the shards) and return its k best:
+// result rows (MaD.py:451), match counts and the global row-major pair rank hi_row * N_lo + lo_row -- the key that lets
+// mad_amd.dist.merge_topk reproduce python's stable sort over the unsharded pair list (Exchange 2).
+extern "C" int mad_match_shard_topk(mad_ctx *ctx, const mad_set *hi, const mad_set *lo, const uint8_t *used_hi_all,
+                                    const uint8_t *used_lo_all, double dist, int64_t k, double *results, int64_t *pair_rank,
+                                    int32_t *counts, int64_t *n_out, int64_t *l_hi) {
+    if (!ctx || !hi || !lo || !used_hi_all || !used_lo_all || !results || !pair_rank || !counts || !n_out) return MAD_EINVAL;
+    mad_use_lane(ctx, 0);
+    *n_out = 0;
+    if (l_hi) *l_hi = 0;
+    if (ctx->match.shard_hi != hi || ctx->match.shard_lo != lo) return mad_fail(ctx, MAD_EINVAL, "mad_match_shard_topk: call mad_match_shard_pairs for these sets first");
+    if (!(dist > 0) || k < 1) return mad_fail(ctx, MAD_EINVAL, "mad_match_shard_topk: dist %g k %lld", dist, (long long)k);
+    int64_t n_lo = 0;
+    MAD_TRY(set_rows(ctx, lo, &n_lo));
+    const int64_t np = ctx->match.shard_pairs, begin = ctx->match.shard_begin, nb = ctx->match.shard_end - begin;
+    int32_t *st = zero_status(ctx);
+    int32_t *hist = st + ST_COUNT;
+    uint8_t *d_used_hi = (uint8_t *)(hist + hi->n_anchors + 17), *d_used_lo = d_used_hi + ((hi->n_anchors + 31) & ~31);
+    // the global flags replace the shard's own; the histogram of the top-k selection starts from zero
+    MAD_HIP(hipMemcpyAsync(d_used_hi, used_hi_all, (size_t)hi->n_anchors, hipMemcpyHostToDevice, ctx->stream));
+    MAD_HIP(hipMemcpyAsync(d_used_lo, used_lo_all, (size_t)lo->n_anchors, hipMemcpyHostToDevice, ctx->stream));
+    MAD_HIP(hipMemsetAsync(hist, 0, (size_t)(hi->n_anchors + 17) * 4, ctx->stream));
+    MAD_HIP(hipMemsetAsync(st + ST_NKEYS, 0, 4, ctx->stream));
+    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_HI_CLOUD), (size_t)hi->n_anchors * 24 + 24));
+    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_SEL_OUT), (size_t)(k + 8) * 8));
+    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_RESULTS), (size_t)(k + 1) * MAD_RESULT_COLS * 8));
+    hipLaunchKernelGGL(k_compact_cloud, dim3(1), dim3(1024), 0, ctx->stream, (const double *)hi->anc_subv.p, d_used_hi, hi->n_anchors,
+                       scratch<double>(ctx, S_HI_CLOUD), st + ST_LHI, (const int32_t *)nullptr, (const int32_t *)nullptr, st);
+    MAD_HIP(hipGetLastError());
+    if (np > 0) {
+        const Side H = side_of(hi), L = side_block(lo, begin, st + ST_NLO, nb);
+        const int64_t cap_pairs = ctx->match.shard_cap_pairs;
+        const bool fits = clouds_fit_lds(hi->n_anchors, lo->n_anchors);
+        CellGrid G;
+        if (!fits) {
+            if (!lo->cells_ready || lo->cell_size != dist) {
+                MAD_TRY(mad_build_cells(ctx, const_cast<mad_set *>(lo), dist));
+                MAD_HIP(hipStreamSynchronize(ctx->stream));
+            }
+            G.start = (const int32_t *)lo->cell_start.p; G.pts = (const double *)lo->cell_pts.p; G.ids = (const int32_t *)lo->cell_ids.p;
+            for (int d = 0; d < 3; d++) { G.mn[d] = lo->cell_min[d]; G.dim[d] = lo->cell_dim[d]; }
+            G.cell = lo->cell_size;
+            G.used = d_used_lo;
+        }
+        MAD_TRY(pose_device(ctx, H, L, st, cap_pairs, scratch<double>(ctx, S_HI_CLOUD), hi->n_anchors, (const double *)lo->anc_subv.p,
+                            lo->n_anchors, d_used_lo, lo->bb_min, lo->bb_max, fits ? nullptr : &G, dist));
+        MAD_TRY(topk_device(ctx, scratch<int32_t>(ctx, S_COUNTS), st, cap_pairs, k, hi->n_anchors, scratch<int64_t>(ctx, S_SEL_OUT), hist));
+        hipLaunchKernelGGL(k_results, dim3((unsigned)mad_ceil_div(k, 256)), dim3(256), 0, ctx->stream, scratch<int64_t>(ctx, S_SEL_OUT),
+                           st + ST_NKEYS, k, scratch<int32_t>(ctx, S_PAIR_HI), scratch<int32_t>(ctx, S_PAIR_LO),
+                           scratch<double>(ctx, S_PAIR_SCORE), scratch<int32_t>(ctx, S_COUNTS), st, H.p, H.R, H.meta, L.p, L.Rinv, L.meta,
+                           H.row_anchor, L.row_anchor, scratch<double>(ctx, S_RESULTS), 0);
+        MAD_HIP(hipGetLastError());
+    }
+    MAD_HIP(hipMemcpyAsync(&ctx->pinned[0], st, ST_COUNT * 4, hipMemcpyDeviceToHost, ctx->stream));
+    MAD_HIP(hipStreamSynchronize(ctx->stream));
+    const int32_t *hs = (const int32_t *)&ctx->pinned[0];
+    if (l_hi) *l_hi = hs[ST_LHI];
+    const int64_t got = np > 0 ? std::min<int64_t>(hs[ST_NKEYS], k) : 0;
+    if (got > 0) {
+        std::vector<int64_t> sel((size_t)got);
+        std::vector<int32_t> ph((size_t)np), pl((size_t)np), cn((size_t)np);
+        MAD_HIP(hipMemcpyAsync(sel.data(), mad_sb(ctx, S_SEL_OUT).p, (size_t)got * 8, hipMemcpyDeviceToHost, ctx->stream));
+        MAD_HIP(hipMemcpyAsync(ph.data(), mad_sb(ctx, S_PAIR_HI).p, (size_t)np * 4, hipMemcpyDeviceToHost, ctx->stream));
+        MAD_HIP(hipMemcpyAsync(pl.data(), mad_sb(ctx, S_PAIR_LO).p, (size_t)np * 4, hipMemcpyDeviceToHost, ctx->stream));
+        MAD_HIP(hipMemcpyAsync(cn.data(), mad_sb(ctx, S_COUNTS).p, (size_t)np * 4, hipMemcpyDeviceToHost, ctx->stream));
+        MAD_HIP(hipMemcpyAsync(results, mad_sb(ctx, S_RESULTS).p, (size_t)got * MAD_RESULT_COLS * 8, hipMemcpyDeviceToHost, ctx->stream));
+        MAD_HIP(hipStreamSynchronize(ctx->stream));
+        for (int64_t t = 0; t < got; t++) {
+            const int64_t p = sel[(size_t)t];
+            counts[t] = cn[(size_t)p];
+            pair_rank[t] = (int64_t)ph[(size_t)p] * n_lo + (begin + pl[(size_t)p]);
+        }
+    }
+    *n_out = got;
+    return MAD_OK;
 }
 
 extern "C" int mad_match_fetch(mad_ctx *ctx, int32_t *pair_hi, int32_t *pair_lo, double *pair_score, int32_t *counts,

@@ -99,6 +99,64 @@ def merge_topk(shard_rows, shard_counts, shard_pair_rank, k):
     return rows[order], cnt[order], rank[order]
 
 
+def lo_row_block(n_lo_rows, rank, world):
+    """Contiguous block of map rows rank `rank` of `world` scores (the GEMM operand must be contiguous)."""
+    return n_lo_rows * rank // world, n_lo_rows * (rank + 1) // world
+
+
+def sharded_match(lib, hi, lo, cc, dist, k, rank, world, reduce_flags=None, gather=None, group=None):
+    """ONE subunit against the map with the pair grid split over `world` ranks by blocks of map rows
+    (stages B-C): every rank holds both sets, correlates hi against its own lo rows, the "anchor takes
+    part in a pair" flags are OR-reduced (Exchange 1: the clouds of MaD.py:427-428 are global), every rank scores its
+    own pairs against the global clouds and the per-rank top-k lists are gathered and merged (Exchange 2) into the
+    unsharded order of MaD.py:480.  Returns (rows (<= k, 23), counts, global pair ranks), identical on every rank.
+
+    `reduce_flags(uint8 array) -> uint8 array` and `gather(list of arrays) -> list over ranks of such lists` default to
+    the torch.distributed collectives (RCCL over xGMI on the node); tests pass single-process stand-ins."""
+    n_lo, _ = lo.size()
+    b, e = lo_row_block(n_lo, rank, world)
+    used_hi, used_lo, _ = lib.match_shard_pairs(hi, lo, b, e, cc)
+    if reduce_flags is None:
+        def reduce_flags(f):
+            return or_reduce_flags(f, group=group)
+    flags = reduce_flags(np.concatenate([used_hi, used_lo]))
+    used_hi_all, used_lo_all = flags[:len(used_hi)], flags[len(used_hi):]
+    rows, cnt, prank, _ = lib.match_shard_topk(hi, lo, used_hi_all, used_lo_all, dist, k)
+    if gather is None:
+        def gather(parts):
+            return all_gather_arrays(parts, k, group=group)
+    shards = gather([rows, cnt, prank])
+    return merge_topk([s[0] for s in shards], [s[1] for s in shards], [s[2] for s in shards], k)
+
+
+def all_gather_arrays(parts, k, group=None, device=None):
+    """All-gather of one rank's (rows (m, 23), counts (m,), ranks (m,)) with m <= k: one fused collective of a
+    fixed-size float64 payload [m, rows..., counts..., ranks...] per rank.  -> list over ranks of [rows, counts, ranks]."""
+    import torch
+    import torch.distributed as dist
+    rows, cnt, prank = parts
+    m = len(rows)
+    payload = np.zeros(1 + k * (RESULT_COLS + 2))
+    payload[0] = m
+    payload[1:1 + m * RESULT_COLS] = np.asarray(rows, dtype=np.float64).reshape(-1)
+    payload[1 + k * RESULT_COLS:1 + k * RESULT_COLS + m] = cnt
+    payload[1 + k * (RESULT_COLS + 1):1 + k * (RESULT_COLS + 1) + m] = prank      # < 2^53: exact in float64
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        out = payload[None]
+    else:
+        dev = device if device is not None else ("cuda" if dist.get_backend(group) == "nccl" else "cpu")
+        t = torch.from_numpy(payload).to(dev)
+        o = torch.empty(dist.get_world_size(group) * t.numel(), dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(o, t, group=group)
+        out = o.view(-1, t.numel()).cpu().numpy()
+    res = []
+    for row in out:
+        m = int(row[0])
+        res.append([row[1:1 + m * RESULT_COLS].reshape(m, RESULT_COLS).copy(), row[1 + k * RESULT_COLS:1 + k * RESULT_COLS + m].astype(np.int64),
+                    row[1 + k * (RESULT_COLS + 1):1 + k * (RESULT_COLS + 1) + m].astype(np.int64)])
+    return res
+
+
 def or_reduce_flags(flags, group=None, device=None):
     """Bitwise-OR all-reduce of a uint8 flag vector (the "row takes part in a pair" masks that make the
     hi / lo clouds global when the pair grid of one subunit is sharded, MaD.py:427-428)."""

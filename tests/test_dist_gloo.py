@@ -89,3 +89,70 @@ def test_merge_topk_equals_unsharded_order():
         mr, mc, mp_ = mdist.merge_topk(shard_rows, shard_cnt, shard_rank, k)
         np.testing.assert_array_equal(mp_, pair_rank[full])
         np.testing.assert_array_equal(mr, rows[full])
+
+
+class _FakeShardLib(object):
+    """Stand-in for Lib in the host logic of sharded_match: a fixed pair list with counts, split by lo-row block."""
+
+    def __init__(self, n_hi, n_lo, seed):
+        rng = np.random.default_rng(seed)
+        keep = np.flatnonzero(rng.random(n_hi * n_lo) < 0.15)
+        self.n_lo = n_lo
+        self.rank_all = keep
+        self.cnt_all = rng.integers(0, 7, len(keep)).astype(np.int32)
+        self.rows_all = rng.normal(size=(len(keep), 23))
+        self.n_hi_anchors, self.n_lo_anchors = 9, 13
+        self.block = None
+
+    def match_shard_pairs(self, hi, lo, b, e, cc):
+        lo_row = self.rank_all % self.n_lo
+        self.block = np.flatnonzero((lo_row >= b) & (lo_row < e))
+        uh, ul = np.zeros(self.n_hi_anchors, np.uint8), np.zeros(self.n_lo_anchors, np.uint8)
+        uh[(self.rank_all[self.block] // self.n_lo) % self.n_hi_anchors] = 1
+        ul[lo_row[self.block] % self.n_lo_anchors] = 1
+        return uh, ul, len(self.block)
+
+    def match_shard_topk(self, hi, lo, uh, ul, dist, k):
+        self.flags_seen = np.concatenate([uh, ul])
+        order = np.lexsort((self.rank_all[self.block], -self.cnt_all[self.block].astype(np.int64)))[:k]
+        sel = self.block[order]
+        return self.rows_all[sel], self.cnt_all[sel], self.rank_all[sel], int(uh.sum())
+
+
+class _FakeSet(object):
+    def __init__(self, n_rows):
+        self.n = n_rows
+
+    def size(self):
+        return self.n, 0
+
+
+def _shard_worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lib = _FakeShardLib(30, 101, seed=4)
+    rows, cnt, prank = mdist.sharded_match(lib, _FakeSet(30), _FakeSet(101), 0.6, 4.0, 20, rank, world)
+    np.savez(os.path.join(out_dir, "shard%d.npz" % rank), rows=rows, cnt=cnt, prank=prank, flags=lib.flags_seen)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_match_two_ranks(tmp_path):
+    """Exchange 1 (OR of the cloud flags) and Exchange 2 (all-gather + merge of the per-shard top-k) over gloo."""
+    import torch.multiprocessing as mp
+    world, k = 2, 20
+    mp.spawn(_shard_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    ref = _FakeShardLib(30, 101, seed=4)
+    order = np.lexsort((ref.rank_all, -ref.cnt_all.astype(np.int64)))[:k]
+    uh = np.zeros(ref.n_hi_anchors, np.uint8)
+    ul = np.zeros(ref.n_lo_anchors, np.uint8)
+    uh[(ref.rank_all // ref.n_lo) % ref.n_hi_anchors] = 1
+    ul[(ref.rank_all % ref.n_lo) % ref.n_lo_anchors] = 1
+    for r in range(world):
+        o = np.load(os.path.join(str(tmp_path), "shard%d.npz" % r))
+        np.testing.assert_array_equal(o["prank"], ref.rank_all[order])
+        np.testing.assert_array_equal(o["cnt"], ref.cnt_all[order])
+        np.testing.assert_array_equal(o["rows"], ref.rows_all[order])
+        np.testing.assert_array_equal(o["flags"], np.concatenate([uh, ul]))

@@ -358,3 +358,51 @@ def test_lanes_overlap_and_serial_give_identical_results(lib):
             for key in ("anchor", "main", "sec", "R", "dsc"):
                 np.testing.assert_array_equal(ra[key], rb[key])
     assert any(len(o[0]) for o in outs[0][:-1])
+
+
+@pytest.mark.parametrize("world", [1, 3, 8])
+def test_sharded_match_equals_unsharded(lib, world):
+    """One subunit's pair grid split into `world` blocks of map rows (mad_match_shard_pairs / _topk + the host merge of
+    mad_amd.dist): flags OR-ed, per-shard top-k merged by global pair rank -- the unsharded result, rows and order."""
+    from mad_amd import dist as mdist
+    from mad_amd.eqsp import EQSP_Sphere
+    from mad_amd.orient_tables import orientation_matrices
+    e112, e16 = EQSP_Sphere(112), EQSP_Sphere(16)
+    dom, adj = orientation_matrices(e112)
+    lib.set_eqsp(0, e112.sphere_eqsp, dom, adj)
+    lib.set_eqsp(1, e16.sphere_eqsp)
+    shape = (56, 60, 64)
+    vol = synth.blob_volume(shape, n_blobs=60, seed=9, sigma=(1.5, 3.5))
+    slot = lib.new_slot()
+    lib.upload_field(slot, synth.gradient_field(vol))
+    rng = np.random.default_rng(world)
+    sets = []
+    for n in (150, 60):
+        coords = synth.interior_anchors(shape, n, 12, 100 + n)
+        subv = coords.astype(np.float64) * 1.5 + rng.normal(scale=0.2, size=(n, 3))
+        sets.append(lib.set_build([-1, slot], coords, np.ones(n, np.int32), subv, np.arange(n)))
+    lo, hi = sets
+    cc, dist_, k = 0.45, 4.0, 40
+    top, idx, st = lib.match_topk(hi, lo, cc, dist_, k)
+    assert st["n_pairs"] > 200 and len(top) == k
+    ph, pl, _, cnt = lib.match_fetch(st["n_pairs"])
+    n_lo = lo.size()[0]
+    ref_rank = ph[idx].astype(np.int64) * n_lo + pl[idx]
+    # every "rank" in turn on this one GPU: stage B of all shards first (Exchange 1 needs all flags) ...
+    flags = []
+    for r in range(world):
+        b, e = mdist.lo_row_block(n_lo, r, world)
+        uh, ul, _ = lib.match_shard_pairs(hi, lo, b, e, cc)
+        flags.append(np.concatenate([uh, ul]))
+    flags_all = np.bitwise_or.reduce(np.stack(flags), axis=0)
+    # ... then stages B + C per shard with the reduced flags, and Exchange 2 as a plain list
+    shards = []
+    for r in range(world):
+        shards.append(mdist.sharded_match(lib, hi, lo, cc, dist_, k, r, world, reduce_flags=lambda f: flags_all, gather=lambda parts: [parts])[0:3])
+    rows, counts, ranks = mdist.merge_topk([s[0] for s in shards], [s[1] for s in shards], [s[2] for s in shards], k)
+    np.testing.assert_array_equal(ranks, ref_rank)
+    np.testing.assert_array_equal(counts, cnt[idx])
+    np.testing.assert_array_equal(rows, top)
+    for s_ in sets:
+        s_.close()
+    lib.free_field(slot)
