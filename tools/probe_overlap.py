@@ -4,9 +4,9 @@
 
 Builds every set of the benchmark workload serially as the reference, then repeats builds + matches with the lanes
 overlapping and reports every set whose descriptors, and every match whose top-k, differ from the reference.  This
-is the script that exposed the describe-beside-pose interference recorded in DESIGN.md section 5b."""
+is the script that exposed the packed-float32 hazard recorded in DESIGN.md section 5b."""
 import sys, os, numpy as np
-sys.path.insert(0, '.')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from mad_amd import _lib
 from mad_amd.eqsp import EQSP_Sphere
@@ -38,18 +38,11 @@ for it in range(int(os.environ.get("ITERS", "4"))):
         if not (np.array_equal(t, rt) and np.array_equal(i, ri)):
             print("iter", it, "match", mi, "top-k differs from the serial run")
     rows = [s.download() for s in sets]
-    import ctypes as C
-    for si, s_ in enumerate(sets):
-        pass
     for si, (a, b) in enumerate(zip(ref, rows)):
         if not np.array_equal(a["dsc"], b["dsc"]):
             bad = np.argwhere(a["dsc"] != b["dsc"])
             rws = sorted(set(bad[:, 0].tolist()))
             print("iter", it, "set", si, "lane", si % 8, "dsc wrong: rows", rws[:6], "n", len(bad), "of rows", len(a["dsc"]))
-            tex_bad = set(np.flatnonzero(a["main"] != b["main"]).tolist())
-            fast_bad = set(np.flatnonzero(a["sec"] != b["sec"]).tolist())
-            exact_bad = set(np.flatnonzero(a["anchor"] != b["anchor"]).tolist())
-            print("   wrong rows", len(rws), "| texel-checksum differs", len(tex_bad), "| fast-path decisions differ", len(fast_bad & set(rws)), "| exact-path decisions differ", len(exact_bad & set(rws)))
             r0 = rws[0]
             d = b["dsc"][r0].astype(int) - a["dsc"][r0].astype(int)
             nz = np.flatnonzero(d)
