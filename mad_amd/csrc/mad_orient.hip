@@ -137,15 +137,26 @@ __global__ __launch_bounds__(ORI_THREADS) void k_orient(OrientArgs A) {
 
     // step01: fetch, normalise (float32, Orientator.py:139-147), keep weighted voxels only
     const float cutoff = 1e-5f;
-    for (int m = tid; m < A.nmask; m += ORI_THREADS) {
-        const int packed = ((const int *)A.mask_off)[m];      // {dx, dy, dz, 0} as one load
-        const int dx = (int)(int8_t)(packed & 0xff), dy = (int)(int8_t)((packed >> 8) & 0xff), dz = (int)(int8_t)((packed >> 16) & 0xff);
-        const size_t src = ((size_t)(x + dx * stride) * F.ny + (size_t)(y + dy * stride)) * F.nz + (size_t)(z + dz * stride);
-        const float4 t = F.tex[src];
-        if (!(t.w < cutoff)) {
-            float gx = t.x, gy = t.y, gz = t.z;
+    for (int m0 = 0; m0 < A.nmask; m0 += ORI_THREADS) {      // uniform trip count: the ballot below needs whole waves
+        const int m = m0 + tid;
+        bool keep = false;
+        float gx = 0.f, gy = 0.f, gz = 0.f;
+        if (m < A.nmask) {
+            const int packed = ((const int *)A.mask_off)[m];      // {dx, dy, dz, 0} as one load
+            const int dx = (int)(int8_t)(packed & 0xff), dy = (int)(int8_t)((packed >> 8) & 0xff), dz = (int)(int8_t)((packed >> 16) & 0xff);
+            const size_t src = ((size_t)(x + dx * stride) * F.ny + (size_t)(y + dy * stride)) * F.nz + (size_t)(z + dz * stride);
+            const float4 t = F.tex[src];
+            keep = !(t.w < cutoff);
+            gx = t.x; gy = t.y; gz = t.z;
             if (t.w > cutoff) { gx = __fdiv_rn(gx, t.w); gy = __fdiv_rn(gy, t.w); gz = __fdiv_rn(gz, t.w); }
-            const int slot = atomicAdd(&s_nvox, 1);
+        }
+        // one LDS atomic per wave instead of one per voxel (they all hit the same word)
+        const unsigned long long bal = __ballot(keep);
+        int base = 0;
+        if (lane_id() == 0 && bal) base = atomicAdd(&s_nvox, __popcll(bal));
+        base = __shfl(base, 0, MAD_WAVE);
+        if (keep) {
+            const int slot = base + __popcll(bal & lanemask_lt());
             vx[slot] = gx; vy[slot] = gy; vz[slot] = gz;
         }
     }
