@@ -275,6 +275,30 @@ int mad_match_shard_topk(mad_ctx *ctx, const mad_set *hi, const mad_set *lo, con
 int mad_density_ccc(mad_ctx *ctx, const double *atoms, const double *mass, int n_cand, int64_t n,
                     double resolution, double density_isovalue, double ccc_isovalue, double *ccc);
 
+/* ---- next to the path, downstream: occupancy overlap for assembly building ------------ */
+
+/*
+ * structure_utils.get_overlap(g1, g2, voxsp, isovalue) (structure_utils.py:163-259): both grids
+ * (host, float32 [x][y][z], z fastest) are clamped in place (values < isovalue -> 0), the common box
+ * follows from the origins (Angstrom) in voxel units with python's round(), *common = voxels of the
+ * box where both grids are > 0, *n_pos1 = voxels of grid1 that are > 0.  The reference's return value
+ * is common / n_pos1 (0 when n_pos1 == 0 or the boxes do not meet).
+ */
+int mad_grid_overlap(mad_ctx *ctx, float *grid1, const int32_t d1[3], const double o1[3], float *grid2,
+                     const int32_t d2[3], const double o2[3], double voxsp, double isovalue, int64_t *common,
+                     int64_t *n_pos1);
+
+/*
+ * The overlap table of MaD._build_from_single / _build_models (MaD.py:667-686, 760-783) in one call:
+ * structure s = atoms[first_atom[s] .. first_atom[s+1]) (float64 xyz, masses alongside) is turned into
+ * PDB.structure_to_density(resolution, voxsp, isovalue = density_isovalue) on the device, the grids stay
+ * there, and overlap[i * n_struct + j] = get_overlap(grid_i, grid_j, voxsp, overlap_isovalue) for i < j
+ * (0 elsewhere, as the reference leaves its table).  One read-back of the counts.
+ */
+int mad_overlap_matrix(mad_ctx *ctx, const double *atoms, const double *mass, const int64_t *first_atom,
+                       int n_struct, double resolution, double voxsp, double density_isovalue,
+                       double overlap_isovalue, double *overlap);
+
 /* ---- next to the path, upstream: MapSpace.build_space (MapSpace.py:116-189) and the
  *      dense half of Detector.find_anchors (Detector.py:28-29) ------------------------ */
 

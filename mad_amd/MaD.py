@@ -177,12 +177,21 @@ class MaD(object):
                 self.buildable_subunits[ek][1].extend(self._match_filter_refine(pdbfile, n_copies, fk, cc_threshold, weight_threshold, n_samples))
 
     def build_assembly(self, max_models=10, max_overlap_complex=0.1):
-        try:
-            from .assembly import build_assembly
-        except ImportError:
-            print("MaD> assembly building is outside the accelerated hot path and is not available in this build")
-            return
-        build_assembly(self, max_models=max_models, max_overlap_complex=max_overlap_complex)
+        """MaD.py:192-222; the overlap table and the model CCCs are device calls (mad_amd/assembly.py)."""
+        from . import assembly
+        return assembly.build_assembly(self, max_models=max_models, max_overlap_complex=max_overlap_complex)
+
+    def _build_from_single(self, sub_key, homomultimer=False):
+        from . import assembly
+        return assembly.build_from_single(self, sub_key, homomultimer=homomultimer)
+
+    def _build_models(self, sub_sol_dict):
+        from . import assembly
+        return assembly.build_models(self, sub_sol_dict)
+
+    def _write_complex_from_components(self, components, outname):
+        from . import assembly
+        assembly.write_complex(components, outname)
 
     def score_ensembles(self):
         if not self.processed_ensembles:

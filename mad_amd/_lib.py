@@ -24,7 +24,7 @@ SYMBOLS = [
     "mad_set_create", "mad_set_destroy", "mad_set_build", "mad_set_load", "mad_set_size", "mad_set_download",
     "mad_match_topk", "mad_match_topk_many", "mad_match_fetch", "mad_match_results", "mad_match_used",
     "mad_match_shard_pairs", "mad_match_shard_topk",
-    "mad_upload_density", "mad_refine", "mad_structure_to_density", "mad_ccc", "mad_density_ccc",
+    "mad_upload_density", "mad_refine", "mad_structure_to_density", "mad_ccc", "mad_density_ccc", "mad_grid_overlap", "mad_overlap_matrix",
     "mad_space_create", "mad_space_destroy", "mad_space_build", "mad_space_info", "mad_space_download",
     "mad_space_peaks", "mad_space_patches",
 ]
@@ -491,6 +491,34 @@ class Lib(object):
         out = np.zeros(n_cand, np.float64)
         self._chk(self.dll.mad_density_ccc(self.ctx, _p(c), _p(mass), C.c_int(n_cand), C.c_int64(n_atoms), C.c_double(resolution),
                                            C.c_double(density_isovalue), C.c_double(ccc_isovalue), _p(out)))
+        return out
+
+    def grid_overlap(self, g1, o1, g2, o2, voxsp, isovalue=1e-8):
+        """-> (common, positives of g1); both grids (writable C-contiguous float32) are clamped in place."""
+        for g in (g1, g2):
+            if g.dtype != np.float32 or not g.flags.c_contiguous or not g.flags.writeable:
+                raise ValueError("grid_overlap needs writable C-contiguous float32 grids")
+        d1, d2 = np.array(g1.shape, np.int32), np.array(g2.shape, np.int32)
+        o1, o2 = _c(o1, np.float64), _c(o2, np.float64)
+        common, npos = C.c_int64(0), C.c_int64(0)
+        self._chk(self.dll.mad_grid_overlap(self.ctx, _p(g1), _p(d1), _p(o1), _p(g2), _p(d2), _p(o2), C.c_double(voxsp),
+                                            C.c_double(isovalue), C.byref(common), C.byref(npos)))
+        return common.value, npos.value
+
+    def overlap_matrix(self, coords_list, mass_list, resolution=5.0, voxsp=2.0, density_isovalue=0.2, overlap_isovalue=1e-8):
+        """Upper-triangular table of get_overlap between the simulated densities of the given structures."""
+        n = len(coords_list)
+        out = np.zeros((n, n), np.float64)
+        if n < 2:
+            return out
+        first = np.zeros(n + 1, np.int64)
+        first[1:] = np.cumsum([len(c) for c in coords_list])
+        atoms = _c(np.concatenate([np.asarray(c, np.float64).reshape(-1, 3) for c in coords_list]), np.float64)
+        mass = _c(np.concatenate([np.asarray(m, np.float64).reshape(-1) for m in mass_list]), np.float64)
+        if len(mass) != len(atoms):
+            raise ValueError("overlap_matrix: %d masses for %d atoms" % (len(mass), len(atoms)))
+        self._chk(self.dll.mad_overlap_matrix(self.ctx, _p(atoms), _p(mass), _p(first), C.c_int(n), C.c_double(resolution),
+                                              C.c_double(voxsp), C.c_double(density_isovalue), C.c_double(overlap_isovalue), _p(out)))
         return out
 
     def ccc(self, g1, o1, g2, o2, voxsp, isovalue=0.0):

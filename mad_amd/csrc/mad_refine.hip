@@ -671,3 +671,174 @@ extern "C" int mad_density_ccc(mad_ctx *ctx, const double *atoms, const double *
     for (int c = 0; c < n_cand; c++) ccc[c] = is_empty[c] ? 0.0 : h[(size_t)c * 8 + 4] / sqrt(h[(size_t)c * 8 + 5] * h[(size_t)c * 8 + 6]);
     return MAD_OK;
 }
+
+// ---- next to the path, downstream: pairwise occupancy overlap of placed structures ---------------------------------
+// structure_utils.get_overlap (structure_utils.py:163-259) as MaD._build_from_single / _build_models use it
+// (MaD.py:673-686, 775-783): overlap(i, j) = #{voxels of the common box where both grids are > 0} / #{grid_i > 0}.
+
+struct OverlapPair {      // one (i, j) of the table: where the two grids start in the float pool, their strides, the common box
+    unsigned long long off1, off2;
+    int a1, a2, b1, b2;      // y/z extents of grid i and grid j
+    int s1[3], s2[3], e[3];
+};
+
+// positives of each grid after the clamp at `iso` (structure_utils.py:171-172, 255); grid g = blockIdx.y
+__global__ __launch_bounds__(256) void k_clamp_count(float *__restrict__ pool, const unsigned long long *__restrict__ first, float iso,
+                                                     unsigned long long *__restrict__ npos) {
+    const size_t b = first[blockIdx.y], n = first[blockIdx.y + 1] - b;
+    float *g = pool + b;
+    int c = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        float v = g[i];
+        if (v < iso) { v = 0.f; g[i] = v; }
+        c += v > 0.f ? 1 : 0;
+    }
+    c = wave_sum_i32(c);
+    if (lane_id() == 0 && c) atomicAdd(&npos[blockIdx.y], (unsigned long long)c);
+}
+
+// co-occupied voxels of the common box (structure_utils.py:246-254); pair p = blockIdx.y
+__global__ __launch_bounds__(256) void k_overlap_pairs(const float *__restrict__ pool, const OverlapPair *__restrict__ pairs,
+                                                       unsigned long long *__restrict__ common) {
+    const OverlapPair P = pairs[blockIdx.y];
+    const float *g1 = pool + P.off1, *g2 = pool + P.off2;
+    const size_t n = (size_t)P.e[0] * P.e[1] * P.e[2];
+    int c = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int z = (int)(i % P.e[2]), y = (int)((i / P.e[2]) % P.e[1]), x = (int)(i / ((size_t)P.e[2] * P.e[1]));
+        const float a = g1[((size_t)(P.s1[0] + x) * P.a1 + (P.s1[1] + y)) * P.a2 + (P.s1[2] + z)];
+        const float b = g2[((size_t)(P.s2[0] + x) * P.b1 + (P.s2[1] + y)) * P.b2 + (P.s2[2] + z)];
+        c += (a > 0.f && b > 0.f) ? 1 : 0;
+    }
+    c = wave_sum_i32(c);
+    if (lane_id() == 0 && c) atomicAdd(&common[blockIdx.y], (unsigned long long)c);
+}
+
+// shared tail of the two entry points: grids already in `pool` (float32, unclamped), geometry on the host
+static int overlap_run(mad_ctx *ctx, float *pool, const std::vector<unsigned long long> &first, const std::vector<int32_t> &dims,
+                       const std::vector<double> &origin, double voxsp, double isovalue, const std::vector<int> &pi,
+                       const std::vector<int> &pj, std::vector<unsigned long long> &npos, std::vector<unsigned long long> &common) {
+    const int n_grid = (int)first.size() - 1;
+    const size_t n_pair = pi.size();
+    std::vector<OverlapPair> tab;
+    std::vector<long> where(n_pair, -1);
+    for (size_t p = 0; p < n_pair; p++) {
+        const int i = pi[p], j = pj[p];
+        long mn1[3], mn2[3], e[3];
+        if (!ccc_overlap(&dims[3 * i], &origin[3 * i], &dims[3 * j], &origin[3 * j], voxsp, mn1, mn2, e)) continue;      // :241-243
+        if (e[0] <= 0 || e[1] <= 0 || e[2] <= 0) continue;
+        OverlapPair P;
+        P.off1 = first[i]; P.off2 = first[j];
+        P.a1 = dims[3 * i + 1]; P.a2 = dims[3 * i + 2]; P.b1 = dims[3 * j + 1]; P.b2 = dims[3 * j + 2];
+        for (int d = 0; d < 3; d++) { P.s1[d] = (int)mn1[d]; P.s2[d] = (int)mn2[d]; P.e[d] = (int)e[d]; }
+        where[p] = (long)tab.size();
+        tab.push_back(P);
+    }
+    const size_t nt = tab.size();
+    const size_t bytes_first = (size_t)(n_grid + 1) * 8, bytes_cnt = (size_t)(n_grid + nt) * 8, bytes_tab = nt * sizeof(OverlapPair);
+    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_TMP_G), bytes_first + bytes_cnt + bytes_tab + 64));
+    char *blk = scratch<char>(ctx, S_TMP_G);
+    unsigned long long *d_first = (unsigned long long *)blk, *d_cnt = (unsigned long long *)(blk + bytes_first);
+    OverlapPair *d_tab = (OverlapPair *)(blk + bytes_first + bytes_cnt);
+    MAD_HIP(hipMemcpyAsync(d_first, first.data(), bytes_first, hipMemcpyHostToDevice, ctx->stream));
+    if (nt) MAD_HIP(hipMemcpyAsync(d_tab, tab.data(), bytes_tab, hipMemcpyHostToDevice, ctx->stream));
+    MAD_HIP(hipMemsetAsync(d_cnt, 0, bytes_cnt, ctx->stream));
+    hipLaunchKernelGGL(k_clamp_count, dim3(16, n_grid), dim3(256), 0, ctx->stream, pool, d_first, (float)isovalue, d_cnt);
+    for (size_t p0 = 0; p0 < nt; p0 += 32768) {      // gridDim.y limit
+        const unsigned np = (unsigned)std::min<size_t>(nt - p0, 32768);
+        hipLaunchKernelGGL(k_overlap_pairs, dim3(8, np), dim3(256), 0, ctx->stream, pool, d_tab + p0, d_cnt + n_grid + p0);
+    }
+    MAD_HIP(hipGetLastError());
+    std::vector<unsigned long long> h(n_grid + nt);
+    MAD_HIP(hipMemcpyAsync(h.data(), d_cnt, bytes_cnt, hipMemcpyDeviceToHost, ctx->stream));
+    MAD_HIP(hipStreamSynchronize(ctx->stream));
+    npos.assign(h.begin(), h.begin() + n_grid);
+    common.assign(n_pair, 0);
+    for (size_t p = 0; p < n_pair; p++)
+        if (where[p] >= 0) common[p] = h[n_grid + where[p]];
+    return MAD_OK;
+}
+
+extern "C" int mad_grid_overlap(mad_ctx *ctx, float *grid1, const int32_t d1[3], const double o1[3], float *grid2, const int32_t d2[3],
+                                const double o2[3], double voxsp, double isovalue, int64_t *common, int64_t *n_pos1) {
+    if (ctx) mad_use_lane(ctx, 0);
+    if (!ctx || !grid1 || !grid2 || !d1 || !d2 || !o1 || !o2 || !common || !n_pos1)
+        return ctx ? mad_fail(ctx, MAD_EINVAL, "mad_grid_overlap: NULL argument") : MAD_EINVAL;
+    if (!(voxsp > 0)) return mad_fail(ctx, MAD_EINVAL, "mad_grid_overlap: voxsp %g", voxsp);
+    for (int d = 0; d < 3; d++)
+        if (d1[d] <= 0 || d2[d] <= 0) return mad_fail(ctx, MAD_EINVAL, "mad_grid_overlap: empty grid");
+    const size_t n1 = (size_t)d1[0] * d1[1] * d1[2], n2 = (size_t)d2[0] * d2[1] * d2[2];
+    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_TMP_H), (n1 + n2) * 4));
+    float *pool = scratch<float>(ctx, S_TMP_H);
+    MAD_HIP(hipMemcpyAsync(pool, grid1, n1 * 4, hipMemcpyHostToDevice, ctx->stream));
+    MAD_HIP(hipMemcpyAsync(pool + n1, grid2, n2 * 4, hipMemcpyHostToDevice, ctx->stream));
+    std::vector<unsigned long long> first = {0, n1, n1 + n2}, npos, cm;
+    std::vector<int32_t> dims = {d1[0], d1[1], d1[2], d2[0], d2[1], d2[2]};
+    std::vector<double> org = {o1[0], o1[1], o1[2], o2[0], o2[1], o2[2]};
+    MAD_TRY(overlap_run(ctx, pool, first, dims, org, voxsp, isovalue, {0}, {1}, npos, cm));
+    // both grids come back clamped, as the reference leaves them (structure_utils.py:171-172)
+    MAD_HIP(hipMemcpyAsync(grid1, pool, n1 * 4, hipMemcpyDeviceToHost, ctx->stream));
+    MAD_HIP(hipMemcpyAsync(grid2, pool + n1, n2 * 4, hipMemcpyDeviceToHost, ctx->stream));
+    MAD_HIP(hipStreamSynchronize(ctx->stream));
+    *common = (int64_t)cm[0];
+    *n_pos1 = (int64_t)npos[0];
+    return MAD_OK;
+}
+
+extern "C" int mad_overlap_matrix(mad_ctx *ctx, const double *atoms, const double *mass, const int64_t *first_atom, int n_struct,
+                                  double resolution, double voxsp, double density_isovalue, double overlap_isovalue, double *overlap) {
+    if (ctx) mad_use_lane(ctx, 0);
+    if (!ctx || !atoms || !mass || !first_atom || !overlap || n_struct < 0)
+        return ctx ? mad_fail(ctx, MAD_EINVAL, "mad_overlap_matrix: bad argument") : MAD_EINVAL;
+    if (!(voxsp > 0) || !(resolution > 0)) return mad_fail(ctx, MAD_EINVAL, "mad_overlap_matrix: resolution %g voxsp %g", resolution, voxsp);
+    if (n_struct > 4096) return mad_fail(ctx, MAD_EINVAL, "mad_overlap_matrix: %d structures in one call", n_struct);
+    for (size_t i = 0; i < (size_t)n_struct * n_struct; i++) overlap[i] = 0.0;
+    if (n_struct < 2) return MAD_OK;
+    std::vector<DensityPlan> plans(n_struct);
+    std::vector<unsigned long long> first(n_struct + 1, 0);
+    std::vector<int32_t> dims(3 * (size_t)n_struct);
+    std::vector<double> org(3 * (size_t)n_struct);
+    size_t no_max = 0, n_max = 0;
+    for (int s = 0; s < n_struct; s++) {
+        const int64_t n = first_atom[s + 1] - first_atom[s];
+        if (n <= 0) return mad_fail(ctx, MAD_EINVAL, "mad_overlap_matrix: structure %d has no atoms", s);
+        MAD_TRY(density_plan(ctx, atoms + 3 * first_atom[s], n, resolution, voxsp, 0, &plans[s]));
+        const size_t no = (size_t)plans[s].dims[0] * plans[s].dims[1] * plans[s].dims[2];
+        first[s + 1] = first[s] + no;
+        no_max = std::max(no_max, no);
+        n_max = std::max(n_max, (size_t)n);
+        for (int d = 0; d < 3; d++) { dims[3 * s + d] = plans[s].dims[d]; org[3 * s + d] = plans[s].origin[d]; }
+    }
+    const int64_t n_all = first_atom[n_struct];
+    double taps[129];
+    density_taps(plans[0], taps);
+    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_TMP_E), (size_t)n_all * 24));
+    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_TMP_F), (size_t)n_all * 8));
+    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_TMP_H), no_max * 8));
+    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_TMP_I), no_max * 8));
+    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_TMP_J), (size_t)first[n_struct] * 4));
+    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_TMP_D), (size_t)n_struct * 32 + 2048));
+    double *d_atoms = scratch<double>(ctx, S_TMP_E), *d_mass = scratch<double>(ctx, S_TMP_F);
+    double *bufA = scratch<double>(ctx, S_TMP_H), *bufB = scratch<double>(ctx, S_TMP_I);
+    float *pool = scratch<float>(ctx, S_TMP_J);
+    char *blk = scratch<char>(ctx, S_TMP_D);      // per structure 32 bytes: {max of the splat, pad, max of the float32 grid, pad}; then taps
+    double *d_taps = (double *)(blk + (size_t)n_struct * 32);
+    MAD_HIP(hipMemcpyAsync(d_atoms, atoms, (size_t)n_all * 24, hipMemcpyHostToDevice, ctx->stream));
+    MAD_HIP(hipMemcpyAsync(d_mass, mass, (size_t)n_all * 8, hipMemcpyHostToDevice, ctx->stream));
+    MAD_HIP(hipMemcpyAsync(d_taps, taps, sizeof(double) * (2 * plans[0].r + 1), hipMemcpyHostToDevice, ctx->stream));
+    mad_zero_words(ctx, blk, (size_t)n_struct * 32);
+    mad_timer_begin(ctx, MAD_T_DENSITY);
+    for (int s = 0; s < n_struct; s++)
+        density_enqueue(ctx, plans[s], d_atoms + 3 * first_atom[s], d_mass + first_atom[s], first_atom[s + 1] - first_atom[s], voxsp,
+                        density_isovalue, d_taps, (double *)(blk + (size_t)s * 32), (unsigned *)(blk + (size_t)s * 32 + 16), bufA, bufB,
+                        pool + first[s]);
+    mad_timer_end(ctx, MAD_T_DENSITY);
+    std::vector<int> pi, pj;
+    for (int i = 0; i < n_struct; i++)
+        for (int j = i + 1; j < n_struct; j++) { pi.push_back(i); pj.push_back(j); }
+    std::vector<unsigned long long> npos, cm;
+    MAD_TRY(overlap_run(ctx, pool, first, dims, org, voxsp, overlap_isovalue, pi, pj, npos, cm));
+    for (size_t p = 0; p < pi.size(); p++)
+        overlap[(size_t)pi[p] * n_struct + pj[p]] = npos[pi[p]] ? (double)cm[p] / (double)npos[pi[p]] : 0.0;      // :256-258
+    return MAD_OK;
+}

@@ -5,8 +5,8 @@
 dependent gradient-ascent steps run in one persistent HIP workgroup (`k_refine`,
 through `mad_refine`).  `refine_many` refines several placements of one structure in a
 single launch (one workgroup each).  `move_structure` / `move_copy_structure` are plain
-bookkeeping; `get_overlap` belongs to assembly building (out of scope, SURVEY.md
-section 2).
+bookkeeping; `get_overlap` (assembly building) counts on the
+device through `mad_grid_overlap`.
 """
 import numpy as np
 
@@ -84,3 +84,21 @@ def move_copy_structure(original_struct, moved_struct, transform=False, t=[150, 
             pdb.translate_atoms(t)
     pdb.write_pdb(moved_struct)
     return moved_struct
+
+
+def get_overlap(g1, g2, voxsp, isovalue=1e-8):
+    """Fraction of the occupied voxels of grid 1 that grid 2 also occupies -- structure_utils.py:163-259.
+    g1, g2 = (grid, x0, y0, z0).  Like the reference, both grids are clamped in place at `isovalue`."""
+    def device_view(grid):
+        if grid.dtype == np.float32 and grid.flags.c_contiguous and grid.flags.writeable:
+            return grid
+        return np.ascontiguousarray(grid, dtype=np.float32)
+    (grid1, x1, y1, z1), (grid2, x2, y2, z2) = g1, g2
+    a, b = device_view(grid1), device_view(grid2)
+    common, occupied = _lib.get_lib().grid_overlap(a, (x1, y1, z1), b, (x2, y2, z2), voxsp, isovalue)
+    for src, dst in ((a, grid1), (b, grid2)):
+        if src is not dst:
+            dst[...] = src
+    if occupied == 0:
+        return 0
+    return common / occupied

@@ -195,6 +195,41 @@ def ccc(g1, o1, g2, o2, vs, isovalue=0.0):
     return lib().orc_ccc(_opt(g1), _opt(d1), _opt(o1), _opt(g2), _opt(d2), _opt(o2), C.c_double(vs), C.c_double(isovalue))
 
 
+def _common_box(n1, a, n2, b):
+    """One axis of the box shared by two grids that start at a and b (voxel units) and are n1 / n2 long:
+    (start in grid 1, stop in grid 1, start in grid 2, stop in grid 2), structure_utils.py:181-238."""
+    lo1, lo2 = (0, int(round(a - b))) if a > b else ((int(round(b - a)), 0) if a < b else (0, 0))
+    if a + n1 > b + n2:
+        hi1, hi2 = int(round(b + n2 - a)), int(round(n2))
+    elif a + n1 < b + n2:
+        hi1, hi2 = int(round(n1)), int(round(a + n1 - b))
+    else:
+        hi1, hi2 = int(round(n1)), int(round(n2))
+    return lo1, hi1, lo2, hi2
+
+
+def overlap(g1, o1, g2, o2, vs, isovalue=1e-8):
+    """structure_utils.get_overlap (structure_utils.py:163-259): both grids are clamped in place; returns
+    (#voxels of the common box occupied in both, #occupied voxels of g1) -- the reference's value is their ratio."""
+    g1[g1 < isovalue] = 0
+    g2[g2 < isovalue] = 0
+    sl1, sl2 = [], []
+    for d in range(3):
+        lo1, hi1, lo2, hi2 = _common_box(g1.shape[d], o1[d] / vs, g2.shape[d], o2[d] / vs)
+        if hi1 - lo1 < 0:      # :241-243
+            return 0, int(np.count_nonzero(g1 > 0))
+        sl1.append(slice(lo1, hi1))
+        sl2.append(slice(lo2, hi2))
+    a, b = g1[tuple(sl1)], g2[tuple(sl2)]
+    ext = tuple(slice(0, min(x, y)) for x, y in zip(a.shape, b.shape))
+    return int(np.count_nonzero((a[ext] > 0) & (b[ext] > 0))), int(np.count_nonzero(g1 > 0))
+
+
+def overlap_ratio(g1, o1, g2, o2, vs, isovalue=1e-8):
+    common, occupied = overlap(g1, o1, g2, o2, vs, isovalue)
+    return common / occupied if occupied else 0
+
+
 # ---------------------------------------------------------------------------------------------
 # The same four stages on several host cores: the independent units (anchors, rows, hi rows, pairs) are
 # cut into contiguous chunks, every chunk goes through the scalar C function above in its own thread

@@ -16,7 +16,7 @@ Fixtures hold inputs and the reference's outputs only (numpy arrays).  Everythin
 seeded; re-running this script reproduces the files bit for bit on the same numpy /
 scipy build.
 
-Usage:  cd /root/repo && python tests/golden/make_golden.py
+Usage:  cd /root/repo && python tests/golden/make_golden.py [--only-g9]
 """
 import hashlib
 import os
@@ -67,6 +67,87 @@ def sha(path):
         return hashlib.sha256(f.read()).hexdigest()
 
 
+def make_g9(R, synth, work):
+    """G9: assembly building -- get_overlap on pairs of low-resolution densities, the candidate ranking of
+    _build_from_single / _build_models and the files build_assembly writes, all by the reference."""
+    import contextlib
+    import io
+    rng = np.random.default_rng(77)
+    ca, na, ea = synth.random_globule(700, 12.0, seed=3)
+    cb, nb, eb = synth.random_globule(500, 10.0, seed=4)
+    pose = [synth.random_rotation(rng) for _ in range(6)]
+    # true placements: A at two sites, B at one
+    A1, A2 = synth.place(ca, pose[0], [0, 0, 0]), synth.place(ca, pose[1], [30, 4, -3])
+    B1 = synth.place(cb, pose[2], [12, 28, 6])
+    res, vs = 8.0, 1.5
+    asm_pdb = os.path.join(work, "g9_asm.pdb")
+    synth.write_pdb(asm_pdb, np.concatenate([A1, A2, B1]), na * 2 + nb, ea * 2 + eb)
+    map_grid, mx, my, mz = R.PDB.PDB(asm_pdb).structure_to_density(res, vs)
+    map_sit = os.path.join(work, "g9_map.sit")
+    synth.write_situs(map_sit, map_grid, (mx, my, mz), vs)
+    # candidate solutions: the true ones, near-clones, a clashing one and a far one
+    sols_a = [A1, A2, A1 + np.array([3.0, -2.0, 1.0]), synth.place(ca, pose[3], [14, 3, -1]), synth.place(ca, pose[4], [70, 0, 0])]
+    sols_b = [B1, synth.place(cb, pose[5], [4, 6, 2]), B1 + np.array([0.0, 2.0, -2.0])]
+    files_a, files_b = [], []
+    for i, c in enumerate(sols_a):
+        files_a.append(os.path.join(work, "sol_A_%d.pdb" % i))
+        synth.write_pdb(files_a[-1], c, na, ea)
+    for i, c in enumerate(sols_b):
+        files_b.append(os.path.join(work, "sol_B_%d.pdb" % i))
+        synth.write_pdb(files_b[-1], c, nb, eb)
+    g9 = dict(res=res, vs=vs, map_grid=map_grid, map_origin=np.array([mx, my, mz]), atoms_a=np.stack(sols_a), atoms_b=np.stack(sols_b),
+              elements_a=np.array(ea), elements_b=np.array(eb), names_a=np.array(na), names_b=np.array(nb))
+    # pairwise get_overlap exactly as MaD.py:667-686 calls it
+    files = files_a + files_b
+    maps = [list(R.PDB.PDB(f).structure_to_density(5, 2, isovalue=0.2)) for f in files]
+    n = len(files)
+    table = np.zeros((n, n))
+    for i in range(n):
+        for j in range(i + 1, n):
+            table[i, j] = R.SU.get_overlap(maps[i], maps[j], 2)
+    g9["overlap_all"] = table
+    g9["lowres_dims"] = np.array([m[0].shape for m in maps])
+    g9["lowres_origin"] = np.array([[m[1], m[2], m[3]] for m in maps])
+    g9["lowres_grid_0"], g9["lowres_grid_3"] = maps[0][0], maps[3][0]
+    # direct get_overlap cases: different isovalue, swapped arguments, disjoint boxes
+    g9["overlap_03_iso"] = R.SU.get_overlap([maps[0][0].copy()] + maps[0][1:], [maps[3][0].copy()] + maps[3][1:], 2, isovalue=0.5)
+    g9["overlap_30"] = R.SU.get_overlap(maps[3], maps[0], 2)
+    g9["overlap_04"] = R.SU.get_overlap(maps[0], maps[4], 2)
+
+    def run(buildable, tag, **kw):
+        m = R.MaD.MaD()
+        m.out_folder = os.path.join(work, "g9_out_" + tag)
+        os.makedirs(m.out_folder)
+        m.processed_map, m.map_name, m.resolution = map_sit, "g9_map", res
+        m.buildable_subunits = buildable
+        log = io.StringIO()
+        with contextlib.redirect_stdout(log), np.errstate(all="ignore"):
+            m.build_assembly(**kw)
+        out = {}
+        for sub in ("subcomplexes", "assembly_models"):
+            d = os.path.join(m.out_folder, sub)
+            names = sorted(os.listdir(d)) if os.path.isdir(d) else []
+            out[sub] = names
+            for nm in names:
+                pdb = R.PDB.PDB(os.path.join(d, nm))
+                g9["%s_%s_%s_coords" % (tag, sub, nm)] = pdb.coords
+                g9["%s_%s_%s_chain" % (tag, sub, nm)] = np.array([r[3] for r in pdb.info])
+                with open(os.path.join(d, nm)) as fh:
+                    g9["%s_%s_%s_nter" % (tag, sub, nm)] = np.array(sum(1 for l in fh if l.startswith("TER")))
+        g9[tag + "_subcomplexes"] = np.array(out["subcomplexes"], dtype=str)
+        g9[tag + "_models"] = np.array(out["assembly_models"], dtype=str)
+        csvp = os.path.join(m.out_folder, "complex_ranking.csv")
+        g9[tag + "_ranking_csv"] = np.array(open(csvp).read() if os.path.exists(csvp) else "")
+        g9[tag + "_stdout"] = np.array(log.getvalue())
+
+    run({"A": [2, list(files_a)]}, "homo")
+    run({"A": [2, list(files_a)], "B": [1, list(files_b)]}, "hetero")
+    run({"A": [2, list(files_a)], "B": [1, list(files_b)]}, "hetero_loose", max_models=3, max_overlap_complex=0.5)
+    np.savez_compressed(os.path.join(OUT, "g9_assembly.npz"), **g9)
+    print("g9:", {k: (v.shape if hasattr(v, "shape") and v.shape else v) for k, v in g9.items() if k.endswith(("_models", "_subcomplexes"))})
+    print(table.round(3))
+
+
 def main():
     from scipy.interpolate import RegularGridInterpolator as RGI
     R = import_reference()
@@ -74,6 +155,9 @@ def main():
     from mad_amd.Detector import Detector as MyDetector
     os.makedirs(OUT, exist_ok=True)
     work = tempfile.mkdtemp(prefix="mad_golden_")
+    if "--only-g9" in sys.argv:      # the other fixtures are left as they are
+        make_g9(R, synth, work)
+        return
 
     # ---- G1: EQSP tables -----------------------------------------------------------
     g1 = {}
@@ -273,6 +357,8 @@ def main():
               ccc=np.array([f[4] for f in final], dtype=np.float64), score=np.array([f[6] for f in final], dtype=np.float64),
               coords=np.array([f[0].coords for f in final]), truth=np.stack(parts))
     np.savez_compressed(os.path.join(OUT, "g8_solutions.npz"), **g8)
+
+    make_g9(R, synth, work)
 
     sizes = {f: os.path.getsize(os.path.join(OUT, f)) for f in sorted(os.listdir(OUT)) if f.endswith(".npz")}
     print("fixtures:", sizes, "total %.1f MB" % (sum(sizes.values()) / 1e6))
