@@ -49,6 +49,20 @@ def test_run_mad_docks_a_synthetic_dimer(tmp_path, monkeypatch, lib):
         assert float(r["mCC"]) > 0.8
     assert sorted(found) == [0, 1]
     assert mad.buildable_subunits["subunit"][0] == 2 and len(mad.buildable_subunits["subunit"][1]) >= 2
+    # build_assembly (run_MaD.py:76): the best model is the pair of planted copies, clash-free, high CCC
+    mad.build_assembly()
+    with open(os.path.join(out, "complex_ranking.csv")) as fh:
+        models = list(csv.DictReader(fh))
+    assert list(models[0].keys()) == ["#", "CC", "Sum(O)", "Std(O)", "Max(O)", "Composition"]
+    assert os.path.exists(os.path.join(out, "assembly_models", "Model_1.pdb"))
+    assert float(models[0]["Max(O)"]) <= 0.1
+    best = max(models, key=lambda r: float(r["CC"]))
+    assert float(best["CC"]) > 0.85
+    model = PDB(os.path.join(out, "assembly_models", "Model_%s.pdb" % best["#"]))
+    assert model.n_atoms == 2 * len(coords) and {r[3] for r in model.info} == {"A", "B"}
+    halves = [model.coords[:len(coords)], model.coords[len(coords):]]
+    hit = sorted(int(np.argmin([np.sqrt(((h - t) ** 2).sum(1).mean()) for t in truth])) for h in halves)
+    assert hit == [0, 1]
     # a second run hits the descriptor cache and lands in a suffixed folder (MaD.py:304-309)
     mad2 = MaD.MaD()
     mad2.add_map("assembly.pdb", 10.0)
