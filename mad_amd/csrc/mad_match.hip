@@ -334,7 +334,8 @@ __device__ __forceinline__ int pg_cell(double v, double mn, double inv, int dim)
 
 // one workgroup: counting sort of the used points into cells; sorted points and offsets to global
 __global__ __launch_bounds__(1024) void k_pose_grid_build(const double *__restrict__ pts, const uint8_t *__restrict__ used, int n,
-                                                          PoseGrid G, int32_t *__restrict__ cell_start, double *__restrict__ sorted,
+                                                          PoseGrid G, int32_t *__restrict__ cell_start,
+                                                          unsigned short *__restrict__ cell_start16, double *__restrict__ sorted,
                                                           float4 *__restrict__ sorted_f, int32_t *__restrict__ n_used) {
     extern __shared__ __align__(16) unsigned char smem[];
     int *cnt = (int *)smem;
@@ -356,12 +357,15 @@ __global__ __launch_bounds__(1024) void k_pose_grid_build(const double *__restri
         const int v = c < G.ncell ? cnt[c] : 0;
         int tot;
         const int ex = block_excl_scan(v, wt, &tot);
-        if (c < G.ncell) { cnt[c] = carry + ex; cell_start[c] = carry + ex; }
+        if (c < G.ncell) { cnt[c] = carry + ex; cell_start[c] = carry + ex; cell_start16[c] = (unsigned short)(carry + ex); }
         __syncthreads();
         if (threadIdx.x == 0) carry += tot;
         __syncthreads();
     }
-    if (threadIdx.x == 0) { cell_start[G.ncell] = carry; *n_used = carry; }
+    if (threadIdx.x == 0) {
+        cell_start[G.ncell] = carry; *n_used = carry;
+        cell_start16[G.ncell] = (unsigned short)carry; cell_start16[G.ncell + 1] = 0;      // the search kernels copy whole dwords
+    }
     __syncthreads();
     for (int i = threadIdx.x; i < n; i += 1024)
         if (!used || used[i]) {
@@ -376,44 +380,217 @@ __global__ __launch_bounds__(1024) void k_pose_grid_build(const double *__restri
         }
 }
 
+// Copies `bytes` (a multiple of 4) from 16-byte-aligned global memory to 16-byte-aligned LDS with the whole workgroup:
+// 16 bytes per lane and four requests in flight per lane, because a workgroup that waits for one 4-byte load per lane
+// per trip spends tens of microseconds filling 100+ KB of LDS.
+template <int THREADS>
+__device__ __forceinline__ void stage_lds(void *lds_dst, const void *src, size_t bytes) {
+    const uint4 *s4 = (const uint4 *)src;
+    uint4 *d4 = (uint4 *)lds_dst;
+    const int n4 = (int)(bytes >> 4);
+    for (int i = threadIdx.x; i < n4; i += 4 * THREADS) {
+        uint4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            if (i + u * THREADS < n4) v[u] = s4[i + u * THREADS];
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            if (i + u * THREADS < n4) d4[i + u * THREADS] = v[u];
+    }
+    const int tail = (int)((bytes & 15) >> 2);
+    if ((int)threadIdx.x < tail) ((unsigned *)lds_dst)[4 * n4 + threadIdx.x] = ((const unsigned *)src)[4 * n4 + threadIdx.x];
+}
+
+__host__ __device__ __forceinline__ size_t pad16(size_t b) { return (b + 15) & ~(size_t)15; }
+
+// Occupancy bitmap of the lo cloud: bit (x, y, z) is set iff some lo point lies within `rad` of the centre of that voxel
+// (edge h, origin mn), rad = dist + h sqrt(3) / 2 + slack.  A transformed hi point that falls into a clear voxel -- or
+// outside the bitmap -- has no lo point within dist, whatever the float32 rounding of its voxel coordinates (slack =
+// 0.02 A against < 1e-3 A of error), so only the others (about one in seven on the 256^3 workload) go through the exact
+// float64 search.  z-rows are padded to whole 32-bit words.
+struct PoseBits {
+    double mn[3];
+    double h;
+    int dim[3];
+    int wz;      // words per z-row
+};
+
+__global__ __launch_bounds__(256) void k_pose_bits(const double *__restrict__ sorted, const int32_t *__restrict__ cell_start, int ncell,
+                                                   PoseBits B, double rad, unsigned *__restrict__ bits) {
+    const int l_lo = cell_start[ncell];
+    const double inv_h = 1.0 / B.h, rad2 = rad * rad;
+    for (int p = blockIdx.x; p < l_lo; p += gridDim.x) {
+        const double px = sorted[3 * p] - B.mn[0], py = sorted[3 * p + 1] - B.mn[1], pz = sorted[3 * p + 2] - B.mn[2];
+        // voxel k has its centre at (k + 0.5) h; the index ranges below are supersets, the row test is exact
+        const int x0 = max((int)floor((px - rad) * inv_h - 0.5), 0), x1 = min((int)ceil((px + rad) * inv_h - 0.5), B.dim[0] - 1);
+        const int y0 = max((int)floor((py - rad) * inv_h - 0.5), 0), y1 = min((int)ceil((py + rad) * inv_h - 0.5), B.dim[1] - 1);
+        const int ny = y1 - y0 + 1, nrow = (x1 - x0 + 1) * ny;
+        for (int t = threadIdx.x; t < nrow; t += 256) {
+            const int kx = x0 + t / ny, ky = y0 + t % ny;
+            const double dx = (kx + 0.5) * B.h - px, dy = (ky + 0.5) * B.h - py;
+            const double rem = rad2 - dx * dx - dy * dy;
+            if (rem < 0.0) continue;
+            const double sq = sqrt(rem);
+            const int z0 = max((int)floor((pz - sq) * inv_h - 0.5), 0), z1 = min((int)ceil((pz + sq) * inv_h - 0.5), B.dim[2] - 1);
+            if (z1 < z0) continue;
+            unsigned *row = bits + ((size_t)kx * B.dim[1] + ky) * B.wz;
+            for (int w = z0 >> 5; w <= (z1 >> 5); w++) {
+                const int lo = max(z0 - 32 * w, 0), hi = min(z1 - 32 * w, 31);
+                const unsigned m = (hi == 31 ? 0xffffffffu : ((1u << (hi + 1)) - 1u)) & ~((1u << lo) - 1u);
+                atomicOr(&row[w], m);
+            }
+        }
+    }
+}
+
+// float32 map from a hi-cloud point to bitmap voxel coordinates for one pair: v = M c + t
+struct PoseVox {
+    float m[9], t[3];
+};
+
+__device__ __forceinline__ void pose_vox_setup(const double *R, double ph0, double ph1, double ph2, double pl0, double pl1, double pl2,
+                                               const PoseBits &B, PoseVox *V) {
+    const double ih = 1.0 / B.h;
+    for (int i = 0; i < 9; i++) V->m[i] = (float)(R[i] * ih);
+    // x = R (c - ph) + pl = R c + (pl - R ph)
+    V->t[0] = (float)(((pl0 - (ph0 * R[0] + ph1 * R[1] + ph2 * R[2])) - B.mn[0]) * ih);
+    V->t[1] = (float)(((pl1 - (ph0 * R[3] + ph1 * R[4] + ph2 * R[5])) - B.mn[1]) * ih);
+    V->t[2] = (float)(((pl2 - (ph0 * R[6] + ph1 * R[7] + ph2 * R[8])) - B.mn[2]) * ih);
+}
+
+// the bitmap word of a hi-cloud point and the bit to test in it; *word = 0 for points outside the bitmap
+__device__ __forceinline__ void pose_vox_fetch(const PoseVox &V, float cx, float cy, float cz, const PoseBits &B,
+                                               const unsigned *bits, unsigned *word, int *bit) {
+    const float vx = fmaf(cz, V.m[2], fmaf(cy, V.m[1], fmaf(cx, V.m[0], V.t[0])));
+    const float vy = fmaf(cz, V.m[5], fmaf(cy, V.m[4], fmaf(cx, V.m[3], V.t[1])));
+    const float vz = fmaf(cz, V.m[8], fmaf(cy, V.m[7], fmaf(cx, V.m[6], V.t[2])));
+    const int ix = (int)floorf(vx), iy = (int)floorf(vy), iz = (int)floorf(vz);
+    *bit = iz & 31;
+    *word = 0;
+    if ((unsigned)ix < (unsigned)B.dim[0] && (unsigned)iy < (unsigned)B.dim[1] && (unsigned)iz < (unsigned)B.dim[2])
+        *word = bits[((size_t)ix * B.dim[1] + iy) * B.wz + (iz >> 5)];
+}
+
+// Two-phase count for one pair (one wave): the bitmap test for every hi point, survivors collected in the wave's LDS
+// stack, and the exact search `exact(a)` run on them 64 at a time, so that its lanes stay full.  The bitmap words of
+// POSE_BATCH x 64 points are requested before the first one is looked at: the loads are scattered L2 hits, and a wave
+// that waited for each in turn would spend most of its time doing so.
+#define POSE_STACK 128
+#define POSE_BATCH 4
+template <class Cloud32, class Exact>
+__device__ __forceinline__ int pose_count_filtered(int l_hi, const PoseVox &V, const PoseBits &B, const unsigned *bits,
+                                                   unsigned short *stack, Cloud32 cloud32, Exact exact) {
+    const int lane = lane_id();
+    int nq = 0, cnt = 0;
+    for (int a0 = 0; a0 < l_hi; a0 += MAD_WAVE * POSE_BATCH) {
+        unsigned word[POSE_BATCH];
+        int bit[POSE_BATCH];
+#pragma unroll
+        for (int u = 0; u < POSE_BATCH; u++) {
+            const int a = a0 + u * MAD_WAVE + lane;
+            word[u] = 0; bit[u] = 0;
+            if (a < l_hi) {
+                float cx, cy, cz;
+                cloud32(a, cx, cy, cz);
+                pose_vox_fetch(V, cx, cy, cz, B, bits, &word[u], &bit[u]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < POSE_BATCH; u++) {
+            if (a0 + u * MAD_WAVE >= l_hi) break;      // wave-uniform
+            const bool sv = (word[u] >> bit[u]) & 1u;
+            const unsigned long long bal = __ballot(sv);
+            if (sv) stack[nq + __popcll(bal & lanemask_lt())] = (unsigned short)(a0 + u * MAD_WAVE + lane);
+            nq += __popcll(bal);
+            if (nq >= MAD_WAVE) {      // wave-uniform
+                __builtin_amdgcn_wave_barrier();
+                const int a2 = stack[nq - MAD_WAVE + lane];
+                __builtin_amdgcn_wave_barrier();
+                cnt += exact(a2) ? 1 : 0;
+                nq -= MAD_WAVE;
+            }
+        }
+    }
+    if (nq > 0) {
+        __builtin_amdgcn_wave_barrier();
+        const int a2 = lane < nq ? stack[lane] : 0;
+        __builtin_amdgcn_wave_barrier();
+        if (lane < nq) cnt += exact(a2) ? 1 : 0;
+    }
+    return cnt;
+}
+
+// Per-pair rigid transform, written once by k_pose_prep (a thread per pair: the three-level chain pair -> row -> anchor
+// of dependent scattered loads is hidden by the width of that launch) and read back as one contiguous 120-byte record
+// by the search kernels, which fetch the record of their next pair while they work on the current one.
+struct PosePair {
+    double R[9];      // inv(lo.Rfinal) @ hi.Rfinal (MaD.py:438)
+    double ph[3], pl[3];
+};
+
+__global__ __launch_bounds__(256) void k_pose_prep(const int32_t *__restrict__ pair_hi, const int32_t *__restrict__ pair_lo,
+                                                   const int32_t *__restrict__ status, int64_t cap_pairs,
+                                                   const double *__restrict__ hi_p, const double *__restrict__ hi_R,
+                                                   const double *__restrict__ lo_p, const double *__restrict__ lo_Rinv,
+                                                   const int32_t *__restrict__ hi_row_anchor, const int32_t *__restrict__ lo_row_anchor,
+                                                   PosePair *__restrict__ rec) {
+    if (status[ST_FLAG_C] || status[ST_FLAG_PAIRS]) return;
+    const int64_t n_pairs = min((int64_t)status[ST_NPAIRS], cap_pairs);
+    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < n_pairs; p += (int64_t)gridDim.x * 256) {
+        const int ih = pair_hi[p], il = pair_lo[p];
+        PosePair P;
+        mat3_mul(lo_Rinv + 9 * il, hi_R + 9 * ih, P.R);
+        const int ah = hi_row_anchor ? hi_row_anchor[ih] : ih, al = lo_row_anchor ? lo_row_anchor[il] : il;
+        for (int d = 0; d < 3; d++) { P.ph[d] = hi_p[3 * ah + d]; P.pl[d] = lo_p[3 * al + d]; }
+        rec[p] = P;
+    }
+}
+
 #define POSE_LDS_THREADS 1024
 
 // MaD.py:433-448.  One wave per pair, lanes over the hi cloud.  `dd_lim` is the smallest double whose
 // square root is >= dist, so dd < dd_lim is exactly the reference's sqrt(dd) < dist without the root.
-__global__ __launch_bounds__(POSE_LDS_THREADS) void k_pose_lds(const int32_t *__restrict__ pair_hi, const int32_t *__restrict__ pair_lo,
-                                                               const int32_t *__restrict__ status, int64_t cap_pairs,
-                                                               const double *__restrict__ hi_p, const double *__restrict__ hi_R,
-                                                               const double *__restrict__ lo_p, const double *__restrict__ lo_Rinv,
-                                                               const int32_t *__restrict__ hi_row_anchor,
-                                                               const int32_t *__restrict__ lo_row_anchor,
+__global__ __launch_bounds__(POSE_LDS_THREADS) void k_pose_lds(const int32_t *__restrict__ status, int64_t cap_pairs,
+                                                               const PosePair *__restrict__ rec,
                                                                const double *__restrict__ hi_cloud, const double *__restrict__ lo_sorted,
-                                                               const int32_t *__restrict__ cell_start, PoseGrid G, int l_hi_cap,
-                                                               int l_lo_cap, float reach, double dd_lim, int32_t *__restrict__ counts) {
+                                                               const int32_t *__restrict__ cell_start,
+                                                               const unsigned short *__restrict__ cell_start16, PoseGrid G, int l_hi_cap,
+                                                               int l_lo_cap, float reach, double dd_lim, PoseBits B,
+                                                               const unsigned *__restrict__ bits, int32_t *__restrict__ counts) {
     extern __shared__ __align__(16) unsigned char smem[];
     if (status[ST_FLAG_C] || status[ST_FLAG_PAIRS]) return;
-    double *cl = (double *)smem;                                   // hi cloud
-    double *lp = cl + 3 * (size_t)l_hi_cap;                        // sorted lo cloud
-    unsigned short *cs = (unsigned short *)(lp + 3 * (size_t)l_lo_cap);      // cell offsets
+    // LDS regions, each a multiple of 16 bytes (pose_lds_bytes on the host mirrors this)
+    double *cl = (double *)smem;                                                     // hi cloud
+    double *lp = (double *)(smem + pad16((size_t)l_hi_cap * 24));                    // sorted lo cloud
+    float4 *clf = (float4 *)((unsigned char *)lp + pad16((size_t)l_lo_cap * 24));    // hi cloud in float32: the bitmap test reads it
+    unsigned short *cs = (unsigned short *)(clf + l_hi_cap);                         // cell offsets
+    unsigned short *stack0 = (unsigned short *)((unsigned char *)cs + pad16((size_t)(G.ncell + 1) * 2));
+    unsigned short *stack = stack0 + (threadIdx.x >> 6) * POSE_STACK;                // per wave
     const int64_t n_pairs = min((int64_t)status[ST_NPAIRS], cap_pairs);
     const int l_hi = status[ST_LHI];
     const int l_lo = cell_start[G.ncell];
-    for (int i = threadIdx.x; i < 3 * l_hi; i += POSE_LDS_THREADS) cl[i] = hi_cloud[i];
-    for (int i = threadIdx.x; i < 3 * l_lo; i += POSE_LDS_THREADS) lp[i] = lo_sorted[i];
-    for (int i = threadIdx.x; i <= G.ncell; i += POSE_LDS_THREADS) cs[i] = (unsigned short)cell_start[i];
+    stage_lds<POSE_LDS_THREADS>(lp, lo_sorted, (size_t)l_lo * 24);
+    stage_lds<POSE_LDS_THREADS>(cs, cell_start16, (size_t)((G.ncell + 2) & ~1) * 2);
+    stage_lds<POSE_LDS_THREADS>(cl, hi_cloud, (size_t)l_hi * 24);
+    __syncthreads();
+    for (int i = threadIdx.x; i < l_hi; i += POSE_LDS_THREADS)
+        clf[i] = make_float4((float)cl[3 * i], (float)cl[3 * i + 1], (float)cl[3 * i + 2], 0.f);
     __syncthreads();
     const int lane = lane_id();
-    const int64_t wave = (int64_t)blockIdx.x * (POSE_LDS_THREADS / MAD_WAVE) + (threadIdx.x >> 6);
+    const int64_t wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (POSE_LDS_THREADS / MAD_WAVE) + (threadIdx.x >> 6)));
     const int64_t nwaves = (int64_t)gridDim.x * (POSE_LDS_THREADS / MAD_WAVE);
+    PosePair cur;
+    if (wave < n_pairs) cur = rec[wave];
     const float mnx = (float)G.mn[0], mny = (float)G.mn[1], mnz = (float)G.mn[2];
     for (int64_t p = wave; p < n_pairs; p += nwaves) {
-        const int ih = pair_hi[p], il = pair_lo[p];
-        double R[9];      // R = inv(lo.Rfinal) @ hi.Rfinal (MaD.py:438)
-        mat3_mul(lo_Rinv + 9 * il, hi_R + 9 * ih, R);
-        const int ah = hi_row_anchor ? hi_row_anchor[ih] : ih, al = lo_row_anchor ? lo_row_anchor[il] : il;
-        const double ph0 = hi_p[3 * ah], ph1 = hi_p[3 * ah + 1], ph2 = hi_p[3 * ah + 2];
-        const double pl0 = lo_p[3 * al], pl1 = lo_p[3 * al + 1], pl2 = lo_p[3 * al + 2];
-        int cnt = 0;
-        for (int a = lane; a < l_hi; a += MAD_WAVE) {
+        PosePair nxt;      // requested now, needed one iteration later
+        if (p + nwaves < n_pairs) nxt = rec[p + nwaves];
+        const double *R = cur.R;
+        const double ph0 = cur.ph[0], ph1 = cur.ph[1], ph2 = cur.ph[2], pl0 = cur.pl[0], pl1 = cur.pl[1], pl2 = cur.pl[2];
+        PoseVox V;
+        pose_vox_setup(R, ph0, ph1, ph2, pl0, pl1, pl2, B, &V);
+        auto cloud32 = [&](int a, float &cx, float &cy, float &cz) { const float4 c = clf[a]; cx = c.x; cy = c.y; cz = c.z; };
+        auto exact = [&](int a) -> bool {
             const double d0 = cl[3 * a] - ph0, d1 = cl[3 * a + 1] - ph1, d2 = cl[3 * a + 2] - ph2;
             const double x = (d0 * R[0] + d1 * R[1] + d2 * R[2]) + pl0;      // MaD.py:440-444
             const double y = (d0 * R[3] + d1 * R[4] + d2 * R[5]) + pl1;
@@ -445,10 +622,12 @@ __global__ __launch_bounds__(POSE_LDS_THREADS) void k_pose_lds(const int32_t *__
                     hit = (e0 * e0 + e1 * e1 + e2 * e2) < dd_lim;      // MaD.py:447-448
                 }
             }
-            cnt += hit ? 1 : 0;
-        }
+            return hit;
+        };
+        int cnt = pose_count_filtered(l_hi, V, B, bits, stack, cloud32, exact);
         cnt = wave_sum_i32(cnt);
         if (lane == 0) counts[p] = cnt;
+        cur = nxt;
     }
 }
 
@@ -461,40 +640,42 @@ __global__ __launch_bounds__(POSE_LDS_THREADS) void k_pose_lds(const int32_t *__
 // distance falls inside that band (about one sample in 10^4) is re-evaluated with the reference's float64 expression
 // on the float64 point in global memory, so the count is the float64 count.  On clouds that fit both kernels this one
 // is ~20 % slower than k_pose_lds, and ~10 x faster than the global cell list it replaces for the big ones.
-__global__ __launch_bounds__(POSE_LDS_THREADS) void k_pose_lds32(const int32_t *__restrict__ pair_hi, const int32_t *__restrict__ pair_lo,
-                                                                 const int32_t *__restrict__ status, int64_t cap_pairs,
-                                                                 const double *__restrict__ hi_p, const double *__restrict__ hi_R,
-                                                                 const double *__restrict__ lo_p, const double *__restrict__ lo_Rinv,
-                                                                 const int32_t *__restrict__ hi_row_anchor,
-                                                                 const int32_t *__restrict__ lo_row_anchor,
+__global__ __launch_bounds__(POSE_LDS_THREADS) void k_pose_lds32(const int32_t *__restrict__ status, int64_t cap_pairs,
+                                                                 const PosePair *__restrict__ rec,
                                                                  const double *__restrict__ hi_cloud, const double *__restrict__ lo_sorted,
                                                                  const float4 *__restrict__ lo_sorted_f,
-                                                                 const int32_t *__restrict__ cell_start, PoseGrid G, int l_lo_cap,
-                                                                 float reach, double dd_lim, float lim_in, float lim_out,
-                                                                 int32_t *__restrict__ counts) {
+                                                                 const int32_t *__restrict__ cell_start,
+                                                                 const unsigned short *__restrict__ cell_start16, PoseGrid G, int l_lo_cap,
+                                                                 float reach, double dd_lim, float lim_in, float lim_out, PoseBits B,
+                                                                 const unsigned *__restrict__ bits, int32_t *__restrict__ counts) {
     extern __shared__ __align__(16) unsigned char smem[];
     if (status[ST_FLAG_C] || status[ST_FLAG_PAIRS]) return;
     float4 *lpf = (float4 *)smem;                                  // sorted lo cloud, float32 offsets from G.mn
     unsigned short *cs = (unsigned short *)(lpf + l_lo_cap + 1);   // cell offsets
+    unsigned short *stack = (unsigned short *)((unsigned char *)cs + pad16((size_t)(G.ncell + 1) * 2)) + (threadIdx.x >> 6) * POSE_STACK;
     const int64_t n_pairs = min((int64_t)status[ST_NPAIRS], cap_pairs);
     const int l_hi = status[ST_LHI];
     const int l_lo = cell_start[G.ncell];
-    for (int i = threadIdx.x; i < l_lo; i += POSE_LDS_THREADS) lpf[i] = lo_sorted_f[i];
+    stage_lds<POSE_LDS_THREADS>(lpf, lo_sorted_f, (size_t)l_lo * 16);
+    stage_lds<POSE_LDS_THREADS>(cs, cell_start16, (size_t)((G.ncell + 2) & ~1) * 2);
     if (threadIdx.x == 0) lpf[l_lo] = make_float4(1e30f, 1e30f, 1e30f, 0.f);      // pad: the odd partner of a run's last point
-    for (int i = threadIdx.x; i <= G.ncell; i += POSE_LDS_THREADS) cs[i] = (unsigned short)cell_start[i];
     __syncthreads();
     const int lane = lane_id();
-    const int64_t wave = (int64_t)blockIdx.x * (POSE_LDS_THREADS / MAD_WAVE) + (threadIdx.x >> 6);
+    const int64_t wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (POSE_LDS_THREADS / MAD_WAVE) + (threadIdx.x >> 6)));
     const int64_t nwaves = (int64_t)gridDim.x * (POSE_LDS_THREADS / MAD_WAVE);
+    PosePair cur;
+    if (wave < n_pairs) cur = rec[wave];
     for (int64_t p = wave; p < n_pairs; p += nwaves) {
-        const int ih = pair_hi[p], il = pair_lo[p];
-        double R[9];      // R = inv(lo.Rfinal) @ hi.Rfinal (MaD.py:438)
-        mat3_mul(lo_Rinv + 9 * il, hi_R + 9 * ih, R);
-        const int ah = hi_row_anchor ? hi_row_anchor[ih] : ih, al = lo_row_anchor ? lo_row_anchor[il] : il;
-        const double ph0 = hi_p[3 * ah], ph1 = hi_p[3 * ah + 1], ph2 = hi_p[3 * ah + 2];
-        const double pl0 = lo_p[3 * al], pl1 = lo_p[3 * al + 1], pl2 = lo_p[3 * al + 2];
-        int cnt = 0;
-        for (int a = lane; a < l_hi; a += MAD_WAVE) {
+        PosePair nxt;      // requested now, needed one iteration later
+        if (p + nwaves < n_pairs) nxt = rec[p + nwaves];
+        const double *R = cur.R;
+        const double ph0 = cur.ph[0], ph1 = cur.ph[1], ph2 = cur.ph[2], pl0 = cur.pl[0], pl1 = cur.pl[1], pl2 = cur.pl[2];
+        PoseVox V;
+        pose_vox_setup(R, ph0, ph1, ph2, pl0, pl1, pl2, B, &V);
+        auto cloud32 = [&](int a, float &cx, float &cy, float &cz) {
+            cx = (float)hi_cloud[3 * a]; cy = (float)hi_cloud[3 * a + 1]; cz = (float)hi_cloud[3 * a + 2];
+        };
+        auto exact = [&](int a) -> bool {
             const double d0 = hi_cloud[3 * a] - ph0, d1 = hi_cloud[3 * a + 1] - ph1, d2 = hi_cloud[3 * a + 2] - ph2;
             const double x = (d0 * R[0] + d1 * R[1] + d2 * R[2]) + pl0;      // MaD.py:440-444
             const double y = (d0 * R[3] + d1 * R[4] + d2 * R[5]) + pl1;
@@ -542,10 +723,12 @@ __global__ __launch_bounds__(POSE_LDS_THREADS) void k_pose_lds32(const int32_t *
                     }
                 }
             }
-            cnt += hit ? 1 : 0;
-        }
+            return hit;
+        };
+        int cnt = pose_count_filtered(l_hi, V, B, bits, stack, cloud32, exact);
         cnt = wave_sum_i32(cnt);
         if (lane == 0) counts[p] = cnt;
+        cur = nxt;
     }
 }
 
@@ -957,8 +1140,32 @@ static int pose_device(mad_ctx *ctx, const Side &hi, const Side &lo, int32_t *d_
         if (G.dim[d] < 1) G.dim[d] = 1;
         G.ncell *= G.dim[d];
     }
-    const size_t lds = (size_t)(l_hi_max + n_cloud) * 24 + (size_t)(G.ncell + 1) * 2 + 16;
-    const size_t lds32 = (size_t)(n_cloud + 1) * 16 + (size_t)(G.ncell + 1) * 2 + 16;
+    const size_t stacks = (size_t)(POSE_LDS_THREADS / MAD_WAVE) * POSE_STACK * 2;
+    const size_t lds32 = (size_t)(n_cloud + 1) * 16 + pad16((size_t)(G.ncell + 1) * 2) + stacks + 16;
+    // occupancy bitmap of the lo cloud (k_pose_bits), in global memory: voxel edge MAD_POSE_VOXEL (default 0.8 A: 0.6-0.8 measure the same, 1.0 is 3 % slower) unless that
+    // needs more than 16 MB.  It was tried in LDS too: there it has to be coarser (1.7 A beside the C3 clouds), lets 74
+    // instead of 57 points per pair through, and the second round of the exact search that this costs outweighs the
+    // cheaper lookup (0.77 against 0.66 ms per C3 step).
+    const size_t lds_base = pad16((size_t)l_hi_max * 24) + pad16((size_t)n_cloud * 24) + (size_t)l_hi_max * 16 + pad16((size_t)(G.ncell + 1) * 2) +
+                            stacks + 16;      // the regions of k_pose_lds
+    const bool base64 = lds_base <= 150 * 1024;
+    const size_t bits_budget = (size_t)16 << 20;
+    static const double h0 = getenv("MAD_POSE_VOXEL") ? atof(getenv("MAD_POSE_VOXEL")) : 0.8;
+    PoseBits B;
+    const double slack = 0.02;
+    size_t n_words;
+    for (B.h = (h0 >= 0.25 && h0 <= 8.0) ? h0 : 0.8;; B.h *= 1.08) {
+        const double guard = dist + B.h * 0.8660254037844387 + slack + B.h;
+        for (int d = 0; d < 3; d++) {
+            B.mn[d] = bb_min[d] - guard;
+            B.dim[d] = (int)ceil((bb_max[d] - bb_min[d] + 2.0 * guard) / B.h) + 1;
+        }
+        B.wz = (B.dim[2] + 31) / 32;
+        n_words = (size_t)B.dim[0] * B.dim[1] * B.wz;
+        if (n_words * 4 <= bits_budget) break;
+    }
+    const size_t lds = lds_base;
+    const double bits_rad = dist + B.h * 0.8660254037844387 + slack;
     // float32 tier of k_pose_lds32: offsets from the grid origin are below M = extent + reach, each rounded once (error
     // <= ulp(M) / 2); a squared distance near dist^2 is then off by < 2 sqrt(3) (dist + 1) ulp(M) plus ~1e-5 of float32
     // arithmetic.  The band is 4 x that bound.
@@ -967,9 +1174,10 @@ static int pose_device(mad_ctx *ctx, const Side &hi, const Side &lo, int32_t *d_
     const double ulpM = ldexp(1.0, (int)ceil(log2(M)) - 23);
     const double band = 4.0 * (2.0 * sqrt(3.0) * (dist + 1.0) * ulpM + 1e-5 * dist * dist);
     const float lim_in = nextafterf((float)(dist * dist - band), 0.f), lim_out = nextafterf((float)(dist * dist + band), 1e30f);
-    const bool fits64 = lds <= 150 * 1024, fits32 = lds32 <= 150 * 1024 && lim_in > 0.f;
+    const bool fits64 = base64, fits32 = lds32 <= 150 * 1024 && lim_in > 0.f;
     if (!fallback && (fits64 || fits32) && n_cloud < 65535 && G.ncell <= 30000) {
-        MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_PG_START), (size_t)(G.ncell + 2) * 4));
+        MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_PG_START), (size_t)(G.ncell + 2) * 4 + pad16((size_t)(G.ncell + 2) * 2) + 16));
+        unsigned short *d_start16 = (unsigned short *)(scratch<char>(ctx, S_PG_START) + pad16((size_t)(G.ncell + 2) * 4));
         MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_PG_PTS), (size_t)(n_cloud + 2) * 24));
         if (!fits64) MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_PG_PTSF), (size_t)(n_cloud + 2) * 16));
         static bool attr_set = false;
@@ -980,19 +1188,27 @@ static int pose_device(mad_ctx *ctx, const Side &hi, const Side &lo, int32_t *d_
             attr_set = true;
         }
         hipLaunchKernelGGL(k_pose_grid_build, dim3(1), dim3(1024), (size_t)G.ncell * 4, ctx->stream, d_cloud, d_cloud_used, n_cloud, G,
-                           scratch<int32_t>(ctx, S_PG_START), scratch<double>(ctx, S_PG_PTS),
+                           scratch<int32_t>(ctx, S_PG_START), d_start16, scratch<double>(ctx, S_PG_PTS),
                            fits64 ? (float4 *)nullptr : scratch<float4>(ctx, S_PG_PTSF), d_status + ST_LLO);
+        MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_PG_BITS), n_words * 4 + 16));
+        unsigned *d_bits = scratch<unsigned>(ctx, S_PG_BITS);
+        mad_zero_words(ctx, d_bits, n_words * 4);
+        hipLaunchKernelGGL(k_pose_bits, dim3((unsigned)std::min(std::max(n_cloud, 1), ctx->n_cu * 8)), dim3(256), 0, ctx->stream,
+                           (const double *)scratch<double>(ctx, S_PG_PTS), (const int32_t *)scratch<int32_t>(ctx, S_PG_START), G.ncell, B,
+                           bits_rad, d_bits);
+        MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_PG_PAIRS), (size_t)cap_pairs * sizeof(PosePair)));
+        PosePair *d_rec = scratch<PosePair>(ctx, S_PG_PAIRS);
+        hipLaunchKernelGGL(k_pose_prep, dim3(ctx->n_cu * 8), dim3(256), 0, ctx->stream, scratch<int32_t>(ctx, S_PAIR_HI),
+                           scratch<int32_t>(ctx, S_PAIR_LO), d_status, cap_pairs, hi.p, hi.R, lo.p, lo.Rinv, hi.row_anchor, lo.row_anchor, d_rec);
         mad_timer_begin(ctx, MAD_T_POSE);      // the search kernel alone: what the rocprofv3 summary lists as k_pose_lds
         if (fits64)
-            hipLaunchKernelGGL(k_pose_lds, dim3(ctx->n_cu * 2), dim3(POSE_LDS_THREADS), lds, ctx->stream, scratch<int32_t>(ctx, S_PAIR_HI),
-                               scratch<int32_t>(ctx, S_PAIR_LO), d_status, cap_pairs, hi.p, hi.R, lo.p, lo.Rinv, hi.row_anchor,
-                               lo.row_anchor, d_hi_cloud, scratch<double>(ctx, S_PG_PTS), scratch<int32_t>(ctx, S_PG_START), G,
-                               l_hi_max, n_cloud, (float)reach, dd_lim, scratch<int32_t>(ctx, S_COUNTS));
+            hipLaunchKernelGGL(k_pose_lds, dim3(ctx->n_cu * (lds > 80 * 1024 ? 1 : 2)), dim3(POSE_LDS_THREADS), lds, ctx->stream, d_status, cap_pairs, d_rec,
+                               d_hi_cloud, scratch<double>(ctx, S_PG_PTS), scratch<int32_t>(ctx, S_PG_START), d_start16, G,
+                               l_hi_max, n_cloud, (float)reach, dd_lim, B, d_bits, scratch<int32_t>(ctx, S_COUNTS));
         else
-            hipLaunchKernelGGL(k_pose_lds32, dim3(ctx->n_cu), dim3(POSE_LDS_THREADS), lds32, ctx->stream, scratch<int32_t>(ctx, S_PAIR_HI),
-                               scratch<int32_t>(ctx, S_PAIR_LO), d_status, cap_pairs, hi.p, hi.R, lo.p, lo.Rinv, hi.row_anchor,
-                               lo.row_anchor, d_hi_cloud, scratch<double>(ctx, S_PG_PTS), scratch<float4>(ctx, S_PG_PTSF),
-                               scratch<int32_t>(ctx, S_PG_START), G, n_cloud, (float)reach, dd_lim, lim_in, lim_out,
+            hipLaunchKernelGGL(k_pose_lds32, dim3(ctx->n_cu), dim3(POSE_LDS_THREADS), lds32, ctx->stream, d_status, cap_pairs, d_rec,
+                               d_hi_cloud, scratch<double>(ctx, S_PG_PTS), scratch<float4>(ctx, S_PG_PTSF),
+                               scratch<int32_t>(ctx, S_PG_START), d_start16, G, n_cloud, (float)reach, dd_lim, lim_in, lim_out, B, d_bits,
                                scratch<int32_t>(ctx, S_COUNTS));
         mad_timer_end(ctx, MAD_T_POSE);
         MAD_HIP(hipGetLastError());
@@ -1018,7 +1234,8 @@ static int pose_device(mad_ctx *ctx, const Side &hi, const Side &lo, int32_t *d_
 }
 
 static bool clouds_fit_lds(int64_t l_hi, int64_t l_lo) {      // with the largest cell table (30 000 cells)
-    return ((size_t)(l_hi + l_lo) * 24 + 60016 <= 150 * 1024 || (size_t)(l_lo + 1) * 16 + 60016 <= 150 * 1024) && l_lo < 65535;
+    const size_t fixed = 30004 * 2 + (POSE_LDS_THREADS / MAD_WAVE) * POSE_STACK * 2 + 16 + 64;      // as pose_device sizes them (+ its 16-byte paddings)
+    return ((size_t)(l_hi + l_lo) * 24 + (size_t)l_hi * 16 + fixed <= 150 * 1024 || (size_t)(l_lo + 1) * 16 + fixed <= 150 * 1024) && l_lo < 65535;
 }
 
 static int32_t *status_words(mad_ctx *ctx) {      // inside S_MISC
