@@ -185,6 +185,43 @@ def test_pose_score_large_lo_cloud(lib, n_lo_anchor, n_pairs, box):
     np.testing.assert_allclose(got_res, ref_res, rtol=1e-12, atol=1e-12)
 
 
+@pytest.mark.parametrize("n_lo_anchor,box", [(900, 150.0), (5600, 170.0)])
+def test_pose_score_threshold_shell(lib, n_lo_anchor, box):
+    """The occupancy-bitmap prefilter of the search kernels must never drop a point that the float64 test would count:
+    with identity poses the hi cloud IS the set of transformed points, and it is built to sit on the decision surface --
+    at distance dist -/+ {1e-12 .. 0.5} from a lo point in random directions, on voxel faces and corners of the bitmap
+    lattice (multiples of 0.8 A from the cloud's bounding box), and beyond the box."""
+    rng = np.random.default_rng(23)
+    lo_p = np.unique(np.round(rng.uniform(0, box, size=(n_lo_anchor, 3)), 3), axis=0)
+    n_lo_anchor = len(lo_p)
+    pts = []
+    for eps in (1e-12, 1e-9, 1e-6, 1e-4, 1e-3, 1e-2, 0.03, 0.1, 0.5):
+        for sign in (-1.0, 1.0):
+            c = lo_p[rng.integers(0, n_lo_anchor, 60)]
+            u = rng.normal(size=(60, 3))
+            u /= np.linalg.norm(u, axis=1)[:, None]
+            pts.append(c + u * (4.0 + sign * eps))
+    lattice = lo_p.min(0) + 0.8 * rng.integers(-12, int(box / 0.8) + 12, size=(400, 3))      # voxel corners, some outside
+    pts.append(lattice)
+    pts.append(lattice + 1e-6)
+    pts.append(lattice + np.array([0.4, 0.0, 0.0]))
+    pts.append(rng.uniform(-30, box + 30, size=(300, 3)))
+    hi_p = np.unique(np.concatenate(pts), axis=0)
+    n_hi = len(hi_p)
+    eye = np.tile(np.identity(3), (8, 1, 1))
+    # pairs: identity pose (hi anchor 0 onto itself: R = I, p_hi = p_lo) and pure translations by voxel fractions
+    shifts = np.array([[0, 0, 0], [0.8, 0, 0], [0.4, 0.4, 0.4], [1e-7, -1e-7, 0], [3.2, -1.6, 0.8], [box, 0, 0], [0.79999, 0.8, 0.80001], [-0.4, 0.2, 0.1]])
+    hi_anchor = np.concatenate([hi_p[:1] for _ in shifts])
+    lo_anchor = hi_anchor + shifts
+    meta = np.stack([np.arange(8), np.ones(8), np.zeros(8)], 1).astype(np.int32)
+    a = dict(pair_hi=np.arange(8, dtype=np.int32), pair_lo=np.arange(8, dtype=np.int32), pair_score=np.full(8, 0.7), hi_p=hi_anchor, hi_R=eye,
+             hi_meta=meta, lo_p=lo_anchor, lo_R=eye, lo_meta=meta, hi_cloud=hi_p, lo_cloud=lo_p)
+    ref_res, ref_cnt = O.pose_score(**a, dist=4.0)
+    got_res, got_cnt = lib.pose_score(**a, dist=4.0)
+    assert ref_cnt[0] > 400 and ref_cnt[0] < n_hi - 400      # the shell is split by the threshold
+    np.testing.assert_array_equal(got_cnt, ref_cnt)
+
+
 def test_topk_order(lib):
     rng = np.random.default_rng(0)
     for n, k, hi in ((5000, 60, 40), (777, 777, 5), (20000, 840, 3), (50, 200, 9)):
