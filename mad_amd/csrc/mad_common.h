@@ -26,6 +26,20 @@
 // belt first and then testing only that belt's azimuth sectors -- the same
 // strict comparisons against the same table values as the reference's scan of
 // all zones (Orientator.py:324-334).
+// Tables the fast classifier reads per lane, staged in LDS by the kernels.
+struct __attribute__((aligned(16))) EqspFastLds {
+    float g32[MAD_MAX_Z][4];
+    float z_in_lo[MAD_MAX_BELT], z_in_hi[MAD_MAX_BELT], belt_lo0[MAD_MAX_BELT], belt_inv_w[MAD_MAX_BELT];
+    int belt_first[MAD_MAX_BELT], belt_count[MAD_MAX_BELT];
+    unsigned char zlut[MAD_ZLUT];
+    float4 belt_f[MAD_MAX_BELT];      // (z_in_lo, z_in_hi, belt_lo0, belt_inv_w): one 16-byte read per lookup
+    int2 belt_i[MAD_MAX_BELT];        // (first zone, zone count)
+    // the exact float64 bounds as well: the fallback walks them serially, and an LDS read is several times
+    // closer than the L1/L2 path of a global table
+    double th_lo[MAD_MAX_Z], th_hi[MAD_MAX_Z], ph_lo[MAD_MAX_BELT], ph_hi[MAD_MAX_BELT];
+    int nbelt;
+};
+
 struct EqspDev {
     int Z;
     int nbelt;
@@ -49,6 +63,7 @@ struct EqspDev {
     int belt_first32[MAD_MAX_BELT];
     int belt_count32[MAD_MAX_BELT];
     float g32[MAD_MAX_Z][4];        // per zone: cos, sin of (theta_min + guard), cos, sin of (theta_max - guard)
+    EqspFastLds image;              // the LDS copy of the above, byte for byte (mad_set_eqsp builds it, kernels copy it)
 };
 
 #define MAD_EQSP_GUARD 1e-4
@@ -322,32 +337,27 @@ __device__ __forceinline__ void mad_mat3_inv(const double *m, double *o) {      
     o[6] = c02 * id; o[7] = (m[1] * m[6] - m[0] * m[7]) * id; o[8] = (m[0] * m[4] - m[1] * m[3]) * id;
 }
 
-// Tables the fast classifier reads per lane, staged in LDS by the kernels.
-struct EqspFastLds {
-    float g32[MAD_MAX_Z][4];
-    float z_in_lo[MAD_MAX_BELT], z_in_hi[MAD_MAX_BELT], belt_lo0[MAD_MAX_BELT], belt_inv_w[MAD_MAX_BELT];
-    int belt_first[MAD_MAX_BELT], belt_count[MAD_MAX_BELT];
-    unsigned char zlut[MAD_ZLUT];
-    // the exact float64 bounds as well: the fallback walks them serially, and an LDS read is several times
-    // closer than the L1/L2 path of a global table
-    double th_lo[MAD_MAX_Z], th_hi[MAD_MAX_Z], ph_lo[MAD_MAX_BELT], ph_hi[MAD_MAX_BELT];
-    int nbelt;
-};
-
-__device__ __forceinline__ void eqsp_fast_stage(const EqspDev *t, EqspFastLds *l) {
-    for (int i = threadIdx.x; i < t->Z; i += blockDim.x) {
-        l->g32[i][0] = t->g32[i][0]; l->g32[i][1] = t->g32[i][1]; l->g32[i][2] = t->g32[i][2]; l->g32[i][3] = t->g32[i][3];
+// Copies `bytes` (a multiple of 4) from 16-byte-aligned global memory to 16-byte-aligned LDS with the whole workgroup:
+// 16 bytes per lane and four requests in flight per lane, because a workgroup that waits for one 4-byte load per lane
+// per trip spends tens of microseconds filling its tables.
+__device__ __forceinline__ void stage_lds(void *lds_dst, const void *src, size_t bytes) {
+    const uint4 *s4 = (const uint4 *)src;
+    uint4 *d4 = (uint4 *)lds_dst;
+    const int n4 = (int)(bytes >> 4), T = (int)blockDim.x;
+    for (int i = threadIdx.x; i < n4; i += 4 * T) {
+        uint4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            if (i + u * T < n4) v[u] = s4[i + u * T];
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            if (i + u * T < n4) d4[i + u * T] = v[u];
     }
-    for (int i = threadIdx.x; i < MAD_MAX_BELT; i += blockDim.x) {
-        l->z_in_lo[i] = t->z_in_lo[i]; l->z_in_hi[i] = t->z_in_hi[i];
-        l->belt_lo0[i] = t->belt_lo0[i]; l->belt_inv_w[i] = t->belt_inv_w[i];
-        l->belt_first[i] = t->belt_first32[i]; l->belt_count[i] = t->belt_count32[i];
-    }
-    for (int i = threadIdx.x; i < MAD_ZLUT; i += blockDim.x) l->zlut[i] = t->zlut[i];
-    for (int i = threadIdx.x; i < t->Z; i += blockDim.x) { l->th_lo[i] = t->th_lo[i]; l->th_hi[i] = t->th_hi[i]; }
-    for (int i = threadIdx.x; i < MAD_MAX_BELT; i += blockDim.x) { l->ph_lo[i] = t->ph_lo[i]; l->ph_hi[i] = t->ph_hi[i]; }
-    if (threadIdx.x == 0) l->nbelt = t->nbelt;
+    const int tail = (int)((bytes & 15) >> 2);
+    if ((int)threadIdx.x < tail) ((unsigned *)lds_dst)[4 * n4 + threadIdx.x] = ((const unsigned *)src)[4 * n4 + threadIdx.x];
 }
+
+__device__ __forceinline__ void eqsp_fast_stage(const EqspDev *t, EqspFastLds *l) { stage_lds(l, &t->image, sizeof(EqspFastLds)); }
 
 // eqsp_classify on the LDS copy of the table
 template <class F>
@@ -365,16 +375,22 @@ __device__ __forceinline__ void eqsp_classify_lds(const EqspFastLds *t, double t
     }
 }
 
-// atan2 in [0, 2pi) to ~2e-6 rad (odd minimax polynomial on [0, 1] + octant unfolding): a GUESS only
+// atan2 in [0, 2pi) to ~2e-6 rad (odd minimax polynomial on [0, 1] + octant unfolding): a GUESS only.
+// v_rcp_f32 (1 ulp) and fused multiply-adds on purpose: nothing here decides a zone, it only proposes one.
 __device__ __forceinline__ float approx_angle(float x, float y) {
     const float ax = fabsf(x), ay = fabsf(y);
     const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
-    const float q = mn * __frcp_rn(fmaxf(mx, 1e-30f));
+    const float q = mn * __builtin_amdgcn_rcpf(fmaxf(mx, 1e-30f));
     const float q2 = q * q;
-    float a = q * (0.999979854f + q2 * (-0.332655430f + q2 * (0.193669885f + q2 * (-0.116649978f + q2 * (0.052822195f + q2 * -0.011769974f)))));
-    if (ay > ax) a = 1.57079637f - a;
-    if (x < 0.f) a = 3.14159274f - a;
-    if (y < 0.f) a = 6.28318548f - a;
+    float a = fmaf(q2, -0.011769974f, 0.052822195f);
+    a = fmaf(q2, a, -0.116649978f);
+    a = fmaf(q2, a, 0.193669885f);
+    a = fmaf(q2, a, -0.332655430f);
+    a = fmaf(q2, a, 0.999979854f);
+    a *= q;
+    a = ay > ax ? 1.57079637f - a : a;
+    a = x < 0.f ? 3.14159274f - a : a;
+    a = y < 0.f ? 6.28318548f - a : a;
     return a;
 }
 
@@ -384,19 +400,22 @@ __device__ __forceinline__ float approx_angle(float x, float y) {
 // test.  Inputs may carry float32 rounding noise (<= ~1e-6 rad): inside the margin the exact
 // float64 test on the un-noised direction gives this same zone and no other, because the noise
 // is 100x smaller than the guard and neighbouring zones overlap by < 2e-5 rad at most.
+// Branch-free on purpose (three dependent LDS reads, everything else selects): callers classify several
+// points in a row, and straight-line code lets the scheduler overlap their table reads.
 __device__ __forceinline__ int eqsp_fast32(const EqspFastLds *l, float x, float y, float z) {
     const int bin = min(max((int)((z + 1.0f) * (0.5f * MAD_ZLUT)), 0), MAD_ZLUT - 1);
     const int b = l->zlut[bin];
-    if (!(z < l->z_in_lo[b] && z > l->z_in_hi[b])) return -1;
-    const int cnt = l->belt_count[b], first = l->belt_first[b];
-    if (cnt == 1) return first;                       // polar caps span every azimuth
-    float u = approx_angle(x, y) - l->belt_lo0[b];
-    if (u < 0.f) u += 6.28318548f;
-    const int a = first + min(max((int)(u * l->belt_inv_w[b]), 0), cnt - 1);
+    const float4 bf = l->belt_f[b];
+    const int2 bi = l->belt_i[b];
+    const bool in_belt = z < bf.x && z > bf.y;
+    float u = approx_angle(x, y) - bf.z;
+    u = u < 0.f ? u + 6.28318548f : u;
+    const int a = bi.x + min(max((int)(u * bf.w), 0), bi.y - 1);
     const float4 g = *(const float4 *)l->g32[a];
-    const float c1 = g.x * y - g.y * x;      // > 0: counter-clockwise of theta_min + guard
-    const float c2 = x * g.w - y * g.z;      // > 0: clockwise of theta_max - guard
-    return (c1 > 0.f && c2 > 0.f) ? a : -1;
+    const float c1 = fmaf(g.x, y, -(g.y * x));      // > 0: counter-clockwise of theta_min + guard
+    const float c2 = fmaf(x, g.w, -(y * g.z));      // > 0: clockwise of theta_max - guard
+    const bool ok = in_belt && (bi.y == 1 || (c1 > 0.f && c2 > 0.f));      // a polar cap spans every azimuth
+    return ok ? a : -1;
 }
 
 #endif  // __HIPCC__

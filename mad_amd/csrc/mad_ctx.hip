@@ -252,6 +252,21 @@ extern "C" int mad_set_eqsp(mad_ctx *ctx, int which, int Z, const double *bounds
         h.g32[a][0] = (float)cos(h.th_lo[a] + MAD_EQSP_GUARD); h.g32[a][1] = (float)sin(h.th_lo[a] + MAD_EQSP_GUARD);
         h.g32[a][2] = (float)cos(h.th_hi[a] - MAD_EQSP_GUARD); h.g32[a][3] = (float)sin(h.th_hi[a] - MAD_EQSP_GUARD);
     }
+    {      // the image the kernels copy into LDS
+        EqspFastLds &im = h.image;
+        memset(&im, 0, sizeof(im));
+        memcpy(im.g32, h.g32, sizeof(im.g32));
+        for (int b = 0; b < MAD_MAX_BELT; b++) {
+            im.z_in_lo[b] = h.z_in_lo[b]; im.z_in_hi[b] = h.z_in_hi[b]; im.belt_lo0[b] = h.belt_lo0[b]; im.belt_inv_w[b] = h.belt_inv_w[b];
+            im.belt_first[b] = h.belt_first32[b]; im.belt_count[b] = h.belt_count32[b];
+            im.belt_f[b] = make_float4(h.z_in_lo[b], h.z_in_hi[b], h.belt_lo0[b], h.belt_inv_w[b]);
+            im.belt_i[b] = make_int2(h.belt_first32[b], h.belt_count32[b]);
+            im.ph_lo[b] = h.ph_lo[b]; im.ph_hi[b] = h.ph_hi[b];
+        }
+        memcpy(im.zlut, h.zlut, sizeof(im.zlut));
+        for (int a = 0; a < MAD_MAX_Z; a++) { im.th_lo[a] = h.th_lo[a]; im.th_hi[a] = h.th_hi[a]; }
+        im.nbelt = h.nbelt;
+    }
     if (to_dom) memcpy(h.to_dom, to_dom, sizeof(double) * 9 * Z);
     if (adj_sec) memcpy(h.adj_sec, adj_sec, sizeof(double) * 9 * Z);
     MAD_HIP(hipMemcpyAsync(ctx->eq[which], &h, sizeof(EqspDev), hipMemcpyHostToDevice, ctx->stream));

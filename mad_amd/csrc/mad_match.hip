@@ -380,27 +380,6 @@ __global__ __launch_bounds__(1024) void k_pose_grid_build(const double *__restri
         }
 }
 
-// Copies `bytes` (a multiple of 4) from 16-byte-aligned global memory to 16-byte-aligned LDS with the whole workgroup:
-// 16 bytes per lane and four requests in flight per lane, because a workgroup that waits for one 4-byte load per lane
-// per trip spends tens of microseconds filling 100+ KB of LDS.
-template <int THREADS>
-__device__ __forceinline__ void stage_lds(void *lds_dst, const void *src, size_t bytes) {
-    const uint4 *s4 = (const uint4 *)src;
-    uint4 *d4 = (uint4 *)lds_dst;
-    const int n4 = (int)(bytes >> 4);
-    for (int i = threadIdx.x; i < n4; i += 4 * THREADS) {
-        uint4 v[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++)
-            if (i + u * THREADS < n4) v[u] = s4[i + u * THREADS];
-#pragma unroll
-        for (int u = 0; u < 4; u++)
-            if (i + u * THREADS < n4) d4[i + u * THREADS] = v[u];
-    }
-    const int tail = (int)((bytes & 15) >> 2);
-    if ((int)threadIdx.x < tail) ((unsigned *)lds_dst)[4 * n4 + threadIdx.x] = ((const unsigned *)src)[4 * n4 + threadIdx.x];
-}
-
 __host__ __device__ __forceinline__ size_t pad16(size_t b) { return (b + 15) & ~(size_t)15; }
 
 // Occupancy bitmap of the lo cloud: bit (x, y, z) is set iff some lo point lies within `rad` of the centre of that voxel
@@ -569,9 +548,9 @@ __global__ __launch_bounds__(POSE_LDS_THREADS) void k_pose_lds(const int32_t *__
     const int64_t n_pairs = min((int64_t)status[ST_NPAIRS], cap_pairs);
     const int l_hi = status[ST_LHI];
     const int l_lo = cell_start[G.ncell];
-    stage_lds<POSE_LDS_THREADS>(lp, lo_sorted, (size_t)l_lo * 24);
-    stage_lds<POSE_LDS_THREADS>(cs, cell_start16, (size_t)((G.ncell + 2) & ~1) * 2);
-    stage_lds<POSE_LDS_THREADS>(cl, hi_cloud, (size_t)l_hi * 24);
+    stage_lds(lp, lo_sorted, (size_t)l_lo * 24);
+    stage_lds(cs, cell_start16, (size_t)((G.ncell + 2) & ~1) * 2);
+    stage_lds(cl, hi_cloud, (size_t)l_hi * 24);
     __syncthreads();
     for (int i = threadIdx.x; i < l_hi; i += POSE_LDS_THREADS)
         clf[i] = make_float4((float)cl[3 * i], (float)cl[3 * i + 1], (float)cl[3 * i + 2], 0.f);
@@ -656,8 +635,8 @@ __global__ __launch_bounds__(POSE_LDS_THREADS) void k_pose_lds32(const int32_t *
     const int64_t n_pairs = min((int64_t)status[ST_NPAIRS], cap_pairs);
     const int l_hi = status[ST_LHI];
     const int l_lo = cell_start[G.ncell];
-    stage_lds<POSE_LDS_THREADS>(lpf, lo_sorted_f, (size_t)l_lo * 16);
-    stage_lds<POSE_LDS_THREADS>(cs, cell_start16, (size_t)((G.ncell + 2) & ~1) * 2);
+    stage_lds(lpf, lo_sorted_f, (size_t)l_lo * 16);
+    stage_lds(cs, cell_start16, (size_t)((G.ncell + 2) & ~1) * 2);
     if (threadIdx.x == 0) lpf[l_lo] = make_float4(1e30f, 1e30f, 1e30f, 0.f);      // pad: the odd partner of a run's last point
     __syncthreads();
     const int lane = lane_id();

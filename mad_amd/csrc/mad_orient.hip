@@ -459,8 +459,9 @@ __device__ __forceinline__ int describe_exact(const EqspFastLds *eq, float4 t, c
     return zone;
 }
 
+#define DSC_CHUNK 8
 template <int S>
-__global__ __launch_bounds__(DSC_THREADS) void k_describe(DescribeArgs A) {
+__global__ __launch_bounds__(DSC_THREADS, 4) void k_describe(DescribeArgs A) {
     __shared__ int hist[64 * 16];
     __shared__ double sR[9], sInv[9];
     __shared__ int s_oob, s_nq;
@@ -582,32 +583,49 @@ __global__ __launch_bounds__(DSC_THREADS) void k_describe(DescribeArgs A) {
 #pragma unroll
         for (int i = 0; i < S; i++) t[i] = F.tex[idx[i]];
         const float f0 = sRf[0], f1 = sRf[1], f2 = sRf[2], f3 = sRf[3], f4 = sRf[4], f5 = sRf[5], f6 = sRf[6], f7 = sRf[7], f8 = sRf[8];
+        // DSC_CHUNK points at a time: first their zones, in straight-line code (approximate unit direction, rotated in
+        // float32: a guess, verified with guard bands inside eqsp_fast32), so that the table reads of different points
+        // overlap; then the histogram updates and the rare hand-over to the exact path.
 #pragma unroll
-        for (int i = 0; i < S; i++) {
-            const float magn = t[i].w;
-            if (magn < 1e-5f) continue;                                   // Descriptor.py:190 (zone -1)
-            // fast path: approximate unit direction, rotated in float32 (a guess, verified with guard bands)
-            const float inv = __frcp_rn(magn);
-            const float gx = t[i].x * inv, gy = t[i].y * inv, gz = t[i].z * inv;
-            const float rx = gx * f0 + gy * f1 + gz * f2;
-            const float ry = gx * f3 + gy * f4 + gz * f5;
-            const float rz = gx * f6 + gy * f7 + gz * f8;
-            const int sub = (j / q4) * 16 + (i / q4) * 4 + (k / q4);      // Descriptor.py:44-64
-            int zone = eqsp_fast32(&fast, rx, ry, rz);
-            if (zone < 0) {
-                const int slot = atomicAdd(&s_nq, 1);
-                if (slot < DSC_QUEUE) {      // decide later with the exact arithmetic, with full lanes
-                    qv[slot] = t[i]; qsub[slot] = sub;
-                    continue;
-                }
-                zone = describe_exact(&fast, t[i], sR);      // queue full (not seen in practice)
+        for (int i0 = 0; i0 < S; i0 += DSC_CHUNK) {
+            int zone[DSC_CHUNK];
+#pragma unroll
+            for (int u = 0; u < DSC_CHUNK; u++) {
+                const float4 tx = t[i0 + u];
+                const float inv = __builtin_amdgcn_rcpf(fmaxf(tx.w, 1e-30f));
+                const float gx = tx.x * inv, gy = tx.y * inv, gz = tx.z * inv;
+                const float rx = fmaf(gz, f2, fmaf(gy, f1, gx * f0));
+                const float ry = fmaf(gz, f5, fmaf(gy, f4, gx * f3));
+                const float rz = fmaf(gz, f8, fmaf(gy, f7, gx * f6));
+                const int zn = eqsp_fast32(&fast, rx, ry, rz);
+                zone[u] = tx.w < 1e-5f ? -2 : zn;                         // -2: Descriptor.py:190 (zone -1, not counted)
             }
-            atomicAdd(&hist[sub * Z + zone], 1);
+#pragma unroll
+            for (int u = 0; u < DSC_CHUNK; u++) {
+                const int i = i0 + u;
+                const int sub = (j / q4) * 16 + (i / q4) * 4 + (k / q4);      // Descriptor.py:44-64
+                if (zone[u] >= 0) atomicAdd(&hist[sub * Z + zone[u]], 1);
+                else if (zone[u] == -1) {      // decide later with the exact arithmetic, with full lanes
+                    const int slot = atomicAdd(&s_nq, 1);
+                    if (slot < DSC_QUEUE) { qv[slot] = t[i]; qsub[slot] = sub; }
+                }
+            }
         }
     }
     __syncthreads();
-    {
-        const int nq = min(s_nq, DSC_QUEUE);
+    if (s_nq > DSC_QUEUE) {
+        // more undecided points than the queue holds (not seen in practice): redo the whole row with the exact arithmetic
+        __syncthreads();
+        for (int i = tid; i < D; i += DSC_THREADS) hist[i] = 0;
+        __syncthreads();
+        if (active)
+            for (int i = 0; i < S; i++) {
+                const float4 tx = F.tex[idx[i]];
+                if (tx.w < 1e-5f) continue;
+                atomicAdd(&hist[((j / q4) * 16 + (i / q4) * 4 + (k / q4)) * Z + describe_exact(&fast, tx, sR)], 1);
+            }
+    } else {
+        const int nq = s_nq;
         for (int qi = tid; qi < nq; qi += DSC_THREADS) atomicAdd(&hist[qsub[qi] * Z + describe_exact(&fast, qv[qi], sR)], 1);
     }
     __syncthreads();
