@@ -229,8 +229,8 @@ struct OrientOut {
 int mad_orient_device(mad_ctx *ctx, FieldDev f0, FieldDev f1, const int32_t *d_coords, const int32_t *d_octave,
                       int uniform_octave, int n, int r, int lim_main, int lim_sec, OrientOut out);
 int mad_describe_device(mad_ctx *ctx, FieldDev f0, FieldDev f1, const int32_t *d_anc_coords, const int32_t *d_anc_octave,
-                        int uniform_octave, const int32_t *d_row_anchor, const double *d_row_R, const int32_t *d_n_rows,
-                        int64_t grid_rows, int32_t *d_overflow, int r, int16_t *d_dsc, int8_t *d_dsc8 = nullptr,
+                        int uniform_octave, const int32_t *d_row_anchor, const double *d_row_R, const double *d_row_Rinv,
+                        const int32_t *d_n_rows, int64_t grid_rows, int32_t *d_overflow, int r, int16_t *d_dsc, int8_t *d_dsc8 = nullptr,
                         double *d_norm = nullptr);
 void mad_zero_words(mad_ctx *ctx, void *p, size_t bytes);              // one-launch zero fill (bytes rounded up to 16)
 void mad_copy_words(mad_ctx *ctx, void *dst, const void *src, size_t bytes);      // kernel copy, e.g. out of pinned host memory
@@ -343,15 +343,14 @@ __device__ __forceinline__ void mad_mat3_inv(const double *m, double *o) {      
 __device__ __forceinline__ void stage_lds(void *lds_dst, const void *src, size_t bytes) {
     const uint4 *s4 = (const uint4 *)src;
     uint4 *d4 = (uint4 *)lds_dst;
-    const int n4 = (int)(bytes >> 4), T = (int)blockDim.x;
+    const int n4 = (int)(bytes >> 4), T = (int)blockDim.x, last = n4 - 1;
+    // loads at clamped (always valid) addresses, stores predicated: four independent requests per trip, all in registers
     for (int i = threadIdx.x; i < n4; i += 4 * T) {
-        uint4 v[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++)
-            if (i + u * T < n4) v[u] = s4[i + u * T];
-#pragma unroll
-        for (int u = 0; u < 4; u++)
-            if (i + u * T < n4) d4[i + u * T] = v[u];
+        const uint4 v0 = s4[i], v1 = s4[min(i + T, last)], v2 = s4[min(i + 2 * T, last)], v3 = s4[min(i + 3 * T, last)];
+        d4[i] = v0;
+        if (i + T < n4) d4[i + T] = v1;
+        if (i + 2 * T < n4) d4[i + 2 * T] = v2;
+        if (i + 3 * T < n4) d4[i + 3 * T] = v3;
     }
     const int tail = (int)((bytes & 15) >> 2);
     if ((int)threadIdx.x < tail) ((unsigned *)lds_dst)[4 * n4 + threadIdx.x] = ((const unsigned *)src)[4 * n4 + threadIdx.x];

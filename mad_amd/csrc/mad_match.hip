@@ -1431,7 +1431,7 @@ static int set_rows(mad_ctx *ctx, const mad_set *cs, int64_t *n_rows) {
             MAD_HIP(hipMemsetAsync((int32_t *)s->dev_n.p + 3, 0, 4, ctx->stream));
             MAD_TRY(mad_describe_device(ctx, s->last_f[0], s->last_f[1], (const int32_t *)s->anc_coords.p,
                                         (const int32_t *)s->anc_octave.p, 0, (const int32_t *)s->row_anchor.p,
-                                        (const double *)s->row_R.p, (const int32_t *)s->dev_n.p, s->cap_rows,
+                                        (const double *)s->row_R.p, (const double *)s->row_Rinv.p, (const int32_t *)s->dev_n.p, s->cap_rows,
                                         (int32_t *)s->dev_n.p + 3, s->last_r, (int16_t *)s->dsc.p, (int8_t *)s->dsc8.p,
                                         (double *)s->norm.p));
             MAD_HIP(hipEventRecord(s->built, ctx->stream));
@@ -1559,8 +1559,8 @@ extern "C" int mad_set_build(mad_ctx *ctx, mad_set *s, const int *slot_of_octave
     // the describe launch is sized from the row count of this set's previous build when there is one
     const int64_t grid_rows = s->rows_hint > 0 ? std::min<int64_t>(s->cap_rows, s->rows_hint + s->rows_hint / 8 + 64) : s->cap_rows;
     MAD_TRY(mad_describe_device(ctx, f[0], f[1], (const int32_t *)s->anc_coords.p, (const int32_t *)s->anc_octave.p, 0,
-                                (const int32_t *)s->row_anchor.p, (const double *)s->row_R.p, (const int32_t *)s->dev_n.p,
-                                grid_rows, (int32_t *)s->dev_n.p + 3, r, (int16_t *)s->dsc.p, (int8_t *)s->dsc8.p,
+                                (const int32_t *)s->row_anchor.p, (const double *)s->row_R.p, (const double *)s->row_Rinv.p,
+                                (const int32_t *)s->dev_n.p, grid_rows, (int32_t *)s->dev_n.p + 3, r, (int16_t *)s->dsc.p, (int8_t *)s->dsc8.p,
                                 (double *)s->norm.p));      // int8 copy + norms included: counts are <= 64 by construction
     s->last_f[0] = f[0]; s->last_f[1] = f[1]; s->last_r = r;
     s->n_rows_host = -1;

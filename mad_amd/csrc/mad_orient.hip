@@ -436,6 +436,7 @@ struct DescribeArgs {
     int uniform_octave;
     const int32_t *row_anchor;     // row -> anchor, or nullptr (identity)
     const double *row_R;           // n_rows x 9
+    const double *row_Rinv;        // n_rows x 9: inv(Rfinal) by cofactors (mad_mat3_inv), or nullptr -> formed here
     const int32_t *n_rows;         // device: number of rows
     int32_t *overflow;             // device: set when the grid was too small for *n_rows
     int r;
@@ -463,12 +464,10 @@ __device__ __forceinline__ int describe_exact(const EqspFastLds *eq, float4 t, c
 template <int S>
 __global__ __launch_bounds__(DSC_THREADS, 4) void k_describe(DescribeArgs A) {
     __shared__ int hist[64 * 16];
-    __shared__ double sR[9], sInv[9];
     __shared__ int s_oob, s_nq;
     __shared__ EqspFastLds fast;
     __shared__ float4 qv[DSC_QUEUE];         // texels the fast classifier could not decide
     __shared__ int qsub[DSC_QUEUE];
-    __shared__ float sRf[9];
     // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs (b and b + 8 share one), so give
     // each XCD a contiguous run of rows.  Consecutive rows belong to the same anchor (fan-out ~5) or to
     // neighbours in the anchor list and sample the same neighbourhood: running side by side on ONE XCD
@@ -498,28 +497,22 @@ __global__ __launch_bounds__(DSC_THREADS, 4) void k_describe(DescribeArgs A) {
     constexpr int q4 = S / 4;          // S = 2 r samples per axis (16)
     const int D = 64 * Z;
 
-    if (tid == 0) {
-        // inverse of Rfinal by cofactors (np.linalg.inv, Descriptor.py:132)
-        const double *m = A.row_R + 9 * row;
-        const double c00 = m[4] * m[8] - m[5] * m[7];
-        const double c01 = m[5] * m[6] - m[3] * m[8];
-        const double c02 = m[3] * m[7] - m[4] * m[6];
-        const double det = m[0] * c00 + m[1] * c01 + m[2] * c02;
-        const double id = 1.0 / det;
-        sInv[0] = c00 * id; sInv[1] = (m[2] * m[7] - m[1] * m[8]) * id; sInv[2] = (m[1] * m[5] - m[2] * m[4]) * id;
-        sInv[3] = c01 * id; sInv[4] = (m[0] * m[8] - m[2] * m[6]) * id; sInv[5] = (m[2] * m[3] - m[0] * m[5]) * id;
-        sInv[6] = c02 * id; sInv[7] = (m[1] * m[6] - m[0] * m[7]) * id; sInv[8] = (m[0] * m[4] - m[1] * m[3]) * id;
-        for (int i = 0; i < 9; i++) { sR[i] = m[i]; sRf[i] = (float)m[i]; }
-        s_oob = 0;
-        s_nq = 0;
+    // Rfinal and its inverse (np.linalg.inv, Descriptor.py:132; cofactors): the row is uniform over the workgroup, so these
+    // are scalar loads; nobody waits for a thread 0 to publish them through LDS
+    const double *Rrow = A.row_R + 9 * row;
+    double inv9[9];
+    if (A.row_Rinv) {
+        for (int i = 0; i < 9; i++) inv9[i] = A.row_Rinv[9 * row + i];
+    } else {
+        mad_mat3_inv(Rrow, inv9);
     }
+    if (tid == 0) { s_oob = 0; s_nq = 0; }
     for (int i = tid; i < D; i += DSC_THREADS) hist[i] = 0;
     __syncthreads();
 
     const int ic0 = A.anc_coords[3 * a], ic1 = A.anc_coords[3 * a + 1], ic2 = A.anc_coords[3 * a + 2];
     const double c0 = (double)ic0, c1 = (double)ic1, c2 = (double)ic2;
-    const double i0 = sInv[0], i1 = sInv[1], i2 = sInv[2], i3 = sInv[3], i4 = sInv[4], i5 = sInv[5], i6 = sInv[6],
-                 i7 = sInv[7], i8 = sInv[8];
+    const double i0 = inv9[0], i1 = inv9[1], i2 = inv9[2], i3 = inv9[3], i4 = inv9[4], i5 = inv9[5], i6 = inv9[6], i7 = inv9[7], i8 = inv9[8];
     const float h0 = (float)i0, h1 = (float)i1, h2 = (float)i2, h3 = (float)i3, h4 = (float)i4, h5 = (float)i5, h6 = (float)i6,
                 h7 = (float)i7, h8 = (float)i8;
     // this thread's (j, k) column of the S^3 lattice; threads beyond S*S idle (S <= 16)
@@ -582,7 +575,8 @@ __global__ __launch_bounds__(DSC_THREADS, 4) void k_describe(DescribeArgs A) {
         float4 t[S];
 #pragma unroll
         for (int i = 0; i < S; i++) t[i] = F.tex[idx[i]];
-        const float f0 = sRf[0], f1 = sRf[1], f2 = sRf[2], f3 = sRf[3], f4 = sRf[4], f5 = sRf[5], f6 = sRf[6], f7 = sRf[7], f8 = sRf[8];
+        const float f0 = (float)Rrow[0], f1 = (float)Rrow[1], f2 = (float)Rrow[2], f3 = (float)Rrow[3], f4 = (float)Rrow[4], f5 = (float)Rrow[5],
+                    f6 = (float)Rrow[6], f7 = (float)Rrow[7], f8 = (float)Rrow[8];
         // DSC_CHUNK points at a time: first their zones, in straight-line code (approximate unit direction, rotated in
         // float32: a guess, verified with guard bands inside eqsp_fast32), so that the table reads of different points
         // overlap; then the histogram updates and the rare hand-over to the exact path.
@@ -622,11 +616,11 @@ __global__ __launch_bounds__(DSC_THREADS, 4) void k_describe(DescribeArgs A) {
             for (int i = 0; i < S; i++) {
                 const float4 tx = F.tex[idx[i]];
                 if (tx.w < 1e-5f) continue;
-                atomicAdd(&hist[((j / q4) * 16 + (i / q4) * 4 + (k / q4)) * Z + describe_exact(&fast, tx, sR)], 1);
+                atomicAdd(&hist[((j / q4) * 16 + (i / q4) * 4 + (k / q4)) * Z + describe_exact(&fast, tx, Rrow)], 1);
             }
     } else {
         const int nq = s_nq;
-        for (int qi = tid; qi < nq; qi += DSC_THREADS) atomicAdd(&hist[qsub[qi] * Z + describe_exact(&fast, qv[qi], sR)], 1);
+        for (int qi = tid; qi < nq; qi += DSC_THREADS) atomicAdd(&hist[qsub[qi] * Z + describe_exact(&fast, qv[qi], Rrow)], 1);
     }
     __syncthreads();
     int ss = 0;      // counts <= 64, 1024 of them: the sum of squares is exact in int32
@@ -650,8 +644,8 @@ __global__ __launch_bounds__(DSC_THREADS, 4) void k_describe(DescribeArgs A) {
 }
 
 int mad_describe_device(mad_ctx *ctx, FieldDev f0, FieldDev f1, const int32_t *d_anc_coords, const int32_t *d_anc_octave,
-                        int uniform_octave, const int32_t *d_row_anchor, const double *d_row_R, const int32_t *d_n_rows,
-                        int64_t grid_rows, int32_t *d_overflow, int r, int16_t *d_dsc, int8_t *d_dsc8, double *d_norm) {
+                        int uniform_octave, const int32_t *d_row_anchor, const double *d_row_R, const double *d_row_Rinv,
+                        const int32_t *d_n_rows, int64_t grid_rows, int32_t *d_overflow, int r, int16_t *d_dsc, int8_t *d_dsc8, double *d_norm) {
     const int64_t cap_rows = grid_rows;
     if (!ctx->eq_set[1]) return mad_fail(ctx, MAD_EINVAL, "mad_describe: descriptor EQSP table not set");
     if (ctx->eq_host[1].Z != 16) return mad_fail(ctx, MAD_EINVAL, "mad_describe: kernel is built for 16 descriptor zones");
@@ -665,7 +659,7 @@ int mad_describe_device(mad_ctx *ctx, FieldDev f0, FieldDev f1, const int32_t *d
     DescribeArgs A;
     A.f[0] = f0; A.f[1] = f1;
     A.anc_coords = d_anc_coords; A.anc_octave = d_anc_octave; A.uniform_octave = uniform_octave;
-    A.row_anchor = d_row_anchor; A.row_R = d_row_R; A.n_rows = d_n_rows; A.overflow = d_overflow; A.r = r; A.eq = ctx->eq[1]; A.dsc = d_dsc; A.dsc8 = d_dsc8; A.norm = d_norm;
+    A.row_anchor = d_row_anchor; A.row_R = d_row_R; A.row_Rinv = d_row_Rinv; A.n_rows = d_n_rows; A.overflow = d_overflow; A.r = r; A.eq = ctx->eq[1]; A.dsc = d_dsc; A.dsc8 = d_dsc8; A.norm = d_norm;
     mad_timer_begin(ctx, MAD_T_DESCRIBE);
     // enough workgroups to fill the chip a few times over, never more than one per possible row
     const unsigned nblk = (unsigned)(((cap_rows + 7) / 8) * 8 + 8);      // one workgroup per possible row
@@ -701,7 +695,7 @@ extern "C" int mad_describe(mad_ctx *ctx, int slot, int octave, const int32_t *c
     const int32_t n32 = (int32_t)n_rows;
     MAD_HIP(hipMemcpyAsync(d_n, &n32, 4, hipMemcpyHostToDevice, ctx->stream));
     MAD_TRY(mad_describe_device(ctx, f, f, scratch<int32_t>(ctx, S_ROW_COORDS), nullptr, octave, nullptr,
-                                scratch<double>(ctx, S_ROW_R), d_n, n_rows, d_n + 1, r, scratch<int16_t>(ctx, S_DSC)));
+                                scratch<double>(ctx, S_ROW_R), nullptr, d_n, n_rows, d_n + 1, r, scratch<int16_t>(ctx, S_DSC)));
     MAD_HIP(hipMemcpyAsync(dsc, mad_sb(ctx, S_DSC).p, (size_t)n_rows * D * 2, hipMemcpyDeviceToHost, ctx->stream));
     MAD_HIP(hipStreamSynchronize(ctx->stream));
     return MAD_OK;
