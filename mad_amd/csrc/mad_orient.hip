@@ -10,6 +10,8 @@
 // Description: one 256-thread workgroup per oriented row; each thread owns a (j, k)
 // column of the 16^3 sample lattice and gathers its 16 nearest-neighbour texels with
 // 16 independent 16-byte loads; the 64 x 16 histogram lives in LDS.
+#include <type_traits>
+
 #include "mad_common.h"
 
 #define ORI_THREADS 512
@@ -460,11 +462,31 @@ __device__ __forceinline__ int describe_exact(const EqspFastLds *eq, float4 t, c
     return zone;
 }
 
+// Nearest voxel of lattice point l (in the anchor's frame) with the reference's float64 expression; *oob is set when the
+// point leaves the grid (scipy's RegularGridInterpolator, bounds_error=True, MapSpace.py:189).
+__device__ __forceinline__ unsigned lattice_index_exact(double l0, double l1, double l2, const double *inv, double c0, double c1, double c2,
+                                                        const FieldDev &F, bool *oob) {
+    const double p0 = (l0 * inv[0] + l1 * inv[1] + l2 * inv[2]) + c0;      // Descriptor.py:132-133
+    const double p1 = (l0 * inv[3] + l1 * inv[4] + l2 * inv[5]) + c1;
+    const double p2 = (l0 * inv[6] + l1 * inv[7] + l2 * inv[8]) + c2;
+    if (!(p0 >= 0.0) || !(p0 <= (double)(F.nx - 1)) || !(p1 >= 0.0) || !(p1 <= (double)(F.ny - 1)) || !(p2 >= 0.0) ||
+        !(p2 <= (double)(F.nz - 1))) {
+        *oob = true;
+        return 0;
+    }
+    int a0i = min((int)floor(p0), F.nx - 2), a1i = min((int)floor(p1), F.ny - 2), a2i = min((int)floor(p2), F.nz - 2);
+    a0i = (p0 - (double)a0i <= 0.5) ? a0i : a0i + 1;
+    a1i = (p1 - (double)a1i <= 0.5) ? a1i : a1i + 1;
+    a2i = (p2 - (double)a2i <= 0.5) ? a2i : a2i + 1;
+    return (unsigned)(((size_t)a0i * F.ny + a1i) * F.nz + a2i);
+}
+
 #define DSC_CHUNK 8
 template <int S>
 __global__ __launch_bounds__(DSC_THREADS, 4) void k_describe(DescribeArgs A) {
     __shared__ int hist[64 * 16];
     __shared__ int s_oob, s_nq;
+    __shared__ double sInv[9];
     __shared__ EqspFastLds fast;
     __shared__ float4 qv[DSC_QUEUE];         // texels the fast classifier could not decide
     __shared__ int qsub[DSC_QUEUE];
@@ -506,59 +528,65 @@ __global__ __launch_bounds__(DSC_THREADS, 4) void k_describe(DescribeArgs A) {
     } else {
         mad_mat3_inv(Rrow, inv9);
     }
-    if (tid == 0) { s_oob = 0; s_nq = 0; }
+    if (tid == 0) {
+        s_oob = 0; s_nq = 0;
+        for (int i = 0; i < 9; i++) sInv[i] = inv9[i];      // the rare float64 paths read it from here, not from 18 live registers
+    }
     for (int i = tid; i < D; i += DSC_THREADS) hist[i] = 0;
     __syncthreads();
 
     const int ic0 = A.anc_coords[3 * a], ic1 = A.anc_coords[3 * a + 1], ic2 = A.anc_coords[3 * a + 2];
     const double c0 = (double)ic0, c1 = (double)ic1, c2 = (double)ic2;
-    const double i0 = inv9[0], i1 = inv9[1], i2 = inv9[2], i3 = inv9[3], i4 = inv9[4], i5 = inv9[5], i6 = inv9[6], i7 = inv9[7], i8 = inv9[8];
-    const float h0 = (float)i0, h1 = (float)i1, h2 = (float)i2, h3 = (float)i3, h4 = (float)i4, h5 = (float)i5, h6 = (float)i6,
-                h7 = (float)i7, h8 = (float)i8;
+    const float h0 = (float)inv9[0], h1 = (float)inv9[1], h2 = (float)inv9[2], h3 = (float)inv9[3], h4 = (float)inv9[4], h5 = (float)inv9[5],
+                h6 = (float)inv9[6], h7 = (float)inv9[7], h8 = (float)inv9[8];
     // this thread's (j, k) column of the S^3 lattice; threads beyond S*S idle (S <= 16)
     const int j = tid / S, k = tid % S;
     const bool active = tid < S * S;
-    unsigned idx[S];
+    // lattice coordinate along an axis = lbase + lstep * index (Descriptor.py:34-35)
+    const double lbase = oct == 0 ? (double)(-2 * A.r + 1) : -A.r + 0.5, lstep = oct == 0 ? 2.0 : 1.0;
+    const double l1 = lbase + lstep * j, l2 = lbase + lstep * k;
+    // The rotated lattice stays within `reach` voxels of the anchor.  When that ball lies inside the grid with a voxel to
+    // spare (every row of an anchor the Orientator accepted, unless it hugs the border) no sample can leave the grid.
+    const int reach = (int)(1.7320508 * fabs(lbase)) + 2;
+    const bool interior = ic0 - reach >= 1 && ic0 + reach <= F.nx - 2 && ic1 - reach >= 1 && ic1 + reach <= F.ny - 2 &&
+                          ic2 - reach >= 1 && ic2 + reach <= F.nz - 2;      // uniform over the workgroup
+    float4 t[S];
+    unsigned unsure = 0;      // bit i: the float32 guess of sample i is too close to a tie to be trusted
     bool oob = false;
     if (active) {
-        const float fc0 = (float)ic0, fc1 = (float)ic1, fc2 = (float)ic2;
-        const float lim0 = (float)(F.nx - 1) - 1e-3f, lim1 = (float)(F.ny - 1) - 1e-3f, lim2 = (float)(F.nz - 1) - 1e-3f;
+        // float32 guess of the offset from the anchor voxel, |error| < 1e-5 voxel: the nearest voxel is known unless the
+        // fraction is within 2e-4 of the 0.5 tie (or, in a border row, the point is within 1e-3 of the grid edge).
+        // Straight-line code: the (j, k) part of inv(R) l is formed once, every sample adds one fused multiply-add per
+        // axis, and the texel requests go out as the indices appear (clamped into the grid in a border row: a sample that
+        // needed the clamp is marked unsure and fetched again below).
+        const float m1 = (float)l1, m2 = (float)l2;
+        const float b0 = fmaf(m1, h1, m2 * h2), b1 = fmaf(m1, h4, m2 * h5), b2 = fmaf(m1, h7, m2 * h8);
+        auto guess = [&](auto border) {
+            const float fc0 = (float)ic0, fc1 = (float)ic1, fc2 = (float)ic2;
+            const float lim0 = (float)(F.nx - 1) - 1e-3f, lim1 = (float)(F.ny - 1) - 1e-3f, lim2 = (float)(F.nz - 1) - 1e-3f;
 #pragma unroll
-        for (int i = 0; i < S; i++) {
-            double l0, l1, l2;      // Descriptor.py:34-35
-            if (oct == 0) { l0 = -2 * A.r + 1 + 2 * i; l1 = -2 * A.r + 1 + 2 * j; l2 = -2 * A.r + 1 + 2 * k; }
-            else { l0 = -A.r + 0.5 + i; l1 = -A.r + 0.5 + j; l2 = -A.r + 0.5 + k; }
-            // float32 guess of the offset from the anchor voxel: |error| < 1e-5 voxel, so the nearest
-            // voxel is known unless the fraction is within 2e-4 of the 0.5 tie or the point is within
-            // 1e-3 of the grid edge; only then is the reference's float64 expression evaluated.
-            const float m0 = (float)l0, m1 = (float)l1, m2 = (float)l2;
-            const float a0 = m0 * h0 + m1 * h1 + m2 * h2, a1 = m0 * h3 + m1 * h4 + m2 * h5, a2 = m0 * h6 + m1 * h7 + m2 * h8;
-            const float fl0 = floorf(a0), fl1 = floorf(a1), fl2 = floorf(a2);
-            const float fr0 = a0 - fl0, fr1 = a1 - fl1, fr2 = a2 - fl2;
-            const float q0 = a0 + fc0, q1 = a1 + fc1, q2 = a2 + fc2;
-            const bool safe = fabsf(fr0 - 0.5f) > 2e-4f && fabsf(fr1 - 0.5f) > 2e-4f && fabsf(fr2 - 0.5f) > 2e-4f &&
-                              q0 > 1e-3f && q0 < lim0 && q1 > 1e-3f && q1 < lim1 && q2 > 1e-3f && q2 < lim2;
-            if (safe) {
-                const int n0 = ic0 + (int)fl0 + (fr0 > 0.5f ? 1 : 0), n1 = ic1 + (int)fl1 + (fr1 > 0.5f ? 1 : 0),
-                          n2 = ic2 + (int)fl2 + (fr2 > 0.5f ? 1 : 0);
-                idx[i] = (unsigned)(((size_t)n0 * F.ny + n1) * F.nz + n2);
-                continue;
+            for (int i = 0; i < S; i++) {
+                const float m0 = (float)(lbase + lstep * i);
+                const float a0 = fmaf(m0, h0, b0), a1 = fmaf(m0, h3, b1), a2 = fmaf(m0, h6, b2);
+                const float fl0 = floorf(a0), fl1 = floorf(a1), fl2 = floorf(a2);
+                const float fr0 = a0 - fl0, fr1 = a1 - fl1, fr2 = a2 - fl2;
+                bool safe = (fabsf(fr0 - 0.5f) > 2e-4f) & (fabsf(fr1 - 0.5f) > 2e-4f) & (fabsf(fr2 - 0.5f) > 2e-4f);
+                int n0 = ic0 + (int)fl0 + (fr0 > 0.5f ? 1 : 0), n1 = ic1 + (int)fl1 + (fr1 > 0.5f ? 1 : 0),
+                    n2 = ic2 + (int)fl2 + (fr2 > 0.5f ? 1 : 0);
+                if (decltype(border)::value) {
+                    const float q0 = a0 + fc0, q1 = a1 + fc1, q2 = a2 + fc2;
+                    safe &= (q0 > 1e-3f) & (q0 < lim0) & (q1 > 1e-3f) & (q1 < lim1) & (q2 > 1e-3f) & (q2 < lim2);
+                    n0 = min(max(n0, 0), F.nx - 1); n1 = min(max(n1, 0), F.ny - 1); n2 = min(max(n2, 0), F.nz - 1);
+                }
+                t[i] = F.tex[(unsigned)(((size_t)n0 * F.ny + n1) * F.nz + n2)];
+                unsure |= safe ? 0u : (1u << i);
             }
-            const double p0 = (l0 * i0 + l1 * i1 + l2 * i2) + c0;      // Descriptor.py:132-133
-            const double p1 = (l0 * i3 + l1 * i4 + l2 * i5) + c1;
-            const double p2 = (l0 * i6 + l1 * i7 + l2 * i8) + c2;
-            // nearest neighbour of scipy's RegularGridInterpolator, bounds_error=True (MapSpace.py:189)
-            if (!(p0 >= 0.0) || !(p0 <= (double)(F.nx - 1)) || !(p1 >= 0.0) || !(p1 <= (double)(F.ny - 1)) ||
-                !(p2 >= 0.0) || !(p2 <= (double)(F.nz - 1))) {
-                oob = true;
-                idx[i] = 0;
-                continue;
-            }
-            int a0i = min((int)floor(p0), F.nx - 2), a1i = min((int)floor(p1), F.ny - 2), a2i = min((int)floor(p2), F.nz - 2);
-            a0i = (p0 - (double)a0i <= 0.5) ? a0i : a0i + 1;
-            a1i = (p1 - (double)a1i <= 0.5) ? a1i : a1i + 1;
-            a2i = (p2 - (double)a2i <= 0.5) ? a2i : a2i + 1;
-            idx[i] = (unsigned)(((size_t)a0i * F.ny + a1i) * F.nz + a2i);
+        };
+        if (interior) guess(std::false_type()); else guess(std::true_type());
+        if (unsure) {      // rare: the reference's float64 expression for those samples, and their texels again
+#pragma unroll
+            for (int i = 0; i < S; i++)
+                if (unsure & (1u << i)) t[i] = F.tex[lattice_index_exact(lbase + lstep * i, l1, l2, sInv, c0, c1, c2, F, &oob)];
         }
     }
     if (oob) s_oob = 1;
@@ -572,14 +600,14 @@ __global__ __launch_bounds__(DSC_THREADS, 4) void k_describe(DescribeArgs A) {
         return;
     }
     if (active) {
-        float4 t[S];
-#pragma unroll
-        for (int i = 0; i < S; i++) t[i] = F.tex[idx[i]];
         const float f0 = (float)Rrow[0], f1 = (float)Rrow[1], f2 = (float)Rrow[2], f3 = (float)Rrow[3], f4 = (float)Rrow[4], f5 = (float)Rrow[5],
                     f6 = (float)Rrow[6], f7 = (float)Rrow[7], f8 = (float)Rrow[8];
         // DSC_CHUNK points at a time: first their zones, in straight-line code (approximate unit direction, rotated in
         // float32: a guess, verified with guard bands inside eqsp_fast32), so that the table reads of different points
-        // overlap; then the histogram updates and the rare hand-over to the exact path.
+        // overlap; then the histogram updates.  The few points the fast classifier declines (~2 per row) are collected in
+        // a bit mask and handed to the exact path afterwards.
+        unsigned undecided = 0;
+        const int sub_jk = (j / q4) * 16 + (k / q4);      // Descriptor.py:44-64
 #pragma unroll
         for (int i0 = 0; i0 < S; i0 += DSC_CHUNK) {
             int zone[DSC_CHUNK];
@@ -596,14 +624,17 @@ __global__ __launch_bounds__(DSC_THREADS, 4) void k_describe(DescribeArgs A) {
             }
 #pragma unroll
             for (int u = 0; u < DSC_CHUNK; u++) {
-                const int i = i0 + u;
-                const int sub = (j / q4) * 16 + (i / q4) * 4 + (k / q4);      // Descriptor.py:44-64
-                if (zone[u] >= 0) atomicAdd(&hist[sub * Z + zone[u]], 1);
-                else if (zone[u] == -1) {      // decide later with the exact arithmetic, with full lanes
-                    const int slot = atomicAdd(&s_nq, 1);
-                    if (slot < DSC_QUEUE) { qv[slot] = t[i]; qsub[slot] = sub; }
-                }
+                if (zone[u] >= 0) atomicAdd(&hist[(sub_jk + ((i0 + u) / q4) * 4) * Z + zone[u]], 1);
+                undecided |= zone[u] == -1 ? (1u << (i0 + u)) : 0u;
             }
+        }
+        if (undecided) {      // decide later with the exact arithmetic, with full lanes
+#pragma unroll
+            for (int i = 0; i < S; i++)
+                if (undecided & (1u << i)) {
+                    const int slot = atomicAdd(&s_nq, 1);
+                    if (slot < DSC_QUEUE) { qv[slot] = t[i]; qsub[slot] = sub_jk + (i / q4) * 4; }
+                }
         }
     }
     __syncthreads();
@@ -613,8 +644,9 @@ __global__ __launch_bounds__(DSC_THREADS, 4) void k_describe(DescribeArgs A) {
         for (int i = tid; i < D; i += DSC_THREADS) hist[i] = 0;
         __syncthreads();
         if (active)
-            for (int i = 0; i < S; i++) {
-                const float4 tx = F.tex[idx[i]];
+            for (int i = 0; i < S; i++) {      // not unrolled: indices again from the float64 expression
+                bool none = false;
+                const float4 tx = F.tex[lattice_index_exact(lbase + lstep * i, l1, l2, sInv, c0, c1, c2, F, &none)];
                 if (tx.w < 1e-5f) continue;
                 atomicAdd(&hist[((j / q4) * 16 + (i / q4) * 4 + (k / q4)) * Z + describe_exact(&fast, tx, Rrow)], 1);
             }
