@@ -526,9 +526,16 @@ __global__ __launch_bounds__(256) void k_pose_prep(const int32_t *__restrict__ p
 }
 
 #define POSE_LDS_THREADS 1024
+#define POSE_RING 256                       // survivor queue of a wave (entries), a power of two >= 2 x 64
+#define POSE_WAVE_LDS (POSE_RING * 2 + 256) // bytes per wave: the queue + two pair records of 128 bytes
 
-// MaD.py:433-448.  One wave per pair, lanes over the hi cloud.  `dd_lim` is the smallest double whose
-// square root is >= dist, so dd < dd_lim is exactly the reference's sqrt(dd) < dist without the root.
+// MaD.py:433-448.  One wave per pair, lanes over the hi cloud.  `dd_lim` is the smallest double whose square root is >=
+// dist, so dd < dd_lim is exactly the reference's sqrt(dd) < dist without the root.
+// Two phases per pair: every hi point is tested against the occupancy bitmap of the lo cloud (float32, ~40 instructions
+// per 64 points), the survivors (about one in eight) are queued, and the exact float64 search runs on 64 queued points
+// at a time.  A pair leaves fewer than 64 behind; they stay queued and share a round with the first survivors of the
+// wave's NEXT pair (each entry carries a slot bit, the two pairs' transforms sit side by side in LDS), so that the rounds
+// run with full lanes: ~0.9 rounds per pair instead of ~1.3.
 __global__ __launch_bounds__(POSE_LDS_THREADS) void k_pose_lds(const int32_t *__restrict__ status, int64_t cap_pairs,
                                                                const PosePair *__restrict__ rec,
                                                                const double *__restrict__ hi_cloud, const double *__restrict__ lo_sorted,
@@ -538,13 +545,14 @@ __global__ __launch_bounds__(POSE_LDS_THREADS) void k_pose_lds(const int32_t *__
                                                                const unsigned *__restrict__ bits, int32_t *__restrict__ counts) {
     extern __shared__ __align__(16) unsigned char smem[];
     if (status[ST_FLAG_C] || status[ST_FLAG_PAIRS]) return;
-    // LDS regions, each a multiple of 16 bytes (pose_lds_bytes on the host mirrors this)
+    // LDS regions, each a multiple of 16 bytes (pose_device on the host mirrors this)
     double *cl = (double *)smem;                                                     // hi cloud
     double *lp = (double *)(smem + pad16((size_t)l_hi_cap * 24));                    // sorted lo cloud
     float4 *clf = (float4 *)((unsigned char *)lp + pad16((size_t)l_lo_cap * 24));    // hi cloud in float32: the bitmap test reads it
     unsigned short *cs = (unsigned short *)(clf + l_hi_cap);                         // cell offsets
-    unsigned short *stack0 = (unsigned short *)((unsigned char *)cs + pad16((size_t)(G.ncell + 1) * 2));
-    unsigned short *stack = stack0 + (threadIdx.x >> 6) * POSE_STACK;                // per wave
+    unsigned char *wave_lds = (unsigned char *)cs + pad16((size_t)(G.ncell + 1) * 2) + (threadIdx.x >> 6) * POSE_WAVE_LDS;
+    unsigned short *ring = (unsigned short *)wave_lds;                               // this wave's survivor queue
+    double *recs = (double *)(wave_lds + POSE_RING * 2);                             // this wave's two pair records, 16 doubles each
     const int64_t n_pairs = min((int64_t)status[ST_NPAIRS], cap_pairs);
     const int l_hi = status[ST_LHI];
     const int l_lo = cell_start[G.ncell];
@@ -561,53 +569,109 @@ __global__ __launch_bounds__(POSE_LDS_THREADS) void k_pose_lds(const int32_t *__
     PosePair cur;
     if (wave < n_pairs) cur = rec[wave];
     const float mnx = (float)G.mn[0], mny = (float)G.mn[1], mnz = (float)G.mn[2];
+
+    // the exact search for queue entry e = slot << 15 | hi point
+    auto exact = [&](int e) -> bool {
+        const double *P = recs + 16 * (e >> 15);      // R[9], ph[3], pl[3] of the entry's pair
+        const int a = e & 0x7fff;
+        const double d0 = cl[3 * a] - P[9], d1 = cl[3 * a + 1] - P[10], d2 = cl[3 * a + 2] - P[11];
+        const double x = (d0 * P[0] + d1 * P[1] + d2 * P[2]) + P[12];      // MaD.py:440-444
+        const double y = (d0 * P[3] + d1 * P[4] + d2 * P[5]) + P[13];
+        const double z = (d0 * P[6] + d1 * P[7] + d2 * P[8]) + P[14];
+        // cells met by a slightly larger ball (reach = dist + 0.01), in float32: a superset is harmless
+        const float xf = (float)x - mnx, yf = (float)y - mny, zf = (float)z - mnz;
+        const int x0 = (int)floorf((xf - reach) * G.inv_cell_f[0]), x1 = (int)floorf((xf + reach) * G.inv_cell_f[0]);
+        const int y0 = (int)floorf((yf - reach) * G.inv_cell_f[1]), y1 = (int)floorf((yf + reach) * G.inv_cell_f[1]);
+        const int z0 = (int)floorf((zf - reach) * G.inv_cell_f[2]), z1 = (int)floorf((zf + reach) * G.inv_cell_f[2]);
+        bool hit = false;
+        if (x1 >= 0 && x0 < G.dim[0] && y1 >= 0 && y0 < G.dim[1] && z1 >= 0 && z0 < G.dim[2]) {
+            const int zz0 = max(z0, 0), zz1 = min(z1, G.dim[2] - 1) + 1;
+            const int xa = max(x0, 0), xb = min(x1, G.dim[0] - 1), ya = max(y0, 0), yb = min(y1, G.dim[1] - 1);
+            // the ball meets at most 2 x 2 columns: fetch all four z-runs before walking any of them
+            const int c00 = (xa * G.dim[1] + ya) * G.dim[2], c01 = (xa * G.dim[1] + yb) * G.dim[2];
+            const int c10 = (xb * G.dim[1] + ya) * G.dim[2], c11 = (xb * G.dim[1] + yb) * G.dim[2];
+            int s[4], e4[4];
+            s[0] = cs[c00 + zz0]; e4[0] = cs[c00 + zz1];
+            s[1] = cs[c01 + zz0]; e4[1] = (yb != ya) ? cs[c01 + zz1] : s[1];
+            s[2] = cs[c10 + zz0]; e4[2] = (xb != xa) ? cs[c10 + zz1] : s[2];
+            s[3] = cs[c11 + zz0]; e4[3] = (xb != xa && yb != ya) ? cs[c11 + zz1] : s[3];
+            // one loop over the concatenation of the four runs: the wave then iterates max-over-lanes of the
+            // TOTAL candidate count instead of the sum over runs of the per-run maxima
+            const int n0 = e4[0] - s[0], n1 = n0 + (e4[1] - s[1]), n2 = n1 + (e4[2] - s[2]), n3 = n2 + (e4[3] - s[3]);
+            const int b1 = s[1] - n0, b2 = s[2] - n1, b3 = s[3] - n2;
+            for (int t = 0; t < n3 && !hit; t++) {
+                const int q = t + (t < n0 ? s[0] : (t < n1 ? b1 : (t < n2 ? b2 : b3)));
+                const double e0 = lp[3 * q] - x, e1 = lp[3 * q + 1] - y, e2 = lp[3 * q + 2] - z;
+                hit = (e0 * e0 + e1 * e1 + e2 * e2) < dd_lim;      // MaD.py:447-448
+            }
+        }
+        return hit;
+    };
+
+    // queue state, all wave-uniform
+    int head = 0, count = 0;          // ring[(head + i) & (POSE_RING - 1)], i < count, oldest first
+    int slot = 0;                     // slot bit of the pair being filtered
+    int cnt_cur = 0, cnt_old = 0;     // hits so far of that pair / of the previous one
+    int old_left = 0;                 // queued entries that still belong to the previous pair (they are at the head)
+    int64_t p_old = -1;
+    auto round = [&](int n_take) {    // the exact search for the n_take <= 64 oldest entries
+        __builtin_amdgcn_wave_barrier();
+        const int e = lane < n_take ? ring[(head + lane) & (POSE_RING - 1)] : 0;
+        __builtin_amdgcn_wave_barrier();
+        bool hit = false;
+        if (lane < n_take) hit = exact(e);
+        const unsigned long long bal = __ballot(hit), mine = __ballot(lane < n_take && (e >> 15) == slot);
+        cnt_cur += __popcll(bal & mine);
+        cnt_old += __popcll(bal & ~mine);
+        head = (head + n_take) & (POSE_RING - 1);
+        count -= n_take;
+        if (old_left > 0) {
+            old_left = max(old_left - n_take, 0);
+            if (old_left == 0 && lane == 0) counts[p_old] = cnt_old;      // the previous pair is complete
+        }
+    };
     for (int64_t p = wave; p < n_pairs; p += nwaves) {
         PosePair nxt;      // requested now, needed one iteration later
         if (p + nwaves < n_pairs) nxt = rec[p + nwaves];
-        const double *R = cur.R;
-        const double ph0 = cur.ph[0], ph1 = cur.ph[1], ph2 = cur.ph[2], pl0 = cur.pl[0], pl1 = cur.pl[1], pl2 = cur.pl[2];
         PoseVox V;
-        pose_vox_setup(R, ph0, ph1, ph2, pl0, pl1, pl2, B, &V);
-        auto cloud32 = [&](int a, float &cx, float &cy, float &cz) { const float4 c = clf[a]; cx = c.x; cy = c.y; cz = c.z; };
-        auto exact = [&](int a) -> bool {
-            const double d0 = cl[3 * a] - ph0, d1 = cl[3 * a + 1] - ph1, d2 = cl[3 * a + 2] - ph2;
-            const double x = (d0 * R[0] + d1 * R[1] + d2 * R[2]) + pl0;      // MaD.py:440-444
-            const double y = (d0 * R[3] + d1 * R[4] + d2 * R[5]) + pl1;
-            const double z = (d0 * R[6] + d1 * R[7] + d2 * R[8]) + pl2;
-            // cells met by a slightly larger ball (reach = dist + 0.01), in float32: a superset is harmless
-            const float xf = (float)x - mnx, yf = (float)y - mny, zf = (float)z - mnz;
-            const int x0 = (int)floorf((xf - reach) * G.inv_cell_f[0]), x1 = (int)floorf((xf + reach) * G.inv_cell_f[0]);
-            const int y0 = (int)floorf((yf - reach) * G.inv_cell_f[1]), y1 = (int)floorf((yf + reach) * G.inv_cell_f[1]);
-            const int z0 = (int)floorf((zf - reach) * G.inv_cell_f[2]), z1 = (int)floorf((zf + reach) * G.inv_cell_f[2]);
-            bool hit = false;
-            if (x1 >= 0 && x0 < G.dim[0] && y1 >= 0 && y0 < G.dim[1] && z1 >= 0 && z0 < G.dim[2]) {
-                const int zz0 = max(z0, 0), zz1 = min(z1, G.dim[2] - 1) + 1;
-                const int xa = max(x0, 0), xb = min(x1, G.dim[0] - 1), ya = max(y0, 0), yb = min(y1, G.dim[1] - 1);
-                // the ball meets at most 2 x 2 columns: fetch all four z-runs before walking any of them
-                const int c00 = (xa * G.dim[1] + ya) * G.dim[2], c01 = (xa * G.dim[1] + yb) * G.dim[2];
-                const int c10 = (xb * G.dim[1] + ya) * G.dim[2], c11 = (xb * G.dim[1] + yb) * G.dim[2];
-                int s[4], e[4];
-                s[0] = cs[c00 + zz0]; e[0] = cs[c00 + zz1];
-                s[1] = cs[c01 + zz0]; e[1] = (yb != ya) ? cs[c01 + zz1] : s[1];
-                s[2] = cs[c10 + zz0]; e[2] = (xb != xa) ? cs[c10 + zz1] : s[2];
-                s[3] = cs[c11 + zz0]; e[3] = (xb != xa && yb != ya) ? cs[c11 + zz1] : s[3];
-                // one loop over the concatenation of the four runs: the wave then iterates max-over-lanes of the
-                // TOTAL candidate count instead of the sum over runs of the per-run maxima
-                const int n0 = e[0] - s[0], n1 = n0 + (e[1] - s[1]), n2 = n1 + (e[2] - s[2]), n3 = n2 + (e[3] - s[3]);
-                const int b1 = s[1] - n0, b2 = s[2] - n1, b3 = s[3] - n2;
-                for (int t = 0; t < n3 && !hit; t++) {
-                    const int q = t + (t < n0 ? s[0] : (t < n1 ? b1 : (t < n2 ? b2 : b3)));
-                    const double e0 = lp[3 * q] - x, e1 = lp[3 * q + 1] - y, e2 = lp[3 * q + 2] - z;
-                    hit = (e0 * e0 + e1 * e1 + e2 * e2) < dd_lim;      // MaD.py:447-448
+        pose_vox_setup(cur.R, cur.ph[0], cur.ph[1], cur.ph[2], cur.pl[0], cur.pl[1], cur.pl[2], B, &V);
+        if (lane == 0) {      // this pair's transform for the exact search (the slot's previous user is complete by now)
+            double *P = recs + 16 * slot;
+            for (int i = 0; i < 9; i++) P[i] = cur.R[i];
+            for (int i = 0; i < 3; i++) { P[9 + i] = cur.ph[i]; P[12 + i] = cur.pl[i]; }
+        }
+        for (int a0 = 0; a0 < l_hi; a0 += MAD_WAVE * POSE_BATCH) {
+            unsigned word[POSE_BATCH];
+            int bit[POSE_BATCH];
+#pragma unroll
+            for (int u = 0; u < POSE_BATCH; u++) {      // the bitmap words of 4 x 64 points are requested before any is looked at
+                const int a = a0 + u * MAD_WAVE + lane;
+                word[u] = 0; bit[u] = 0;
+                if (a < l_hi) {
+                    const float4 c = clf[a];
+                    pose_vox_fetch(V, c.x, c.y, c.z, B, bits, &word[u], &bit[u]);
                 }
             }
-            return hit;
-        };
-        int cnt = pose_count_filtered(l_hi, V, B, bits, stack, cloud32, exact);
-        cnt = wave_sum_i32(cnt);
-        if (lane == 0) counts[p] = cnt;
+#pragma unroll
+            for (int u = 0; u < POSE_BATCH; u++) {
+                if (a0 + u * MAD_WAVE >= l_hi) break;      // wave-uniform
+                const bool sv = (word[u] >> bit[u]) & 1u;
+                const unsigned long long bal = __ballot(sv);
+                if (sv)
+                    ring[(head + count + __popcll(bal & lanemask_lt())) & (POSE_RING - 1)] =
+                        (unsigned short)((slot << 15) | (a0 + u * MAD_WAVE + lane));
+                count += __popcll(bal);
+                if (count >= MAD_WAVE) round(MAD_WAVE);      // wave-uniform
+            }
+        }
+        if (old_left > 0) round(count);      // rare: too few survivors to reach the previous pair's leftovers; take everything
+        // this pair becomes the previous one; what it left in the queue waits for company
+        p_old = p; cnt_old = cnt_cur; cnt_cur = 0; old_left = count;
+        if (old_left == 0 && lane == 0) counts[p] = cnt_old;
+        slot ^= 1;
         cur = nxt;
     }
+    if (count > 0) round(count);      // completes the last pair
 }
 
 
@@ -1119,7 +1183,7 @@ static int pose_device(mad_ctx *ctx, const Side &hi, const Side &lo, int32_t *d_
         if (G.dim[d] < 1) G.dim[d] = 1;
         G.ncell *= G.dim[d];
     }
-    const size_t stacks = (size_t)(POSE_LDS_THREADS / MAD_WAVE) * POSE_STACK * 2;
+    const size_t stacks = (size_t)(POSE_LDS_THREADS / MAD_WAVE) * POSE_WAVE_LDS;      // per-wave queues (+ pair records in k_pose_lds)
     const size_t lds32 = (size_t)(n_cloud + 1) * 16 + pad16((size_t)(G.ncell + 1) * 2) + stacks + 16;
     // occupancy bitmap of the lo cloud (k_pose_bits), in global memory: voxel edge MAD_POSE_VOXEL (default 0.8 A: 0.6-0.8 measure the same, 1.0 is 3 % slower) unless that
     // needs more than 16 MB.  It was tried in LDS too: there it has to be coarser (1.7 A beside the C3 clouds), lets 74
@@ -1213,7 +1277,7 @@ static int pose_device(mad_ctx *ctx, const Side &hi, const Side &lo, int32_t *d_
 }
 
 static bool clouds_fit_lds(int64_t l_hi, int64_t l_lo) {      // with the largest cell table (30 000 cells)
-    const size_t fixed = 30004 * 2 + (POSE_LDS_THREADS / MAD_WAVE) * POSE_STACK * 2 + 16 + 64;      // as pose_device sizes them (+ its 16-byte paddings)
+    const size_t fixed = 30004 * 2 + (POSE_LDS_THREADS / MAD_WAVE) * POSE_WAVE_LDS + 16 + 64;      // as pose_device sizes them (+ its 16-byte paddings)
     return ((size_t)(l_hi + l_lo) * 24 + (size_t)l_hi * 16 + fixed <= 150 * 1024 || (size_t)(l_lo + 1) * 16 + fixed <= 150 * 1024) && l_lo < 65535;
 }
 
