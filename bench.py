@@ -345,14 +345,20 @@ def main():
         pairs = sum(s["n_pairs"] for s in stats)
         # one roofline entry per kernel group; `roofline` = the group with the largest share of device time
         traffic = {}
-        prof = os.path.join(ROOT, "profiles", "r01_d_bench_c3_serial_summary.json")
-        if args.workload == "c3" and os.path.exists(prof):      # PMC passes of this same command (profiles/README.md)
-            with open(prof) as fh:
+        import glob
+        profs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_c3_serial_summary.json")))      # newest round last
+        pj = {}
+        if args.workload == "c3" and profs:      # PMC passes of this same command (profiles/README.md)
+            with open(profs[-1]) as fh:
                 pj = json.load(fh)
-            for kn, gname in (("k_pose_lds", "pose"), ("k_describe<16>", "describe"), ("k_orient", "orient"), ("k_corr_gemm", "correlate"),
-                              ("k_pair_emit", "pairs")):
-                if kn in pj and "fetch_size_bytes_avg" in pj[kn]:
-                    traffic[gname] = pj[kn]["fetch_size_bytes_avg"] + pj[kn].get("write_size_bytes_avg", 0.0)
+        valu_util = {}
+        for kn, gname in (("k_pose_lds", "pose"), ("k_describe<16>", "describe"), ("k_orient", "orient"), ("k_corr_gemm", "correlate"),
+                          ("k_pair_emit", "pairs")):
+            if kn in pj and "fetch_size_bytes_avg" in pj[kn]:
+                traffic[gname] = pj[kn]["fetch_size_bytes_avg"] + pj[kn].get("write_size_bytes_avg", 0.0)
+            if kn in pj and "SQ_INSTS_VALU_avg" in pj[kn] and pj[kn].get("avg_us"):
+                # share of the SIMDs' issue cycles taken by vector ALU instructions (4 cycles each on a 16-lane SIMD, 1024 SIMDs, 2.4 GHz)
+                valu_util[gname] = 4.0 * pj[kn]["SQ_INSTS_VALU_avg"] / (pj[kn]["avg_us"] * 1e-6 * 2.4e9 * 1024)
         per_step = {g: max(groups[g]["launches"], 1) / n_serial for g in groups}      # launches per step
         alg = {
             "describe": ("k_describe", "hbm", DESCRIBE_BYTES * (rows_lo + rows_hi), HBM_PEAK_GBS, "GB/s", 1e9),
@@ -370,6 +376,8 @@ def main():
             roofs[gname] = dict(kernel=kname, bound=bound, achieved=work / (ms * 1e-3) / scale if ms > 0 else 0.0, peak=peak, unit=unit,
                                 traffic=traffic.get(gname), avg_launch_ms=ms, ms_per_step=groups[gname]["ms_total"] / n_serial)
             roofs[gname]["frac"] = roofs[gname]["achieved"] / peak
+            if gname in valu_util:
+                roofs[gname]["valu_issue_share"] = round(valu_util[gname], 3)      # from the SQ counters of the profiled run (profiles/)
         # `roofline` = the HBM stage SURVEY.md 8(d) names as the binding roofline of the headline metric (the texel
         # gathers of orient + describe), represented by its larger kernel, k_describe.  The pose search takes a larger
         # share of the device time but is bound by float64 VALU issue and LDS latency, which an hbm | mfma roofline
@@ -386,10 +394,11 @@ def main():
                                  achieved=b_hbm / t_hbm / 1e9 if t_hbm > 0 else 0.0, unit="GB/s", frac=(b_hbm / t_hbm / 1e9) / HBM_PEAK_GBS if t_hbm > 0 else 0.0)
         roof["largest_share_of_device_time"] = max(groups, key=lambda g: groups[g]["ms_total"])
         l_hi_mean = float(np.mean([s["l_hi"] for s in stats]))
-        flops = pairs * l_hi_mean * (18 + 8 * 3.5)      # ~18 flop per transformed point + ~8 per candidate lo anchor, float64
-        roofs["pose"]["note"] = ("bound by float64 VALU issue and LDS latency, not by HBM: ~%.1f float64 TFLOP/s of 78.6 peak, ~330 issued "
-                                 "instructions per transformed point; the HBM figure is its algorithmic 12 B/pair"
-                                 % (flops / (groups["pose"]["ms_total"] / n_serial * 1e-3) / 1e12))
+        pts = pairs * l_hi_mean      # transformed hi-cloud points per step
+        roofs["pose"]["note"] = ("not an HBM kernel (the HBM figure is its algorithmic 12 B/pair): every transformed hi point (%.3g per step, %.0f G/s) "
+                                 "goes through a float32 occupancy-bitmap test, the ~1 in 8 that pass through the exact float64 cell search; "
+                                 "vector-ALU issue is the binding resource (valu_issue_share, SQ_INSTS_VALU of the profiled run)"
+                                 % (pts, pts / (groups["pose"]["ms_total"] / n_serial * 1e-3) / 1e9))
         roof["others"] = {g: roofs[g] for g in roofs if g != dom_name}
 
         cpu, agree, cpu_all = (None, None, None)
