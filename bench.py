@@ -127,25 +127,53 @@ def build_inputs(lib, W, rank):
 HOST_T = {}
 
 
-def hot_path_step(lib, the_map, subs, cc, dist, k, sets):
-    """Returns (correlations, [top-k result rows per subunit], stats).  Everything is enqueued
-    asynchronously; the only host round trip is the result read-back that ends each match.
-    `sets` holds the device-resident row sets, rebuilt in place every step."""
+def enqueue_builds(lib, the_map, subs, sets):
+    """orient + describe of the map and of every subunit into `sets` (device-resident, rebuilt in place); asynchronous."""
     t0 = time.perf_counter()
     lo = lib.set_build(the_map.slots, the_map.coords, the_map.octave, the_map.subv, the_map.index, into=sets[0])
     his = [lib.set_build(s.slots, s.coords, s.octave, s.subv, s.index, into=d) for s, d in zip(subs, sets[1:])]
     HOST_T["build_enqueue"] = HOST_T.get("build_enqueue", 0.0) + time.perf_counter() - t0
+    return lo, his
+
+
+def collect(lib, handle, his):
     t0 = time.perf_counter()
     corr, tops, stats = 0, [], []
-    for top, idx, st in lib.match_topk_many(his, lo, cc, dist, k):
+    for top, idx, st in lib.match_topk_many_finish(handle):
         corr += st["n_corr"]
         tops.append(top)
         stats.append(st)
-    HOST_T["match"] = HOST_T.get("match", 0.0) + time.perf_counter() - t0
+    HOST_T["match_wait"] = HOST_T.get("match_wait", 0.0) + time.perf_counter() - t0
     for hi, st in zip(his, stats):
         st["n_hi"], _ = hi.size()
         st["n_lo"] = st["n_corr"] // max(st["n_hi"], 1)
     return corr, tops, stats
+
+
+def hot_path_step(lib, the_map, subs, cc, dist, k, sets):
+    """One step, start to finish: returns (correlations, [top-k result rows per subunit], stats).  Everything is enqueued
+    asynchronously; the only host round trip is the result read-back that ends each match."""
+    lo, his = enqueue_builds(lib, the_map, subs, sets)
+    return collect(lib, lib.match_topk_many_begin(his, lo, cc, dist, k), his)
+
+
+def run_steps(lib, the_map, subs, cc, dist, k, set_groups, n_steps, after_step=None):
+    """n_steps steps, two in flight: while the matches of step i run, the host already enqueues the builds of step i + 1
+    into the other group of device sets, so the device does not idle over the host's turn-around between steps.  Every
+    step does the same work as hot_path_step; `after_step(tops)` is called once per step, in order."""
+    out = None
+    built = enqueue_builds(lib, the_map, subs, set_groups[0]) if n_steps > 0 else None
+    for i in range(n_steps):
+        lo, his = built
+        t0 = time.perf_counter()
+        handle = lib.match_topk_many_begin(his, lo, cc, dist, k)
+        HOST_T["match_enqueue"] = HOST_T.get("match_enqueue", 0.0) + time.perf_counter() - t0
+        if i + 1 < n_steps:
+            built = enqueue_builds(lib, the_map, subs, set_groups[(i + 1) % 2])
+        out = collect(lib, handle, his)
+        if after_step is not None:
+            after_step(out[1])
+    return out
 
 
 def refine_ccc_leg(lib, the_map, subs, tops, W, n_cand=8):
@@ -291,22 +319,29 @@ def main():
         from mad_amd import dist as mdist
         return mdist.TopkExchange(tops, k, world * W["n_sub"], rank, world)
 
-    sets = [_lib.DeviceSet(lib) for _ in range(1 + len(subs))]
+    set_groups = [[_lib.DeviceSet(lib) for _ in range(1 + len(subs))] for _ in range(2)]
+    sets = set_groups[0]
     if args.serial:
         lib.set_overlap(False)
-    for _ in range(args.warmup):
-        corr, tops, stats = hot_path_step(lib, the_map, subs, cc, dist_thr, k, sets)
-        exchange(tops).finish()
+    # Setup, not a step: both groups of device sets are created, sized and given their launch-size hints here (a set sizes
+    # its describe grid and a match its pair capacity from what the previous use of the same objects needed), the way an
+    # allocator is warmed before a run.  The W warm-up steps and the K timed steps that follow all do the full work.
+    for grp in set_groups:
+        for _ in range(2):
+            hot_path_step(lib, the_map, subs, cc, dist_thr, k, grp)
+    run_steps(lib, the_map, subs, cc, dist_thr, k, set_groups, args.warmup, after_step=lambda tops: exchange(tops).finish())
     HOST_T.clear()
     barrier()
     t0 = time.perf_counter()
-    pending = None
-    for _ in range(args.steps):
-        corr, tops, stats = hot_path_step(lib, the_map, subs, cc, dist_thr, k, sets)
-        if pending is not None:
-            gathered = pending.finish()
-        pending = exchange(tops)
-    gathered = pending.finish()      # every step's exchange completes inside the timed region
+    pending = [None]
+
+    def after_step(tops):      # the exchange of step i completes while step i + 1 runs
+        if pending[0] is not None:
+            pending[0].finish()
+        pending[0] = exchange(tops)
+
+    corr, tops, stats = run_steps(lib, the_map, subs, cc, dist_thr, k, set_groups, args.steps, after_step=after_step)
+    gathered = pending[0].finish()      # every step's exchange completes inside the timed region
     barrier()
     dt = time.perf_counter() - t0
     # Per-kernel durations for the rooflines: in the timed region the builds of the five sets and the four matches
@@ -429,6 +464,7 @@ def main():
                        "subunit_anchors": anchors_hi, "subunit_rows": rows_hi, "pairs_over_cc": pairs,
                        "cc_threshold": cc, "top_k": k, "correlations_per_step_per_gpu": corr,
                        "parallelism": "1 process per GPU, subunits sharded, RCCL all-gather of top-k" if world > 1 else "single GPU",
+                       "pipelining": "2 steps in flight: the builds of step i+1 are enqueued before the results of step i are awaited; every step does the full work",
                        "topk_agrees_with_cpu_oracle": agree, "setup_s": t_setup,
                        "setup_detail_s": {k_: round(v, 4) for k_, v in SETUP_T.items()}},
             "roofline": roof,

@@ -197,6 +197,17 @@ int mad_match_topk(mad_ctx *ctx, const mad_set *hi, const mad_set *lo, double cc
  */
 int mad_match_topk_many(mad_ctx *ctx, int n, const mad_set *const *hi, const mad_set *lo, double cc, double dist,
                         int64_t k, double *results, int64_t *pair_index, int64_t *n_out, int64_t *stats);
+
+/*
+ * The same call in two halves, for callers that keep the device fed: _begin enqueues every match and returns
+ * (the output arrays belong to the bracket until _finish returns: _finish fills them; _begin itself only does so for a
+ * match whose lane it has to reuse, n > 8).  Between the two the caller may enqueue other work -- typically
+ * mad_set_build of the NEXT batch into other sets: sets read by the open bracket must not be rebuilt or destroyed, and
+ * no other match call may be made.  One bracket at a time per ctx.
+ */
+int mad_match_topk_many_begin(mad_ctx *ctx, int n, const mad_set *const *hi, const mad_set *lo, double cc, double dist,
+                              int64_t k, double *results, int64_t *pair_index, int64_t *n_out, int64_t *stats);
+int mad_match_topk_many_finish(mad_ctx *ctx);
 /* After mad_match_topk: all pairs of that call (for MaD._match_dsc's full return value). */
 int mad_match_fetch(mad_ctx *ctx, int32_t *pair_hi, int32_t *pair_lo, double *pair_score,
                     int32_t *counts, int64_t cap);

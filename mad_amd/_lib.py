@@ -22,7 +22,7 @@ SYMBOLS = [
     "mad_set_eqsp", "mad_upload_field", "mad_upload_field_device", "mad_free_field",
     "mad_orient", "mad_describe", "mad_correlate", "mad_pose_score", "mad_topk",
     "mad_set_create", "mad_set_destroy", "mad_set_build", "mad_set_load", "mad_set_size", "mad_set_download",
-    "mad_match_topk", "mad_match_topk_many", "mad_match_fetch", "mad_match_results", "mad_match_used",
+    "mad_match_topk", "mad_match_topk_many", "mad_match_topk_many_begin", "mad_match_topk_many_finish", "mad_match_fetch", "mad_match_results", "mad_match_used",
     "mad_match_shard_pairs", "mad_match_shard_topk",
     "mad_upload_density", "mad_refine", "mad_structure_to_density", "mad_ccc", "mad_density_ccc", "mad_grid_overlap", "mad_overlap_matrix",
     "mad_space_create", "mad_space_destroy", "mad_space_build", "mad_space_info", "mad_space_download",
@@ -410,6 +410,27 @@ class Lib(object):
             g = int(n_out[i])
             out.append((res[i, :g], idx[i, :g], dict(n_pairs=int(stats[i, 0]), l_hi=int(stats[i, 1]), l_lo=int(stats[i, 2]),
                                                      n_corr=int(stats[i, 3]))))
+        return out
+
+    def match_topk_many_begin(self, his, lo, cc, dist, k):
+        """Enqueue every match and return a handle; `match_topk_many_finish(handle)` waits and unpacks.  In between
+        the caller may build the sets of its next batch (not the ones this bracket reads)."""
+        k = int(k)
+        n = len(his)
+        h = dict(n=n, k=k, res=np.zeros((max(n, 1), max(k, 1), RESULT_COLS)), idx=np.zeros((max(n, 1), max(k, 1)), np.int64),
+                 n_out=np.zeros(max(n, 1), np.int64), stats=np.zeros((max(n, 1), 4), np.int64), sets=(list(his), lo))
+        arr = (C.c_void_p * max(n, 1))(*[x.h.value for x in his])
+        self._chk(self.dll.mad_match_topk_many_begin(self.ctx, C.c_int(n), arr, lo.h, C.c_double(cc), C.c_double(dist), C.c_int64(k),
+                                                     _p(h["res"]), _p(h["idx"]), _p(h["n_out"]), _p(h["stats"])))
+        return h
+
+    def match_topk_many_finish(self, h):
+        self._chk(self.dll.mad_match_topk_many_finish(self.ctx))
+        out = []
+        for i in range(h["n"]):
+            g = int(h["n_out"][i])
+            st = h["stats"][i]
+            out.append((h["res"][i, :g], h["idx"][i, :g], dict(n_pairs=int(st[0]), l_hi=int(st[1]), l_lo=int(st[2]), n_corr=int(st[3]))))
         return out
 
     def match_shard_pairs(self, hi, lo, lo_begin, lo_end, cc):

@@ -144,6 +144,7 @@ struct mad_ctx {
     int next_pinned = 64;
     DensityDev dens;
     MatchState match;
+    void *many = nullptr;                    // open mad_match_topk_many_begin bracket (ManyState, mad_match.hip)
     bool timing = false;
     TimerGroup timers[MAD_T_COUNT];
     int n_cu = 256;
@@ -232,6 +233,7 @@ int mad_describe_device(mad_ctx *ctx, FieldDev f0, FieldDev f1, const int32_t *d
                         int uniform_octave, const int32_t *d_row_anchor, const double *d_row_R, const double *d_row_Rinv,
                         const int32_t *d_n_rows, int64_t grid_rows, int32_t *d_overflow, int r, int16_t *d_dsc, int8_t *d_dsc8 = nullptr,
                         double *d_norm = nullptr);
+void mad_many_abandon(mad_ctx *ctx);
 void mad_zero_words(mad_ctx *ctx, void *p, size_t bytes);              // one-launch zero fill (bytes rounded up to 16)
 void mad_copy_words(mad_ctx *ctx, void *dst, const void *src, size_t bytes);      // kernel copy, e.g. out of pinned host memory
 int mad_build_cells(mad_ctx *ctx, mad_set *set, double cell);

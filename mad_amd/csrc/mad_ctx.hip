@@ -87,6 +87,7 @@ extern "C" int mad_init(int device, mad_ctx **out) {
 }
 
 extern "C" void mad_destroy(mad_ctx *ctx) {
+    if (ctx) { mad_synchronize(ctx); mad_many_abandon(ctx); }
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     for (int l = 0; l < MAD_LANES; l++) (void)hipStreamSynchronize(ctx->lane_stream[l]);

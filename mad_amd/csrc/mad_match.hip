@@ -1847,51 +1847,97 @@ extern "C" int mad_match_topk(mad_ctx *ctx, const mad_set *hi, const mad_set *lo
 // Several subunits against one map.  Match i runs in the lane of its hi set, so up to MAD_LANES matches are in
 // flight before the host waits for the oldest: the GPU never idles on a result read-back.
 // results: n x k x 23, pair_index (nullable): n x k, n_out: n, stats (nullable): n x 4.
-extern "C" int mad_match_topk_many(mad_ctx *ctx, int n, const mad_set *const *hi, const mad_set *lo, double cc, double dist, int64_t k,
-                                   double *results, int64_t *pair_index, int64_t *n_out, int64_t *stats) {
-    if (!ctx || !hi || !lo || !n_out || n < 0) return MAD_EINVAL;
-    if (k < 1) k = 1;
+// State of one mad_match_topk_many_begin .. _finish bracket (ctx->many).
+struct ManyState {
+    int n = 0;
+    std::vector<const mad_set *> hi;
+    const mad_set *lo = nullptr;
+    double cc = 0, dist = 0;
+    int64_t k = 1;
+    double *results = nullptr;
+    int64_t *pair_index = nullptr, *n_out = nullptr, *stats = nullptr;
     MatchPlan plans[MAD_LANES];
     int pending[MAD_LANES];
-    for (int l = 0; l < MAD_LANES; l++) pending[l] = -1;
+};
+
+static int many_retire(mad_ctx *ctx, ManyState &M, int lane) {
+    const int i = M.pending[lane];
+    if (i < 0) return MAD_OK;
+    M.pending[lane] = -1;
+    MAD_HIP(hipEventSynchronize(ctx->lane_done[lane]));
+    double *res_i = M.results ? M.results + (size_t)i * M.k * MAD_RESULT_COLS : nullptr;
+    int64_t *idx_i = M.pair_index ? M.pair_index + (size_t)i * M.k : nullptr;
+    int64_t *st_i = M.stats ? M.stats + 4 * i : nullptr;
+    int rc = match_finish(ctx, lane, M.hi[i], M.lo, &M.plans[lane], res_i, idx_i, &M.n_out[i], st_i);
+    for (int attempt = 0; rc == 1 && attempt < 5; attempt++) {      // rare: repeat this one synchronously
+        mad_use_lane(ctx, lane);
+        MAD_TRY(match_enqueue(ctx, M.hi[i], M.lo, M.cc, M.dist, M.plans[lane]));
+        MAD_HIP(hipStreamSynchronize(ctx->stream));
+        rc = match_finish(ctx, lane, M.hi[i], M.lo, &M.plans[lane], res_i, idx_i, &M.n_out[i], st_i);
+    }
+    if (rc == 1) return mad_fail(ctx, MAD_EHIP, "mad_match_topk_many: capacity negotiation did not converge");
+    return rc;
+}
+
+extern "C" int mad_match_topk_many_begin(mad_ctx *ctx, int n, const mad_set *const *hi, const mad_set *lo, double cc, double dist, int64_t k,
+                                         double *results, int64_t *pair_index, int64_t *n_out, int64_t *stats) {
+    if (!ctx || !hi || !lo || !n_out || n < 0) return MAD_EINVAL;
+    if (ctx->many) return mad_fail(ctx, MAD_EINVAL, "mad_match_topk_many_begin: the previous call has not been finished");
+    if (k < 1) k = 1;
+    ManyState *Mp = new ManyState();
+    ManyState &M = *Mp;
+    M.n = n; M.hi.assign(hi, hi + n); M.lo = lo; M.cc = cc; M.dist = dist; M.k = k;
+    M.results = results; M.pair_index = pair_index; M.n_out = n_out; M.stats = stats;
+    for (int l = 0; l < MAD_LANES; l++) M.pending[l] = -1;
+    ctx->many = Mp;
     int rc_all = MAD_OK;
-    auto retire = [&](int lane) -> int {
-        const int i = pending[lane];
-        if (i < 0) return MAD_OK;
-        pending[lane] = -1;
-        MAD_HIP(hipEventSynchronize(ctx->lane_done[lane]));
-        double *res_i = results ? results + (size_t)i * k * MAD_RESULT_COLS : nullptr;
-        int64_t *idx_i = pair_index ? pair_index + (size_t)i * k : nullptr;
-        int rc = match_finish(ctx, lane, hi[i], lo, &plans[lane], res_i, idx_i, &n_out[i], stats ? stats + 4 * i : nullptr);
-        for (int attempt = 0; rc == 1 && attempt < 5; attempt++) {      // rare: repeat this one synchronously
-            mad_use_lane(ctx, lane);
-            MAD_TRY(match_enqueue(ctx, hi[i], lo, cc, dist, plans[lane]));
-            MAD_HIP(hipStreamSynchronize(ctx->stream));
-            rc = match_finish(ctx, lane, hi[i], lo, &plans[lane], res_i, idx_i, &n_out[i], stats ? stats + 4 * i : nullptr);
-        }
-        if (rc == 1) return mad_fail(ctx, MAD_EHIP, "mad_match_topk_many: capacity negotiation did not converge");
-        return rc;
-    };
     for (int i = 0; i < n && rc_all == MAD_OK; i++) {
         n_out[i] = 0;
         if (stats) { stats[4 * i] = stats[4 * i + 1] = stats[4 * i + 2] = stats[4 * i + 3] = 0; }
         if (!hi[i]) { rc_all = mad_fail(ctx, MAD_EINVAL, "mad_match_topk_many: set %d is NULL", i); break; }
         if (match_trivial(hi[i], lo)) continue;
         const int lane = hi[i]->lane;      // where its hi set was built: no cross-lane wait for it, and the matches spread like the sets
-        rc_all = retire(lane);
+        rc_all = many_retire(ctx, M, lane);
         if (rc_all != MAD_OK) break;
         mad_use_lane(ctx, lane);
-        rc_all = match_prepare(ctx, hi[i], lo, dist, k, &plans[lane]);
+        rc_all = match_prepare(ctx, hi[i], lo, dist, k, &M.plans[lane]);
         if (rc_all != MAD_OK) break;
-        rc_all = match_enqueue(ctx, hi[i], lo, cc, dist, plans[lane]);
-        pending[lane] = i;
-    }
-    for (int l = 0; l < MAD_LANES; l++) {
-        const int rc = retire(l);
-        if (rc_all == MAD_OK) rc_all = rc;
+        rc_all = match_enqueue(ctx, hi[i], lo, cc, dist, M.plans[lane]);
+        M.pending[lane] = i;
     }
     mad_use_lane(ctx, ctx->match.lane);
+    if (rc_all != MAD_OK) {      // leave nothing in flight behind a failed call
+        for (int l = 0; l < MAD_LANES; l++)
+            if (M.pending[l] >= 0) { (void)hipEventSynchronize(ctx->lane_done[l]); M.pending[l] = -1; }
+        delete Mp;
+        ctx->many = nullptr;
+    }
     return rc_all;
+}
+
+extern "C" int mad_match_topk_many_finish(mad_ctx *ctx) {
+    if (!ctx) return MAD_EINVAL;
+    if (!ctx->many) return mad_fail(ctx, MAD_EINVAL, "mad_match_topk_many_finish: nothing was begun");
+    ManyState *Mp = (ManyState *)ctx->many;
+    int rc_all = MAD_OK;
+    for (int l = 0; l < MAD_LANES; l++) {
+        const int rc = many_retire(ctx, *Mp, l);
+        if (rc_all == MAD_OK) rc_all = rc;
+    }
+    delete Mp;
+    ctx->many = nullptr;
+    mad_use_lane(ctx, ctx->match.lane);
+    return rc_all;
+}
+
+void mad_many_abandon(mad_ctx *ctx) {      // mad_destroy: a bracket left open
+    if (ctx && ctx->many) { delete (ManyState *)ctx->many; ctx->many = nullptr; }
+}
+
+extern "C" int mad_match_topk_many(mad_ctx *ctx, int n, const mad_set *const *hi, const mad_set *lo, double cc, double dist, int64_t k,
+                                   double *results, int64_t *pair_index, int64_t *n_out, int64_t *stats) {
+    MAD_TRY(mad_match_topk_many_begin(ctx, n, hi, lo, cc, dist, k, results, pair_index, n_out, stats));
+    return mad_match_topk_many_finish(ctx);
 }
 
 // ---------------------------------------------------------------------------
