@@ -382,11 +382,14 @@ __global__ __launch_bounds__(1024) void k_pose_grid_build(const double *__restri
 
 __host__ __device__ __forceinline__ size_t pad16(size_t b) { return (b + 15) & ~(size_t)15; }
 
-// Occupancy bitmap of the lo cloud: bit (x, y, z) is set iff some lo point lies within `rad` of the centre of that voxel
-// (edge h, origin mn), rad = dist + h sqrt(3) / 2 + slack.  A transformed hi point that falls into a clear voxel -- or
-// outside the bitmap -- has no lo point within dist, whatever the float32 rounding of its voxel coordinates (slack =
-// 0.02 A against < 1e-3 A of error), so only the others (about one in seven on the 256^3 workload) go through the exact
-// float64 search.  z-rows are padded to whole 32-bit words.
+// Occupancy bitmaps of the lo cloud over voxels of edge h (origin mn), two planes interleaved word by word:
+//   outer: bit set iff some lo point lies within dist + h sqrt(3)/2 + slack of the voxel centre.  A transformed hi point that
+//          falls into a clear voxel -- or outside the bitmap -- has no lo point within dist;
+//   inner: bit set iff some lo point lies within dist - h sqrt(3)/2 - slack of the voxel centre.  A point in such a voxel has
+//          a lo point within dist for certain and is counted without a search.
+// Both hold whatever the float32 rounding of the point's voxel coordinates does (slack = 0.02 A against < 1e-3 A of error),
+// so only the points in the shell between the two (about one in eleven on the 256^3 workload) go through the exact float64
+// search, and the counts are those of the unfiltered search.  z-rows are padded to whole 32-bit words.
 struct PoseBits {
     double mn[3];
     double h;
@@ -395,7 +398,7 @@ struct PoseBits {
 };
 
 __global__ __launch_bounds__(256) void k_pose_bits(const double *__restrict__ sorted, const int32_t *__restrict__ cell_start, int ncell,
-                                                   PoseBits B, double rad, unsigned *__restrict__ bits) {
+                                                   PoseBits B, double rad, int plane, unsigned *__restrict__ bits) {
     const int l_lo = cell_start[ncell];
     const double inv_h = 1.0 / B.h, rad2 = rad * rad;
     for (int p = blockIdx.x; p < l_lo; p += gridDim.x) {
@@ -410,13 +413,15 @@ __global__ __launch_bounds__(256) void k_pose_bits(const double *__restrict__ so
             const double rem = rad2 - dx * dx - dy * dy;
             if (rem < 0.0) continue;
             const double sq = sqrt(rem);
-            const int z0 = max((int)floor((pz - sq) * inv_h - 0.5), 0), z1 = min((int)ceil((pz + sq) * inv_h - 0.5), B.dim[2] - 1);
+            // outer plane: a superset of the voxels within rad is harmless; inner plane: it must be a subset
+            const int z0 = max(plane == 0 ? (int)floor((pz - sq) * inv_h - 0.5) : (int)ceil((pz - sq) * inv_h - 0.5 + 1e-9), 0);
+            const int z1 = min(plane == 0 ? (int)ceil((pz + sq) * inv_h - 0.5) : (int)floor((pz + sq) * inv_h - 0.5 - 1e-9), B.dim[2] - 1);
             if (z1 < z0) continue;
-            unsigned *row = bits + ((size_t)kx * B.dim[1] + ky) * B.wz;
+            unsigned *row = bits + 2 * ((size_t)kx * B.dim[1] + ky) * B.wz + plane;      // planes interleaved: [outer][inner] per word
             for (int w = z0 >> 5; w <= (z1 >> 5); w++) {
                 const int lo = max(z0 - 32 * w, 0), hi = min(z1 - 32 * w, 31);
                 const unsigned m = (hi == 31 ? 0xffffffffu : ((1u << (hi + 1)) - 1u)) & ~((1u << lo) - 1u);
-                atomicOr(&row[w], m);
+                atomicOr(&row[2 * w], m);
             }
         }
     }
@@ -437,17 +442,17 @@ __device__ __forceinline__ void pose_vox_setup(const double *R, double ph0, doub
     V->t[2] = (float)(((pl2 - (ph0 * R[6] + ph1 * R[7] + ph2 * R[8])) - B.mn[2]) * ih);
 }
 
-// the bitmap word of a hi-cloud point and the bit to test in it; *word = 0 for points outside the bitmap
+// the two bitmap words (outer, inner) of a hi-cloud point and the bit to test in them; zero for points outside the bitmap
 __device__ __forceinline__ void pose_vox_fetch(const PoseVox &V, float cx, float cy, float cz, const PoseBits &B,
-                                               const unsigned *bits, unsigned *word, int *bit) {
+                                               const unsigned *bits, uint2 *word, int *bit) {
     const float vx = fmaf(cz, V.m[2], fmaf(cy, V.m[1], fmaf(cx, V.m[0], V.t[0])));
     const float vy = fmaf(cz, V.m[5], fmaf(cy, V.m[4], fmaf(cx, V.m[3], V.t[1])));
     const float vz = fmaf(cz, V.m[8], fmaf(cy, V.m[7], fmaf(cx, V.m[6], V.t[2])));
     const int ix = (int)floorf(vx), iy = (int)floorf(vy), iz = (int)floorf(vz);
     *bit = iz & 31;
-    *word = 0;
+    *word = make_uint2(0u, 0u);
     if ((unsigned)ix < (unsigned)B.dim[0] && (unsigned)iy < (unsigned)B.dim[1] && (unsigned)iz < (unsigned)B.dim[2])
-        *word = bits[((size_t)ix * B.dim[1] + iy) * B.wz + (iz >> 5)];
+        *word = ((const uint2 *)bits)[((size_t)ix * B.dim[1] + iy) * B.wz + (iz >> 5)];
 }
 
 // Two-phase count for one pair (one wave): the bitmap test for every hi point, survivors collected in the wave's LDS
@@ -462,12 +467,12 @@ __device__ __forceinline__ int pose_count_filtered(int l_hi, const PoseVox &V, c
     const int lane = lane_id();
     int nq = 0, cnt = 0;
     for (int a0 = 0; a0 < l_hi; a0 += MAD_WAVE * POSE_BATCH) {
-        unsigned word[POSE_BATCH];
+        uint2 word[POSE_BATCH];
         int bit[POSE_BATCH];
 #pragma unroll
         for (int u = 0; u < POSE_BATCH; u++) {
             const int a = a0 + u * MAD_WAVE + lane;
-            word[u] = 0; bit[u] = 0;
+            word[u] = make_uint2(0u, 0u); bit[u] = 0;
             if (a < l_hi) {
                 float cx, cy, cz;
                 cloud32(a, cx, cy, cz);
@@ -477,7 +482,9 @@ __device__ __forceinline__ int pose_count_filtered(int l_hi, const PoseVox &V, c
 #pragma unroll
         for (int u = 0; u < POSE_BATCH; u++) {
             if (a0 + u * MAD_WAVE >= l_hi) break;      // wave-uniform
-            const bool sv = (word[u] >> bit[u]) & 1u;
+            const bool certain = (word[u].y >> bit[u]) & 1u;      // inner plane: counted without a search
+            cnt += certain ? 1 : 0;
+            const bool sv = ((word[u].x >> bit[u]) & 1u) && !certain;
             const unsigned long long bal = __ballot(sv);
             if (sv) stack[nq + __popcll(bal & lanemask_lt())] = (unsigned short)(a0 + u * MAD_WAVE + lane);
             nq += __popcll(bal);
@@ -641,12 +648,12 @@ __global__ __launch_bounds__(POSE_LDS_THREADS) void k_pose_lds(const int32_t *__
             for (int i = 0; i < 3; i++) { P[9 + i] = cur.ph[i]; P[12 + i] = cur.pl[i]; }
         }
         for (int a0 = 0; a0 < l_hi; a0 += MAD_WAVE * POSE_BATCH) {
-            unsigned word[POSE_BATCH];
+            uint2 word[POSE_BATCH];
             int bit[POSE_BATCH];
 #pragma unroll
             for (int u = 0; u < POSE_BATCH; u++) {      // the bitmap words of 4 x 64 points are requested before any is looked at
                 const int a = a0 + u * MAD_WAVE + lane;
-                word[u] = 0; bit[u] = 0;
+                word[u] = make_uint2(0u, 0u); bit[u] = 0;
                 if (a < l_hi) {
                     const float4 c = clf[a];
                     pose_vox_fetch(V, c.x, c.y, c.z, B, bits, &word[u], &bit[u]);
@@ -655,7 +662,9 @@ __global__ __launch_bounds__(POSE_LDS_THREADS) void k_pose_lds(const int32_t *__
 #pragma unroll
             for (int u = 0; u < POSE_BATCH; u++) {
                 if (a0 + u * MAD_WAVE >= l_hi) break;      // wave-uniform
-                const bool sv = (word[u] >> bit[u]) & 1u;
+                const bool certain = (word[u].y >> bit[u]) & 1u;      // inner plane: a lo point within dist for certain
+                cnt_cur += __popcll(__ballot(certain));
+                const bool sv = ((word[u].x >> bit[u]) & 1u) && !certain;
                 const unsigned long long bal = __ballot(sv);
                 if (sv)
                     ring[(head + count + __popcll(bal & lanemask_lt())) & (POSE_RING - 1)] =
@@ -1204,11 +1213,11 @@ static int pose_device(mad_ctx *ctx, const Side &hi, const Side &lo, int32_t *d_
             B.dim[d] = (int)ceil((bb_max[d] - bb_min[d] + 2.0 * guard) / B.h) + 1;
         }
         B.wz = (B.dim[2] + 31) / 32;
-        n_words = (size_t)B.dim[0] * B.dim[1] * B.wz;
+        n_words = 2 * (size_t)B.dim[0] * B.dim[1] * B.wz;      // two planes
         if (n_words * 4 <= bits_budget) break;
     }
     const size_t lds = lds_base;
-    const double bits_rad = dist + B.h * 0.8660254037844387 + slack;
+    const double bits_rad = dist + B.h * 0.8660254037844387 + slack, bits_rad_in = dist - B.h * 0.8660254037844387 - slack;
     // float32 tier of k_pose_lds32: offsets from the grid origin are below M = extent + reach, each rounded once (error
     // <= ulp(M) / 2); a squared distance near dist^2 is then off by < 2 sqrt(3) (dist + 1) ulp(M) plus ~1e-5 of float32
     // arithmetic.  The band is 4 x that bound.
@@ -1238,7 +1247,11 @@ static int pose_device(mad_ctx *ctx, const Side &hi, const Side &lo, int32_t *d_
         mad_zero_words(ctx, d_bits, n_words * 4);
         hipLaunchKernelGGL(k_pose_bits, dim3((unsigned)std::min(std::max(n_cloud, 1), ctx->n_cu * 8)), dim3(256), 0, ctx->stream,
                            (const double *)scratch<double>(ctx, S_PG_PTS), (const int32_t *)scratch<int32_t>(ctx, S_PG_START), G.ncell, B,
-                           bits_rad, d_bits);
+                           bits_rad, 0, d_bits);
+        if (bits_rad_in > 0.5)
+            hipLaunchKernelGGL(k_pose_bits, dim3((unsigned)std::min(std::max(n_cloud, 1), ctx->n_cu * 8)), dim3(256), 0, ctx->stream,
+                               (const double *)scratch<double>(ctx, S_PG_PTS), (const int32_t *)scratch<int32_t>(ctx, S_PG_START), G.ncell, B,
+                               bits_rad_in, 1, d_bits);
         MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_PG_PAIRS), (size_t)cap_pairs * sizeof(PosePair)));
         PosePair *d_rec = scratch<PosePair>(ctx, S_PG_PAIRS);
         hipLaunchKernelGGL(k_pose_prep, dim3(ctx->n_cu * 8), dim3(256), 0, ctx->stream, scratch<int32_t>(ctx, S_PAIR_HI),
