@@ -179,9 +179,10 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_corr_gemm(const int8_t *__rest
                 for (int n = 0; n < 4; n++) {
                     const int64_t c = col0 + wn * 64 + n * 16 + (lane & 15);
                     const int d = acc[m][n][j];
-                    C[r * lp + c] = d;
                     const float t = th * tl[n];
-                    bal[n] = __ballot((float)d > t - fabsf(t) * 4e-6f);
+                    const bool cand = (float)d > t - fabsf(t) * 4e-6f;
+                    if (cand) C[r * lp + c] = d;      // only candidates are ever read back (k_pair_count / k_pair_emit): ~0.4 % of the entries
+                    bal[n] = __ballot(cand);
                 }
                 // bits 16 g .. 16 g + 15 of a ballot = row group g (= lane >> 4), columns n * 16 ..: lanes 0..7 write
                 // the two 32-bit words of the four rows (lane & 3 = row group, lane >> 2 = word)
@@ -1170,6 +1171,15 @@ static int correlate_device(mad_ctx *ctx, const Side &hi, const Side &lo, int D,
     return MAD_OK;
 }
 
+// Workgroups of the persistent pose search per CU.  Two fill a CU completely (16 waves x 64 registers per SIMD, 130 KB of
+// LDS) and run the kernel 4 % faster on its own; one leaves half of the registers and 95 KB of LDS to the kernels of the
+// other lanes (the orient / describe launches of the next batch are latency-bound and fill the issue slots the pose search
+// leaves), which is worth 3-4 % of the whole step.  MAD_POSE_WGS=2 restores the former.
+static int pose_wgs_per_cu() {
+    static const int v = getenv("MAD_POSE_WGS") ? atoi(getenv("MAD_POSE_WGS")) : 1;
+    return v == 2 ? 2 : 1;
+}
+
 // Scores the pairs in S_PAIR_* into S_COUNTS.  The lo cloud is the set of points `d_cloud[0..n_cloud)` whose flag in
 // `d_cloud_used` is set (all when nullptr); `fallback` (cell = dist, built over the same points) is used when the clouds
 // do not fit LDS.
@@ -1258,7 +1268,7 @@ static int pose_device(mad_ctx *ctx, const Side &hi, const Side &lo, int32_t *d_
                            scratch<int32_t>(ctx, S_PAIR_LO), d_status, cap_pairs, hi.p, hi.R, lo.p, lo.Rinv, hi.row_anchor, lo.row_anchor, d_rec);
         mad_timer_begin(ctx, MAD_T_POSE);      // the search kernel alone: what the rocprofv3 summary lists as k_pose_lds
         if (fits64)
-            hipLaunchKernelGGL(k_pose_lds, dim3(ctx->n_cu * (lds > 80 * 1024 ? 1 : 2)), dim3(POSE_LDS_THREADS), lds, ctx->stream, d_status, cap_pairs, d_rec,
+            hipLaunchKernelGGL(k_pose_lds, dim3(ctx->n_cu * (lds > 80 * 1024 ? 1 : pose_wgs_per_cu())), dim3(POSE_LDS_THREADS), lds, ctx->stream, d_status, cap_pairs, d_rec,
                                d_hi_cloud, scratch<double>(ctx, S_PG_PTS), scratch<int32_t>(ctx, S_PG_START), d_start16, G,
                                l_hi_max, n_cloud, (float)reach, dd_lim, B, d_bits, scratch<int32_t>(ctx, S_COUNTS));
         else
