@@ -100,6 +100,20 @@ def test_sets_and_matches_with_nothing_in_them(ctx):
     assert lib.match_topk_many([], full, 0.5, 4.0, 10) == []
     res = lib.match_topk_many([empty, full, empty], full, 0.5, 4.0, 10)
     assert [len(r[0]) for r in res][0] == 0 and len(res[1][0]) == 10 and len(res[2][0]) == 0
+    # the two-call form: same answer; a second bracket while one is open, or a finish without a begin, is refused
+    from mad_amd._lib import MadBackendError
+    h = lib.match_topk_many_begin([empty, full, empty], full, 0.5, 4.0, 10)
+    with pytest.raises(MadBackendError):
+        lib.match_topk_many_begin([full], full, 0.5, 4.0, 10)
+    other = lib.set_build([-1, slot], coords, np.ones(n, np.int32), subv, np.arange(n))      # building another set in between is allowed
+    res2 = lib.match_topk_many_finish(h)
+    for a, b in zip(res, res2):
+        np.testing.assert_array_equal(a[0], b[0])
+        np.testing.assert_array_equal(a[1], b[1])
+    with pytest.raises(MadBackendError):
+        lib.match_topk_many_finish(h)
+    np.testing.assert_array_equal(other.download()["dsc"], full.download()["dsc"])
+    other.close()
     # a set against itself: every row pairs with itself at score 1 and rebuilds the identity pose
     top, idx, st = lib.match_topk(full, full, 0.999999, 4.0, 5)
     assert len(top) == 5 and np.allclose(top[:, 0], 1.0) and np.allclose(top[:, 1], 100.0)
