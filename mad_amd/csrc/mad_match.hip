@@ -1236,7 +1236,8 @@ static int pose_device(mad_ctx *ctx, const Side &hi, const Side &lo, int32_t *d_
     const double ulpM = ldexp(1.0, (int)ceil(log2(M)) - 23);
     const double band = 4.0 * (2.0 * sqrt(3.0) * (dist + 1.0) * ulpM + 1e-5 * dist * dist);
     const float lim_in = nextafterf((float)(dist * dist - band), 0.f), lim_out = nextafterf((float)(dist * dist + band), 1e30f);
-    const bool fits64 = base64, fits32 = lds32 <= 150 * 1024 && lim_in > 0.f;
+    // queue entries are 15 (k_pose_lds) / 16 (k_pose_lds32) bits of hi-cloud index
+    const bool fits64 = base64 && l_hi_max < 32768, fits32 = lds32 <= 150 * 1024 && lim_in > 0.f && l_hi_max < 65536;
     if (!fallback && (fits64 || fits32) && n_cloud < 65535 && G.ncell <= 30000) {
         MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_PG_START), (size_t)(G.ncell + 2) * 4 + pad16((size_t)(G.ncell + 2) * 2) + 16));
         unsigned short *d_start16 = (unsigned short *)(scratch<char>(ctx, S_PG_START) + pad16((size_t)(G.ncell + 2) * 4));
@@ -1301,7 +1302,8 @@ static int pose_device(mad_ctx *ctx, const Side &hi, const Side &lo, int32_t *d_
 
 static bool clouds_fit_lds(int64_t l_hi, int64_t l_lo) {      // with the largest cell table (30 000 cells)
     const size_t fixed = 30004 * 2 + (POSE_LDS_THREADS / MAD_WAVE) * POSE_WAVE_LDS + 16 + 64;      // as pose_device sizes them (+ its 16-byte paddings)
-    return ((size_t)(l_hi + l_lo) * 24 + (size_t)l_hi * 16 + fixed <= 150 * 1024 || (size_t)(l_lo + 1) * 16 + fixed <= 150 * 1024) && l_lo < 65535;
+    return ((size_t)(l_hi + l_lo) * 24 + (size_t)l_hi * 16 + fixed <= 150 * 1024 || (size_t)(l_lo + 1) * 16 + fixed <= 150 * 1024) && l_lo < 65535 &&
+           l_hi < 65536;      // (the first alternative implies l_hi < 32768)
 }
 
 static int32_t *status_words(mad_ctx *ctx) {      // inside S_MISC
