@@ -210,7 +210,7 @@ class MaD(object):
                     ranking.append([fk] + [float(np.mean([float(r[c]) for r in rows])) for c in ("Repeatability", "Weight", "mCC", "RWmCC")])
             print("MaD> Ranking for ensemble %s: " % ek)
             for col, title in ((1, "Repeatability"), (2, "Weight"), (3, "Cross-corr."), (4, "MaD score")):
-                print("     Top 3 - %s:" % title)
+                print("%s     Top 3 - %s:" % ("" if col == 1 else "\n", title))      # blank line between the tables (MaD.py:267-273)
                 for i, r in enumerate(sorted(ranking, key=itemgetter(col), reverse=True)[:3]):
                     print("     %i: %6.2f %s" % (i + 1, r[col], r[0]))
 

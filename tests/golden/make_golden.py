@@ -143,6 +143,29 @@ def make_g9(R, synth, work):
     run({"A": [2, list(files_a)]}, "homo")
     run({"A": [2, list(files_a)], "B": [1, list(files_b)]}, "hetero")
     run({"A": [2, list(files_a)], "B": [1, list(files_b)]}, "hetero_loose", max_models=3, max_overlap_complex=0.5)
+    # score_ensembles (MaD.py:225-287) on made-up solution tables of a 5-frame ensemble: the printed ranking
+    m = R.MaD.MaD()
+    m.out_folder = os.path.join(work, "g9_out_ens")
+    os.makedirs(m.out_folder)
+    frames = ["frame_%02d" % i for i in (3, 1, 4, 0, 2)]
+    m.processed_ensembles = {"ens": {f: ["unused.pdb", 1] for f in frames}}
+    erng = np.random.default_rng(5)
+    tables = {}
+    for f in frames:
+        n = int(erng.integers(1, 6))
+        tab = np.column_stack([np.arange(n), erng.uniform(5, 60, n), erng.integers(4, 30, n), erng.uniform(0.3, 0.95, n), erng.uniform(10, 900, n)])
+        tables[f] = tab
+        with open(os.path.join(m.out_folder, "Solutions_refined_%s.csv" % f), "w") as fh:
+            fh.write("ID,Repeatability,Weight,mCC,RWmCC\n")
+            for r in tab:
+                fh.write("%d,%r,%d,%r,%r\n" % (r[0], float(r[1]), int(r[2]), float(r[3]), float(r[4])))
+    log = io.StringIO()
+    with contextlib.redirect_stdout(log):
+        m.score_ensembles()
+    g9["ens_frames"] = np.array(frames, dtype=str)
+    for f in frames:
+        g9["ens_table_" + f] = tables[f]
+    g9["ens_stdout"] = np.array(log.getvalue())
     np.savez_compressed(os.path.join(OUT, "g9_assembly.npz"), **g9)
     print("g9:", {k: (v.shape if hasattr(v, "shape") and v.shape else v) for k, v in g9.items() if k.endswith(("_models", "_subcomplexes"))})
     print(table.round(3))

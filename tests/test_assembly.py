@@ -144,6 +144,23 @@ def test_write_ranking_matches_pandas_text(tmp_path, g9):
         assert a[0] == b[0] and a[2:] == b[2:] and abs(a[1] - b[1]) < 1e-7
 
 
+def test_score_ensembles_prints_the_reference_ranking(tmp_path, g9, capsys):
+    """MaD.score_ensembles (MaD.py:225-287) on the solution tables of a 5-frame ensemble: the printed ranking is the
+    reference's, line for line (the bar plot it also saves is visualisation and not reproduced)."""
+    from mad_amd.MaD import MaD
+    m = MaD()
+    m.out_folder = str(tmp_path)
+    frames = [str(f) for f in g9["ens_frames"]]
+    m.processed_ensembles = {"ens": {f: ["unused.pdb", 1] for f in frames}}
+    for f in frames:
+        with open(os.path.join(m.out_folder, "Solutions_refined_%s.csv" % f), "w") as fh:
+            fh.write("ID,Repeatability,Weight,mCC,RWmCC\n")
+            for r in g9["ens_table_" + f]:
+                fh.write("%d,%r,%d,%r,%r\n" % (r[0], float(r[1]), int(r[2]), float(r[3]), float(r[4])))
+    m.score_ensembles()
+    assert capsys.readouterr().out == str(g9["ens_stdout"])
+
+
 # ------------------------------------------------------------------------------------------- GPU
 @pytest.fixture()
 def default_lib(lib):
