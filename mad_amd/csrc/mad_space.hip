@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void k_grad_tex(const T *__restrict__ g, Dims 
         if (z == 0) gz = g[i + 1] - g[i]; else if (z == d.n[2] - 1) gz = g[i] - g[i - 1]; else gz = (g[i + 1] - g[i - 1]) / (T)2;
         const float fx = (float)gx, fy = (float)gy, fz = (float)gz;
         const float s = __fadd_rn(__fadd_rn(__fmul_rn(fx, fx), __fmul_rn(fy, fy)), __fmul_rn(fz, fz));
-        tex[i] = make_float4(fx, fy, fz, __fsqrt_rn(s));
+        tex[i] = make_float4(fx, fy, fz, sqrtf(s));      // correctly rounded (see k_pack_field)
     }
 }
 

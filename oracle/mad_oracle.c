@@ -77,6 +77,19 @@ static double orc_clamp1(double z) { return z > 1.0 ? 1.0 : (z < -1.0 ? -1.0 : z
 
 /* Zone test of Orientator.py:328-331 / Descriptor.py:181-184: strict, on theta,
  * theta+2pi and phi.  Returns the LAST matching zone or -1. */
+/* Orientator.process_df_gradient (Orientator.py:326-334) sums the weights zone by zone, so a direction inside the sliver where
+ * the rounded bounds of two zones overlap (theta in (0, 6.2832 - 2 pi) matches the first AND the last zone of a belt) is counted in
+ * both; the Descriptor (Descriptor.py:173-187) assigns one zone id per sample, the last match winning (orc_zone below). */
+static void orc_count_zones(double th, double sth, double ph, const double *bounds, int Z, int w, int32_t *cnt) {
+    for (int a = 0; a < Z; a++) {
+        const double *b = bounds + 4 * a;
+        int thm = (th < b[2]) && (th > b[0]);
+        int sthm = (sth < b[2]) && (sth > b[0]);
+        int phm = (ph < b[3]) && (ph > b[1]);
+        if ((thm || sthm) && phm) cnt[a] += w;
+    }
+}
+
 static int orc_zone(double th, double sth, double ph, const double *bounds, int Z) {
     int hit = -1;
     for (int a = 0; a < Z; a++) {
@@ -106,7 +119,16 @@ void orc_eqsp_belt_first(const double *bounds, int Z, int32_t *belt_first) {
 
 /* Orientator.py:198-205 (+ eqsp.py:29-31): matrix that brings the centre of
  * zone `a` onto +z; identity for a == 0 (Orientator.py:211). */
+/* The two matrix tables as the reference's numpy code produces them (oracle.py builds them with the reference's own expressions:
+ * numpy's dot / sin / cos are not bit-identical to a scalar C restatement, and a direction that the rotation puts exactly on a zone
+ * bound is decided by that last bit).  When set, orc_to_dom_mat / orc_adj_sec_mat read the tables; the C formulas below remain
+ * for callers without numpy tables and agree with them to 1e-15. */
+static const double *g_tab_dom = 0, *g_tab_adj = 0;
+static int g_tab_Z = 0;
+void orc_set_matrix_tables(const double *dom, const double *adj, int Z) { g_tab_dom = dom; g_tab_adj = adj; g_tab_Z = Z; }
+
 void orc_to_dom_mat(const double *centers, int a, double m[9]) {
+    if (g_tab_dom && a >= 0 && a < g_tab_Z) { memcpy(m, g_tab_dom + 9 * a, 9 * sizeof(double)); return; }
     if (a == 0) { memset(m, 0, 9 * sizeof(double)); m[0] = m[4] = m[8] = 1.0; return; }
     double th = centers[2 * a], ph = centers[2 * a + 1];
     double c[3] = { sin(ph) * cos(th), sin(ph) * sin(th), cos(ph) }, u[3];
@@ -120,6 +142,7 @@ void orc_to_dom_mat(const double *centers, int a, double m[9]) {
 /* Orientator.py:253-263: z-rotation that brings the centre of zone `s` onto the
  * azimuth of the first zone of its belt. */
 void orc_adj_sec_mat(const double *bounds, const double *centers, int Z, int s, double m[9]) {
+    if (g_tab_adj && Z == g_tab_Z && s >= 0 && s < Z) { memcpy(m, g_tab_adj + 9 * s, 9 * sizeof(double)); return; }
     int32_t bf[ORC_MAX_Z];
     orc_eqsp_belt_first(bounds, Z, bf);
     double ftheta = -1.0 * (centers[2 * s] - centers[2 * bf[s]]);
@@ -197,8 +220,7 @@ int orc_orient(const float *gx, const float *gy, const float *gz, int nx, int ny
             if (th < 0.0f) th = th + two_pi_f;
             float sth = th + two_pi_f;
             float ph = (float)acos(orc_clamp1((double)box[3 * v + 2]));
-            int zn = orc_zone((double)th, (double)sth, (double)ph, bounds, Z);
-            if (zn >= 0) cnt[zn] += w[v];
+            orc_count_zones((double)th, (double)sth, (double)ph, bounds, Z, w[v], cnt);
         }
         if (!orc_quantise(cnt, Z, q)) continue;   /* no bins > 0.8*0 -> no rows */
         /* Orientator.py:181-184 */
@@ -225,8 +247,7 @@ int orc_orient(const float *gx, const float *gy, const float *gz, int nx, int ny
                     if (th < 0) th += ORC_TWO_PI;
                     double sth = th + ORC_TWO_PI;
                     double ph = acos(orc_clamp1(rz));
-                    int zn = orc_zone(th, sth, ph, bounds, Z);
-                    if (zn >= 0) c1[zn] += w[v];
+                    orc_count_zones(th, sth, ph, bounds, Z, w[v], c1);
                 }
                 if (!orc_quantise(c1, Z, q1)) memcpy(q1, c1, sizeof(int32_t) * Z);
             } else {

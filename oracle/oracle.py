@@ -65,6 +65,49 @@ def adj_sec_mat(bounds, centers, s):
     return m.reshape(3, 3)
 
 
+def _unit(v):
+    v = np.asarray(v, dtype=np.float64)
+    return v / np.sqrt(np.dot(v, v))                                   # math_utils.py:5-13
+
+
+def _rod(axis, angle):
+    """math_utils.py:15-27, element for element."""
+    axis = np.asarray(axis, dtype=np.float64)
+    a = np.cos(angle / 2.0)
+    b, c, d = -axis * np.sin(angle / 2.0)
+    aa, bb, cc, dd = a * a, b * b, c * c, d * d
+    bc, ad, ac, ab, bd, cd = b * c, a * d, a * c, a * b, b * d, c * d
+    return np.array([[aa + bb - cc - dd, 2 * (bc + ad), 2 * (bd - ac)],
+                     [2 * (bc - ad), aa + cc - bb - dd, 2 * (cd + ab)],
+                     [2 * (bd + ac), 2 * (cd - ab), aa + dd - bb - cc]])
+
+
+_tables = {}
+
+
+def matrix_tables(bounds, centers):
+    """to_dom_mat / adj_sec_mat of every zone with the reference's numpy expressions (eqsp.py:31-33 for the cartesian centres,
+    Orientator.py:198-205 and :253-263): the C functions then use these bits instead of their own scalar restatement."""
+    key = (bounds.tobytes(), centers.tobytes())
+    if key not in _tables:
+        Z = len(bounds)
+        from math import sin, cos
+        dom, adj = np.zeros((Z, 3, 3)), np.zeros((Z, 3, 3))
+        first = belt_first(bounds)
+        for a in range(Z):
+            pol = centers[a]
+            cart = np.array([sin(pol[1]) * cos(pol[0]), sin(pol[1]) * sin(pol[0]), cos(pol[1])])      # eqsp.py:31-33
+            if a == 0:
+                dom[a] = np.identity(3)                                                               # Orientator.py:211
+            else:
+                c = _unit(cart)
+                angle = np.arccos(np.clip(np.dot(c, [0, 0, 1]), -1.0, 1.0))
+                dom[a] = _rod(_unit(np.cross(c, [0, 0, 1])), angle)
+            adj[a] = _rod([0, 0, 1], -1 * (centers[a][0] - centers[first[a]][0]))
+        _tables[key] = (np.ascontiguousarray(dom.reshape(Z, 9)), np.ascontiguousarray(adj.reshape(Z, 9)))
+    return _tables[key]
+
+
 def orient(gx, gy, gz, octave, coords, bounds, centers, r=8, lim_main=6, lim_sec=6, want_counts=True):
     gx, gy, gz = _c(gx, np.float32), _c(gy, np.float32), _c(gz, np.float32)
     coords = _c(coords, np.int32).reshape(-1, 3)
@@ -78,6 +121,8 @@ def orient(gx, gy, gz, octave, coords, bounds, centers, r=8, lim_main=6, lim_sec
     nrows = C.c_int64(0)
     nrej = C.c_int32(0)
     nx, ny, nz = gx.shape
+    dom, adj = matrix_tables(bounds, centers)
+    lib().orc_set_matrix_tables(_opt(dom), _opt(adj), C.c_int(Z))
     rc = lib().orc_orient(_opt(gx), _opt(gy), _opt(gz), C.c_int(nx), C.c_int(ny), C.c_int(nz), C.c_int(octave),
                           _opt(coords), C.c_int(n), C.c_int(r), C.c_int(lim_main), C.c_int(lim_sec),
                           _opt(bounds), _opt(centers), C.c_int(Z),

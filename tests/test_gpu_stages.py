@@ -73,6 +73,51 @@ def test_describe_matches_oracle(lib, fields, octave):
     np.testing.assert_array_equal(got, ref)
 
 
+def _bound_hugging_field(shape, table, seed):
+    """A gradient field whose every voxel points (to float32 accuracy) at a bound of the EQSP table: theta on a zone edge
+    or phi on a belt edge, displaced by 0, +-1e-7 ... +-1e-4 rad, including the theta = 0 / 2 pi seam and the caps."""
+    rng = np.random.default_rng(seed)
+    n = int(np.prod(shape))
+    b = table[rng.integers(0, len(table), n)]      # rows [theta_min, phi_min, theta_max, phi_max]
+    eps = rng.choice([0.0, 1e-7, -1e-7, 1e-6, -1e-6, 3e-6, -3e-6, 1e-5, -1e-5, 1e-4, -1e-4], n)
+    on_theta = rng.random(n) < 0.5
+    lo = rng.random(n) < 0.5
+    theta = np.where(on_theta, np.where(lo, b[:, 0], b[:, 2]) + eps, rng.uniform(b[:, 0], b[:, 2]))
+    phi = np.where(on_theta, rng.uniform(b[:, 1], np.minimum(b[:, 3], np.pi)), np.where(lo, b[:, 1], b[:, 3]) + eps)
+    # not the poles themselves: a polar direction is turned by to_dom_mat onto the meridian of the main bin's centre, which is
+    # exactly a zone edge in belts with twice as many zones, and which side of it atan2 then reports is a matter of the last
+    # bit of the math library (device libm, glibc and numpy differ there) -- outside what any implementation can pin
+    phi = np.clip(phi, 0.02, np.pi - 0.02)
+    mag = rng.uniform(0.01, 2.0, n)
+    g = np.stack([np.sin(phi) * np.cos(theta), np.sin(phi) * np.sin(theta), np.cos(phi)]) * mag
+    return np.ascontiguousarray(g.reshape((3,) + tuple(shape)).astype(np.float32))
+
+
+def test_classifier_on_the_bounds(lib):
+    """The exact classification has a cross-product tier in front of atan2 / acos (eqsp_tier2): fields made of directions
+    that sit on the table's bounds must still give the oracle's histograms bit for bit -- the Orientator's float32 first
+    pass and float64 rotated pass on the 112-zone table, the Descriptor on the 16-zone table."""
+    shape = (44, 44, 44)
+    for table, seed in ((E112.sphere_eqsp, 5), (E16.sphere_eqsp, 6)):
+        g = _bound_hugging_field(shape, np.asarray(table, dtype=np.float64), seed)
+        slot = lib.new_slot()
+        lib.upload_field(slot, g)
+        try:
+            coords = synth.interior_anchors(shape, 40, 14, seed)
+            ref = O.orient(g[0], g[1], g[2], 1, coords, E112.sphere_eqsp, E112.p_centers_eqsp)
+            got = lib.orient(slot, 1, coords)
+            for key in ("anchor", "main", "sec", "counts"):
+                np.testing.assert_array_equal(got[key], ref[key])
+            rng = np.random.default_rng(seed)
+            R = np.stack([np.identity(3)] * 20 + [synth.random_rotation(rng) for _ in range(20)])
+            want = O.describe(g[0], g[1], g[2], 1, coords, R, E16.sphere_eqsp)
+            have = lib.describe(slot, 1, coords, R)
+            np.testing.assert_array_equal(have, want)
+            assert want.sum() > 1000
+        finally:
+            lib.free_field(slot)
+
+
 def _random_descriptors(n, seed, base=None):
     rng = np.random.default_rng(seed)
     d = np.zeros((n, 1024), np.int16)
