@@ -246,6 +246,8 @@ def test_pose_score_threshold_shell(lib, n_lo_anchor, box):
             u = rng.normal(size=(60, 3))
             u /= np.linalg.norm(u, axis=1)[:, None]
             pts.append(c + u * (4.0 + sign * eps))
+    for off in ([4.0, 0, 0], [0, -4.0, 0], [0, 0, 4.0], [2.4, 3.2, 0], [0, -2.4, 3.2], [4.0, 0, 0.0000001]):      # exactly dist: sqrt(d2) < dist is false
+        pts.append(lo_p[rng.integers(0, n_lo_anchor, 40)] + np.array(off))
     lattice = lo_p.min(0) + 0.8 * rng.integers(-12, int(box / 0.8) + 12, size=(400, 3))      # voxel corners, some outside
     pts.append(lattice)
     pts.append(lattice + 1e-6)
