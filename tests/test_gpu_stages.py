@@ -147,6 +147,27 @@ def test_correlate_matches_oracle(lib):
         np.testing.assert_allclose(gs, rs, rtol=1e-12, atol=0)
 
 
+def test_correlate_threshold_on_a_score(lib):
+    """cc within 1e-12 ... 1e-6 (relative) of the score of existing pairs, on either side: the GEMM's float32 candidate test
+    in front of the exact float64 comparison must not lose a pair that sits just above the threshold, nor the exact test admit
+    one just below.  (At one ulp the comparison is not defined: dot / (|h| |l|) here, a dgemm over normalised rows in the
+    reference, 1e-15 apart -- SURVEY.md a11.)"""
+    lo = _random_descriptors(260, 15)
+    hi = _random_descriptors(120, 16, base=lo[40:])
+    hi[7] = lo[99]      # an identical pair: score exactly 1.0
+    nh, nl = np.linalg.norm(hi.astype(np.float64), axis=1), np.linalg.norm(lo.astype(np.float64), axis=1)
+    _, _, rs, _ = O.correlate(hi, lo, 0.3)
+    picks = list(np.quantile(rs, [0.1, 0.5, 0.9], method="nearest")) + [1.0]
+    for sc in picks:
+        for cc in [sc * (1.0 + sgn * rel) for rel in (1e-12, 1e-9, 1e-7, 1e-6) for sgn in (-1.0, 1.0)]:
+            rh, rl, rsc, _ = O.correlate(hi, lo, cc)
+            gh, gl, gs = lib.correlate(hi, lo, cc)
+            np.testing.assert_array_equal(gh, rh)
+            np.testing.assert_array_equal(gl, rl)
+            assert (len(rsc) == 0 or rsc.min() > cc)
+    assert nh[7] == nl[99]
+
+
 def test_correlate_rejects_out_of_range(lib):
     from mad_amd._lib import MadBackendError
     hi = np.full((4, 1024), 200, np.int16)
