@@ -1,8 +1,8 @@
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT && mkdir -p gpurun_out/r01f && \
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r01f/trace -- python3 bench.py --serial --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/r01f/trace.log 2>&1 && \
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/r01f/pmc_fetch -- python3 bench.py --serial --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/r01f/pmc_fetch.log 2>&1 && \
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/r01f/pmc_write -- python3 bench.py --serial --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/r01f/pmc_write.log 2>&1 && \
-rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d gpurun_out/r01f/pmc_tcc -- python3 bench.py --serial --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/r01f/pmc_tcc.log 2>&1 && \
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d gpurun_out/r01f/pmc_sq -- python3 bench.py --serial --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/r01f/pmc_sq.log 2>&1 && \
-python tools/pmc_summary.py gpurun_out/r01f/summary.json gpurun_out/r01f/trace gpurun_out/r01f/pmc_fetch gpurun_out/r01f/pmc_write gpurun_out/r01f/pmc_tcc gpurun_out/r01f/pmc_sq > gpurun_out/r01f/summary.txt 2>&1 && \
-python bench.py --steps 10 --warmup 3 > gpurun_out/r01f/line.json 2> gpurun_out/r01f/line.err; tail -3 gpurun_out/r01f/summary.txt; ls gpurun_out/r01f/trace/*/ | head; find gpurun_out/r01f/trace -name "*stats*" | head
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT && mkdir -p gpurun_out/r01g && \
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r01g/trace -- python3 bench.py --serial --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/r01g/trace.log 2>&1 && \
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/r01g/pmc_fetch -- python3 bench.py --serial --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/r01g/pmc_fetch.log 2>&1 && \
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/r01g/pmc_write -- python3 bench.py --serial --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/r01g/pmc_write.log 2>&1 && \
+rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d gpurun_out/r01g/pmc_tcc -- python3 bench.py --serial --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/r01g/pmc_tcc.log 2>&1 && \
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d gpurun_out/r01g/pmc_sq -- python3 bench.py --serial --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/r01g/pmc_sq.log 2>&1 && \
+python tools/pmc_summary.py gpurun_out/r01g/summary.json gpurun_out/r01g/trace gpurun_out/r01g/pmc_fetch gpurun_out/r01g/pmc_write gpurun_out/r01g/pmc_tcc gpurun_out/r01g/pmc_sq > gpurun_out/r01g/summary.txt 2>&1 && \
+python bench.py --steps 10 --warmup 3 > gpurun_out/r01g/line.json 2> gpurun_out/r01g/line.err; tail -3 gpurun_out/r01g/summary.txt; ls gpurun_out/r01g/trace/*/ | head; find gpurun_out/r01g/trace -name "*stats*" | head
