@@ -16,7 +16,7 @@ Fixtures hold inputs and the reference's outputs only (numpy arrays).  Everythin
 seeded; re-running this script reproduces the files bit for bit on the same numpy /
 scipy build.
 
-Usage:  cd /root/repo && python tests/golden/make_golden.py [--only-g9]
+Usage:  cd /root/repo && python tests/golden/make_golden.py [--only-g9 | --only-g10]
 """
 import hashlib
 import os
@@ -171,6 +171,51 @@ def make_g9(R, synth, work):
     print(table.round(3))
 
 
+def make_g10(R, synth):
+    """G10: a gradient field made of zone bounds (every voxel points at an edge of the 16-zone table, displaced by 0 ... 1e-4 rad;
+    poles excluded) through the reference's Orientator and Descriptor: the cases where one rounding decides the zone."""
+    from scipy.interpolate import RegularGridInterpolator as RGI
+    shape = (38, 38, 38)
+    table = np.asarray(R.EQ.EQSP_Sphere(size=16).sphere_eqsp, dtype=np.float64)
+    rng = np.random.default_rng(6)
+    n = int(np.prod(shape))
+    b = table[rng.integers(0, len(table), n)]
+    eps = rng.choice([0.0, 1e-7, -1e-7, 1e-6, -1e-6, 3e-6, -3e-6, 1e-5, -1e-5, 1e-4, -1e-4], n)
+    on_theta = rng.random(n) < 0.5
+    lo = rng.random(n) < 0.5
+    theta = np.where(on_theta, np.where(lo, b[:, 0], b[:, 2]) + eps, rng.uniform(b[:, 0], b[:, 2]))
+    phi = np.where(on_theta, rng.uniform(b[:, 1], np.minimum(b[:, 3], np.pi)), np.where(lo, b[:, 1], b[:, 3]) + eps)
+    phi = np.clip(phi, 0.02, np.pi - 0.02)
+    mag = rng.uniform(0.01, 2.0, n)
+    g = (np.stack([np.sin(phi) * np.cos(theta), np.sin(phi) * np.sin(theta), np.cos(phi)]) * mag).reshape((3,) + shape).astype(np.float32)
+    grad = np.ascontiguousarray(np.moveaxis(g, 0, -1))
+    ms = types.SimpleNamespace(grad_list=[grad, grad], rgi_space=[RGI(points=[np.arange(s_) for s_ in shape], values=grad, method="nearest")] * 2)
+    coords = synth.interior_anchors(shape, 24, 14, 6)
+    ori = R.Ori.Orientator()
+    ori.step1_reject = 0
+    dfs = []
+    for i, c in enumerate(coords):
+        df = R.DF.DensityFeature()
+        df.set_detector_info(i, 1, [int(c[0]), int(c[1]), int(c[2])], np.zeros(3), np.zeros(3), 1.0)
+        dfs.append(df)
+    rows = ori.assign_orientations(ms, dfs)
+    g10 = dict(field=g, coords=coords, row_anchor=np.array([r.index for r in rows], np.int32), row_main=np.array([r.main_bin for r in rows], np.int32),
+               row_sec=np.array([r.sec_bin for r in rows], np.int32), row_count=np.array([r.ar_count for r in rows], np.int32))
+    rr = np.random.default_rng(7)
+    Rm = np.stack([np.identity(3)] * 12 + [synth.random_rotation(rr) for _ in range(12)])
+    dd = []
+    for i, c in enumerate(coords):
+        df = R.DF.DensityFeature()
+        df.set_detector_info(i, 1, [int(c[0]), int(c[1]), int(c[2])], np.zeros(3), np.zeros(3), 1.0)
+        df.Rfinal = Rm[i].copy()
+        dd.append(df)
+    R.Dsc.Descriptor().generate_descriptors(ms, dd)
+    g10["dsc_R"] = Rm
+    g10["dsc"] = np.array([d.lin_ar_subeqsp for d in dd], np.int16)
+    np.savez_compressed(os.path.join(OUT, "g10_bounds.npz"), **g10)
+    print("g10: rows", len(rows), "descriptor sum", int(g10["dsc"].sum()))
+
+
 def main():
     from scipy.interpolate import RegularGridInterpolator as RGI
     R = import_reference()
@@ -180,6 +225,9 @@ def main():
     work = tempfile.mkdtemp(prefix="mad_golden_")
     if "--only-g9" in sys.argv:      # the other fixtures are left as they are
         make_g9(R, synth, work)
+        return
+    if "--only-g10" in sys.argv:
+        make_g10(R, synth)
         return
 
     # ---- G1: EQSP tables -----------------------------------------------------------
@@ -382,6 +430,7 @@ def main():
     np.savez_compressed(os.path.join(OUT, "g8_solutions.npz"), **g8)
 
     make_g9(R, synth, work)
+    make_g10(R, synth)
 
     sizes = {f: os.path.getsize(os.path.join(OUT, f)) for f in sorted(os.listdir(OUT)) if f.endswith(".npz")}
     print("fixtures:", sizes, "total %.1f MB" % (sum(sizes.values()) / 1e6))

@@ -225,3 +225,19 @@ def test_pdb_and_dmap_classes(default_lib, tmp_path):
     ccc = d.get_CCC_with_grid(grid, x0, y0, z0)
     # Dmap truncates the MRC origin to integers exactly like the reference (Dmap.py:38): only sanity here
     assert 0.0 < ccc <= 1.0
+
+
+def test_g10_fields_made_of_zone_bounds(lib):
+    """The HIP path on the reference's outputs for the field of zone bounds (see tests/test_oracle_golden.py)."""
+    g = load("g10_bounds.npz")
+    slot = lib.new_slot()
+    lib.upload_field(slot, g["field"])
+    try:
+        rows = lib.orient(slot, 1, g["coords"])
+        np.testing.assert_array_equal(rows["anchor"], g["row_anchor"])
+        np.testing.assert_array_equal(rows["main"], g["row_main"])
+        np.testing.assert_array_equal(rows["sec"], g["row_sec"])
+        np.testing.assert_array_equal(rows["counts"], g["row_count"])
+        np.testing.assert_array_equal(lib.describe(slot, 1, g["coords"], g["dsc_R"]), g["dsc"])
+    finally:
+        lib.free_field(slot)

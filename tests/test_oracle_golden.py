@@ -131,3 +131,25 @@ def test_ccc_against_reference():
         else:
             assert abs(got - ref) <= 1e-5 * max(abs(ref), 1e-3), (sh, got, ref)
     assert g["ccc"][0] > 0.5 and g["ccc"][-1] == 0
+
+
+def test_g10_fields_made_of_zone_bounds():
+    """The oracle on the reference's own outputs for a gradient field whose every voxel points at an edge of the 16-zone
+    table (tests/golden/make_golden.py::make_g10): Orientator rows (bins and 112-zone histograms) and Descriptor rows,
+    identical.  This is the fixture that pins the sliver where two zones overlap (a voxel there counts in both zones of the
+    Orientator) and the bit-exact to_dom matrices."""
+    from mad_amd.eqsp import EQSP_Sphere
+    from oracle import oracle as O
+    import os
+    with np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g10_bounds.npz"), allow_pickle=False) as z:
+        g = {k: z[k] for k in z.files}
+    e112, e16 = EQSP_Sphere(112), EQSP_Sphere(16)
+    f = g["field"]
+    rows = O.orient(f[0], f[1], f[2], 1, g["coords"], e112.sphere_eqsp, e112.p_centers_eqsp)
+    assert len(g["row_anchor"]) > 40
+    np.testing.assert_array_equal(rows["anchor"], g["row_anchor"])
+    np.testing.assert_array_equal(rows["main"], g["row_main"])
+    np.testing.assert_array_equal(rows["sec"], g["row_sec"])
+    np.testing.assert_array_equal(rows["counts"], g["row_count"])
+    dsc = O.describe(f[0], f[1], f[2], 1, g["coords"], g["dsc_R"], e16.sphere_eqsp)
+    np.testing.assert_array_equal(dsc, g["dsc"])
