@@ -16,7 +16,7 @@ Fixtures hold inputs and the reference's outputs only (numpy arrays).  Everythin
 seeded; re-running this script reproduces the files bit for bit on the same numpy /
 scipy build.
 
-Usage:  cd /root/repo && python tests/golden/make_golden.py [--only-g9 | --only-g10]
+Usage:  cd /root/repo && python tests/golden/make_golden.py [--only-g9 | --only-g10 | --only-g11]
 """
 import hashlib
 import os
@@ -216,6 +216,38 @@ def make_g10(R, synth):
     print("g10: rows", len(rows), "descriptor sum", int(g10["dsc"].sum()))
 
 
+def make_g11(R):
+    """G11: MaD._match_dsc with the hi cloud on the decision surface of the repeatability count: points exactly 4 A from a lo
+    anchor, one ulp inside / outside, +-1e-12, along the axes and in random directions; identical descriptors (every pair
+    passes cc) and identity rotations, so that the pair (row 0, row 0) scores the untransformed cloud."""
+    rng = np.random.default_rng(3)
+    N, M = 24, 46
+    lo_p = np.round(rng.uniform(-40, 40, size=(N, 3)), 2)
+    lo_p[0] = 0.0
+    u = rng.normal(size=(200, 3))
+    u /= np.linalg.norm(u, axis=1)[:, None]
+    offs = []
+    for k, d in enumerate([4.0, np.nextafter(4.0, 0), np.nextafter(4.0, 9), 4.0 - 1e-12, 4.0 + 1e-12, 3.999999, 4.000001, 2.0, 7.0]):
+        offs += [np.array([d, 0, 0]), np.array([0, -d, 0]), np.array([0, 0, d]), u[k] * d, u[k + 50] * d]
+    hi_p = np.concatenate([[np.zeros(3)], lo_p[rng.integers(0, N, M - 1)] + np.array(offs)[: M - 1]])
+    base = rng.integers(0, 60, 1024).astype(np.int16)
+
+    def mk(i, p):
+        df = R.DF.DensityFeature()
+        df.set_detector_info(i, 1, [0, 0, 0], p.copy(), p.copy(), 1.0)
+        df.main_bin, df.sec_bin = 3, 5
+        df.Rfinal = np.identity(3)
+        df.lin_ar_subeqsp = base.copy()
+        return df
+
+    lo = [mk(i, p) for i, p in enumerate(lo_p)]
+    hi = [mk(i, p) for i, p in enumerate(hi_p)]
+    res, lo_cloud, hi_cloud = R.MaD.MaD()._match_dsc(lo, hi, anchor_dist_thresh=4, cc_threshold=0.5)
+    np.savez_compressed(os.path.join(OUT, "g11_pose_threshold.npz"), lo_p=lo_p, hi_p=hi_p, dsc=base, results=np.array(res), lo_cloud=lo_cloud,
+                        hi_cloud=hi_cloud)
+    print("g11: pairs", len(res), "distinct repeatabilities", len(np.unique(np.array(res)[:, 1])))
+
+
 def main():
     from scipy.interpolate import RegularGridInterpolator as RGI
     R = import_reference()
@@ -228,6 +260,9 @@ def main():
         return
     if "--only-g10" in sys.argv:
         make_g10(R, synth)
+        return
+    if "--only-g11" in sys.argv:
+        make_g11(R)
         return
 
     # ---- G1: EQSP tables -----------------------------------------------------------
@@ -431,6 +466,7 @@ def main():
 
     make_g9(R, synth, work)
     make_g10(R, synth)
+    make_g11(R)
 
     sizes = {f: os.path.getsize(os.path.join(OUT, f)) for f in sorted(os.listdir(OUT)) if f.endswith(".npz")}
     print("fixtures:", sizes, "total %.1f MB" % (sum(sizes.values()) / 1e6))

@@ -241,3 +241,20 @@ def test_g10_fields_made_of_zone_bounds(lib):
         np.testing.assert_array_equal(lib.describe(slot, 1, g["coords"], g["dsc_R"]), g["dsc"])
     finally:
         lib.free_field(slot)
+
+
+def test_g11_pose_count_at_the_distance_threshold(lib):
+    """The HIP pose scoring (bitmap prefilter + exact search) on the reference's counts for a hi cloud on the 4 A decision surface."""
+    g = load("g11_pose_threshold.npz")
+    M, N = len(g["hi_p"]), len(g["lo_p"])
+    ph, pl = np.divmod(np.arange(M * N), N)
+    eye = np.tile(np.identity(3), (max(M, N), 1, 1))
+    meta_h = np.stack([np.arange(M), np.ones(M), np.full(M, 3)], 1).astype(np.int32)
+    meta_l = np.stack([np.arange(N), np.ones(N), np.full(N, 3)], 1).astype(np.int32)
+    ref = g["results"]
+    assert len(ref) == M * N and len(np.unique(ref[:, 1])) > 8
+    want_cnt = np.rint(ref[:, 1] * len(g["hi_cloud"]) / 100.0).astype(np.int32)
+    res, cnt = lib.pose_score(ph.astype(np.int32), pl.astype(np.int32), ref[:, 0].copy(), g["hi_p"], eye[:M], meta_h, g["lo_p"], eye[:N], meta_l,
+                              g["hi_cloud"], g["lo_cloud"], dist=4.0)
+    np.testing.assert_array_equal(cnt, want_cnt)
+    np.testing.assert_allclose(res, ref, rtol=0, atol=1e-12)

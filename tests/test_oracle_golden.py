@@ -153,3 +153,22 @@ def test_g10_fields_made_of_zone_bounds():
     np.testing.assert_array_equal(rows["counts"], g["row_count"])
     dsc = O.describe(f[0], f[1], f[2], 1, g["coords"], g["dsc_R"], e16.sphere_eqsp)
     np.testing.assert_array_equal(dsc, g["dsc"])
+
+
+def test_g11_pose_count_at_the_distance_threshold():
+    """MaD._match_dsc of the reference on a hi cloud that sits on the 4 A decision surface (exactly 4, one ulp either side,
+    +-1e-12): the oracle's counts and result rows."""
+    from oracle import oracle as O
+    g = load("g11_pose_threshold.npz")
+    M, N = len(g["hi_p"]), len(g["lo_p"])
+    ph, pl = np.divmod(np.arange(M * N), N)
+    eye = np.tile(np.identity(3), (max(M, N), 1, 1))
+    meta_h = np.stack([np.arange(M), np.ones(M), np.full(M, 3)], 1).astype(np.int32)
+    meta_l = np.stack([np.arange(N), np.ones(N), np.full(N, 3)], 1).astype(np.int32)
+    ref = g["results"]
+    assert len(ref) == M * N and len(np.unique(ref[:, 1])) > 8
+    want_cnt = np.rint(ref[:, 1] * len(g["hi_cloud"]) / 100.0).astype(np.int32)
+    res, cnt = O.pose_score(ph.astype(np.int32), pl.astype(np.int32), ref[:, 0].copy(), g["hi_p"], eye[:M], meta_h, g["lo_p"], eye[:N], meta_l,
+                            g["hi_cloud"], g["lo_cloud"], dist=4.0)
+    np.testing.assert_array_equal(cnt, want_cnt)
+    np.testing.assert_allclose(res, ref, rtol=0, atol=1e-12)
