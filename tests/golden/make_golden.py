@@ -143,6 +143,21 @@ def make_g9(R, synth, work):
     run({"A": [2, list(files_a)]}, "homo")
     run({"A": [2, list(files_a)], "B": [1, list(files_b)]}, "hetero")
     run({"A": [2, list(files_a)], "B": [1, list(files_b)]}, "hetero_loose", max_models=3, max_overlap_complex=0.5)
+    # get_overlap with the two origins half a voxel apart: python's round() (half to even) picks the box (structure_utils.py:181-238).
+    # Where the rounded boxes end up with different shapes the reference raises; those cases are recorded as NaN.
+    hrng = np.random.default_rng(12)
+    hv_a = (hrng.random((14, 15, 16)) * (hrng.random((14, 15, 16)) > 0.4)).astype(np.float32)
+    hv_b = (hrng.random((12, 16, 13)) * (hrng.random((12, 16, 13)) > 0.4)).astype(np.float32)
+    hv_o = np.array([10.0, -6.0, 4.0])
+    hv_off = np.array([[0.5, 0, 0], [1.5, 0, 0], [2.5, 0, 0], [-0.5, 0, 0], [-1.5, 0, 0], [0, 0.5, -2.5], [3.5, -4.5, 0.5],
+                       [0.49999, 1.50001, -0.50001], [20.0, 0, 0], [-13.5, 0, 0], [0, 0, 0]])
+    hv_val = []
+    for dv in hv_off:
+        try:
+            hv_val.append(float(R.SU.get_overlap([hv_a.copy(), *hv_o], [hv_b.copy(), *(hv_o + dv * 2.0)], 2.0)))
+        except ValueError:
+            hv_val.append(np.nan)
+    g9["hv_a"], g9["hv_b"], g9["hv_origin"], g9["hv_offsets_voxels"], g9["hv_overlap"] = hv_a, hv_b, hv_o, hv_off, np.array(hv_val)
     # score_ensembles (MaD.py:225-287) on made-up solution tables of a 5-frame ensemble: the printed ranking
     m = R.MaD.MaD()
     m.out_folder = os.path.join(work, "g9_out_ens")

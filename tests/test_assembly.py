@@ -65,6 +65,21 @@ def test_oracle_overlap_table_from_atoms(g9):
     np.testing.assert_array_equal(table, g9["overlap_all"])
 
 
+def _half_voxel_cases(g9):
+    for dv, want in zip(g9["hv_offsets_voxels"], g9["hv_overlap"]):
+        if not np.isnan(want):      # NaN: the reference raises there (boxes of different shapes after rounding)
+            yield g9["hv_a"].copy(), g9["hv_origin"], g9["hv_b"].copy(), g9["hv_origin"] + dv * 2.0, float(want)
+
+
+def test_oracle_overlap_with_origins_half_a_voxel_apart(g9):
+    from oracle import oracle
+    n = 0
+    for a, oa, b, ob, want in _half_voxel_cases(g9):
+        assert oracle.overlap_ratio(a, oa, b, ob, 2.0) == want
+        n += 1
+    assert n >= 8
+
+
 def test_rank_copies_reproduces_homomer_ranking(g9):
     table = g9["overlap_all"][:5, :5]
     ranked = assembly.rank_copies(table, 2)
@@ -196,6 +211,8 @@ def test_gpu_get_overlap(default_lib, g9):
     assert get_overlap([a64, *o[0]], [b2, *o[3]], 2, isovalue=0.5) == float(g9["overlap_03_iso"])
     assert not np.any((a64 > 0) & (a64 < 0.5)) and not np.any((b2 > 0) & (b2 < 0.5))      # clamped in place, like the reference
     assert get_overlap([a, *o[0]], [b, o[3][0] + 1000.0, o[3][1], o[3][2]], 2) == 0
+    for ga, oa, gb, ob, want in _half_voxel_cases(g9):      # python round(): half to even
+        assert get_overlap([ga, *oa], [gb, *ob], 2.0) == want
     z = np.zeros((4, 4, 4), np.float32)
     assert get_overlap([z, 0.0, 0.0, 0.0], [b, *o[3]], 2) == 0
 
