@@ -16,7 +16,7 @@ Fixtures hold inputs and the reference's outputs only (numpy arrays).  Everythin
 seeded; re-running this script reproduces the files bit for bit on the same numpy /
 scipy build.
 
-Usage:  cd /root/repo && python tests/golden/make_golden.py [--only-g9 | --only-g10 | --only-g11]
+Usage:  cd /root/repo && python tests/golden/make_golden.py [--only-g9 | --only-g10 | --only-g11 | --only-g12]
 """
 import hashlib
 import os
@@ -263,6 +263,44 @@ def make_g11(R):
     print("g11: pairs", len(res), "distinct repeatabilities", len(np.unique(np.array(res)[:, 1])))
 
 
+PDB_TORTURE = """HEADER    TEST
+ATOM      1  N   MET A   1      27.340  24.430   2.614  1.00  9.67           N
+ATOM      2  CA  MET A   1      26.266  25.413   2.842  1.00 10.38           C
+ATOM      3  C   MET A   1      26.913  26.639   3.531  1.00  9.62           C
+ATOM      4  O   MET A   1      27.886  26.463   4.263  1.00  9.62           O
+ATOM      5 HG21 ILE A   2    -107.112   8.200-113.904  1.00  0.00           H
+ANISOU    5 HG21 ILE A   2     1234   1234   1234   1234   1234   1234       H
+HETATM    6 ZN    ZN B 301      10.000 -20.500  30.250  1.00 20.00          ZN
+ATOM      7  CA  GLY B  12       1.000   2.000   3.000  1.00  0.00
+ATOM     x8  CB  ALA B  13       4.000   5.000   6.000  1.00  0.00           C
+ATOM      9  CB  ALA B  1x       7.000   8.000   9.000  1.00  0.00           C
+TER      10      ALA B  13
+ATOM     11  OXT ALA C9999    9999.999-999.999   0.001  1.00  0.00           O
+ATOM  99999  CA ALYS D  -5      12.345  67.890 -12.345  0.50 99.99           C
+ATOM     13  N   bad line
+END
+"""
+
+
+def make_g12(R, work):
+    """G12: the reference's PDB reader and writer (PDB.py:19-97) on a file with the awkward records: 4-letter atom names,
+    HETATM, missing element column, unparsable serial / residue number (the previous atom's values are kept), TER / ANISOU
+    lines, touching coordinate columns, negative residue numbers, altLoc, a truncated line."""
+    src = os.path.join(work, "torture.pdb")
+    with open(src, "w") as fh:
+        fh.write(PDB_TORTURE)
+    pdb = R.PDB.PDB(src)
+    out = os.path.join(work, "torture_out.pdb")
+    pdb.write_pdb(out)
+    g12 = dict(text=np.array(PDB_TORTURE), coords=pdb.coords, serial=np.array([r[0] for r in pdb.info]), name=np.array([r[1] for r in pdb.info]),
+               resname=np.array([r[2] for r in pdb.info]), chain=np.array([r[3] for r in pdb.info]), resnum=np.array([r[4] for r in pdb.info]),
+               element=np.array([r[5] for r in pdb.info]), record=np.array([r[6] for r in pdb.info]), ca_idx=np.array(pdb.CA_idx),
+               bb_idx=np.array(pdb.BB_idx), n_atoms=np.array(pdb.n_atoms), written=np.array(open(out).read()),
+               rgyr=np.array(pdb.rgyr()) if hasattr(pdb, "center") else np.array(np.nan))
+    np.savez_compressed(os.path.join(OUT, "g12_pdb.npz"), **g12)
+    print("g12: atoms", pdb.n_atoms, "CA", pdb.CA_idx, "BB", pdb.BB_idx)
+
+
 def main():
     from scipy.interpolate import RegularGridInterpolator as RGI
     R = import_reference()
@@ -278,6 +316,9 @@ def main():
         return
     if "--only-g11" in sys.argv:
         make_g11(R)
+        return
+    if "--only-g12" in sys.argv:
+        make_g12(R, work)
         return
 
     # ---- G1: EQSP tables -----------------------------------------------------------
@@ -482,6 +523,7 @@ def main():
     make_g9(R, synth, work)
     make_g10(R, synth)
     make_g11(R)
+    make_g12(R, work)
 
     sizes = {f: os.path.getsize(os.path.join(OUT, f)) for f in sorted(os.listdir(OUT)) if f.endswith(".npz")}
     print("fixtures:", sizes, "total %.1f MB" % (sum(sizes.values()) / 1e6))

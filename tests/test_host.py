@@ -170,3 +170,27 @@ def test_descriptor_cache_round_trip(tmp_path, monkeypatch):
         np.testing.assert_array_equal(a.lin_ar_subeqsp, b.lin_ar_subeqsp)
         np.testing.assert_array_equal(a.Rfinal, b.Rfinal)
         np.testing.assert_array_equal(a.subv_map_coords, b.subv_map_coords)
+
+
+def test_pdb_reader_and_writer_on_awkward_records(tmp_path):
+    """mad_amd.PDB against the reference's PDB (PDB.py:19-97) on a file with 4-letter atom names, HETATM, a missing element
+    column, unparsable serial / residue numbers (the previous atom's values are kept), TER / ANISOU lines, touching
+    coordinate columns and a truncated line: parsed fields, CA / backbone indices and the written file, text for text."""
+    import os
+    from mad_amd.PDB import PDB
+    with np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g12_pdb.npz"), allow_pickle=False) as z:
+        g = {k: z[k] for k in z.files}
+    src = str(tmp_path / "torture.pdb")
+    with open(src, "w") as fh:
+        fh.write(str(g["text"]))
+    pdb = PDB(src)
+    assert pdb.n_atoms == int(g["n_atoms"])
+    np.testing.assert_array_equal(pdb.coords, g["coords"])
+    assert [r[0] for r in pdb.info] == [int(v) for v in g["serial"]]
+    assert [r[4] for r in pdb.info] == [int(v) for v in g["resnum"]]
+    for col, key in ((1, "name"), (2, "resname"), (3, "chain"), (5, "element"), (6, "record")):
+        assert [r[col] for r in pdb.info] == [str(v) for v in g[key]], key
+    assert tuple(pdb.CA_idx) == tuple(int(v) for v in g["ca_idx"]) and list(pdb.BB_idx) == [int(v) for v in g["bb_idx"]]
+    out = str(tmp_path / "out.pdb")
+    pdb.write_pdb(out)
+    assert open(out).read() == str(g["written"])
