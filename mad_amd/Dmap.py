@@ -85,4 +85,5 @@ class Dmap(object):
         mapio.write_mrc(outname, self.grid3d, (self.xi, self.yi, self.zi), self.voxsp)
 
     def write_to_sit(self, outname):
+        print(">Dmap> Writing density map as %s" % outname)      # Dmap.py:379
         mapio.write_situs(outname, self.grid3d, (self.xi, self.yi, self.zi), self.voxsp)

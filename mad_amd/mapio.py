@@ -27,9 +27,11 @@ def write_situs(path, grid, origin, voxsp):
     g = np.asarray(grid)
     with open(path, "w") as fh:
         fh.write("%f %f %f %f %i %i %i\n\n" % (voxsp, origin[0], origin[1], origin[2], g.shape[0], g.shape[1], g.shape[2]))
+        # Dmap.py:382-389, character for character: x fastest, "   %6.6f " per voxel, a line break after every tenth
         flat = g.reshape(-1, order="F")
         for i in range(0, len(flat), 10):
-            fh.write("".join("   %6.6f   " % v for v in flat[i:i + 10]) + "\n")
+            chunk = flat[i:i + 10]
+            fh.write("".join("   %6.6f " % v for v in chunk) + ("\n" if len(chunk) == 10 else ""))
 
 
 _MRC_DTYPES = {0: np.int8, 1: np.int16, 2: np.float32, 6: np.uint16, 12: np.float16}

@@ -16,7 +16,7 @@ Fixtures hold inputs and the reference's outputs only (numpy arrays).  Everythin
 seeded; re-running this script reproduces the files bit for bit on the same numpy /
 scipy build.
 
-Usage:  cd /root/repo && python tests/golden/make_golden.py [--only-g9 | --only-g10 | --only-g11 | --only-g12]
+Usage:  cd /root/repo && python tests/golden/make_golden.py [--only-g9 | --only-g10 | --only-g11 | --only-g12 | --only-g13]
 """
 import hashlib
 import os
@@ -301,6 +301,30 @@ def make_g12(R, work):
     print("g12: atoms", pdb.n_atoms, "CA", pdb.CA_idx, "BB", pdb.BB_idx)
 
 
+def make_g13(R, synth, work):
+    """G13: the reference's Dmap on a Situs file (Dmap.py:7-97, 377-390): loading with an isovalue and normalisation, padding,
+    reduce_void, and the Situs text it writes back."""
+    rng = np.random.default_rng(13)
+    vol = synth.blob_volume((22, 26, 19), n_blobs=9, seed=13, sigma=(1.2, 2.5)).astype(np.float64) * 3.7
+    vol[:4] = 0.0
+    vol[:, -5:] = 0.0
+    vol[vol < 0.15] *= rng.choice([0.0, 1.0], size=int((vol < 0.15).sum()))
+    src = os.path.join(work, "g13.sit")
+    synth.write_situs(src, vol, (-12.5, 3.25, 40.0), 1.7)
+    g13 = dict(sit_text=np.array(open(src).read()))
+    for tag, kw in (("plain", {}), ("iso", dict(isovalue=0.8)), ("raw", dict(isovalue=0.3, normalize=False, pad=3)), ("huge_iso", dict(isovalue=50.0))):
+        d = R.Dmap.Dmap(src, **kw)
+        g13[tag + "_grid"], g13[tag + "_geo"] = d.grid3d.copy(), np.array([d.xi, d.yi, d.zi, d.voxsp, d.xb, d.yb, d.zb], dtype=np.float64)
+        if tag == "iso":
+            d.reduce_void(zeros_padding=4)
+            g13["reduced_grid"], g13["reduced_geo"] = d.grid3d.copy(), np.array([d.xi, d.yi, d.zi, d.voxsp, d.xb, d.yb, d.zb], dtype=np.float64)
+            out = os.path.join(work, "g13_out.sit")
+            d.write_to_sit(out)
+            g13["reduced_sit_text"] = np.array(open(out).read())
+    np.savez_compressed(os.path.join(OUT, "g13_dmap.npz"), **g13)
+    print("g13:", {k: v.shape for k, v in g13.items() if k.endswith("_grid")})
+
+
 def main():
     from scipy.interpolate import RegularGridInterpolator as RGI
     R = import_reference()
@@ -319,6 +343,9 @@ def main():
         return
     if "--only-g12" in sys.argv:
         make_g12(R, work)
+        return
+    if "--only-g13" in sys.argv:
+        make_g13(R, synth, work)
         return
 
     # ---- G1: EQSP tables -----------------------------------------------------------
@@ -524,6 +551,7 @@ def main():
     make_g10(R, synth)
     make_g11(R)
     make_g12(R, work)
+    make_g13(R, synth, work)
 
     sizes = {f: os.path.getsize(os.path.join(OUT, f)) for f in sorted(os.listdir(OUT)) if f.endswith(".npz")}
     print("fixtures:", sizes, "total %.1f MB" % (sum(sizes.values()) / 1e6))

@@ -194,3 +194,33 @@ def test_pdb_reader_and_writer_on_awkward_records(tmp_path):
     out = str(tmp_path / "out.pdb")
     pdb.write_pdb(out)
     assert open(out).read() == str(g["written"])
+
+
+def test_dmap_on_a_situs_file_against_the_reference(tmp_path, capsys):
+    """mad_amd.Dmap against the reference's Dmap (Dmap.py:7-97, 377-390) on the same Situs file: isovalue + normalisation,
+    padding, an isovalue above the maximum (warning, then 0), reduce_void, and the Situs text written back."""
+    import os
+    from mad_amd.Dmap import Dmap
+    with np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g13_dmap.npz"), allow_pickle=False) as z:
+        g = {k: z[k] for k in z.files}
+    src = str(tmp_path / "g13.sit")
+    with open(src, "w") as fh:
+        fh.write(str(g["sit_text"]))
+
+    def geo(d):
+        return np.array([d.xi, d.yi, d.zi, d.voxsp, d.xb, d.yb, d.zb], dtype=np.float64)
+
+    for tag, kw in (("plain", {}), ("iso", dict(isovalue=0.8)), ("raw", dict(isovalue=0.3, normalize=False, pad=3)), ("huge_iso", dict(isovalue=50.0))):
+        d = Dmap(src, **kw)
+        assert d.grid3d.dtype == g[tag + "_grid"].dtype, tag
+        np.testing.assert_array_equal(d.grid3d, g[tag + "_grid"], err_msg=tag)
+        np.testing.assert_array_equal(geo(d), g[tag + "_geo"], err_msg=tag)
+        if tag == "iso":
+            d.reduce_void(zeros_padding=4)
+            np.testing.assert_array_equal(d.grid3d, g["reduced_grid"])
+            np.testing.assert_array_equal(geo(d), g["reduced_geo"])
+            out = str(tmp_path / "out.sit")
+            d.write_to_sit(out)
+            same_text = open(out).read() == str(g["reduced_sit_text"])      # not inside the assert: pytest would diff 100 KB strings
+            assert same_text
+    assert "larger than maximum density" in capsys.readouterr().out
