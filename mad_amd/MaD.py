@@ -462,12 +462,14 @@ class MaD(object):
         if table:
             with open(os.path.join(self.out_folder, "Solutions_refined_%s.csv" % sub_key), "w") as fh:
                 fh.write("ID,Repeatability,Weight,mCC,RWmCC\n")
+                def num(v):      # as pandas.to_csv prints it: shortest repr in the value's own precision
+                    return str(v) if isinstance(v, (np.floating, np.integer)) else repr(v)
                 for row in table:
-                    fh.write("%i,%s,%s,%s,%s\n" % (row[0], repr(float(row[1])), repr(int(row[2])), repr(float(row[3])), repr(float(row[4]))))
+                    fh.write("%i,%s,%s,%s,%s\n" % (row[0], num(row[1]), num(row[2]), num(row[3]), num(row[4])))
         return files
 
     def _save_coords_as_pdb(self, coords, outname):
         with open(outname, "w") as fh:
             for i, c in enumerate(coords):
                 fh.write("%-6s%5i  %-3s %3s%2s%4i    %8.3f%8.3f%8.3f%6.2f%6.2f          %-2s\n"
-                         % ("ATOM", i % 100000, "O", "EPC", "E", i % 10000, c[0], c[1], c[2], 1.0, 0.0, "O"))
+                         % ("ATOM", i % 100000, "O", "EPC", "E", i % 10000, c[0], c[1], c[2], 1.0, i / len(coords), "O"))      # B = rank in the list (MaD.py:1001)

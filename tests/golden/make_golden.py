@@ -16,7 +16,7 @@ Fixtures hold inputs and the reference's outputs only (numpy arrays).  Everythin
 seeded; re-running this script reproduces the files bit for bit on the same numpy /
 scipy build.
 
-Usage:  cd /root/repo && python tests/golden/make_golden.py [--only-g9 | --only-g10 | --only-g11 | --only-g12 | --only-g13]
+Usage:  cd /root/repo && python tests/golden/make_golden.py [--only-g9 | --only-g10 | --only-g11 | --only-g12 | --only-g13 | --only-g14]
 """
 import hashlib
 import os
@@ -325,6 +325,41 @@ def make_g13(R, synth, work):
     print("g13:", {k: v.shape for k, v in g13.items() if k.endswith("_grid")})
 
 
+def make_g14(R, synth, work):
+    """G14: MaD._save_solutions_refined of the reference (MaD.py:923-958): the solutions table it prints, Solutions_refined_<key>.csv
+    as pandas writes it, the solution PDBs and the corresp_anchors PDBs (the oriented-anchor PDB / BLD files it also writes are
+    visualisation aids and are not reproduced)."""
+    import contextlib
+    import io
+    rng = np.random.default_rng(14)
+    coords, names, elems = synth.random_globule(60, 6.0, seed=14)
+    src = os.path.join(work, "g14_sub.pdb")
+    synth.write_pdb(src, coords, names, elems)
+    m = R.MaD.MaD()
+    m.out_folder = os.path.join(work, "g14_out")
+    os.makedirs(m.out_folder)
+    sols = []
+    for i in range(3):
+        pdb = R.PDB.PDB(src)
+        pdb.translate_atoms(rng.normal(scale=20, size=3))
+        corresp = np.round(rng.uniform(-50, 150, size=(int(rng.integers(1, 7)), 3)), 3)
+        clustered = [[rng.uniform(0, 50, 3), rng.uniform(0, 50, 3), float(rng.integers(0, 112)), float(rng.integers(0, 112))] for _ in range(int(rng.integers(1, 4)))]
+        repeat, weight, ccc = float(rng.uniform(5, 90)), int(rng.integers(4, 40)), float(np.float32(rng.uniform(0.2, 0.95)))
+        sols.append([pdb, corresp, repeat, weight, np.float32(ccc), clustered, repeat * weight * ccc])
+    log = io.StringIO()
+    with contextlib.redirect_stdout(log):
+        files = m._save_solutions_refined(sols, "subA")
+    g14 = dict(sub_text=np.array(open(src).read()), stdout=np.array(log.getvalue()), files=np.array([os.path.basename(f) for f in files]),
+               csv=np.array(open(os.path.join(m.out_folder, "Solutions_refined_subA.csv")).read()))
+    for i, sol in enumerate(sols):
+        g14["coords_%d" % i], g14["corresp_%d" % i] = sol[0].coords, sol[1]
+        g14["row_%d" % i] = np.array([sol[2], sol[3], sol[4], sol[6]], dtype=np.float64)
+        g14["sol_pdb_%d" % i] = np.array(open(os.path.join(m.out_folder, "individual_solutions", "sol_subA_%d.pdb" % i)).read())
+        g14["corresp_pdb_%d" % i] = np.array(open(os.path.join(m.out_folder, "individual_solutions", "anchor_files", "corresp_anchors_subA_%d.pdb" % i)).read())
+    np.savez_compressed(os.path.join(OUT, "g14_solutions_io.npz"), **g14)
+    print("g14 csv:\n" + str(g14["csv"]))
+
+
 def main():
     from scipy.interpolate import RegularGridInterpolator as RGI
     R = import_reference()
@@ -346,6 +381,9 @@ def main():
         return
     if "--only-g13" in sys.argv:
         make_g13(R, synth, work)
+        return
+    if "--only-g14" in sys.argv:
+        make_g14(R, synth, work)
         return
 
     # ---- G1: EQSP tables -----------------------------------------------------------
@@ -552,6 +590,7 @@ def main():
     make_g11(R)
     make_g12(R, work)
     make_g13(R, synth, work)
+    make_g14(R, synth, work)
 
     sizes = {f: os.path.getsize(os.path.join(OUT, f)) for f in sorted(os.listdir(OUT)) if f.endswith(".npz")}
     print("fixtures:", sizes, "total %.1f MB" % (sum(sizes.values()) / 1e6))

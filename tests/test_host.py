@@ -224,3 +224,34 @@ def test_dmap_on_a_situs_file_against_the_reference(tmp_path, capsys):
             same_text = open(out).read() == str(g["reduced_sit_text"])      # not inside the assert: pytest would diff 100 KB strings
             assert same_text
     assert "larger than maximum density" in capsys.readouterr().out
+
+
+def test_save_solutions_refined_against_the_reference(tmp_path, capsys):
+    """MaD._save_solutions_refined (MaD.py:923-958) on three made-up solutions: the printed table, Solutions_refined_<key>.csv as
+    pandas writes it, the solution PDBs and the corresp_anchors PDBs, text for text."""
+    import os
+    from mad_amd.MaD import MaD
+    from mad_amd.PDB import PDB
+    with np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g14_solutions_io.npz"), allow_pickle=False) as z:
+        g = {k: z[k] for k in z.files}
+    src = str(tmp_path / "sub.pdb")
+    with open(src, "w") as fh:
+        fh.write(str(g["sub_text"]))
+    m = MaD()
+    m.out_folder = str(tmp_path / "out")
+    os.makedirs(m.out_folder)
+    sols = []
+    for i in range(3):
+        pdb = PDB(src)
+        pdb.set_coords(g["coords_%d" % i])
+        repeat, weight, ccc, score = g["row_%d" % i]
+        sols.append([pdb, g["corresp_%d" % i], float(repeat), int(weight), np.float32(ccc), [], float(score)])
+    files = m._save_solutions_refined(sols, "subA")
+    assert [os.path.basename(f) for f in files] == [str(f) for f in g["files"]]
+    out = capsys.readouterr().out
+    same = [out == str(g["stdout"]), open(os.path.join(m.out_folder, "Solutions_refined_subA.csv")).read() == str(g["csv"])]
+    for i in range(3):
+        same.append(open(os.path.join(m.out_folder, "individual_solutions", "sol_subA_%d.pdb" % i)).read() == str(g["sol_pdb_%d" % i]))
+        same.append(open(os.path.join(m.out_folder, "individual_solutions", "anchor_files", "corresp_anchors_subA_%d.pdb" % i)).read()
+                    == str(g["corresp_pdb_%d" % i]))
+    assert same == [True] * len(same), same
