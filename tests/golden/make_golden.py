@@ -16,7 +16,7 @@ Fixtures hold inputs and the reference's outputs only (numpy arrays).  Everythin
 seeded; re-running this script reproduces the files bit for bit on the same numpy /
 scipy build.
 
-Usage:  cd /root/repo && python tests/golden/make_golden.py [--only-g9 | --only-g10 | --only-g11 | --only-g12 | --only-g13 | --only-g14]
+Usage:  cd /root/repo && python tests/golden/make_golden.py [--only-g9 | --only-g10 | --only-g11 | --only-g12 | --only-g13 | --only-g14 | --only-g15]
 """
 import hashlib
 import os
@@ -360,6 +360,22 @@ def make_g14(R, synth, work):
     print("g14 csv:\n" + str(g14["csv"]))
 
 
+def make_g15(R, synth, work):
+    """G15: structure_utils.move_structure / move_copy_structure of the reference (structure_utils.py:8-57): the PDB files they write."""
+    coords, names, elems = synth.random_globule(40, 5.0, seed=15)
+    src = os.path.join(work, "g15.pdb")
+    synth.write_pdb(src, coords + np.array([31.0, -12.0, 77.5]), names, elems)
+    g15 = dict(src=np.array(open(src).read()))
+    g15["moved_default"] = np.array(open(R.SU.move_structure(src)).read())
+    g15["moved_t"] = np.array(open(R.SU.move_structure(src, t=[1.5, -2.0, 3.25], a=0.1, b=-0.2, c=0.3, suffix="_b")).read())
+    for tag, kw in (("copy", {}), ("copy_transform", dict(transform=True)), ("copy_transform_t0", dict(transform=True, t=[]))):
+        dst = os.path.join(work, "g15_%s.pdb" % tag)
+        R.SU.move_copy_structure(src, dst, **kw)
+        g15[tag] = np.array(open(dst).read())
+    np.savez_compressed(os.path.join(OUT, "g15_move_structure.npz"), **g15)
+    print("g15 done")
+
+
 def main():
     from scipy.interpolate import RegularGridInterpolator as RGI
     R = import_reference()
@@ -384,6 +400,9 @@ def main():
         return
     if "--only-g14" in sys.argv:
         make_g14(R, synth, work)
+        return
+    if "--only-g15" in sys.argv:
+        make_g15(R, synth, work)
         return
 
     # ---- G1: EQSP tables -----------------------------------------------------------
@@ -591,6 +610,7 @@ def main():
     make_g12(R, work)
     make_g13(R, synth, work)
     make_g14(R, synth, work)
+    make_g15(R, synth, work)
 
     sizes = {f: os.path.getsize(os.path.join(OUT, f)) for f in sorted(os.listdir(OUT)) if f.endswith(".npz")}
     print("fixtures:", sizes, "total %.1f MB" % (sum(sizes.values()) / 1e6))

@@ -255,3 +255,21 @@ def test_save_solutions_refined_against_the_reference(tmp_path, capsys):
         same.append(open(os.path.join(m.out_folder, "individual_solutions", "anchor_files", "corresp_anchors_subA_%d.pdb" % i)).read()
                     == str(g["corresp_pdb_%d" % i]))
     assert same == [True] * len(same), same
+
+
+def test_move_structure_against_the_reference(tmp_path):
+    """structure_utils.move_structure / move_copy_structure (structure_utils.py:8-57): the PDB files they write."""
+    import os
+    from mad_amd.structure_utils import move_copy_structure, move_structure
+    with np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g15_move_structure.npz"), allow_pickle=False) as z:
+        g = {k: str(z[k]) for k in z.files}
+    src = str(tmp_path / "g15.pdb")
+    with open(src, "w") as fh:
+        fh.write(g["src"])
+    same = [open(move_structure(src)).read() == g["moved_default"],
+            open(move_structure(src, t=[1.5, -2.0, 3.25], a=0.1, b=-0.2, c=0.3, suffix="_b")).read() == g["moved_t"]]
+    for tag, kw in (("copy", {}), ("copy_transform", dict(transform=True)), ("copy_transform_t0", dict(transform=True, t=[]))):
+        dst = str(tmp_path / ("%s.pdb" % tag))
+        move_copy_structure(src, dst, **kw)
+        same.append(open(dst).read() == g[tag])
+    assert same == [True] * 5, same
