@@ -69,7 +69,8 @@ class Detector(object):
 
     def check_localize(self, grid, oricoord):
         """Quadratic sub-voxel localisation with saddle rejection (Detector.py:53-123)."""
-        x, y, z = (int(v) for v in oricoord)
+        # numpy integers, as the peak search hands them over: int64 + float32 offset is a float64 sum (Detector.py:117-119)
+        x, y, z = (np.int64(v) for v in oricoord)
         max_off = 0.6
         offset = np.zeros(3)
         H = np.zeros((3, 3))

@@ -16,7 +16,7 @@ Fixtures hold inputs and the reference's outputs only (numpy arrays).  Everythin
 seeded; re-running this script reproduces the files bit for bit on the same numpy /
 scipy build.
 
-Usage:  cd /root/repo && python tests/golden/make_golden.py [--only-g9 | --only-g10 | --only-g11 | --only-g12 | --only-g13 | --only-g14 | --only-g15]
+Usage:  cd /root/repo && python tests/golden/make_golden.py [--only-g9 | --only-g10 | --only-g11 | --only-g12 | --only-g13 | --only-g14 | --only-g15 | --only-g16]
 """
 import hashlib
 import os
@@ -57,9 +57,10 @@ def import_reference():
     import mad.structure_utils as rSU
     import mad.math_utils as rMU
     import mad.eqsp.eqsp as rEQ
+    import mad.Detector as rDet
     assert rMaD.__file__.startswith(REF), rMaD.__file__
     sys.path.insert(1, REPO)
-    return types.SimpleNamespace(MaD=rMaD, Ori=rOri, Dsc=rDsc, DF=rDF, PDB=rPDB, Dmap=rDmap, MS=rMS, SU=rSU, MU=rMU, EQ=rEQ)
+    return types.SimpleNamespace(MaD=rMaD, Ori=rOri, Dsc=rDsc, DF=rDF, PDB=rPDB, Dmap=rDmap, MS=rMS, SU=rSU, MU=rMU, EQ=rEQ, Det=rDet)
 
 
 def sha(path):
@@ -376,6 +377,37 @@ def make_g15(R, synth, work):
     print("g15 done")
 
 
+def make_g16(R, synth):
+    """G16: Detector.check_localize of the reference (Detector.py:53-123) -- the quadratic sub-voxel fit with saddle rejection that
+    follows the peak search -- on every strict local maximum of two smooth volumes (float32 and float64) and on a set of
+    off-peak starting voxels, which exercise the walk of up to five steps."""
+    det = R.Det.Detector()
+    g16 = {}
+    for tag, dtype, seed in (("f32", np.float32, 16), ("f64", np.float64, 17)):
+        vol = synth.blob_volume((40, 42, 38), n_blobs=60, seed=seed, sigma=(1.2, 3.0)).astype(dtype)
+        vol = (vol * 7.3 - 0.4).astype(dtype)
+        c = vol[1:-1, 1:-1, 1:-1]
+        is_max = np.ones(c.shape, bool)
+        for dx in (-1, 0, 1):
+            for dy in (-1, 0, 1):
+                for dz in (-1, 0, 1):
+                    if dx or dy or dz:
+                        is_max &= c > vol[1 + dx:vol.shape[0] - 1 + dx, 1 + dy:vol.shape[1] - 1 + dy, 1 + dz:vol.shape[2] - 1 + dz]
+        peaks = np.argwhere(is_max) + 1
+        peaks = peaks[np.all((peaks >= 4) & (peaks < np.array(vol.shape) - 4), axis=1)]
+        rng = np.random.default_rng(seed)
+        extra = np.stack([rng.integers(5, s_ - 5, 150) for s_ in vol.shape], 1)
+        cand = np.concatenate([peaks, extra])
+        good, coord, sub = [], [], []
+        for p_ in cand:
+            ok, cc, sc = det.check_localize(vol, np.array(p_))
+            good.append(bool(ok)); coord.append([int(v) for v in cc]); sub.append([float(v) for v in sc])
+        g16[tag + "_vol"], g16[tag + "_cand"] = vol, cand
+        g16[tag + "_good"], g16[tag + "_coord"], g16[tag + "_sub"] = np.array(good), np.array(coord), np.array(sub)
+        print("g16", tag, "candidates", len(cand), "accepted", int(np.sum(good)), "moved", int(np.sum(np.any(np.array(coord) != cand, axis=1) & np.array(good))))
+    np.savez_compressed(os.path.join(OUT, "g16_localize.npz"), **g16)
+
+
 def main():
     from scipy.interpolate import RegularGridInterpolator as RGI
     R = import_reference()
@@ -403,6 +435,9 @@ def main():
         return
     if "--only-g15" in sys.argv:
         make_g15(R, synth, work)
+        return
+    if "--only-g16" in sys.argv:
+        make_g16(R, synth)
         return
 
     # ---- G1: EQSP tables -----------------------------------------------------------
@@ -611,6 +646,7 @@ def main():
     make_g13(R, synth, work)
     make_g14(R, synth, work)
     make_g15(R, synth, work)
+    make_g16(R, synth)
 
     sizes = {f: os.path.getsize(os.path.join(OUT, f)) for f in sorted(os.listdir(OUT)) if f.endswith(".npz")}
     print("fixtures:", sizes, "total %.1f MB" % (sum(sizes.values()) / 1e6))

@@ -273,3 +273,24 @@ def test_move_structure_against_the_reference(tmp_path):
         move_copy_structure(src, dst, **kw)
         same.append(open(dst).read() == g[tag])
     assert same == [True] * 5, same
+
+
+def test_check_localize_against_the_reference():
+    """Detector.check_localize (Detector.py:53-123): verdict, voxel and sub-voxel position for every local maximum of two smooth
+    volumes and for 150 off-peak starts each, against the reference's results (the peak search in front of it stays unpinned:
+    scikit-image is not available)."""
+    import os
+    from mad_amd.Detector import Detector
+    with np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g16_localize.npz"), allow_pickle=False) as z:
+        g = {k: z[k] for k in z.files}
+    det = Detector()
+    for tag in ("f32", "f64"):
+        vol = g[tag + "_vol"]
+        n_good = 0
+        for p_, ok, cc, sc in zip(g[tag + "_cand"], g[tag + "_good"], g[tag + "_coord"], g[tag + "_sub"]):
+            got_ok, got_c, got_s = det.check_localize(vol, np.array(p_))
+            assert bool(got_ok) == bool(ok), (tag, p_)
+            assert [int(v) for v in got_c] == [int(v) for v in cc], (tag, p_)
+            np.testing.assert_array_equal(np.array([float(v) for v in got_s]), sc)
+            n_good += bool(ok)
+        assert n_good >= 40
