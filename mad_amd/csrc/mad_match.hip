@@ -1202,8 +1202,9 @@ static int pose_device(mad_ctx *ctx, const Side &hi, const Side &lo, int32_t *d_
         if (G.dim[d] < 1) G.dim[d] = 1;
         G.ncell *= G.dim[d];
     }
-    const size_t stacks = (size_t)(POSE_LDS_THREADS / MAD_WAVE) * POSE_WAVE_LDS;      // per-wave queues (+ pair records in k_pose_lds)
-    const size_t lds32 = (size_t)(n_cloud + 1) * 16 + pad16((size_t)(G.ncell + 1) * 2) + stacks + 16;
+    const size_t stacks = (size_t)(POSE_LDS_THREADS / MAD_WAVE) * POSE_WAVE_LDS;      // k_pose_lds: per-wave queue + two pair records
+    const size_t stacks32 = (size_t)(POSE_LDS_THREADS / MAD_WAVE) * POSE_STACK * 2;   // k_pose_lds32: per-wave survivor stack only
+    const size_t lds32 = (size_t)(n_cloud + 1) * 16 + pad16((size_t)(G.ncell + 1) * 2) + stacks32 + 16;
     // occupancy bitmap of the lo cloud (k_pose_bits), in global memory: voxel edge MAD_POSE_VOXEL (default 0.8 A: 0.6-0.8 measure the same, 1.0 is 3 % slower) unless that
     // needs more than 16 MB.  It was tried in LDS too: there it has to be coarser (1.7 A beside the C3 clouds), lets 74
     // instead of 57 points per pair through, and the second round of the exact search that this costs outweighs the
@@ -1301,8 +1302,11 @@ static int pose_device(mad_ctx *ctx, const Side &hi, const Side &lo, int32_t *d_
 }
 
 static bool clouds_fit_lds(int64_t l_hi, int64_t l_lo) {      // with the largest cell table (30 000 cells)
-    const size_t fixed = 30004 * 2 + (POSE_LDS_THREADS / MAD_WAVE) * POSE_WAVE_LDS + 16 + 64;      // as pose_device sizes them (+ its 16-byte paddings)
-    return ((size_t)(l_hi + l_lo) * 24 + (size_t)l_hi * 16 + fixed <= 150 * 1024 || (size_t)(l_lo + 1) * 16 + fixed <= 150 * 1024) && l_lo < 65535 &&
+    // as pose_device sizes them (+ its 16-byte paddings): the float64 kernel carries a queue and two pair records per wave, the
+    // float32 one a survivor stack
+    const size_t cells = 30004 * 2 + 16 + 64;
+    const size_t fixed = cells + (POSE_LDS_THREADS / MAD_WAVE) * POSE_WAVE_LDS, fixed32 = cells + (POSE_LDS_THREADS / MAD_WAVE) * POSE_STACK * 2;
+    return ((size_t)(l_hi + l_lo) * 24 + (size_t)l_hi * 16 + fixed <= 150 * 1024 || (size_t)(l_lo + 1) * 16 + fixed32 <= 150 * 1024) && l_lo < 65535 &&
            l_hi < 65536;      // (the first alternative implies l_hi < 32768)
 }
 
