@@ -208,6 +208,13 @@ int mad_match_topk_many(mad_ctx *ctx, int n, const mad_set *const *hi, const mad
 int mad_match_topk_many_begin(mad_ctx *ctx, int n, const mad_set *const *hi, const mad_set *lo, double cc, double dist,
                               int64_t k, double *results, int64_t *pair_index, int64_t *n_out, int64_t *stats);
 int mad_match_topk_many_finish(mad_ctx *ctx);
+
+/*
+ * Which pose-scoring kernel the most recently enqueued match used: 0 = k_pose_lds (both clouds in LDS as float64),
+ * 1 = k_pose_lds32 (lo cloud as float32 offsets in LDS), 2 = k_pose (global cell list), -1 = none yet.  For tests and
+ * diagnostics: the three give identical counts, so only this tells when a sizing change has demoted a workload.
+ */
+int mad_last_pose_kernel(mad_ctx *ctx);
 /* After mad_match_topk: all pairs of that call (for MaD._match_dsc's full return value). */
 int mad_match_fetch(mad_ctx *ctx, int32_t *pair_hi, int32_t *pair_lo, double *pair_score,
                     int32_t *counts, int64_t cap);

@@ -22,7 +22,7 @@ SYMBOLS = [
     "mad_set_eqsp", "mad_upload_field", "mad_upload_field_device", "mad_free_field",
     "mad_orient", "mad_describe", "mad_correlate", "mad_pose_score", "mad_topk",
     "mad_set_create", "mad_set_destroy", "mad_set_build", "mad_set_load", "mad_set_size", "mad_set_download",
-    "mad_match_topk", "mad_match_topk_many", "mad_match_topk_many_begin", "mad_match_topk_many_finish", "mad_match_fetch", "mad_match_results", "mad_match_used",
+    "mad_match_topk", "mad_match_topk_many", "mad_match_topk_many_begin", "mad_match_topk_many_finish", "mad_last_pose_kernel", "mad_match_fetch", "mad_match_results", "mad_match_used",
     "mad_match_shard_pairs", "mad_match_shard_topk",
     "mad_upload_density", "mad_refine", "mad_structure_to_density", "mad_ccc", "mad_density_ccc", "mad_grid_overlap", "mad_overlap_matrix",
     "mad_space_create", "mad_space_destroy", "mad_space_build", "mad_space_info", "mad_space_download",
@@ -411,6 +411,10 @@ class Lib(object):
             out.append((res[i, :g], idx[i, :g], dict(n_pairs=int(stats[i, 0]), l_hi=int(stats[i, 1]), l_lo=int(stats[i, 2]),
                                                      n_corr=int(stats[i, 3]))))
         return out
+
+    def last_pose_kernel(self):
+        """0 k_pose_lds, 1 k_pose_lds32, 2 k_pose (global cell list): the kernel of the most recently enqueued match."""
+        return int(self.dll.mad_last_pose_kernel(self.ctx))
 
     def match_topk_many_begin(self, his, lo, cc, dist, k):
         """Enqueue every match and return a handle; `match_topk_many_finish(handle)` waits and unpacks.  In between

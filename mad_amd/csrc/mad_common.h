@@ -152,6 +152,7 @@ struct mad_ctx {
     int next_pinned = 64;
     DensityDev dens;
     MatchState match;
+    int last_pose_kernel = -1;               // 0 k_pose_lds, 1 k_pose_lds32, 2 k_pose (mad_last_pose_kernel)
     void *many = nullptr;                    // open mad_match_topk_many_begin bracket (ManyState, mad_match.hip)
     bool timing = false;
     TimerGroup timers[MAD_T_COUNT];

@@ -1268,6 +1268,7 @@ static int pose_device(mad_ctx *ctx, const Side &hi, const Side &lo, int32_t *d_
         PosePair *d_rec = scratch<PosePair>(ctx, S_PG_PAIRS);
         hipLaunchKernelGGL(k_pose_prep, dim3(ctx->n_cu * 8), dim3(256), 0, ctx->stream, scratch<int32_t>(ctx, S_PAIR_HI),
                            scratch<int32_t>(ctx, S_PAIR_LO), d_status, cap_pairs, hi.p, hi.R, lo.p, lo.Rinv, hi.row_anchor, lo.row_anchor, d_rec);
+        ctx->last_pose_kernel = fits64 ? 0 : 1;
         mad_timer_begin(ctx, MAD_T_POSE);      // the search kernel alone: what the rocprofv3 summary lists as k_pose_lds
         if (fits64)
             hipLaunchKernelGGL(k_pose_lds, dim3(ctx->n_cu * (lds > 80 * 1024 ? 1 : pose_wgs_per_cu())), dim3(POSE_LDS_THREADS), lds, ctx->stream, d_status, cap_pairs, d_rec,
@@ -1292,6 +1293,7 @@ static int pose_device(mad_ctx *ctx, const Side &hi, const Side &lo, int32_t *d_
                            d_status + ST_LLO);
     else
         MAD_HIP(hipMemcpyAsync(d_status + ST_LLO, &n_cloud, 4, hipMemcpyHostToDevice, ctx->stream));
+    ctx->last_pose_kernel = 2;
     mad_timer_begin(ctx, MAD_T_POSE);
     hipLaunchKernelGGL(k_pose, dim3(ctx->n_cu * 8), dim3(POSE_THREADS), lds2, ctx->stream, scratch<int32_t>(ctx, S_PAIR_HI),
                        scratch<int32_t>(ctx, S_PAIR_LO), d_status, cap_pairs, hi.p, hi.R, lo.p, lo.Rinv, hi.row_anchor, lo.row_anchor,
@@ -1301,10 +1303,10 @@ static int pose_device(mad_ctx *ctx, const Side &hi, const Side &lo, int32_t *d_
     return MAD_OK;
 }
 
-static bool clouds_fit_lds(int64_t l_hi, int64_t l_lo) {      // with the largest cell table (30 000 cells)
+static bool clouds_fit_lds(int64_t l_hi, int64_t l_lo) {      // with the largest cell table pose_device makes (25^3 cells)
     // as pose_device sizes them (+ its 16-byte paddings): the float64 kernel carries a queue and two pair records per wave, the
     // float32 one a survivor stack
-    const size_t cells = 30004 * 2 + 16 + 64;
+    const size_t cells = 15632 * 2 + 16 + 64;      // pose_device caps the grid at 25 cells per axis
     const size_t fixed = cells + (POSE_LDS_THREADS / MAD_WAVE) * POSE_WAVE_LDS, fixed32 = cells + (POSE_LDS_THREADS / MAD_WAVE) * POSE_STACK * 2;
     return ((size_t)(l_hi + l_lo) * 24 + (size_t)l_hi * 16 + fixed <= 150 * 1024 || (size_t)(l_lo + 1) * 16 + fixed32 <= 150 * 1024) && l_lo < 65535 &&
            l_hi < 65536;      // (the first alternative implies l_hi < 32768)
@@ -1943,6 +1945,8 @@ extern "C" int mad_match_topk_many_begin(mad_ctx *ctx, int n, const mad_set *con
     }
     return rc_all;
 }
+
+extern "C" int mad_last_pose_kernel(mad_ctx *ctx) { return ctx ? ctx->last_pose_kernel : -1; }
 
 extern "C" int mad_match_topk_many_finish(mad_ctx *ctx) {
     if (!ctx) return MAD_EINVAL;

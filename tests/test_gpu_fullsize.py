@@ -37,6 +37,7 @@ def test_full_size_properties(lib, workload):
         ref_dsc = [s.download()["dsc"] for s in sets]
         lib.set_overlap(True)
         assert corr == sum(s["n_hi"] * s["n_lo"] for s in stats)
+        assert lib.last_pose_kernel() == (1 if workload == "c5" else 0)      # 512^3: lo cloud as float32 offsets in LDS, not the global cell list
         # overlapped lanes must reproduce it bit for bit, every time (atomics only ever feed order-independent sums)
         for _ in range(6 if workload != "c5" else 3):
             corr2, tops2, _ = bench.hot_path_step(lib, the_map, subs, cc, dist, k, sets)

@@ -215,6 +215,7 @@ def test_pose_score_matches_oracle(lib):
     a = _pose_inputs(3)
     ref_res, ref_cnt = O.pose_score(**a, dist=4.0)
     got_res, got_cnt = lib.pose_score(**a, dist=4.0)
+    assert lib.last_pose_kernel() == 0
     assert ref_cnt.max() > 20, "planted poses should bring many anchors into coincidence"
     np.testing.assert_array_equal(got_cnt, ref_cnt)
     np.testing.assert_allclose(got_res, ref_res, rtol=1e-12, atol=1e-12)
@@ -246,6 +247,7 @@ def test_pose_score_large_lo_cloud(lib, n_lo_anchor, n_pairs, box):
              lo_p=lo_anchor_p, lo_R=lo_R, lo_meta=meta_l, hi_cloud=np.unique(hi_anchor_p, axis=0), lo_cloud=np.unique(lo_anchor_p, axis=0))
     ref_res, ref_cnt = O.pose_score(**a, dist=4.0)
     got_res, got_cnt = lib.pose_score(**a, dist=4.0)
+    assert lib.last_pose_kernel() == (1 if n_lo_anchor == 5600 else 2)      # the kernel this case is meant for
     assert ref_cnt.max() > 100 and ref_cnt.mean() > 1
     np.testing.assert_array_equal(got_cnt, ref_cnt)
     np.testing.assert_allclose(got_res, ref_res, rtol=1e-12, atol=1e-12)
