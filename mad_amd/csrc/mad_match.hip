@@ -693,12 +693,13 @@ __global__ __launch_bounds__(POSE_LDS_THREADS) void k_pose_lds(const int32_t *__
 // distance falls inside that band (about one sample in 10^4) is re-evaluated with the reference's float64 expression
 // on the float64 point in global memory, so the count is the float64 count.  On clouds that fit both kernels this one
 // is ~20 % slower than k_pose_lds, and ~10 x faster than the global cell list it replaces for the big ones.
+template <bool HI_LDS>
 __global__ __launch_bounds__(POSE_LDS_THREADS) void k_pose_lds32(const int32_t *__restrict__ status, int64_t cap_pairs,
                                                                  const PosePair *__restrict__ rec,
                                                                  const double *__restrict__ hi_cloud, const double *__restrict__ lo_sorted,
                                                                  const float4 *__restrict__ lo_sorted_f,
                                                                  const int32_t *__restrict__ cell_start,
-                                                                 const unsigned short *__restrict__ cell_start16, PoseGrid G, int l_lo_cap,
+                                                                 const unsigned short *__restrict__ cell_start16, PoseGrid G, int l_lo_cap, int l_hi_cap,
                                                                  float reach, double dd_lim, float lim_in, float lim_out, PoseBits B,
                                                                  const unsigned *__restrict__ bits, int32_t *__restrict__ counts) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -709,10 +710,20 @@ __global__ __launch_bounds__(POSE_LDS_THREADS) void k_pose_lds32(const int32_t *
     const int64_t n_pairs = min((int64_t)status[ST_NPAIRS], cap_pairs);
     const int l_hi = status[ST_LHI];
     const int l_lo = cell_start[G.ncell];
+    // HI_LDS: the hi cloud too, as float64 for the exact search and as float32 for the bitmap test (when it fits beside the lo cloud)
+    double *cl = (double *)((unsigned char *)cs + pad16((size_t)(G.ncell + 1) * 2) + (POSE_LDS_THREADS / MAD_WAVE) * POSE_STACK * 2);
+    float4 *clf = (float4 *)((unsigned char *)cl + pad16((size_t)l_hi_cap * 24));
     stage_lds(lpf, lo_sorted_f, (size_t)l_lo * 16);
     stage_lds(cs, cell_start16, (size_t)((G.ncell + 2) & ~1) * 2);
+    if (HI_LDS) stage_lds(cl, hi_cloud, (size_t)l_hi * 24);
     if (threadIdx.x == 0) lpf[l_lo] = make_float4(1e30f, 1e30f, 1e30f, 0.f);      // pad: the odd partner of a run's last point
     __syncthreads();
+    if (HI_LDS) {
+        for (int i = threadIdx.x; i < l_hi; i += POSE_LDS_THREADS)
+            clf[i] = make_float4((float)cl[3 * i], (float)cl[3 * i + 1], (float)cl[3 * i + 2], 0.f);
+        __syncthreads();
+    }
+    const double *hc = HI_LDS ? (const double *)cl : hi_cloud;      // where the exact search reads the hi cloud
     const int lane = lane_id();
     const int64_t wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (POSE_LDS_THREADS / MAD_WAVE) + (threadIdx.x >> 6)));
     const int64_t nwaves = (int64_t)gridDim.x * (POSE_LDS_THREADS / MAD_WAVE);
@@ -726,10 +737,11 @@ __global__ __launch_bounds__(POSE_LDS_THREADS) void k_pose_lds32(const int32_t *
         PoseVox V;
         pose_vox_setup(R, ph0, ph1, ph2, pl0, pl1, pl2, B, &V);
         auto cloud32 = [&](int a, float &cx, float &cy, float &cz) {
-            cx = (float)hi_cloud[3 * a]; cy = (float)hi_cloud[3 * a + 1]; cz = (float)hi_cloud[3 * a + 2];
+            if (HI_LDS) { const float4 c = clf[a]; cx = c.x; cy = c.y; cz = c.z; }
+            else { cx = (float)hi_cloud[3 * a]; cy = (float)hi_cloud[3 * a + 1]; cz = (float)hi_cloud[3 * a + 2]; }
         };
         auto exact = [&](int a) -> bool {
-            const double d0 = hi_cloud[3 * a] - ph0, d1 = hi_cloud[3 * a + 1] - ph1, d2 = hi_cloud[3 * a + 2] - ph2;
+            const double d0 = hc[3 * a] - ph0, d1 = hc[3 * a + 1] - ph1, d2 = hc[3 * a + 2] - ph2;
             const double x = (d0 * R[0] + d1 * R[1] + d2 * R[2]) + pl0;      // MaD.py:440-444
             const double y = (d0 * R[3] + d1 * R[4] + d2 * R[5]) + pl1;
             const double z = (d0 * R[6] + d1 * R[7] + d2 * R[8]) + pl2;
@@ -1205,6 +1217,8 @@ static int pose_device(mad_ctx *ctx, const Side &hi, const Side &lo, int32_t *d_
     const size_t stacks = (size_t)(POSE_LDS_THREADS / MAD_WAVE) * POSE_WAVE_LDS;      // k_pose_lds: per-wave queue + two pair records
     const size_t stacks32 = (size_t)(POSE_LDS_THREADS / MAD_WAVE) * POSE_STACK * 2;   // k_pose_lds32: per-wave survivor stack only
     const size_t lds32 = (size_t)(n_cloud + 1) * 16 + pad16((size_t)(G.ncell + 1) * 2) + stacks32 + 16;
+    const size_t lds32_hi = lds32 + pad16((size_t)l_hi_max * 24) + (size_t)l_hi_max * 16;      // with the hi cloud in LDS as well
+    const bool hi_in_lds = lds32_hi <= 150 * 1024;
     // occupancy bitmap of the lo cloud (k_pose_bits), in global memory: voxel edge MAD_POSE_VOXEL (default 0.8 A: 0.6-0.8 measure the same, 1.0 is 3 % slower) unless that
     // needs more than 16 MB.  It was tried in LDS too: there it has to be coarser (1.7 A beside the C3 clouds), lets 74
     // instead of 57 points per pair through, and the second round of the exact search that this costs outweighs the
@@ -1246,7 +1260,8 @@ static int pose_device(mad_ctx *ctx, const Side &hi, const Side &lo, int32_t *d_
         if (!fits64) MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_PG_PTSF), (size_t)(n_cloud + 2) * 16));
         static bool attr_set = false;
         if (!attr_set) {
-            MAD_HIP(hipFuncSetAttribute((const void *)k_pose_lds32, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            MAD_HIP(hipFuncSetAttribute((const void *)k_pose_lds32<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            MAD_HIP(hipFuncSetAttribute((const void *)k_pose_lds32<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             MAD_HIP(hipFuncSetAttribute((const void *)k_pose_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             MAD_HIP(hipFuncSetAttribute((const void *)k_pose_grid_build, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
             attr_set = true;
@@ -1274,10 +1289,15 @@ static int pose_device(mad_ctx *ctx, const Side &hi, const Side &lo, int32_t *d_
             hipLaunchKernelGGL(k_pose_lds, dim3(ctx->n_cu * (lds > 80 * 1024 ? 1 : pose_wgs_per_cu())), dim3(POSE_LDS_THREADS), lds, ctx->stream, d_status, cap_pairs, d_rec,
                                d_hi_cloud, scratch<double>(ctx, S_PG_PTS), scratch<int32_t>(ctx, S_PG_START), d_start16, G,
                                l_hi_max, n_cloud, (float)reach, dd_lim, B, d_bits, scratch<int32_t>(ctx, S_COUNTS));
-        else
-            hipLaunchKernelGGL(k_pose_lds32, dim3(ctx->n_cu), dim3(POSE_LDS_THREADS), lds32, ctx->stream, d_status, cap_pairs, d_rec,
+        else if (hi_in_lds)
+            hipLaunchKernelGGL(k_pose_lds32<true>, dim3(ctx->n_cu), dim3(POSE_LDS_THREADS), lds32_hi, ctx->stream, d_status, cap_pairs, d_rec,
                                d_hi_cloud, scratch<double>(ctx, S_PG_PTS), scratch<float4>(ctx, S_PG_PTSF),
-                               scratch<int32_t>(ctx, S_PG_START), d_start16, G, n_cloud, (float)reach, dd_lim, lim_in, lim_out, B, d_bits,
+                               scratch<int32_t>(ctx, S_PG_START), d_start16, G, n_cloud, l_hi_max, (float)reach, dd_lim, lim_in, lim_out, B, d_bits,
+                               scratch<int32_t>(ctx, S_COUNTS));
+        else
+            hipLaunchKernelGGL(k_pose_lds32<false>, dim3(ctx->n_cu), dim3(POSE_LDS_THREADS), lds32, ctx->stream, d_status, cap_pairs, d_rec,
+                               d_hi_cloud, scratch<double>(ctx, S_PG_PTS), scratch<float4>(ctx, S_PG_PTSF),
+                               scratch<int32_t>(ctx, S_PG_START), d_start16, G, n_cloud, l_hi_max, (float)reach, dd_lim, lim_in, lim_out, B, d_bits,
                                scratch<int32_t>(ctx, S_COUNTS));
         mad_timer_end(ctx, MAD_T_POSE);
         MAD_HIP(hipGetLastError());
