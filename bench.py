@@ -158,21 +158,34 @@ def hot_path_step(lib, the_map, subs, cc, dist, k, sets):
 
 
 def run_steps(lib, the_map, subs, cc, dist, k, set_groups, n_steps, after_step=None):
-    """n_steps steps, two in flight: while the matches of step i run, the host already enqueues the builds of step i + 1
-    into the other group of device sets, so the device does not idle over the host's turn-around between steps.  Every
-    step does the same work as hot_path_step; `after_step(tops)` is called once per step, in order."""
-    out = None
+    """n_steps steps with len(set_groups) of them in flight (2 or 3): while the matches of step i run, the host already
+    enqueues the builds of step i + 1 into the next group of device sets and, with three groups, the matches of step i are
+    only collected after those of step i + 1 have been enqueued (two open match brackets), so the device does not idle over
+    the host's turn-around between steps.  Every step does the same work as hot_path_step; `after_step(tops)` is called once
+    per step, in order."""
+    depth = len(set_groups)
+    lag = depth - 2      # how many steps behind the enqueue front the results are collected
+    out, open_steps = None, []
     built = enqueue_builds(lib, the_map, subs, set_groups[0]) if n_steps > 0 else None
+
+    def finish_oldest():
+        handle, his = open_steps.pop(0)
+        res = collect(lib, handle, his)
+        if after_step is not None:
+            after_step(res[1])
+        return res
+
     for i in range(n_steps):
         lo, his = built
         t0 = time.perf_counter()
-        handle = lib.match_topk_many_begin(his, lo, cc, dist, k)
+        open_steps.append((lib.match_topk_many_begin(his, lo, cc, dist, k), his))
         HOST_T["match_enqueue"] = HOST_T.get("match_enqueue", 0.0) + time.perf_counter() - t0
-        if i + 1 < n_steps:
-            built = enqueue_builds(lib, the_map, subs, set_groups[(i + 1) % 2])
-        out = collect(lib, handle, his)
-        if after_step is not None:
-            after_step(out[1])
+        if i + 1 < n_steps:      # its group was last read by step i + 1 - depth, collected by now
+            built = enqueue_builds(lib, the_map, subs, set_groups[(i + 1) % depth])
+        if len(open_steps) > lag:
+            out = finish_oldest()
+    while open_steps:
+        out = finish_oldest()
     return out
 
 
@@ -268,6 +281,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--in-flight", type=int, default=3, choices=(2, 3), help="steps in flight (groups of device sets)")
     ap.add_argument("--serial", action="store_true", help="lanes serialised for the whole run: the mode the rocprofv3 summaries in profiles/ are "
                     "taken in, so that a kernel's average duration there is the one the roofline pass measures")
     args = ap.parse_args()
@@ -319,7 +333,7 @@ def main():
         from mad_amd import dist as mdist
         return mdist.TopkExchange(tops, k, world * W["n_sub"], rank, world)
 
-    set_groups = [[_lib.DeviceSet(lib) for _ in range(1 + len(subs))] for _ in range(2)]
+    set_groups = [[_lib.DeviceSet(lib) for _ in range(1 + len(subs))] for _ in range(args.in_flight)]
     sets = set_groups[0]
     if args.serial:
         lib.set_overlap(False)
@@ -464,7 +478,7 @@ def main():
                        "subunit_anchors": anchors_hi, "subunit_rows": rows_hi, "pairs_over_cc": pairs,
                        "cc_threshold": cc, "top_k": k, "correlations_per_step_per_gpu": corr,
                        "parallelism": "1 process per GPU, subunits sharded, RCCL all-gather of top-k" if world > 1 else "single GPU",
-                       "pipelining": "2 steps in flight: the builds of step i+1 are enqueued before the results of step i are awaited; every step does the full work",
+                       "pipelining": "%d steps in flight: the builds (and, with 3, the matches) of the next step are enqueued before the results of a step are awaited; every step does the full work" % args.in_flight,
                        "topk_agrees_with_cpu_oracle": agree, "setup_s": t_setup,
                        "setup_detail_s": {k_: round(v, 4) for k_, v in SETUP_T.items()}},
             "roofline": roof,

@@ -203,7 +203,8 @@ int mad_match_topk_many(mad_ctx *ctx, int n, const mad_set *const *hi, const mad
  * (the output arrays belong to the bracket until _finish returns: _finish fills them; _begin itself only does so for a
  * match whose lane it has to reuse, n > 8).  Between the two the caller may enqueue other work -- typically
  * mad_set_build of the NEXT batch into other sets: sets read by the open bracket must not be rebuilt or destroyed, and
- * no other match call may be made.  One bracket at a time per ctx.
+ * no other match call may be made.  Up to two brackets may be open at once (each has its own pinned result staging);
+ * _finish completes the older one.
  */
 int mad_match_topk_many_begin(mad_ctx *ctx, int n, const mad_set *const *hi, const mad_set *lo, double cc, double dist,
                               int64_t k, double *results, int64_t *pair_index, int64_t *n_out, int64_t *stats);

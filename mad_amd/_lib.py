@@ -426,10 +426,15 @@ class Lib(object):
         arr = (C.c_void_p * max(n, 1))(*[x.h.value for x in his])
         self._chk(self.dll.mad_match_topk_many_begin(self.ctx, C.c_int(n), arr, lo.h, C.c_double(cc), C.c_double(dist), C.c_int64(k),
                                                      _p(h["res"]), _p(h["idx"]), _p(h["n_out"]), _p(h["stats"])))
+        self._open_brackets = getattr(self, "_open_brackets", []) + [h]      # at most two; they finish in the order they began
         return h
 
     def match_topk_many_finish(self, h):
+        pending = getattr(self, "_open_brackets", [])
+        if not pending or pending[0] is not h:
+            raise MadBackendError("MaD> match_topk_many_finish: brackets finish in the order they were begun")
         self._chk(self.dll.mad_match_topk_many_finish(self.ctx))
+        self._open_brackets = pending[1:]
         out = []
         for i in range(h["n"]):
             g = int(h["n_out"][i])

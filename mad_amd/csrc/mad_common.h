@@ -144,16 +144,20 @@ struct mad_ctx {
     // named grow-only scratch buffers
     DevBuf scratch[64 * MAD_LANES];   // MAD_LANES independent copies: matches in flight do not share scratch
     int lane = 0;                    // the copy the current call works in
-    hipEvent_t lane_done[MAD_LANES]; // recorded behind the last operation enqueued in each lane
-    void *host_res[MAD_LANES] = {};   // pinned staging of a match's results / indices / status
-    size_t host_res_cap[MAD_LANES] = {};
+    // two result slots per lane: one per open mad_match_topk_many bracket, so that a second batch of matches can be enqueued
+    // (and deliver into its own pinned staging) before the first one has been collected
+    hipEvent_t lane_done[2][MAD_LANES]; // recorded behind the last operation a bracket enqueued in each lane
+    void *host_res[2][MAD_LANES] = {};   // pinned staging of a match's results / indices / status
+    size_t host_res_cap[2][MAD_LANES] = {};
+    int res_slot = 0;                    // the slot the match calls below read and write
     // host pinned staging for small read-backs
     int64_t *pinned = nullptr;     // 1024 slots: [16 * lane ..] read-backs of the lane, [64..] two per mad_set
     int next_pinned = 64;
     DensityDev dens;
     MatchState match;
     int last_pose_kernel = -1;               // 0 k_pose_lds, 1 k_pose_lds32, 2 k_pose (mad_last_pose_kernel)
-    void *many = nullptr;                    // open mad_match_topk_many_begin bracket (ManyState, mad_match.hip)
+    void *many[2] = {nullptr, nullptr};      // open mad_match_topk_many_begin brackets (ManyState, mad_match.hip), by result slot
+    int many_oldest = 0;                     // the slot _finish collects next when both are open
     bool timing = false;
     TimerGroup timers[MAD_T_COUNT];
     int n_cu = 256;

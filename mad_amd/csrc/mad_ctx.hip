@@ -81,7 +81,8 @@ extern "C" int mad_init(int device, mad_ctx **out) {
             (void)hipEventCreate(&ctx->timers[g].start[i]);
             (void)hipEventCreate(&ctx->timers[g].stop[i]);
         }
-    for (int l = 0; l < MAD_LANES; l++) (void)hipEventCreateWithFlags(&ctx->lane_done[l], hipEventDisableTiming);
+    for (int r = 0; r < 2; r++)
+        for (int l = 0; l < MAD_LANES; l++) (void)hipEventCreateWithFlags(&ctx->lane_done[r][l], hipEventDisableTiming);
     *out = ctx;
     return MAD_OK;
 }
@@ -106,8 +107,10 @@ extern "C" void mad_destroy(mad_ctx *ctx) {
             (void)hipEventDestroy(ctx->timers[g].stop[i]);
         }
     for (int l = 0; l < MAD_LANES; l++) {
-        (void)hipEventDestroy(ctx->lane_done[l]);
-        if (ctx->host_res[l]) (void)hipHostFree(ctx->host_res[l]);
+        for (int r = 0; r < 2; r++) {
+            (void)hipEventDestroy(ctx->lane_done[r][l]);
+            if (ctx->host_res[r][l]) (void)hipHostFree(ctx->host_res[r][l]);
+        }
     }
     for (int l = 0; l < MAD_LANES; l++)
         if (ctx->lane_stream[l]) (void)hipStreamDestroy(ctx->lane_stream[l]);

@@ -1783,8 +1783,8 @@ static int match_enqueue(mad_ctx *ctx, const mad_set *hi, const mad_set *lo, dou
                        st, H.p, H.R, H.meta, L.p, L.Rinv, L.meta, H.row_anchor, L.row_anchor, scratch<double>(ctx, S_RESULTS), 1);
     MAD_HIP(hipGetLastError());
     // rows, pair ranks and status come back in ONE copy into pinned memory: the host is never blocked by it
-    MAD_HIP(hipMemcpyAsync(ctx->host_res[ctx->lane], mad_sb(ctx, S_RESULTS).p, tail_bytes(P.k), hipMemcpyDeviceToHost, ctx->stream));
-    MAD_HIP(hipEventRecord(ctx->lane_done[ctx->lane], ctx->stream));
+    MAD_HIP(hipMemcpyAsync(ctx->host_res[ctx->res_slot][ctx->lane], mad_sb(ctx, S_RESULTS).p, tail_bytes(P.k), hipMemcpyDeviceToHost, ctx->stream));
+    MAD_HIP(hipEventRecord(ctx->lane_done[ctx->res_slot][ctx->lane], ctx->stream));
     return MAD_OK;
 }
 
@@ -1796,15 +1796,15 @@ static int match_prepare(mad_ctx *ctx, const mad_set *hi, const mad_set *lo, dou
     MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_HI_CLOUD), (size_t)hi->n_anchors * 24 + 24));
     MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_SEL_OUT), (size_t)(P->k + 8) * 8));
     MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_RESULTS), tail_bytes(P->k) + 64));
-    if (ctx->host_res_cap[ctx->lane] < tail_bytes(P->k)) {
-        if (ctx->host_res[ctx->lane]) {
+    if (ctx->host_res_cap[ctx->res_slot][ctx->lane] < tail_bytes(P->k)) {
+        if (ctx->host_res[ctx->res_slot][ctx->lane]) {
             MAD_HIP(hipStreamSynchronize(ctx->stream));
-            (void)hipHostFree(ctx->host_res[ctx->lane]);
-            ctx->host_res[ctx->lane] = nullptr;
+            (void)hipHostFree(ctx->host_res[ctx->res_slot][ctx->lane]);
+            ctx->host_res[ctx->res_slot][ctx->lane] = nullptr;
         }
         const size_t want = tail_bytes(P->k) * 2;
-        if (hipHostMalloc(&ctx->host_res[ctx->lane], want) != hipSuccess) return mad_fail(ctx, MAD_ENOMEM, "pinned result staging of %zu bytes", want);
-        ctx->host_res_cap[ctx->lane] = want;
+        if (hipHostMalloc(&ctx->host_res[ctx->res_slot][ctx->lane], want) != hipSuccess) return mad_fail(ctx, MAD_ENOMEM, "pinned result staging of %zu bytes", want);
+        ctx->host_res_cap[ctx->res_slot][ctx->lane] = want;
     }
     // capacity hints: the score matrix for ~8 rows per anchor, pairs for 2 % of the matrix; both grow on demand
     const int64_t full_c = (mad_ceil_div(hi->cap_rows, 128) * 128) * (mad_ceil_div(lo->cap_rows, 128) * 128);
@@ -1830,7 +1830,7 @@ static int match_prepare(mad_ctx *ctx, const mad_set *hi, const mad_set *lo, dou
 // larger capacities (updated in P), 0 when it is final (outputs filled), negative on error.
 static int match_finish(mad_ctx *ctx, int lane, const mad_set *hi, const mad_set *lo, MatchPlan *P, double *results,
                         int64_t *pair_index, int64_t *n_out, int64_t *stats) {
-    const char *base = (const char *)ctx->host_res[lane];
+    const char *base = (const char *)ctx->host_res[ctx->res_slot][lane];
     const int64_t *h_idx = (const int64_t *)(base + (size_t)P->k * MAD_RESULT_COLS * 8);
     const int32_t *hs = (const int32_t *)(h_idx + P->k);
     if (hs[ST_NHI + 3] || hs[ST_NLO + 3]) {
@@ -1909,13 +1909,15 @@ struct ManyState {
     int64_t *pair_index = nullptr, *n_out = nullptr, *stats = nullptr;
     MatchPlan plans[MAD_LANES];
     int pending[MAD_LANES];
+    int slot = 0;      // result slot (pinned staging + completion events) of this bracket
 };
 
 static int many_retire(mad_ctx *ctx, ManyState &M, int lane) {
     const int i = M.pending[lane];
     if (i < 0) return MAD_OK;
     M.pending[lane] = -1;
-    MAD_HIP(hipEventSynchronize(ctx->lane_done[lane]));
+    ctx->res_slot = M.slot;
+    MAD_HIP(hipEventSynchronize(ctx->lane_done[M.slot][lane]));
     double *res_i = M.results ? M.results + (size_t)i * M.k * MAD_RESULT_COLS : nullptr;
     int64_t *idx_i = M.pair_index ? M.pair_index + (size_t)i * M.k : nullptr;
     int64_t *st_i = M.stats ? M.stats + 4 * i : nullptr;
@@ -1933,14 +1935,17 @@ static int many_retire(mad_ctx *ctx, ManyState &M, int lane) {
 extern "C" int mad_match_topk_many_begin(mad_ctx *ctx, int n, const mad_set *const *hi, const mad_set *lo, double cc, double dist, int64_t k,
                                          double *results, int64_t *pair_index, int64_t *n_out, int64_t *stats) {
     if (!ctx || !hi || !lo || !n_out || n < 0) return MAD_EINVAL;
-    if (ctx->many) return mad_fail(ctx, MAD_EINVAL, "mad_match_topk_many_begin: the previous call has not been finished");
+    if (ctx->many[0] && ctx->many[1]) return mad_fail(ctx, MAD_EINVAL, "mad_match_topk_many_begin: two brackets are open already");
     if (k < 1) k = 1;
     ManyState *Mp = new ManyState();
     ManyState &M = *Mp;
+    M.slot = ctx->many[0] ? 1 : 0;
+    if (!ctx->many[0] && !ctx->many[1]) ctx->many_oldest = M.slot;
+    ctx->res_slot = M.slot;
     M.n = n; M.hi.assign(hi, hi + n); M.lo = lo; M.cc = cc; M.dist = dist; M.k = k;
     M.results = results; M.pair_index = pair_index; M.n_out = n_out; M.stats = stats;
     for (int l = 0; l < MAD_LANES; l++) M.pending[l] = -1;
-    ctx->many = Mp;
+    ctx->many[M.slot] = Mp;
     int rc_all = MAD_OK;
     for (int i = 0; i < n && rc_all == MAD_OK; i++) {
         n_out[i] = 0;
@@ -1959,10 +1964,13 @@ extern "C" int mad_match_topk_many_begin(mad_ctx *ctx, int n, const mad_set *con
     mad_use_lane(ctx, ctx->match.lane);
     if (rc_all != MAD_OK) {      // leave nothing in flight behind a failed call
         for (int l = 0; l < MAD_LANES; l++)
-            if (M.pending[l] >= 0) { (void)hipEventSynchronize(ctx->lane_done[l]); M.pending[l] = -1; }
+            if (M.pending[l] >= 0) { (void)hipEventSynchronize(ctx->lane_done[M.slot][l]); M.pending[l] = -1; }
+        const int slot = M.slot;
         delete Mp;
-        ctx->many = nullptr;
+        ctx->many[slot] = nullptr;
+        ctx->many_oldest = slot ^ 1;
     }
+    ctx->res_slot = 0;
     return rc_all;
 }
 
@@ -1970,21 +1978,25 @@ extern "C" int mad_last_pose_kernel(mad_ctx *ctx) { return ctx ? ctx->last_pose_
 
 extern "C" int mad_match_topk_many_finish(mad_ctx *ctx) {
     if (!ctx) return MAD_EINVAL;
-    if (!ctx->many) return mad_fail(ctx, MAD_EINVAL, "mad_match_topk_many_finish: nothing was begun");
-    ManyState *Mp = (ManyState *)ctx->many;
+    if (!ctx->many[0] && !ctx->many[1]) return mad_fail(ctx, MAD_EINVAL, "mad_match_topk_many_finish: nothing was begun");
+    const int slot = ctx->many[ctx->many_oldest] ? ctx->many_oldest : ctx->many_oldest ^ 1;      // the older of the open brackets
+    ManyState *Mp = (ManyState *)ctx->many[slot];
     int rc_all = MAD_OK;
     for (int l = 0; l < MAD_LANES; l++) {
         const int rc = many_retire(ctx, *Mp, l);
         if (rc_all == MAD_OK) rc_all = rc;
     }
     delete Mp;
-    ctx->many = nullptr;
+    ctx->many[slot] = nullptr;
+    ctx->many_oldest = slot ^ 1;
+    ctx->res_slot = 0;
     mad_use_lane(ctx, ctx->match.lane);
     return rc_all;
 }
 
 void mad_many_abandon(mad_ctx *ctx) {      // mad_destroy: a bracket left open
-    if (ctx && ctx->many) { delete (ManyState *)ctx->many; ctx->many = nullptr; }
+    for (int r = 0; ctx && r < 2; r++)
+        if (ctx->many[r]) { delete (ManyState *)ctx->many[r]; ctx->many[r] = nullptr; }
 }
 
 extern "C" int mad_match_topk_many(mad_ctx *ctx, int n, const mad_set *const *hi, const mad_set *lo, double cc, double dist, int64_t k,

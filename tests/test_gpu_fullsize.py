@@ -48,20 +48,24 @@ def test_full_size_properties(lib, workload):
                 np.testing.assert_array_equal(s.download()["dsc"], r)
         # two steps in flight (bench.run_steps: the builds of step i + 1 are enqueued between match_topk_many_begin and
         # _finish of step i, into a second group of sets): every step must still give the serial result
-        groups = [sets, [_lib.DeviceSet(lib) for _ in range(1 + len(subs))]]
+        groups = [sets, [_lib.DeviceSet(lib) for _ in range(1 + len(subs))], [_lib.DeviceSet(lib) for _ in range(1 + len(subs))]]
         try:
-            seen = []
-            corr3, tops3, _ = bench.run_steps(lib, the_map, subs, cc, dist, k, groups, 5 if workload != "c5" else 3,
-                                              after_step=lambda t: seen.append([x.copy() for x in t]))
-            assert corr3 == corr and len(seen) == (5 if workload != "c5" else 3)
-            for step_tops in seen:
-                for a, b in zip(tops, step_tops):
-                    np.testing.assert_array_equal(a, b)
-            for s, r in zip(groups[1], ref_dsc):
-                np.testing.assert_array_equal(s.download()["dsc"], r)
+            for depth in (2, 3):      # 3: two match brackets open at once, each with its own result staging
+                seen = []
+                n_steps = 6 if workload != "c5" else 4
+                corr3, tops3, _ = bench.run_steps(lib, the_map, subs, cc, dist, k, groups[:depth], n_steps,
+                                                  after_step=lambda t: seen.append([x.copy() for x in t]))
+                assert corr3 == corr and len(seen) == n_steps
+                for step_tops in seen:
+                    for a, b in zip(tops, step_tops):
+                        np.testing.assert_array_equal(a, b)
+                for grp in groups[1:depth]:
+                    for s, r in zip(grp, ref_dsc):
+                        np.testing.assert_array_equal(s.download()["dsc"], r)
         finally:
-            for s in groups[1]:
-                s.close()
+            for grp in groups[1:]:
+                for s in grp:
+                    s.close()
         # descriptor invariants (Descriptor.py:193-198): counts of <= 64 samples per sub-cube, <= 4096 per row
         for s in sets:
             rows = s.download()
