@@ -225,52 +225,58 @@ def refine_ccc_leg(lib, the_map, subs, tops, W, n_cand=8):
                 note="mad_refine + mad_density_ccc (one host round trip each per batch); not part of the headline metric")
 
 
-def cpu_baseline(the_map, sub, cc, dist, k, lib, n_lo_anchor=800, n_hi_anchor=250, threads=1):
-    """The CPU oracle on a bounded sample of the same workload: base-octave anchors only.  threads > 1: the same
-    scalar C functions on contiguous chunks of the work in that many host threads (oracle.py, *_mt)."""
+def cpu_baseline(the_map, subs, cc, dist, k, lib, n_lo_anchor=800, n_hi_anchor=250, threads=1):
+    """The CPU oracle on a bounded sample of the same workload: the base-octave anchors of the map and of every subunit (the
+    map described once, every subunit docked into it: ~10 s on one core).  threads > 1: the same scalar C functions on
+    contiguous chunks of the work in that many host threads (oracle.py, *_mt)."""
     from mad_amd.eqsp import EQSP_Sphere
     from oracle import oracle as O
     e112, e16 = EQSP_Sphere(112), EQSP_Sphere(16)
 
-    def sample(st, n):
+    def described(st, n):
         sel = np.flatnonzero(st.octave == 1)[:n]
         g = st.base_gradient()
-        return g[0], g[1], g[2], st.coords[sel], st.subv[sel], sel
+        coords, subv = st.coords[sel], st.subv[sel]
+        rows = O.orient_mt(g[0], g[1], g[2], 1, coords, e112.sphere_eqsp, e112.p_centers_eqsp, threads, want_counts=False)
+        dsc = O.describe_mt(g[0], g[1], g[2], 1, coords[rows["anchor"]], rows["R"], e16.sphere_eqsp, threads)
+        return dict(rows=rows, dsc=dsc, subv=subv, coords=coords)
 
-    out = {}
     t0 = time.perf_counter()
-    sets = []
-    for st, n in ((the_map, n_lo_anchor), (sub, n_hi_anchor)):
-        gx, gy, gz, coords, subv, sel = sample(st, n)
-        rows = O.orient_mt(gx, gy, gz, 1, coords, e112.sphere_eqsp, e112.p_centers_eqsp, threads, want_counts=False)
-        dsc = O.describe_mt(gx, gy, gz, 1, coords[rows["anchor"]], rows["R"], e16.sphere_eqsp, threads)
-        sets.append(dict(rows=rows, dsc=dsc, subv=subv, coords=coords, sel=sel))
-    lo_s, hi_s = sets
-    ph, pl, ps, _ = O.correlate_mt(hi_s["dsc"], lo_s["dsc"], cc, threads)
-    hi_p, lo_p = hi_s["subv"][hi_s["rows"]["anchor"]], lo_s["subv"][lo_s["rows"]["anchor"]]
-    order = np.zeros(0, np.int64)
-    if len(ph):
-        hi_cloud = np.unique(hi_p[np.unique(ph)], axis=0)
-        lo_cloud = np.unique(lo_p[np.unique(pl)], axis=0)
-        meta_h = np.stack([hi_s["rows"]["anchor"], np.ones_like(hi_s["rows"]["anchor"]), hi_s["rows"]["main"]], 1)
-        meta_l = np.stack([lo_s["rows"]["anchor"], np.ones_like(lo_s["rows"]["anchor"]), lo_s["rows"]["main"]], 1)
-        res, cnt = O.pose_score_mt(ph, pl, ps, hi_p, hi_s["rows"]["R"], meta_h, lo_p, lo_s["rows"]["R"], meta_l, hi_cloud, lo_cloud, dist, threads)
-        order = O.topk(cnt, k)
+    lo_s = described(the_map, n_lo_anchor)
+    lo_p = lo_s["subv"][lo_s["rows"]["anchor"]]
+    meta_l = np.stack([lo_s["rows"]["anchor"], np.ones_like(lo_s["rows"]["anchor"]), lo_s["rows"]["main"]], 1)
+    his, n_corr, n_pairs = [], 0, 0
+    for sub in subs:
+        hi_s = described(sub, n_hi_anchor)
+        ph, pl, ps, _ = O.correlate_mt(hi_s["dsc"], lo_s["dsc"], cc, threads)
+        hi_s["pairs"], hi_s["order"], hi_s["res"] = len(ph), np.zeros(0, np.int64), None
+        if len(ph):
+            hi_p = hi_s["subv"][hi_s["rows"]["anchor"]]
+            meta_h = np.stack([hi_s["rows"]["anchor"], np.ones_like(hi_s["rows"]["anchor"]), hi_s["rows"]["main"]], 1)
+            res, cnt = O.pose_score_mt(ph, pl, ps, hi_p, hi_s["rows"]["R"], meta_h, lo_p, lo_s["rows"]["R"], meta_l,
+                                       np.unique(hi_p[np.unique(ph)], axis=0), np.unique(lo_p[np.unique(pl)], axis=0), dist, threads)
+            hi_s["order"], hi_s["res"] = O.topk(cnt, k), res
+        n_corr += len(hi_s["dsc"]) * len(lo_s["dsc"])
+        n_pairs += len(ph)
+        his.append(hi_s)
     dt = time.perf_counter() - t0
-    n_corr = len(hi_s["dsc"]) * len(lo_s["dsc"])
-    # the same sample through the GPU path: top-k pose agreement (identity and order)
-    agree = None
-    if len(ph):
-        lo_d = lib.set_build(the_map.slots, lo_s["coords"], np.ones(len(lo_s["coords"]), np.int32), lo_s["subv"], np.arange(len(lo_s["coords"])))
+    # the same sample through the GPU path: top-k pose agreement (identity and order) for every subunit
+    lo_d = lib.set_build(the_map.slots, lo_s["coords"], np.ones(len(lo_s["coords"]), np.int32), lo_s["subv"], np.arange(len(lo_s["coords"])))
+    agree = True
+    for sub, hi_s in zip(subs, his):
+        if not hi_s["pairs"]:
+            continue
         hi_d = lib.set_build(sub.slots, hi_s["coords"], np.ones(len(hi_s["coords"]), np.int32), hi_s["subv"], np.arange(len(hi_s["coords"])))
         top, idx, st = lib.match_topk(hi_d, lo_d, cc, dist, k)
-        agree = bool(st["n_pairs"] == len(ph) and np.array_equal(idx, order) and np.array_equal(top[:, 1], res[order][:, 1]))
-        lo_d.close()
+        agree = agree and bool(st["n_pairs"] == hi_s["pairs"] and np.array_equal(idx, hi_s["order"]) and
+                               np.array_equal(top[:, 1], hi_s["res"][hi_s["order"]][:, 1]))
         hi_d.close()
+    lo_d.close()
     out = dict(value=n_corr / dt, unit="correlations/s", cores=threads, kind="port",
-               sample="CPU oracle (scalar C, %d thread%s) on %d map x %d subunit base-octave anchors of the same workload: "
-                      "%d x %d rows, %d pairs, %.1f s" % (threads, "" if threads == 1 else "s", len(lo_s["coords"]), len(hi_s["coords"]),
-                                                        len(hi_s["dsc"]), len(lo_s["dsc"]), len(ph), dt))
+               sample="CPU oracle (scalar C, %d thread%s) on the base-octave anchors of the same workload: %d map anchors (%d rows) x %d subunits of "
+                      "%s anchors (%d rows), %d pairs over cc, %.1f s" % (threads, "" if threads == 1 else "s", len(lo_s["coords"]), len(lo_s["dsc"]),
+                                                                          len(subs), "/".join(str(len(h["coords"])) for h in his),
+                                                                          sum(len(h["dsc"]) for h in his), n_pairs, dt))
     return out, agree
 
 
@@ -452,11 +458,11 @@ def main():
 
         cpu, agree, cpu_all = (None, None, None)
         if world == 1 and not args.no_cpu_baseline:
-            cpu, agree = cpu_baseline(the_map, subs[0], cc, dist_thr, k, lib)
+            cpu, agree = cpu_baseline(the_map, subs, cc, dist_thr, k, lib)
             n_host = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
             n_host = min(n_host, 16)      # a one-GPU box's CPU share
             if n_host > 1:      # the same sample on the host cores of this box's share
-                cpu_all, agree_all = cpu_baseline(the_map, subs[0], cc, dist_thr, k, lib, threads=n_host)
+                cpu_all, agree_all = cpu_baseline(the_map, subs, cc, dist_thr, k, lib, threads=n_host)
                 agree = bool(agree and agree_all)
         refine_line = None
         if world == 1:

@@ -170,7 +170,7 @@ struct mad_set {
     // per anchor: views into anc_blob = [dev_n 64 B][subv n x 3 f64][coords n x 3 i32][octave n i32][index n i32], which one
     // copy from the pinned staging buffer fills (a copy from pageable memory would block the host on the stream)
     DevBuf anc_blob;
-    DevBuf anc_coords, anc_octave, anc_subv, anc_index;
+    DevBuf anc_coords, anc_octave, anc_subv, anc_index, anc_canon;      // views into anc_blob
     void *host_stage = nullptr;
     size_t host_stage_cap = 0;
     hipEvent_t uploaded = nullptr;      // recorded behind the staging copy: the buffer may be rewritten after it

@@ -244,7 +244,8 @@ __global__ __launch_bounds__(256) void k_pair_emit(const int32_t *__restrict__ C
                                                    const int32_t *__restrict__ row_off, int64_t cap_pairs,
                                                    int32_t *__restrict__ pair_hi, int32_t *__restrict__ pair_lo,
                                                    double *__restrict__ pair_score, const int32_t *__restrict__ hi_row_anchor,
-                                                   const int32_t *__restrict__ lo_row_anchor, uint8_t *__restrict__ used_hi,
+                                                   const int32_t *__restrict__ lo_row_anchor, const int32_t *__restrict__ hi_canon,
+                                                   const int32_t *__restrict__ lo_canon, uint8_t *__restrict__ used_hi,
                                                    uint8_t *__restrict__ used_lo, int32_t *__restrict__ status) {
     __shared__ int wt[5];
     if (status[ST_FLAG_C]) return;
@@ -270,12 +271,12 @@ __global__ __launch_bounds__(256) void k_pair_emit(const int32_t *__restrict__ C
                 pair_hi[o] = (int32_t)i;
                 pair_lo[o] = (int32_t)j;
                 pair_score[o] = corr_score(C[i * ldc + j], nh, ln[j]);
-                if (used_lo) used_lo[lo_row_anchor ? lo_row_anchor[j] : j] = 1;
+                if (used_lo) { const int a = lo_row_anchor ? lo_row_anchor[j] : (int)j; used_lo[lo_canon ? lo_canon[a] : a] = 1; }
                 o++;
             }
             base += tot;
         }
-        if (threadIdx.x == 0 && used_hi) used_hi[hi_row_anchor ? hi_row_anchor[i] : i] = 1;
+        if (threadIdx.x == 0 && used_hi) { const int a = hi_row_anchor ? hi_row_anchor[i] : (int)i; used_hi[hi_canon ? hi_canon[a] : a] = 1; }
     }
 }
 
@@ -1148,6 +1149,7 @@ struct Side {      // one side of a match, all device pointers
     const double *Rinv;         // per row
     const int32_t *meta;        // per row x 3
     const int32_t *row_anchor;  // row -> entry of `p` (nullptr: identity)
+    const int32_t *anc_canon;   // anchor -> first anchor with the same coordinates (nullptr: identity)
     const double *p;            // sub-voxel coordinates (per anchor, or per row when row_anchor == nullptr)
     const int32_t *n_rows;      // device
     int64_t cap_rows;           // upper bound of *n_rows
@@ -1177,7 +1179,8 @@ static int correlate_device(mad_ctx *ctx, const Side &hi, const Side &lo, int D,
     mad_scan_small(ctx, scratch<int32_t>(ctx, S_ROWCNT), scratch<int32_t>(ctx, S_ROWOFF), hi.n_rows, d_status + ST_NPAIRS);
     hipLaunchKernelGGL(k_pair_emit, dim3(ctx->n_cu * 8), dim3(256), 0, ctx->stream, C, mask, hi.n_rows, lo.n_rows, hi.norm, lo.norm,
                        scratch<int32_t>(ctx, S_ROWOFF), cap_pairs, scratch<int32_t>(ctx, S_PAIR_HI), scratch<int32_t>(ctx, S_PAIR_LO),
-                       scratch<double>(ctx, S_PAIR_SCORE), hi.row_anchor, lo.row_anchor, d_used_hi, d_used_lo, d_status);
+                       scratch<double>(ctx, S_PAIR_SCORE), hi.row_anchor, lo.row_anchor, hi.anc_canon, lo.anc_canon, d_used_hi, d_used_lo,
+                       d_status);
     mad_timer_end(ctx, MAD_T_PAIRS);
     MAD_HIP(hipGetLastError());
     return MAD_OK;
@@ -1371,8 +1374,8 @@ extern "C" int mad_correlate(mad_ctx *ctx, const int16_t *hi, int64_t n_hi, cons
     MAD_TRY(stage_rows(ctx, hi, n_hi, D, S_HI16, S_HI8, S_HNORM, st + ST_NHI, st + ST_BAD));
     MAD_TRY(stage_rows(ctx, lo, n_lo, D, S_LO16, S_LO8, S_LNORM, st + ST_NLO, st + ST_BAD));
     const int64_t hp = mad_ceil_div(n_hi, GEMM_BM) * GEMM_BM, lp = mad_ceil_div(n_lo, GEMM_BN) * GEMM_BN;
-    const Side H = {scratch<int8_t>(ctx, S_HI8), scratch<double>(ctx, S_HNORM), nullptr, nullptr, nullptr, nullptr, nullptr, st + ST_NHI, n_hi};
-    const Side L = {scratch<int8_t>(ctx, S_LO8), scratch<double>(ctx, S_LNORM), nullptr, nullptr, nullptr, nullptr, nullptr, st + ST_NLO, n_lo};
+    const Side H = {scratch<int8_t>(ctx, S_HI8), scratch<double>(ctx, S_HNORM), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, st + ST_NHI, n_hi};
+    const Side L = {scratch<int8_t>(ctx, S_LO8), scratch<double>(ctx, S_LNORM), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, st + ST_NLO, n_lo};
     const int32_t *hs = (const int32_t *)&ctx->pinned[0];
     int64_t cap_pairs = std::max<int64_t>(cap, 1);
     for (int attempt = 0; attempt < 2; attempt++) {
@@ -1437,9 +1440,9 @@ extern "C" int mad_pose_score(mad_ctx *ctx, const int32_t *pair_hi, const int32_
             if (i == 0 || v > bmx[d]) bmx[d] = v;
         }
     const Side H = {nullptr, nullptr, scratch<double>(ctx, S_TMP_F), nullptr, scratch<int32_t>(ctx, S_TMP_G), nullptr,
-                    scratch<double>(ctx, S_TMP_E), st + ST_NHI, n_hi};
+                    nullptr, scratch<double>(ctx, S_TMP_E), st + ST_NHI, n_hi};
     const Side L = {nullptr, nullptr, scratch<double>(ctx, S_TMP_I), scratch<double>(ctx, S_TMP_A), scratch<int32_t>(ctx, S_TMP_J),
-                    nullptr, scratch<double>(ctx, S_TMP_H), st + ST_NLO, n_lo};
+                    nullptr, nullptr, scratch<double>(ctx, S_TMP_H), st + ST_NLO, n_lo};
     CellGrid G;
     const bool fits = clouds_fit_lds(l_hi, l_lo);
     if (!fits) {      // global cell list (cell = dist) over the lo cloud
@@ -1565,8 +1568,8 @@ static int set_upload_anchors(mad_ctx *ctx, mad_set *s, const int32_t *anc_coord
                               const double *anc_subv, const int32_t *anc_index, int n, int32_t rows0 = 0) {
     s->n_anchors = n;
     const size_t m = (size_t)(n > 0 ? n : 1);
-    const size_t o_subv = 64, o_coords = o_subv + m * 24, o_oct = o_coords + m * 12, o_idx = o_oct + m * 4,
-                 total = (o_idx + m * 4 + 15) / 16 * 16;
+    const size_t o_subv = 64, o_coords = o_subv + m * 24, o_oct = o_coords + m * 12, o_idx = o_oct + m * 4, o_canon = o_idx + m * 4,
+                 total = (o_canon + m * 4 + 15) / 16 * 16;
     if (s->host_stage_cap < total) {
         if (s->host_stage) {
             MAD_HIP(hipEventSynchronize(s->uploaded));
@@ -1584,6 +1587,7 @@ static int set_upload_anchors(mad_ctx *ctx, mad_set *s, const int32_t *anc_coord
     char *h = (char *)s->host_stage, *d = (char *)s->anc_blob.p;
     s->dev_n.p = d;
     s->anc_subv.p = d + o_subv; s->anc_coords.p = d + o_coords; s->anc_octave.p = d + o_oct; s->anc_index.p = d + o_idx;
+    s->anc_canon.p = d + o_canon;
     memset(h, 0, 64);      // the device counters start from zero
     ((int32_t *)h)[0] = rows0;
     if (n > 0) {
@@ -1592,6 +1596,19 @@ static int set_upload_anchors(mad_ctx *ctx, mad_set *s, const int32_t *anc_coord
         else memset(h + o_coords, 0, (size_t)n * 12);
         memcpy(h + o_oct, anc_octave, (size_t)n * 4);
         memcpy(h + o_idx, anc_index, (size_t)n * 4);
+        // Anchors with identical coordinates are ONE point of a cloud: the reference builds its clouds with
+        // np.unique(subv_map_coords, axis=0) (MaD.py:427-428), and two detector peaks do now and then converge on the same
+        // sub-voxel position.  canon[i] = the first anchor with the coordinates of anchor i; the "takes part in a pair" flags
+        // are raised on the canonical anchor only, so the cloud and its size l count such a position once.
+        int32_t *canon = (int32_t *)(h + o_canon);
+        std::vector<int32_t> order(n);
+        for (int i = 0; i < n; i++) order[i] = i;
+        std::sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
+            const int c = memcmp(anc_subv + 3 * a, anc_subv + 3 * b, 24);
+            return c != 0 ? c < 0 : a < b;
+        });
+        for (int i = 0; i < n; i++)
+            canon[order[i]] = (i > 0 && memcmp(anc_subv + 3 * order[i], anc_subv + 3 * order[i - 1], 24) == 0) ? canon[order[i - 1]] : order[i];
     }
     // a kernel reads the pinned buffer directly: in stream order, without the copy engine's start-up latency
     mad_copy_words(ctx, d, h, n > 0 ? total : 64);
@@ -1740,6 +1757,7 @@ static Side side_of(const mad_set *s) {
     x.dsc8 = (const int8_t *)s->dsc8.p; x.norm = (const double *)s->norm.p; x.R = (const double *)s->row_R.p;
     x.Rinv = (const double *)s->row_Rinv.p; x.meta = (const int32_t *)s->row_meta.p; x.row_anchor = (const int32_t *)s->row_anchor.p;
     x.p = (const double *)s->anc_subv.p; x.n_rows = (const int32_t *)s->dev_n.p; x.cap_rows = s->cap_rows;
+    x.anc_canon = (const int32_t *)s->anc_canon.p;
     return x;
 }
 

@@ -425,6 +425,39 @@ def test_set_pipeline_and_batched_match(lib, fields):
     np.testing.assert_array_equal(s2.download()["dsc"], dsc)
 
 
+def test_anchors_with_identical_coordinates_count_once(lib, fields):
+    """Two detector peaks that converge on the same sub-voxel position are ONE point of a cloud: the reference builds the
+    clouds with np.unique(coords, axis=0) (MaD.py:427-428).  Sets built on the device get the same clouds (and sizes l)."""
+    f = fields[1]
+    built, host = [], []
+    for seed, n in ((41, 40), (42, 24)):
+        coords = synth.interior_anchors(f["shape"], n, 10, seed)
+        subv = coords.astype(np.float64) * 1.5 + 0.37
+        # the last quarter repeats the sub-voxel position (and voxel) of the first quarter
+        q = n // 4
+        coords[-q:], subv[-q:] = coords[:q], subv[:q]
+        built.append(lib.set_build([-1, f["slot"]], coords, np.ones(n, np.int32), subv, np.arange(n)))
+        rows = O.orient(f["gx"], f["gy"], f["gz"], 1, coords, E112.sphere_eqsp, E112.p_centers_eqsp, want_counts=False)
+        dsc = O.describe(f["gx"], f["gy"], f["gz"], 1, coords[rows["anchor"]], rows["R"], E16.sphere_eqsp)
+        host.append(dict(rows=rows, dsc=dsc, subv=subv))
+    (lo, hi), (hl, hh) = built, host
+    cc, k = 0.3, 30
+    top, idx, st = lib.match_topk(hi, lo, cc, 4.0, k)
+    ph, pl, ps, _ = O.correlate(hh["dsc"], hl["dsc"], cc)
+    assert st["n_pairs"] == len(ph) > 50
+    hi_p, lo_p = hh["subv"][hh["rows"]["anchor"]], hl["subv"][hl["rows"]["anchor"]]
+    hi_cloud, lo_cloud = np.unique(hi_p[np.unique(ph)], axis=0), np.unique(lo_p[np.unique(pl)], axis=0)
+    assert len(hi_cloud) < len(np.unique(hh["rows"]["anchor"][np.unique(ph)]))      # the case does hold duplicates
+    assert (st["l_hi"], st["l_lo"]) == (len(hi_cloud), len(lo_cloud))
+    mh = np.stack([hh["rows"]["anchor"], np.ones_like(hh["rows"]["anchor"]), hh["rows"]["main"]], 1)
+    ml = np.stack([hl["rows"]["anchor"], np.ones_like(hl["rows"]["anchor"]), hl["rows"]["main"]], 1)
+    res, cnt = O.pose_score(ph, pl, ps, hi_p, hh["rows"]["R"], mh, lo_p, hl["rows"]["R"], ml, hi_cloud, lo_cloud, 4.0)
+    np.testing.assert_array_equal(lib.match_fetch(st["n_pairs"])[3], cnt)
+    order = O.topk(cnt, k)
+    np.testing.assert_array_equal(idx, order)
+    np.testing.assert_allclose(top, res[order], rtol=1e-10, atol=1e-10)
+
+
 def test_lanes_overlap_and_serial_give_identical_results(lib):
     """Builds and matches of several structures spread over the lanes (streams); serialising the lanes with
     mad_set_overlap(0) must not change a bit of the output."""
