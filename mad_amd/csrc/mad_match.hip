@@ -108,6 +108,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_corr_gemm(const int8_t *__rest
                                                             const double *__restrict__ ln, double cc, uint32_t *__restrict__ mask) {
     __shared__ __align__(16) int8_t sA[GEMM_BM * GEMM_LDA];
     __shared__ __align__(16) int8_t sB[GEMM_BN * GEMM_LDA];
+    __shared__ float sT[GEMM_BM + GEMM_BN];
     const int64_t hp = ((int64_t)*n_hi_ptr + GEMM_BM - 1) / GEMM_BM * GEMM_BM;
     const int64_t lp = ((int64_t)*n_lo_ptr + GEMM_BN - 1) / GEMM_BN * GEMM_BN;
     if (hp * lp > cap_c) {
@@ -118,16 +119,31 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_corr_gemm(const int8_t *__rest
     const int tid = threadIdx.x;
     const int lane = tid & 63, w = tid >> 6;
     const int wm = w >> 1, wn = w & 1;
-    for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
-        const int64_t row0 = (t / tiles_n) * GEMM_BM, col0 = (t % tiles_n) * GEMM_BN;
+    // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  XCD x takes a contiguous run
+    // of the tiles in column-major order, i.e. ~1/8 of the lo rows (1 MB on the C3 map) against all hi rows: both operands
+    // of its tiles then live in its L2 instead of every XCD streaming the whole lo set once per hi row block.
+    const int64_t tiles_m = hp / GEMM_BM, per_xcd = (tiles + 7) / 8;
+    const int xcd = blockIdx.x & 7;
+    const int64_t t_end = per_xcd * (xcd + 1) < tiles ? per_xcd * (xcd + 1) : tiles;
+    for (int64_t t = per_xcd * xcd + (blockIdx.x >> 3); t < t_end; t += gridDim.x >> 3) {
+        const int64_t row0 = (t % tiles_m) * GEMM_BM, col0 = (t / tiles_m) * GEMM_BN;
         v4i acc[4][4];
 #pragma unroll
         for (int m = 0; m < 4; m++)
 #pragma unroll
             for (int n = 0; n < 4; n++) acc[m][n] = (v4i){0, 0, 0, 0};
-        for (int k0 = 0; k0 < K; k0 += GEMM_BK) {
-            // stage 128 rows x 128 B of each operand: 1024 16-byte chunks per operand, 4 per thread
-            v4i ra[4], rb[4];
+        // The norms the epilogue needs, fetched before the K loop and parked in LDS (|h| per row, cc |l| per column; zero
+        // rows count as norm 1, MaD.py:416): sixteen dependent round trips after the loop would cost more than the loop
+        // itself, and as registers they would halve the occupancy.
+        {
+            const double v = tid < GEMM_BM ? hn[row0 + tid] : ln[col0 + tid - GEMM_BM];
+            const double u = v > 0 ? v : 1.0;
+            sT[tid] = tid < GEMM_BM ? (float)u : (float)(cc * u);
+        }
+        // stage = 128 rows x 128 B of each operand: 1024 16-byte chunks per operand, 4 per thread.  The global loads of
+        // stage k + 1 are issued before the MFMAs of stage k, so their latency runs under the arithmetic.
+        v4i ra[4], rb[4];
+        auto fetch = [&](int k0) {
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 const int c = tid + GEMM_THREADS * i;
@@ -135,6 +151,9 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_corr_gemm(const int8_t *__rest
                 ra[i] = *(const v4i *)(A + (row0 + r) * K + k0 + q * 16);
                 rb[i] = *(const v4i *)(B + (col0 + r) * K + k0 + q * 16);
             }
+        };
+        fetch(0);
+        for (int k0 = 0; k0 < K; k0 += GEMM_BK) {
             __syncthreads();      // previous stage fully consumed
 #pragma unroll
             for (int i = 0; i < 4; i++) {
@@ -144,6 +163,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_corr_gemm(const int8_t *__rest
                 *(v4i *)(sB + r * GEMM_LDA + q * 16) = rb[i];
             }
             __syncthreads();
+            if (k0 + GEMM_BK < K) fetch(k0 + GEMM_BK);
 #pragma unroll
             for (int kk = 0; kk < GEMM_BK / 64; kk++) {
                 v4i fa[4], fb[4];
@@ -161,26 +181,24 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_corr_gemm(const int8_t *__rest
         }
         // C/D layout of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg
         const int64_t ldm = lp / 32;
-        float tl[4];      // cc |l| of this lane's four columns (zero rows count as norm 1, MaD.py:416)
+        float tl[4];
 #pragma unroll
-        for (int n = 0; n < 4; n++) {
-            const double v = ln[col0 + wn * 64 + n * 16 + (lane & 15)];
-            tl[n] = (float)(cc * (v > 0 ? v : 1.0));
+        for (int n = 0; n < 4; n++) {      // cc |l| moved towards "candidate" by the margin (|h| > 0, so the product moves with it)
+            const float v = sT[GEMM_BM + wn * 64 + n * 16 + (lane & 15)];
+            tl[n] = v - fabsf(v) * 4e-6f;
         }
 #pragma unroll
         for (int m = 0; m < 4; m++)
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const int64_t r = row0 + wm * 64 + m * 16 + (lane >> 4) * 4 + j;
-                const double hv = hn[r];
-                const float th = (float)(hv > 0 ? hv : 1.0);
+                const float th = sT[wm * 64 + m * 16 + (lane >> 4) * 4 + j];
                 unsigned long long bal[4];
 #pragma unroll
                 for (int n = 0; n < 4; n++) {
                     const int64_t c = col0 + wn * 64 + n * 16 + (lane & 15);
                     const int d = acc[m][n][j];
-                    const float t = th * tl[n];
-                    const bool cand = (float)d > t - fabsf(t) * 4e-6f;
+                    const bool cand = (float)d > th * tl[n];
                     if (cand) C[r * lp + c] = d;      // only candidates are ever read back (k_pair_count / k_pair_emit): ~0.4 % of the entries
                     bal[n] = __ballot(cand);
                 }
