@@ -99,3 +99,71 @@ def test_full_size_properties(lib, workload):
             s.close()
         for st_ in [the_map] + subs:
             st_.ms.release_device()
+
+
+@pytest.mark.parametrize("workload", ["c3", pytest.param("c5", marks=pytest.mark.skipif(
+    os.environ.get("MAD_TEST_C5_ORACLE", "0") == "0", reason="512^3 against the oracle takes minutes: MAD_TEST_C5_ORACLE=1"))])
+def test_whole_workload_equals_the_oracle(lib, workload):
+    """The benchmark's own workload (c3: 256^3 map, 4 subunits, every anchor of both octaves) through the CPU oracle on
+    the host threads and through the device path: rows, descriptors, pair lists, match counts and top-k must be
+    identical (~10 s on 16 threads).  c5 (512^3, its first 4 subunits; the pose search then runs in k_pose_lds32) is the
+    same comparison at the largest size, run on request."""
+    import bench
+    from mad_amd.eqsp import EQSP_Sphere
+    from mad_amd.orient_tables import orientation_matrices
+    from oracle import oracle as O
+    e112, e16 = EQSP_Sphere(112), EQSP_Sphere(16)
+    dom, adj = orientation_matrices(e112)
+    lib.set_eqsp(0, e112.sphere_eqsp, dom, adj)
+    lib.set_eqsp(1, e16.sphere_eqsp)
+    cc, dist, k = 0.6, 4.0, 60
+    threads = min(16, os.cpu_count() or 1)
+    the_map, subs, _ = bench.build_inputs(lib, bench.WORKLOADS[workload], 0)
+    subs = subs[:4]
+
+    def described(st):
+        parts = []
+        for octave in (0, 1):
+            sel = np.flatnonzero(st.octave == octave)
+            if not len(sel):
+                continue
+            g = np.ascontiguousarray(np.moveaxis(st.ms.grad_list[octave], -1, 0), dtype=np.float32)
+            rows = O.orient_mt(g[0], g[1], g[2], octave, st.coords[sel], e112.sphere_eqsp, e112.p_centers_eqsp, threads, want_counts=False)
+            dsc = O.describe_mt(g[0], g[1], g[2], octave, st.coords[sel][rows["anchor"]], rows["R"], e16.sphere_eqsp, threads)
+            parts.append((sel[rows["anchor"]], rows, dsc, octave))
+        anchor = np.concatenate([p[0] for p in parts])
+        assert np.all(np.diff(anchor) >= 0)      # the Detector lists octave 0 first: row order = anchor order
+        return dict(anchor=anchor, R=np.concatenate([p[1]["R"] for p in parts]), main=np.concatenate([p[1]["main"] for p in parts]),
+                    dsc=np.concatenate([p[2] for p in parts]), octave=np.concatenate([np.full(len(p[0]), p[3]) for p in parts]))
+
+    def on_device(st):
+        return lib.set_build(st.slots, st.coords, st.octave, st.subv, st.index)
+
+    lo_h, lo_d = described(the_map), on_device(the_map)
+    got = lo_d.download()
+    np.testing.assert_array_equal(got["anchor"], lo_h["anchor"])
+    assert np.array_equal(got["dsc"], lo_h["dsc"])
+    lo_p = the_map.subv[lo_h["anchor"]]
+    meta_l = np.stack([lo_h["anchor"], lo_h["octave"], lo_h["main"]], 1)
+    assert len(np.unique(the_map.octave)) == 2 and len(lo_h["dsc"]) > 7000
+    for sub in subs:
+        hi_h, hi_d = described(sub), on_device(sub)
+        got = hi_d.download()
+        np.testing.assert_array_equal(got["anchor"], hi_h["anchor"])
+        assert np.array_equal(got["dsc"], hi_h["dsc"])
+        ph, pl, ps, _ = O.correlate_mt(hi_h["dsc"], lo_h["dsc"], cc, threads)
+        hi_p = sub.subv[hi_h["anchor"]]
+        meta_h = np.stack([hi_h["anchor"], hi_h["octave"], hi_h["main"]], 1)
+        res, cnt = O.pose_score_mt(ph, pl, ps, hi_p, hi_h["R"], meta_h, lo_p, lo_h["R"], meta_l,
+                                   np.unique(hi_p[np.unique(ph)], axis=0), np.unique(lo_p[np.unique(pl)], axis=0), dist, threads)
+        order = O.topk(cnt, k)
+        top, idx, st = lib.match_topk(hi_d, lo_d, cc, dist, k)
+        assert st["n_pairs"] == len(ph) > 10000
+        assert lib.last_pose_kernel() == (1 if workload == "c5" else 0)
+        gph, gpl, gps, gcnt = lib.match_fetch(st["n_pairs"])
+        assert np.array_equal(gph, ph) and np.array_equal(gpl, pl)
+        assert np.array_equal(gcnt, cnt)
+        np.testing.assert_array_equal(idx, order)
+        np.testing.assert_allclose(top, res[order], rtol=1e-10, atol=1e-10)
+        hi_d.close()
+    lo_d.close()
