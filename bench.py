@@ -448,6 +448,10 @@ def main():
         roof["hbm_stage"] = dict(kernels="k_orient + k_describe", algorithmic_bytes_per_step=b_hbm, seconds_per_step=t_hbm,
                                  achieved=b_hbm / t_hbm / 1e9 if t_hbm > 0 else 0.0, unit="GB/s", frac=(b_hbm / t_hbm / 1e9) / HBM_PEAK_GBS if t_hbm > 0 else 0.0)
         roof["largest_share_of_device_time"] = max(groups, key=lambda g: groups[g]["ms_total"])
+        roof["note"] = ("HBM traffic (PMC) ~ algorithmic bytes, no wasted re-reads; what the kernel waits for is not HBM but the scattered 16-byte "
+                        "texel requests between a CU and its XCD's L2 (one L1 access per lane-load, ~half of them L2 requests, the L1 stalled on "
+                        "pending misses half of its active cycles; fields that fit the Infinity Cache run no faster per row), and its own "
+                        "arithmetic takes 2/3 of its time (probes and counters in DESIGN.md section 6)")
         l_hi_mean = float(np.mean([s["l_hi"] for s in stats]))
         pts = pairs * l_hi_mean      # transformed hi-cloud points per step
         roofs["pose"]["note"] = ("not an HBM kernel (the HBM figure is its algorithmic 12 B/pair): every transformed hi point (%.3g per step, %.0f G/s) "
