@@ -371,6 +371,20 @@ __device__ __forceinline__ void stage_lds(void *lds_dst, const void *src, size_t
     if ((int)threadIdx.x < tail) ((unsigned *)lds_dst)[4 * n4 + threadIdx.x] = ((const unsigned *)src)[4 * n4 + threadIdx.x];
 }
 
+// floor / round-half-up of a float32 straight to int32: one instruction each on gfx950 where floorf + a cast take two or three.
+// cvt_round is floor(x + 0.5) with the sum rounded to float32: exact except within an ulp of a tie, which every caller treats
+// as undecided anyway.  Both saturate (NaN -> 0).
+__device__ __forceinline__ int cvt_floor(float x) {
+    int r;
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+__device__ __forceinline__ int cvt_round(float x) {
+    int r;
+    asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+
 __device__ __forceinline__ void eqsp_fast_stage(const EqspDev *t, EqspFastLds *l) { stage_lds(l, &t->image, sizeof(EqspFastLds)); }
 
 // eqsp_classify on the LDS copy of the table

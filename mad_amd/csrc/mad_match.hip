@@ -468,7 +468,7 @@ __device__ __forceinline__ void pose_vox_fetch(const PoseVox &V, float cx, float
     const float vx = fmaf(cz, V.m[2], fmaf(cy, V.m[1], fmaf(cx, V.m[0], V.t[0])));
     const float vy = fmaf(cz, V.m[5], fmaf(cy, V.m[4], fmaf(cx, V.m[3], V.t[1])));
     const float vz = fmaf(cz, V.m[8], fmaf(cy, V.m[7], fmaf(cx, V.m[6], V.t[2])));
-    const int ix = (int)floorf(vx), iy = (int)floorf(vy), iz = (int)floorf(vz);
+    const int ix = cvt_floor(vx), iy = cvt_floor(vy), iz = cvt_floor(vz);
     *bit = iz & 31;
     *word = make_uint2(0u, 0u);
     if ((unsigned)ix < (unsigned)B.dim[0] && (unsigned)iy < (unsigned)B.dim[1] && (unsigned)iz < (unsigned)B.dim[2])
@@ -607,9 +607,9 @@ __global__ __launch_bounds__(POSE_LDS_THREADS) void k_pose_lds(const int32_t *__
         const double z = (d0 * P[6] + d1 * P[7] + d2 * P[8]) + P[14];
         // cells met by a slightly larger ball (reach = dist + 0.01), in float32: a superset is harmless
         const float xf = (float)x - mnx, yf = (float)y - mny, zf = (float)z - mnz;
-        const int x0 = (int)floorf((xf - reach) * G.inv_cell_f[0]), x1 = (int)floorf((xf + reach) * G.inv_cell_f[0]);
-        const int y0 = (int)floorf((yf - reach) * G.inv_cell_f[1]), y1 = (int)floorf((yf + reach) * G.inv_cell_f[1]);
-        const int z0 = (int)floorf((zf - reach) * G.inv_cell_f[2]), z1 = (int)floorf((zf + reach) * G.inv_cell_f[2]);
+        const int x0 = cvt_floor((xf - reach) * G.inv_cell_f[0]), x1 = cvt_floor((xf + reach) * G.inv_cell_f[0]);
+        const int y0 = cvt_floor((yf - reach) * G.inv_cell_f[1]), y1 = cvt_floor((yf + reach) * G.inv_cell_f[1]);
+        const int z0 = cvt_floor((zf - reach) * G.inv_cell_f[2]), z1 = cvt_floor((zf + reach) * G.inv_cell_f[2]);
         bool hit = false;
         if (x1 >= 0 && x0 < G.dim[0] && y1 >= 0 && y0 < G.dim[1] && z1 >= 0 && z0 < G.dim[2]) {
             const int zz0 = max(z0, 0), zz1 = min(z1, G.dim[2] - 1) + 1;
@@ -767,9 +767,9 @@ __global__ __launch_bounds__(POSE_LDS_THREADS) void k_pose_lds32(const int32_t *
             // offsets from the grid origin, rounded once to float32
             const float xf = (float)(x - G.mn[0]), yf = (float)(y - G.mn[1]), zf = (float)(z - G.mn[2]);
             // cells met by a slightly larger ball (reach = dist + 0.01), in float32: a superset is harmless
-            const int x0 = (int)floorf((xf - reach) * G.inv_cell_f[0]), x1 = (int)floorf((xf + reach) * G.inv_cell_f[0]);
-            const int y0 = (int)floorf((yf - reach) * G.inv_cell_f[1]), y1 = (int)floorf((yf + reach) * G.inv_cell_f[1]);
-            const int z0 = (int)floorf((zf - reach) * G.inv_cell_f[2]), z1 = (int)floorf((zf + reach) * G.inv_cell_f[2]);
+            const int x0 = cvt_floor((xf - reach) * G.inv_cell_f[0]), x1 = cvt_floor((xf + reach) * G.inv_cell_f[0]);
+            const int y0 = cvt_floor((yf - reach) * G.inv_cell_f[1]), y1 = cvt_floor((yf + reach) * G.inv_cell_f[1]);
+            const int z0 = cvt_floor((zf - reach) * G.inv_cell_f[2]), z1 = cvt_floor((zf + reach) * G.inv_cell_f[2]);
             bool hit = false;
             if (x1 >= 0 && x0 < G.dim[0] && y1 >= 0 && y0 < G.dim[1] && z1 >= 0 && z0 < G.dim[2]) {
                 const int zz0 = max(z0, 0), zz1 = min(z1, G.dim[2] - 1) + 1;

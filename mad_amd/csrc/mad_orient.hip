@@ -570,11 +570,10 @@ __global__ __launch_bounds__(DSC_THREADS, 4) void k_describe(DescribeArgs A) {
             for (int i = 0; i < S; i++) {
                 const float m0 = (float)(lbase + lstep * i);
                 const float a0 = fmaf(m0, h0, b0), a1 = fmaf(m0, h3, b1), a2 = fmaf(m0, h6, b2);
-                const float fl0 = floorf(a0), fl1 = floorf(a1), fl2 = floorf(a2);
-                const float fr0 = a0 - fl0, fr1 = a1 - fl1, fr2 = a2 - fl2;
+                // nearest voxel = floor(a + 0.5) unless the fraction is within 2e-4 of the tie (then the float64 expression decides)
+                const float fr0 = __builtin_amdgcn_fractf(a0), fr1 = __builtin_amdgcn_fractf(a1), fr2 = __builtin_amdgcn_fractf(a2);
                 bool safe = (fabsf(fr0 - 0.5f) > 2e-4f) & (fabsf(fr1 - 0.5f) > 2e-4f) & (fabsf(fr2 - 0.5f) > 2e-4f);
-                int n0 = ic0 + (int)fl0 + (fr0 > 0.5f ? 1 : 0), n1 = ic1 + (int)fl1 + (fr1 > 0.5f ? 1 : 0),
-                    n2 = ic2 + (int)fl2 + (fr2 > 0.5f ? 1 : 0);
+                int n0 = ic0 + cvt_round(a0), n1 = ic1 + cvt_round(a1), n2 = ic2 + cvt_round(a2);
                 if (decltype(border)::value) {
                     const float q0 = a0 + fc0, q1 = a1 + fc1, q2 = a2 + fc2;
                     safe &= (q0 > 1e-3f) & (q0 < lim0) & (q1 > 1e-3f) & (q1 < lim1) & (q2 > 1e-3f) & (q2 < lim2);
