@@ -471,8 +471,9 @@ __device__ __forceinline__ void pose_vox_fetch(const PoseVox &V, float cx, float
     const int ix = cvt_floor(vx), iy = cvt_floor(vy), iz = cvt_floor(vz);
     *bit = iz & 31;
     *word = make_uint2(0u, 0u);
-    if ((unsigned)ix < (unsigned)B.dim[0] && (unsigned)iy < (unsigned)B.dim[1] && (unsigned)iz < (unsigned)B.dim[2])
-        *word = ((const uint2 *)bits)[((size_t)ix * B.dim[1] + iy) * B.wz + (iz >> 5)];
+    // one test, 24-bit multiplies (full rate; a 32-bit integer multiply costs four issue slots): the bitmap holds at most 2^21 word pairs
+    const bool in = ((unsigned)ix < (unsigned)B.dim[0]) & ((unsigned)iy < (unsigned)B.dim[1]) & ((unsigned)iz < (unsigned)B.dim[2]);
+    if (in) *word = ((const uint2 *)bits)[__umul24(__umul24((unsigned)ix, (unsigned)B.dim[1]) + (unsigned)iy, (unsigned)B.wz) + (unsigned)(iz >> 5)];
 }
 
 // Two-phase count for one pair (one wave): the bitmap test for every hi point, survivors collected in the wave's LDS
@@ -615,8 +616,8 @@ __global__ __launch_bounds__(POSE_LDS_THREADS) void k_pose_lds(const int32_t *__
             const int zz0 = max(z0, 0), zz1 = min(z1, G.dim[2] - 1) + 1;
             const int xa = max(x0, 0), xb = min(x1, G.dim[0] - 1), ya = max(y0, 0), yb = min(y1, G.dim[1] - 1);
             // the ball meets at most 2 x 2 columns: fetch all four z-runs before walking any of them
-            const int c00 = (xa * G.dim[1] + ya) * G.dim[2], c01 = (xa * G.dim[1] + yb) * G.dim[2];
-            const int c10 = (xb * G.dim[1] + ya) * G.dim[2], c11 = (xb * G.dim[1] + yb) * G.dim[2];
+            const int c00 = __mul24(__mul24(xa, G.dim[1]) + ya, G.dim[2]), c01 = __mul24(__mul24(xa, G.dim[1]) + yb, G.dim[2]);      // <= 30 000 cells
+            const int c10 = __mul24(__mul24(xb, G.dim[1]) + ya, G.dim[2]), c11 = __mul24(__mul24(xb, G.dim[1]) + yb, G.dim[2]);
             int s[4], e4[4];
             s[0] = cs[c00 + zz0]; e4[0] = cs[c00 + zz1];
             s[1] = cs[c01 + zz0]; e4[1] = (yb != ya) ? cs[c01 + zz1] : s[1];

@@ -579,7 +579,7 @@ __global__ __launch_bounds__(DSC_THREADS, 4) void k_describe(DescribeArgs A) {
                     safe &= (q0 > 1e-3f) & (q0 < lim0) & (q1 > 1e-3f) & (q1 < lim1) & (q2 > 1e-3f) & (q2 < lim2);
                     n0 = min(max(n0, 0), F.nx - 1); n1 = min(max(n1, 0), F.ny - 1); n2 = min(max(n2, 0), F.nz - 1);
                 }
-                t[i] = F.tex[(unsigned)(((size_t)n0 * F.ny + n1) * F.nz + n2)];
+                t[i] = F.tex[__umul24(__umul24((unsigned)n0, (unsigned)F.ny) + (unsigned)n1, (unsigned)F.nz) + (unsigned)n2];      // nx ny < 2^24 (checked on the host)
                 unsure |= safe ? 0u : (1u << i);
             }
         };
@@ -686,8 +686,8 @@ int mad_describe_device(mad_ctx *ctx, FieldDev f0, FieldDev f1, const int32_t *d
     if (cap_rows <= 0) return MAD_OK;
     for (int o = 0; o < 2; o++) {
         const FieldDev &f = o ? f1 : f0;
-        if (f.tex && (size_t)f.nx * f.ny * f.nz >= (size_t)1 << 32)
-            return mad_fail(ctx, MAD_EINVAL, "mad_describe: field of %dx%dx%d texels exceeds 2^32", f.nx, f.ny, f.nz);
+        if (f.tex && ((size_t)f.nx * f.ny * f.nz >= (size_t)1 << 32 || (size_t)f.nx * f.ny >= (size_t)1 << 24 || f.nz >= 1 << 24))
+            return mad_fail(ctx, MAD_EINVAL, "mad_describe: field of %dx%dx%d texels exceeds 2^32 (or 2^24 per x-y plane)", f.nx, f.ny, f.nz);
     }
     DescribeArgs A;
     A.f[0] = f0; A.f[1] = f1;
