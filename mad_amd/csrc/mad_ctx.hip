@@ -316,6 +316,9 @@ int mad_field_alloc(mad_ctx *ctx, int slot, int nx, int ny, int nz, size_t *n_ou
     if (slot < 0 || slot >= MAD_MAX_FIELDS) return mad_fail(ctx, MAD_EINVAL, "field slot %d out of range", slot);
     if (nx < 2 || ny < 2 || nz < 2) return mad_fail(ctx, MAD_EINVAL, "field dims %dx%dx%d", nx, ny, nz);
     const size_t n = (size_t)nx * ny * nz;
+    // the kernels index texels with 24-bit multiplies: (x ny + y) and nz below 2^24, the whole field below 2^32 texels
+    if (n >= ((size_t)1 << 32) || (size_t)nx * ny >= ((size_t)1 << 24) || nz >= (1 << 24))
+        return mad_fail(ctx, MAD_EINVAL, "field of %dx%dx%d texels: more than 2^32 texels or 2^24 per x-y plane", nx, ny, nz);
     if (ctx->field_mem[slot]) {
         MAD_HIP(hipStreamSynchronize(ctx->stream));
         (void)hipFree(ctx->field_mem[slot]);

@@ -775,8 +775,8 @@ __global__ __launch_bounds__(POSE_LDS_THREADS) void k_pose_lds32(const int32_t *
             if (x1 >= 0 && x0 < G.dim[0] && y1 >= 0 && y0 < G.dim[1] && z1 >= 0 && z0 < G.dim[2]) {
                 const int zz0 = max(z0, 0), zz1 = min(z1, G.dim[2] - 1) + 1;
                 const int xa = max(x0, 0), xb = min(x1, G.dim[0] - 1), ya = max(y0, 0), yb = min(y1, G.dim[1] - 1);
-                const int c00 = (xa * G.dim[1] + ya) * G.dim[2], c01 = (xa * G.dim[1] + yb) * G.dim[2];
-                const int c10 = (xb * G.dim[1] + ya) * G.dim[2], c11 = (xb * G.dim[1] + yb) * G.dim[2];
+                const int c00 = __mul24(__mul24(xa, G.dim[1]) + ya, G.dim[2]), c01 = __mul24(__mul24(xa, G.dim[1]) + yb, G.dim[2]);      // <= 30 000 cells
+                const int c10 = __mul24(__mul24(xb, G.dim[1]) + ya, G.dim[2]), c11 = __mul24(__mul24(xb, G.dim[1]) + yb, G.dim[2]);
                 int s[4], e[4];
                 s[0] = cs[c00 + zz0]; e[0] = cs[c00 + zz1];
                 s[1] = cs[c01 + zz0]; e[1] = (yb != ya) ? cs[c01 + zz1] : s[1];

@@ -147,7 +147,9 @@ __global__ __launch_bounds__(ORI_THREADS) void k_orient(OrientArgs A) {
         if (m < A.nmask) {
             const int packed = ((const int *)A.mask_off)[m];      // {dx, dy, dz, 0} as one load
             const int dx = (int)(int8_t)(packed & 0xff), dy = (int)(int8_t)((packed >> 8) & 0xff), dz = (int)(int8_t)((packed >> 16) & 0xff);
-            const size_t src = ((size_t)(x + dx * stride) * F.ny + (size_t)(y + dy * stride)) * F.nz + (size_t)(z + dz * stride);
+            // 24-bit multiplies (full rate): nx ny < 2^24 is checked on the host, the sum stays below 2^32 texels
+            const unsigned src = __umul24(__umul24((unsigned)(x + __mul24(dx, stride)), (unsigned)F.ny) + (unsigned)(y + __mul24(dy, stride)), (unsigned)F.nz) +
+                                 (unsigned)(z + __mul24(dz, stride));
             const float4 t = F.tex[src];
             keep = !(t.w < cutoff);
             gx = t.x; gy = t.y; gz = t.z;
