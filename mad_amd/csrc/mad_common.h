@@ -379,6 +379,12 @@ __device__ __forceinline__ int cvt_floor(float x) {
     asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(x));
     return r;
 }
+// a * b + c with a, b < 2^24: one full-rate instruction (the compiler, unsure of the ranges, otherwise picks a 64-bit multiply-add)
+__device__ __forceinline__ unsigned mad_u24(unsigned a, unsigned b, unsigned c) {
+    unsigned r;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 __device__ __forceinline__ int cvt_round(float x) {
     int r;
     asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(x));

@@ -473,7 +473,7 @@ __device__ __forceinline__ void pose_vox_fetch(const PoseVox &V, float cx, float
     *word = make_uint2(0u, 0u);
     // one test, 24-bit multiplies (full rate; a 32-bit integer multiply costs four issue slots): the bitmap holds at most 2^21 word pairs
     const bool in = ((unsigned)ix < (unsigned)B.dim[0]) & ((unsigned)iy < (unsigned)B.dim[1]) & ((unsigned)iz < (unsigned)B.dim[2]);
-    if (in) *word = ((const uint2 *)bits)[__umul24(__umul24((unsigned)ix, (unsigned)B.dim[1]) + (unsigned)iy, (unsigned)B.wz) + (unsigned)(iz >> 5)];
+    if (in) *word = ((const uint2 *)bits)[mad_u24(mad_u24((unsigned)ix, (unsigned)B.dim[1], (unsigned)iy), (unsigned)B.wz, (unsigned)(iz >> 5))];
 }
 
 // Two-phase count for one pair (one wave): the bitmap test for every hi point, survivors collected in the wave's LDS

@@ -565,12 +565,13 @@ __global__ __launch_bounds__(DSC_THREADS, 4) void k_describe(DescribeArgs A) {
         // needed the clamp is marked unsure and fetched again below).
         const float m1 = (float)l1, m2 = (float)l2;
         const float b0 = fmaf(m1, h1, m2 * h2), b1 = fmaf(m1, h4, m2 * h5), b2 = fmaf(m1, h7, m2 * h8);
+        const float lbf = (float)lbase, lsf = (float)lstep;
         auto guess = [&](auto border) {
             const float fc0 = (float)ic0, fc1 = (float)ic1, fc2 = (float)ic2;
             const float lim0 = (float)(F.nx - 1) - 1e-3f, lim1 = (float)(F.ny - 1) - 1e-3f, lim2 = (float)(F.nz - 1) - 1e-3f;
 #pragma unroll
             for (int i = 0; i < S; i++) {
-                const float m0 = (float)(lbase + lstep * i);
+                const float m0 = lbf + lsf * (float)i;      // exact: half-integers below 32
                 const float a0 = fmaf(m0, h0, b0), a1 = fmaf(m0, h3, b1), a2 = fmaf(m0, h6, b2);
                 // nearest voxel = floor(a + 0.5) unless the fraction is within 2e-4 of the tie (then the float64 expression decides)
                 const float fr0 = __builtin_amdgcn_fractf(a0), fr1 = __builtin_amdgcn_fractf(a1), fr2 = __builtin_amdgcn_fractf(a2);
@@ -581,7 +582,7 @@ __global__ __launch_bounds__(DSC_THREADS, 4) void k_describe(DescribeArgs A) {
                     safe &= (q0 > 1e-3f) & (q0 < lim0) & (q1 > 1e-3f) & (q1 < lim1) & (q2 > 1e-3f) & (q2 < lim2);
                     n0 = min(max(n0, 0), F.nx - 1); n1 = min(max(n1, 0), F.ny - 1); n2 = min(max(n2, 0), F.nz - 1);
                 }
-                t[i] = F.tex[__umul24(__umul24((unsigned)n0, (unsigned)F.ny) + (unsigned)n1, (unsigned)F.nz) + (unsigned)n2];      // nx ny < 2^24 (checked on the host)
+                t[i] = F.tex[mad_u24(mad_u24((unsigned)n0, (unsigned)F.ny, (unsigned)n1), (unsigned)F.nz, (unsigned)n2)];      // nx ny < 2^24 (checked at allocation)
                 unsure |= safe ? 0u : (1u << i);
             }
         };
