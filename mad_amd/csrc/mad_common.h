@@ -436,6 +436,10 @@ __device__ __forceinline__ float approx_angle(float x, float y) {
 // is 100x smaller than the guard and neighbouring zones overlap by < 2e-5 rad at most.
 // Branch-free on purpose (three dependent LDS reads, everything else selects): callers classify several
 // points in a row, and straight-line code lets the scheduler overlap their table reads.
+// FLAT: the final test written without short-circuit operators, so that no control flow appears and the table reads of
+// several points overlap (k_orient: -3 %); in k_describe, which sits at its register limit, the overlap spills (2x slower),
+// so it keeps the short-circuit form.
+template <bool FLAT = false>
 __device__ __forceinline__ int eqsp_fast32(const EqspFastLds *l, float x, float y, float z) {
     const int bin = min(max((int)((z + 1.0f) * (0.5f * MAD_ZLUT)), 0), MAD_ZLUT - 1);
     const int b = l->zlut[bin];
@@ -448,7 +452,8 @@ __device__ __forceinline__ int eqsp_fast32(const EqspFastLds *l, float x, float 
     const float4 g = *(const float4 *)l->g32[a];
     const float c1 = fmaf(g.x, y, -(g.y * x));      // > 0: counter-clockwise of theta_min + guard
     const float c2 = fmaf(x, g.w, -(y * g.z));      // > 0: clockwise of theta_max - guard
-    const bool ok = in_belt && (bi.y == 1 || (c1 > 0.f && c2 > 0.f));      // a polar cap spans every azimuth
+    const bool ok = FLAT ? (in_belt & ((bi.y == 1) | ((c1 > 0.f) & (c2 > 0.f))))
+                         : (in_belt && (bi.y == 1 || (c1 > 0.f && c2 > 0.f)));      // a polar cap spans every azimuth
     return ok ? a : -1;
 }
 

@@ -171,7 +171,7 @@ __global__ __launch_bounds__(ORI_THREADS) void k_orient(OrientArgs A) {
     // step02: first binning on the float32 box (Orientator.py:307-334).  Directions well inside a zone
     // take the guard-banded float32 path; the few near a bound are queued for the exact test.
     for (int v = tid; v < nvox; v += ORI_THREADS) {
-        const int zn = eqsp_fast32(&fast, vx[v], vy[v], vz[v]);
+        const int zn = eqsp_fast32<true>(&fast, vx[v], vy[v], vz[v]);
         if (zn >= 0) atomicAdd(&hist[0][zn], 1);
         else queue[atomicAdd(&s_nq, 1)] = v;
     }
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(ORI_THREADS) void k_orient(OrientArgs A) {
             const float rx = g0 * d[0] + g1 * d[1] + g2 * d[2];
             const float ry = g0 * d[3] + g1 * d[4] + g2 * d[5];
             const float rz = g0 * d[6] + g1 * d[7] + g2 * d[8];
-            const int zn = eqsp_fast32(&fast, rx, ry, rz);
+            const int zn = eqsp_fast32<true>(&fast, rx, ry, rz);
             if (zn >= 0) { atomicAdd(&hist[1 + c][zn], 1); continue; }
             const int slot = atomicAdd(&s_nq, 1);
             if (slot < A.nmask) { queue[slot] = v | (c << 16); continue; }
