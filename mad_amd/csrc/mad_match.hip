@@ -671,13 +671,34 @@ __global__ __launch_bounds__(POSE_LDS_THREADS) void k_pose_lds(const int32_t *__
         for (int a0 = 0; a0 < l_hi; a0 += MAD_WAVE * POSE_BATCH) {
             uint2 word[POSE_BATCH];
             int bit[POSE_BATCH];
+            if (a0 + MAD_WAVE * POSE_BATCH <= l_hi) {      // wave-uniform: a full batch, in straight-line code -- the four LDS reads and transforms overlap
+                unsigned idx[POSE_BATCH];
+                bool in[POSE_BATCH];
 #pragma unroll
-            for (int u = 0; u < POSE_BATCH; u++) {      // the bitmap words of 4 x 64 points are requested before any is looked at
-                const int a = a0 + u * MAD_WAVE + lane;
-                word[u] = make_uint2(0u, 0u); bit[u] = 0;
-                if (a < l_hi) {
-                    const float4 c = clf[a];
-                    pose_vox_fetch(V, c.x, c.y, c.z, B, bits, &word[u], &bit[u]);
+                for (int u = 0; u < POSE_BATCH; u++) {
+                    const float4 c = clf[a0 + u * MAD_WAVE + lane];
+                    const float vx = fmaf(c.z, V.m[2], fmaf(c.y, V.m[1], fmaf(c.x, V.m[0], V.t[0])));
+                    const float vy = fmaf(c.z, V.m[5], fmaf(c.y, V.m[4], fmaf(c.x, V.m[3], V.t[1])));
+                    const float vz = fmaf(c.z, V.m[8], fmaf(c.y, V.m[7], fmaf(c.x, V.m[6], V.t[2])));
+                    const int ix = cvt_floor(vx), iy = cvt_floor(vy), iz = cvt_floor(vz);
+                    bit[u] = iz & 31;
+                    in[u] = ((unsigned)ix < (unsigned)B.dim[0]) & ((unsigned)iy < (unsigned)B.dim[1]) & ((unsigned)iz < (unsigned)B.dim[2]);
+                    idx[u] = mad_u24(mad_u24((unsigned)ix, (unsigned)B.dim[1], (unsigned)iy), (unsigned)B.wz, (unsigned)(iz >> 5));
+                }
+#pragma unroll
+                for (int u = 0; u < POSE_BATCH; u++) {
+                    word[u] = make_uint2(0u, 0u);
+                    if (in[u]) word[u] = ((const uint2 *)bits)[idx[u]];      // a point outside the bitmap box pays nothing
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < POSE_BATCH; u++) {      // the bitmap words of 4 x 64 points are requested before any is looked at
+                    const int a = a0 + u * MAD_WAVE + lane;
+                    word[u] = make_uint2(0u, 0u); bit[u] = 0;
+                    if (a < l_hi) {
+                        const float4 c = clf[a];
+                        pose_vox_fetch(V, c.x, c.y, c.z, B, bits, &word[u], &bit[u]);
+                    }
                 }
             }
 #pragma unroll
