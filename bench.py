@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the MaD hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|small]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c4|c2|c5|small]
 
 One "step" = one pass of the hot path over one batch of synthetic input already resident
 in HBM: orientation + description of the map and of every subunit (mad_set_build),
@@ -9,10 +9,17 @@ then, per subunit, int8-MFMA correlation, pair compaction, pose scoring and top-
 (mad_match_topk).  Metric = (sum over subunits of N_hi_rows x N_lo_rows) / wall time,
 "anchor-pair x rotation correlations/s" (BASELINE.json; unit definition SURVEY.md 8(d)).
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): weak scaling -- every rank
-holds the same map and its OWN 4 subunits, so per-GPU work is fixed; the one exchange of
-the path, the all-gather of the per-subunit top-k poses (RCCL over xGMI), is inside the
-timed region.  value = correlations of all ranks / max-over-ranks time.
+N = 1 defaults to C3 (BASELINE configs[2]: 256^3 map, 4 subunits), the configuration the metric is quoted on.
+N > 1 defaults to C4 (configs[3]: 256^3 map, 8 subunits, seeds 30-37) with STRONG scaling: the same total work at every
+N.  One process per GPU (`python bench.py --gpus N` starts them itself, before anything touches a GPU; under
+torch.distributed.run it joins the ranks it is given):
+  * stage A -- the map's anchors are dealt round-robin to the ranks, each rank orients + describes its share, ONE RCCL
+    all-gather of the rows (int8 descriptors, norms, bin ids) gives every rank the full map set (mad_amd/dist.py,
+    ShardedSetBuild; SURVEY.md 8(e));
+  * the subunits are dealt round-robin to the ranks; each rank builds and matches its own against the full map set
+    (no data-path collective: the pair grid of a subunit is independent of the others);
+  * ONE all-gather of the per-subunit top-k poses per step, collected a step later (overlaps the next step's kernels).
+value = correlations of ALL ranks / max-over-ranks time.  `--workload c4 --gpus 1` is the one-GPU point of that curve.
 
 Inputs are synthetic (seeded pseudo-atom assemblies).  The density grids
 come from this library's own GPU density simulation, the scale space and the anchors from
@@ -24,8 +31,11 @@ stream inside the timed region) and `cpu_baseline` (the CPU oracle timed on a bo
 sample of the same workload, rank 0, N = 1 only).
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -35,16 +45,31 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 WORKLOADS = {
-    # name: map size N, voxel spacing, resolution, subunits per rank, atoms per subunit, globule radius, lattice
-    "c3": dict(N=256, vs=1.2, res=7.0, n_sub=4, n_atoms=26000, radius=46.0, grid=(2, 2, 1), desc="C3: 256^3 map, 4 subunits, EQSP-112/16"),
-    "c2": dict(N=128, vs=1.5, res=8.0, n_sub=4, n_atoms=14000, radius=34.0, grid=(2, 2, 1), desc="C2: 128^3 tetramer map"),
-    "c5": dict(N=512, vs=1.0, res=6.0, n_sub=12, n_atoms=26000, radius=46.0, grid=(3, 2, 2), desc="C5: 512^3 map, 12 subunits, EQSP-112/16"),
-    "small": dict(N=64, vs=2.0, res=10.0, n_sub=2, n_atoms=1500, radius=16.0, grid=(2, 1, 1), desc="C1: 64^3 dimer map"),
+    # name: map size N, voxel spacing, resolution, subunits, first seed, atoms per subunit, globule radius, lattice
+    "c3": dict(N=256, vs=1.2, res=7.0, n_sub=4, seed0=20, n_atoms=26000, radius=46.0, grid=(2, 2, 1), desc="C3: 256^3 map, 4 subunits, EQSP-112/16"),
+    "c4": dict(N=256, vs=1.2, res=7.0, n_sub=8, seed0=30, n_atoms=26000, radius=46.0, grid=(2, 2, 2), desc="C4: 256^3 map, 8 subunits (seeds 30-37), EQSP-112/16"),
+    "c2": dict(N=128, vs=1.5, res=8.0, n_sub=4, seed0=20, n_atoms=14000, radius=34.0, grid=(2, 2, 1), desc="C2: 128^3 tetramer map"),
+    "c5": dict(N=512, vs=1.0, res=6.0, n_sub=12, seed0=20, n_atoms=26000, radius=46.0, grid=(3, 2, 2), desc="C5: 512^3 map, 12 subunits, EQSP-112/16"),
+    "small": dict(N=64, vs=2.0, res=10.0, n_sub=2, seed0=20, n_atoms=1500, radius=16.0, grid=(2, 1, 1), desc="C1: 64^3 dimer map"),
 }
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 I8_PEAK_TOPS = 5000.0      # dense int8 MFMA = 2x bf16 (~2.5 PF)
 ORIENT_BYTES = 58956       # 17^3 x 3 x f32 read per anchor
 DESCRIBE_BYTES = 51200     # 4096 x 12 B gathered + 2048 B written per row
+REFINE_BYTES = 96          # 8 corners x 12 B gathered per atom per refinement step
+CCC_BYTES = 8              # two float32 grids read per voxel of the overlap box
+REFERENCE_PY_CORR_S = 2.0e4      # SURVEY.md section 6 [probe]: the reference itself (python + numpy, one thread), 1.5e5 correlations in 6.9 s
+
+
+def source_fingerprint():
+    """sha256 over the kernel sources: ties a committed PMC summary (profiles/) to the build it was taken on."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "mad_amd", "csrc")
+    for fn in sorted(os.listdir(d)):
+        if fn.endswith((".hip", ".h")) or fn == "Makefile":
+            with open(os.path.join(d, fn), "rb") as fh:
+                h.update(fn.encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
 
 
 # --------------------------------------------------------------------------------------------
@@ -90,13 +115,23 @@ class Structure(object):
         self.octave = np.array([a.oct_scale for a in anchors], np.int32)
         self.subv = np.array([a.subv_map_coords for a in anchors], np.float64).reshape(-1, 3)
         self.index = np.arange(len(anchors), dtype=np.int32)
+        self.item = 0      # position of a subunit in the workload's list
 
     def base_gradient(self):
         """(3, X, Y, Z) float32 gradient of the base octave on the host, for the CPU baseline sample."""
-        return np.ascontiguousarray(np.moveaxis(self.ms.grad_list[1], -1, 0), dtype=np.float32)
+        return self.gradient(1)
+
+    def gradient(self, octave):
+        """(3, X, Y, Z) float32 gradient of one octave on the host (what the CPU oracle samples); kept after the first call."""
+        cache = self.__dict__.setdefault("_g", {})
+        if octave not in cache:
+            cache[octave] = np.ascontiguousarray(np.moveaxis(self.ms.grad_list[octave], -1, 0), dtype=np.float32)
+        return cache[octave]
 
 
-def build_inputs(lib, W, rank):
+def build_inputs(lib, W, rank=0, world=1):
+    """-> (map, this rank's subunits, setup seconds).  The map (all n_sub subunits placed on a jittered lattice) is the same on
+    every rank; subunit s belongs to rank s % world (strong scaling: the workload does not grow with the ranks)."""
     from mad_amd import synth
     rng = np.random.default_rng(1234)
     subs, placed, placed_mass = [], [], []
@@ -104,19 +139,19 @@ def build_inputs(lib, W, rank):
     cells = [(i, j, k) for i in range(W["grid"][0]) for j in range(W["grid"][1]) for k in range(W["grid"][2])]
     centre = (np.array(W["grid"]) - 1) * sp / 2
     for s in range(W["n_sub"]):
-        # the map is the same on every rank (seeds 20..); every rank docks its own subunits into it
-        atoms, names, elems = synth.random_globule(W["n_atoms"], W["radius"], seed=20 + s)
+        atoms, names, elems = synth.random_globule(W["n_atoms"], W["radius"], seed=W["seed0"] + s)
         placed.append(synth.place(atoms, synth.random_rotation(rng), np.array(cells[s]) * sp - centre + rng.normal(scale=2.0, size=3)))
         placed_mass.append(synth.masses(elems))
-        if rank == 0:
-            subs.append((atoms, synth.masses(elems)))
-        else:
-            a2, _, e2 = synth.random_globule(W["n_atoms"], W["radius"], seed=1000 * rank + 20 + s)
-            subs.append((a2, synth.masses(e2)))
+        if s % world == rank:
+            subs.append((s, atoms, synth.masses(elems)))
     mass_all = np.concatenate(placed_mass)
     t0 = time.time()
     the_map = Structure(lib, np.concatenate(placed), mass_all, W["res"], W["vs"], N=W["N"], tag="map")
-    sub_structs = [Structure(lib, a, m, W["res"], W["vs"]) for a, m in subs]
+    sub_structs = []
+    for s, a, m in subs:
+        st = Structure(lib, a, m, W["res"], W["vs"])
+        st.item = s
+        sub_structs.append(st)
     return the_map, sub_structs, time.time() - t0
 
 
@@ -128,9 +163,13 @@ HOST_T = {}
 
 
 def enqueue_builds(lib, the_map, subs, sets):
-    """orient + describe of the map and of every subunit into `sets` (device-resident, rebuilt in place); asynchronous."""
+    """orient + describe of the map and of every subunit into `sets` (device-resident, rebuilt in place); asynchronous.
+    sets[0] is the map's DeviceSet, or a dist.ShardedSetBuild when the map's rows are built in shares over the ranks."""
     t0 = time.perf_counter()
-    lo = lib.set_build(the_map.slots, the_map.coords, the_map.octave, the_map.subv, the_map.index, into=sets[0])
+    if hasattr(sets[0], "enqueue"):
+        lo = sets[0].enqueue()
+    else:
+        lo = lib.set_build(the_map.slots, the_map.coords, the_map.octave, the_map.subv, the_map.index, into=sets[0])
     his = [lib.set_build(s.slots, s.coords, s.octave, s.subv, s.index, into=d) for s, d in zip(subs, sets[1:])]
     HOST_T["build_enqueue"] = HOST_T.get("build_enqueue", 0.0) + time.perf_counter() - t0
     return lo, his
@@ -197,8 +236,8 @@ def refine_ccc_leg(lib, the_map, subs, tops, W, n_cand=8):
     lib.timing_reset()
     lib.synchronize()
     t0 = time.perf_counter()
-    n_done, n_conv, best = 0, 0, []
-    # all candidates of all subunits are refined in ONE launch (a persistent workgroup each)
+    n_done, n_conv, best, steps_total = 0, 0, [], 0
+    # all candidates of all subunits are refined in ONE launch
     starts, owner = [], []
     for si, (sub, top) in enumerate(zip(subs, tops)):
         m = min(n_cand, len(top))
@@ -207,77 +246,129 @@ def refine_ccc_leg(lib, the_map, subs, tops, W, n_cand=8):
         R = top[:m, 14:23].reshape(m, 3, 3)
         starts.append(np.einsum("aj,cij->cai", sub.atoms, R) + (top[:m, 11:14] - np.einsum("cij,cj->ci", R, top[:m, 8:11]))[:, None, :])
         owner += [si] * m
+    vox = 0
     if starts and len({len(s_.atoms) for s_ in subs}) == 1:
-        refined, conv, _ = lib.refine(np.concatenate(starts))
+        refined, conv, last = lib.refine(np.concatenate(starts))
         per_sub = {}
         owner = np.array(owner)
         for si, sub in enumerate(subs):      # density simulation + CCC of a subunit's candidates: one call, device-resident
             sel = np.flatnonzero(owner == si)
             if len(sel):
                 per_sub[si] = lib.density_ccc(refined[sel], sub.mass, W["res"])
+                vox += len(sel) * int(np.prod(sub.shape))
         n_done, n_conv = len(owner), int(np.sum(conv))
+        steps_total = int(np.sum(np.asarray(last) + 1))
         best = [float(np.max(v)) for _, v in sorted(per_sub.items())]
     lib.synchronize()
     dt = time.perf_counter() - t0
     ms = {g: lib.timing_get(g)[0] for g in ("refine", "density", "ccc")}
-    return dict(value=n_done / dt, unit="candidates/s", candidates=n_done, converged=n_conv, seconds=dt, atoms_per_candidate=int(len(subs[0].atoms)),
-                best_ccc_per_subunit=[round(float(b), 4) for b in best], kernel_ms=ms,
+    n_atoms = int(len(subs[0].atoms)) if subs else 0
+    roofs = {}
+    if ms["refine"] > 0:      # trilinear gather of the map gradient at every atom, every step (structure_utils.py:106)
+        a = REFINE_BYTES * n_atoms * steps_total / (ms["refine"] * 1e-3) / 1e9
+        roofs["refine"] = dict(kernel="k_refine", bound="hbm", achieved=a, peak=HBM_PEAK_GBS, unit="GB/s", frac=a / HBM_PEAK_GBS, refine_steps=steps_total,
+                               note="latency-bound by construction: <= 500 dependent steps per candidate, the gathers of one step are L2-resident")
+    if ms["ccc"] > 0 and vox:
+        a = CCC_BYTES * vox / (ms["ccc"] * 1e-3) / 1e9
+        roofs["ccc"] = dict(kernel="k_ccc", bound="hbm", achieved=a, peak=HBM_PEAK_GBS, unit="GB/s", frac=a / HBM_PEAK_GBS, voxels=vox)
+    if ms["density"] > 0 and vox:      # splat + three separable blur passes (float64 read + write each) + float32 conversion
+        a = (3 * 16 + 12) * vox / (ms["density"] * 1e-3) / 1e9
+        roofs["density"] = dict(kernel="k_splat + k_blur_axis x3 + k_to_f32", bound="hbm", achieved=a, peak=HBM_PEAK_GBS, unit="GB/s", frac=a / HBM_PEAK_GBS)
+    return dict(value=n_done / dt, unit="candidates/s", candidates=n_done, converged=n_conv, seconds=dt, atoms_per_candidate=n_atoms,
+                best_ccc_per_subunit=[round(float(b), 4) for b in best], kernel_ms=ms, roofline=roofs,
                 note="mad_refine + mad_density_ccc (one host round trip each per batch); not part of the headline metric")
 
 
-def cpu_baseline(the_map, subs, cc, dist, k, lib, n_lo_anchor=800, n_hi_anchor=250, threads=1):
-    """The CPU oracle on a bounded sample of the same workload: the base-octave anchors of the map and of every subunit (the
-    map described once, every subunit docked into it: ~10 s on one core).  threads > 1: the same scalar C functions on
-    contiguous chunks of the work in that many host threads (oracle.py, *_mt)."""
+def cpu_baseline(the_map, subs, cc, dist, k, lib, n_lo_anchor=800, n_hi_anchor=250, threads=1, whole=False):
+    """The CPU oracle on the same workload.  whole=False: a bounded sample, the base-octave anchors of the map and of every
+    subunit (the map described once, every subunit docked into it: ~10 s on one core).  whole=True: EVERY anchor of both
+    octaves -- the full step, which is also what the top-k agreement of the line is checked on.  threads > 1: the same scalar C
+    functions on contiguous chunks of the work in that many host threads (oracle.py, *_mt)."""
     from mad_amd.eqsp import EQSP_Sphere
     from oracle import oracle as O
     e112, e16 = EQSP_Sphere(112), EQSP_Sphere(16)
 
     def described(st, n):
-        sel = np.flatnonzero(st.octave == 1)[:n]
-        g = st.base_gradient()
-        coords, subv = st.coords[sel], st.subv[sel]
-        rows = O.orient_mt(g[0], g[1], g[2], 1, coords, e112.sphere_eqsp, e112.p_centers_eqsp, threads, want_counts=False)
-        dsc = O.describe_mt(g[0], g[1], g[2], 1, coords[rows["anchor"]], rows["R"], e16.sphere_eqsp, threads)
-        return dict(rows=rows, dsc=dsc, subv=subv, coords=coords)
+        parts = []
+        for octave in ((0, 1) if whole else (1,)):
+            sel = np.flatnonzero(st.octave == octave)
+            if not whole:
+                sel = sel[:n]
+            if not len(sel):
+                continue
+            g = st.gradient(octave)
+            rows = O.orient_mt(g[0], g[1], g[2], octave, st.coords[sel], e112.sphere_eqsp, e112.p_centers_eqsp, threads, want_counts=False)
+            dsc = O.describe_mt(g[0], g[1], g[2], octave, st.coords[sel][rows["anchor"]], rows["R"], e16.sphere_eqsp, threads)
+            parts.append((sel, rows, dsc, octave))
+        sel_all = np.concatenate([p[0] for p in parts])
+        first = np.cumsum([0] + [len(p[0]) for p in parts])
+        anchor = np.concatenate([f + p[1]["anchor"] for f, p in zip(first, parts)])      # index into sel_all; the Detector lists octave 0 first
+        return dict(sel=sel_all, anchor=anchor, R=np.concatenate([p[1]["R"] for p in parts]), main=np.concatenate([p[1]["main"] for p in parts]),
+                    dsc=np.concatenate([p[2] for p in parts]), octave=np.concatenate([np.full(len(p[1]["anchor"]), p[3]) for p in parts]),
+                    coords=st.coords[sel_all], subv=st.subv[sel_all], anc_octave=st.octave[sel_all])
 
+    for st in [the_map] + list(subs):      # host copies of the fields (a download + np.gradient): not part of the CPU's time
+        for o in ((0, 1) if whole else (1,)):
+            st.gradient(o)
     t0 = time.perf_counter()
     lo_s = described(the_map, n_lo_anchor)
-    lo_p = lo_s["subv"][lo_s["rows"]["anchor"]]
-    meta_l = np.stack([lo_s["rows"]["anchor"], np.ones_like(lo_s["rows"]["anchor"]), lo_s["rows"]["main"]], 1)
+    lo_p = lo_s["subv"][lo_s["anchor"]]
+    meta_l = np.stack([lo_s["anchor"], lo_s["octave"], lo_s["main"]], 1)
     his, n_corr, n_pairs = [], 0, 0
     for sub in subs:
         hi_s = described(sub, n_hi_anchor)
         ph, pl, ps, _ = O.correlate_mt(hi_s["dsc"], lo_s["dsc"], cc, threads)
         hi_s["pairs"], hi_s["order"], hi_s["res"] = len(ph), np.zeros(0, np.int64), None
         if len(ph):
-            hi_p = hi_s["subv"][hi_s["rows"]["anchor"]]
-            meta_h = np.stack([hi_s["rows"]["anchor"], np.ones_like(hi_s["rows"]["anchor"]), hi_s["rows"]["main"]], 1)
-            res, cnt = O.pose_score_mt(ph, pl, ps, hi_p, hi_s["rows"]["R"], meta_h, lo_p, lo_s["rows"]["R"], meta_l,
+            hi_p = hi_s["subv"][hi_s["anchor"]]
+            meta_h = np.stack([hi_s["anchor"], hi_s["octave"], hi_s["main"]], 1)
+            res, cnt = O.pose_score_mt(ph, pl, ps, hi_p, hi_s["R"], meta_h, lo_p, lo_s["R"], meta_l,
                                        np.unique(hi_p[np.unique(ph)], axis=0), np.unique(lo_p[np.unique(pl)], axis=0), dist, threads)
             hi_s["order"], hi_s["res"] = O.topk(cnt, k), res
         n_corr += len(hi_s["dsc"]) * len(lo_s["dsc"])
         n_pairs += len(ph)
         his.append(hi_s)
     dt = time.perf_counter() - t0
-    # the same sample through the GPU path: top-k pose agreement (identity and order) for every subunit
-    lo_d = lib.set_build(the_map.slots, lo_s["coords"], np.ones(len(lo_s["coords"]), np.int32), lo_s["subv"], np.arange(len(lo_s["coords"])))
+    # the same anchors through the GPU path: top-k pose agreement (identity and order) for every subunit
+    lo_d = lib.set_build(the_map.slots, lo_s["coords"], lo_s["anc_octave"], lo_s["subv"], np.arange(len(lo_s["coords"])))
     agree = True
     for sub, hi_s in zip(subs, his):
         if not hi_s["pairs"]:
             continue
-        hi_d = lib.set_build(sub.slots, hi_s["coords"], np.ones(len(hi_s["coords"]), np.int32), hi_s["subv"], np.arange(len(hi_s["coords"])))
+        hi_d = lib.set_build(sub.slots, hi_s["coords"], hi_s["anc_octave"], hi_s["subv"], np.arange(len(hi_s["coords"])))
         top, idx, st = lib.match_topk(hi_d, lo_d, cc, dist, k)
         agree = agree and bool(st["n_pairs"] == hi_s["pairs"] and np.array_equal(idx, hi_s["order"]) and
                                np.array_equal(top[:, 1], hi_s["res"][hi_s["order"]][:, 1]))
         hi_d.close()
     lo_d.close()
+    what = "EVERY anchor of both octaves (the full step)" if whole else "the base-octave anchors"
     out = dict(value=n_corr / dt, unit="correlations/s", cores=threads, kind="port",
-               sample="CPU oracle (scalar C, %d thread%s) on the base-octave anchors of the same workload: %d map anchors (%d rows) x %d subunits of "
-                      "%s anchors (%d rows), %d pairs over cc, %.1f s" % (threads, "" if threads == 1 else "s", len(lo_s["coords"]), len(lo_s["dsc"]),
+               sample="CPU oracle (scalar C, %d thread%s) on %s of the same workload: %d map anchors (%d rows) x %d subunits of "
+                      "%s anchors (%d rows), %d pairs over cc, %.1f s" % (threads, "" if threads == 1 else "s", what, len(lo_s["coords"]), len(lo_s["dsc"]),
                                                                           len(subs), "/".join(str(len(h["coords"])) for h in his),
-                                                                          sum(len(h["dsc"]) for h in his), n_pairs, dt))
+                                                                          sum(len(h["dsc"]) for h in his), n_pairs, dt),
+               reference_python_corr_per_s=REFERENCE_PY_CORR_S,
+               reference_python_note="the reference itself (python + numpy, one thread) as measured in the BUILD container on a 272 x 549-row case "
+                                     "(SURVEY.md section 6 [probe]); it cannot travel to the GPU box, the C oracle is its port")
     return out, agree
+
+
+# --------------------------------------------------------------------------------------------
+# launching
+# --------------------------------------------------------------------------------------------
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start one rank per GPU with torch.distributed.run as a CHILD process --
+    this parent has not touched a GPU (no HIP call, no torch import) and never does; it relays the children's output and exit code."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -285,20 +376,26 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="auto", choices=sorted(WORKLOADS) + ["auto"], help="auto: c3 on one GPU, c4 (strong scaling) on several")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--in-flight", type=int, default=3, choices=(2, 3), help="steps in flight (groups of device sets)")
     ap.add_argument("--serial", action="store_true", help="lanes serialised for the whole run: the mode the rocprofv3 summaries in profiles/ are "
                     "taken in, so that a kernel's average duration there is the one the roofline pass measures")
+    ap.add_argument("--emulate-rank-of", type=int, default=0, metavar="N", help="REHEARSAL on one GPU: do the per-step work of rank 0 of an N-rank "
+                    "job (its share of the map build, the import of all N shares, its subunits); the other ranks' map rows are built once, untimed.  "
+                    "The line is labelled as an estimate and is not a multi-GPU measurement")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
 
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 or world > 1:
-        assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     # MAD_DIST_BACKEND=gloo rehearses the N > 1 path on a box with fewer GPUs than ranks (all ranks then share
@@ -307,13 +404,20 @@ def main():
     if backend != "nccl":
         local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("MAD_DIST_FORCE", "0") == "1"      # MAD_DIST_FORCE=1: the collectives of the N > 1 path at world 1 (RCCL on one GPU)
+    if use_dist:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend)
 
     from mad_amd import _lib
+    from mad_amd import dist as mdist
     from mad_amd.eqsp import EQSP_Sphere
     from mad_amd.orient_tables import orientation_matrices
     lib = _lib.Lib(local)
@@ -322,9 +426,20 @@ def main():
     lib.set_eqsp(0, e112.sphere_eqsp, dom, adj)
     lib.set_eqsp(1, e16.sphere_eqsp)
 
-    W = WORKLOADS[args.workload]
+    emu = args.emulate_rank_of if (world == 1 and args.emulate_rank_of > 1) else 0
+    wl = args.workload if args.workload != "auto" else ("c4" if (world > 1 or emu) else "c3")
+    W = WORKLOADS[wl]
     cc, dist_thr, k = 0.6, 4.0, 60
-    the_map, subs, t_setup = build_inputs(lib, W, rank)
+    the_map, subs, t_setup = build_inputs(lib, W, 0 if emu else rank, emu if emu else world)
+    if world > 1:      # one anchor list for everybody: the shares of the map build are indices into it
+        for arr in (the_map.coords, the_map.octave, the_map.subv, the_map.index):
+            t = torch.from_numpy(arr).to("cuda" if backend == "nccl" else "cpu")
+            n_all = torch.tensor([t.numel()], dtype=torch.int64, device=t.device)
+            dist.broadcast(n_all, 0)
+            if int(n_all.item()) != t.numel():
+                sys.exit("bench.py: rank %d detected %d map anchor values, rank 0 %d" % (rank, t.numel(), int(n_all.item())))
+            dist.broadcast(t, 0)
+            arr[...] = t.cpu().numpy()
 
     def barrier():
         torch.cuda.synchronize()
@@ -333,19 +448,27 @@ def main():
             dist.barrier()
 
     def exchange(tops):
-        """The path's one exchange: every rank receives every rank's per-subunit top-k poses
-        (one fused RCCL all-gather of world x n_sub x k x 23 float64, mad_amd/dist.py).  It is started
-        asynchronously and collected one step later, so it overlaps the next step's kernels."""
-        from mad_amd import dist as mdist
-        return mdist.TopkExchange(tops, k, world * W["n_sub"], rank, world)
+        """The step's second exchange: every rank receives every subunit's top-k poses (one fused all-gather of
+        n_sub x k x 23 float64, mad_amd/dist.py).  It is started asynchronously and collected one step later, so it
+        overlaps the next step's kernels."""
+        return mdist.TopkExchange(tops, k, W["n_sub"], rank, world)
 
-    set_groups = [[_lib.DeviceSet(lib) for _ in range(1 + len(subs))] for _ in range(args.in_flight)]
+    sharded = world > 1 or emu or use_dist      # use_dist at world 1 (MAD_DIST_FORCE): export -> RCCL all-gather -> import of the one share
+
+    def map_set():
+        if sharded:
+            return mdist.ShardedSetBuild(lib, the_map.slots, the_map.coords, the_map.octave, the_map.subv, the_map.index, rank, world,
+                                         emulate=(emu, 0) if emu else None, force=True)
+        return _lib.DeviceSet(lib)
+
+    set_groups = [[map_set()] + [_lib.DeviceSet(lib) for _ in subs] for _ in range(args.in_flight)]
     sets = set_groups[0]
     if args.serial:
         lib.set_overlap(False)
-    # Setup, not a step: both groups of device sets are created, sized and given their launch-size hints here (a set sizes
-    # its describe grid and a match its pair capacity from what the previous use of the same objects needed), the way an
-    # allocator is warmed before a run.  The W warm-up steps and the K timed steps that follow all do the full work.
+    # Setup, not a step: all groups of device sets are created, sized and given their launch-size hints here (a set sizes
+    # its describe grid and a match its pair capacity from what the previous use of the same objects needed; the wire images
+    # of a sharded map build are sized by a blocking first build), the way an allocator is warmed before a run.  The W
+    # warm-up steps and the K timed steps that follow all do the full work.
     for grp in set_groups:
         for _ in range(2):
             hot_path_step(lib, the_map, subs, cc, dist_thr, k, grp)
@@ -361,10 +484,28 @@ def main():
         pending[0] = exchange(tops)
 
     corr, tops, stats = run_steps(lib, the_map, subs, cc, dist_thr, k, set_groups, args.steps, after_step=after_step)
-    gathered = pending[0].finish()      # every step's exchange completes inside the timed region
+    gathered = pending[0].finish() if pending[0] is not None else []      # every step's exchange completes inside the timed region
     barrier()
     dt = time.perf_counter() - t0
-    # Per-kernel durations for the rooflines: in the timed region the builds of the five sets and the four matches
+    host_overlapped = {k_: 1e3 * v / max(args.steps, 1) for k_, v in HOST_T.items()}
+    if sharded:      # the pieces of build_enqueue that belong to the sharded map build, per call, over the whole run so far
+        for grp in set_groups:
+            for k_, v in grp[0].host_s.items():
+                if k_ != "calls" and grp[0].host_s["calls"]:
+                    host_overlapped["map_" + k_] = host_overlapped.get("map_" + k_, 0.0) + 1e3 * v / grp[0].host_s["calls"] / len(set_groups)
+
+    # One step at a time, lanes overlapped, nothing else in flight: what a caller who docks ONE batch waits for.
+    lat = []
+    for _ in range(min(args.steps, 10)):
+        barrier()
+        t1 = time.perf_counter()
+        _, tops_l, _ = hot_path_step(lib, the_map, subs, cc, dist_thr, k, sets)
+        exchange(tops_l).finish()
+        lib.synchronize()
+        lat.append(time.perf_counter() - t1)
+    lat_all = torch.tensor([float(np.median(lat)) if lat else 0.0], dtype=torch.float64)
+
+    # Per-kernel durations for the rooflines: in the timed region the builds of the sets and the matches
     # overlap on the device (one lane per structure), so a launch's elapsed time there depends on what ran beside it.  The same
     # steps are therefore repeated with the lanes serialised onto one stream, HIP events around every launch.
     n_serial = min(args.steps, 5)
@@ -383,30 +524,77 @@ def main():
     red_dev = "cuda" if (world == 1 or backend == "nccl") else "cpu"
     t_all = torch.tensor([dt], dtype=torch.float64, device=red_dev)
     c_all = torch.tensor([float(corr)], dtype=torch.float64, device=red_dev)
+    lat_all = lat_all.to(red_dev)
     if world > 1:
         dist.all_reduce(t_all, op=dist.ReduceOp.MAX)
         dist.all_reduce(c_all, op=dist.ReduceOp.SUM)
+        dist.all_reduce(lat_all, op=dist.ReduceOp.MAX)
     t_max, corr_total = float(t_all.item()), float(c_all.item())
+
+    # N > 1: (a) the map set assembled from the ranks' shares must be the set one GPU builds from the whole anchor list, bit
+    # for bit; (b) rank 0 then runs the WHOLE workload alone (all subunits, unsharded map build), outside the timed region:
+    # the one-GPU point of the strong-scaling curve measured in the same run, and the top-k every rank's result is held to.
+    shard_check, one_gpu = None, None
+    if sharded:
+        lo_sh = sets[0].enqueue()      # a collective: every rank takes part
+        lib.synchronize()
+    if sharded and rank == 0:
+        a = lo_sh.download()
+        ref_set = lib.set_build(the_map.slots, the_map.coords, the_map.octave, the_map.subv, the_map.index)
+        b = ref_set.download()
+        shard_check = bool(all(np.array_equal(a[f], b[f]) for f in ("anchor", "main", "sec", "R", "dsc")))
+        ref_set.close()
+        _, all_subs, _ = build_inputs(lib, W, 0, 1)
+        groups1 = [[_lib.DeviceSet(lib) for _ in range(1 + len(all_subs))] for _ in range(args.in_flight)]
+        for grp in groups1:
+            for _ in range(2):
+                hot_path_step(lib, the_map, all_subs, cc, dist_thr, k, grp)
+        run_steps(lib, the_map, all_subs, cc, dist_thr, k, groups1, args.warmup)
+        lib.synchronize()
+        t1 = time.perf_counter()
+        corr1, tops1, _ = run_steps(lib, the_map, all_subs, cc, dist_thr, k, groups1, args.steps)
+        lib.synchronize()
+        dt1 = time.perf_counter() - t1
+        same = None
+        if not emu:
+            same = bool(len(gathered) == len(tops1) and all(np.array_equal(g, t) for g, t in zip(gathered, tops1)))
+        else:
+            same = bool(all(np.array_equal(tops1[s.item], t) for s, t in zip(subs, tops)))
+        one_gpu = dict(value=corr1 * args.steps / dt1, unit="correlations/s", ms_per_step=1e3 * dt1 / args.steps,
+                       topk_identical_to_sharded_run=same,
+                       note="rank 0 running the whole workload alone after the timed region (same build, same box): the N = 1 point of this strong-scaling run")
+        for grp in groups1:
+            for s_ in grp:
+                s_.close()
+    if world > 1:
+        dist.barrier()
 
     if rank == 0:
         groups = {}
         for gname in ("orient", "describe", "correlate", "pairs", "pose", "topk"):
             ms, n = lib.timing_get(gname)
             groups[gname] = dict(ms_total=ms, launches=n)
-        n_anchor_lo = len(the_map.coords)
-        rows_lo = stats[0]["n_lo"]
+        n_anchor_lo = len(the_map.coords) if not sharded else len(mdist.share_of(len(the_map.coords), 0, emu if emu else world))
+        rows_lo = stats[0]["n_lo"] if stats else 0
+        rows_lo_built = rows_lo if not sharded else sets[0].share.size()[0]
         rows_hi = sum(s["n_hi"] for s in stats)
         anchors_hi = sum(len(s.coords) for s in subs)
         pairs = sum(s["n_pairs"] for s in stats)
-        # one roofline entry per kernel group; `roofline` = the group with the largest share of device time
-        traffic = {}
+        # one roofline entry per kernel group; counters (HBM traffic, VALU issue share) come from the committed PMC summary of THIS
+        # build, identified by the fingerprint of the kernel sources -- a summary of another build is named but not used
+        traffic, valu_util, counters_from = {}, {}, None
         import glob
         profs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_c3_serial_summary.json")))      # newest round last
         pj = {}
-        if args.workload == "c3" and profs:      # PMC passes of this same command (profiles/README.md)
+        if wl == "c3" and world == 1 and profs:      # PMC passes of this same command (profiles/README.md)
             with open(profs[-1]) as fh:
                 pj = json.load(fh)
-        valu_util = {}
+            meta = pj.get("_meta", {})
+            fresh = meta.get("source_fingerprint") == source_fingerprint()
+            counters_from = dict(file=os.path.relpath(profs[-1], ROOT), git=meta.get("git"), source_fingerprint=meta.get("source_fingerprint"),
+                                 this_build=source_fingerprint(), stale=not fresh)
+            if not fresh:
+                pj = {}
         for kn, gname in (("k_pose_lds", "pose"), ("k_describe<16>", "describe"), ("k_orient", "orient"), ("k_corr_gemm", "correlate"),
                           ("k_pair_emit", "pairs")):
             if kn in pj and "fetch_size_bytes_avg" in pj[kn]:
@@ -416,7 +604,7 @@ def main():
                 valu_util[gname] = 4.0 * pj[kn]["SQ_INSTS_VALU_avg"] / (pj[kn]["avg_us"] * 1e-6 * 2.4e9 * 1024)
         per_step = {g: max(groups[g]["launches"], 1) / n_serial for g in groups}      # launches per step
         alg = {
-            "describe": ("k_describe", "hbm", DESCRIBE_BYTES * (rows_lo + rows_hi), HBM_PEAK_GBS, "GB/s", 1e9),
+            "describe": ("k_describe", "hbm", DESCRIBE_BYTES * (rows_lo_built + rows_hi), HBM_PEAK_GBS, "GB/s", 1e9),
             "orient": ("k_orient", "hbm", ORIENT_BYTES * (n_anchor_lo + anchors_hi), HBM_PEAK_GBS, "GB/s", 1e9),
             "correlate": ("k_corr_gemm", "mfma", 2.0 * 1024 * corr, I8_PEAK_TOPS, "TOP/s", 1e12),
             # pose scoring reads a pair (8 B) and writes a count (4 B); its real limit is float64 VALU + LDS latency
@@ -434,17 +622,19 @@ def main():
             if gname in valu_util:
                 roofs[gname]["valu_issue_share"] = round(valu_util[gname], 3)      # from the SQ counters of the profiled run (profiles/)
         # `roofline` = the HBM stage SURVEY.md 8(d) names as the binding roofline of the headline metric (the texel
-        # gathers of orient + describe), represented by its larger kernel, k_describe.  The pose search takes a larger
-        # share of the device time but is bound by float64 VALU issue and LDS latency, which an hbm | mfma roofline
+        # gathers of orient + describe), represented by its larger kernel, k_describe.  The pose search takes a comparable
+        # share of the device time but is bound by VALU issue and LDS latency, which an hbm | mfma roofline
         # cannot express: it is listed under `others` with its own note.
         dom_name = "describe"
         roof = dict(roofs[dom_name])
+        roof["counters_from"] = counters_from
         roof["kernel_ms_per_step"] = {g: groups[g]["ms_total"] / n_serial for g in groups}
         roof["timing"] = ("HIP events around every launch over %d steps with the lanes serialised onto one stream (%.3f ms/step); "
                           "the timed region overlaps the lanes (%.3f ms/step)" % (n_serial, 1e3 * dt_serial / n_serial, 1e3 * t_max / args.steps))
         roof["host_ms_per_step"] = {k_: 1e3 * v / n_serial for k_, v in HOST_T.items()}
+        roof["host_ms_per_step_timed_region"] = host_overlapped
         t_hbm = (groups["orient"]["ms_total"] + groups["describe"]["ms_total"]) / n_serial * 1e-3
-        b_hbm = ORIENT_BYTES * (n_anchor_lo + anchors_hi) + DESCRIBE_BYTES * (rows_lo + rows_hi)
+        b_hbm = ORIENT_BYTES * (n_anchor_lo + anchors_hi) + DESCRIBE_BYTES * (rows_lo_built + rows_hi)
         roof["hbm_stage"] = dict(kernels="k_orient + k_describe", algorithmic_bytes_per_step=b_hbm, seconds_per_step=t_hbm,
                                  achieved=b_hbm / t_hbm / 1e9 if t_hbm > 0 else 0.0, unit="GB/s", frac=(b_hbm / t_hbm / 1e9) / HBM_PEAK_GBS if t_hbm > 0 else 0.0)
         roof["largest_share_of_device_time"] = max(groups, key=lambda g: groups[g]["ms_total"])
@@ -452,52 +642,69 @@ def main():
                         "texel requests between a CU and its XCD's L2 (one L1 access per lane-load, ~half of them L2 requests, the L1 stalled on "
                         "pending misses half of its active cycles; fields that fit the Infinity Cache run no faster per row), and its own "
                         "arithmetic takes 2/3 of its time (probes and counters in DESIGN.md section 6)")
-        l_hi_mean = float(np.mean([s["l_hi"] for s in stats]))
+        l_hi_mean = float(np.mean([s["l_hi"] for s in stats])) if stats else 0.0
         pts = pairs * l_hi_mean      # transformed hi-cloud points per step
+        t_pose = groups["pose"]["ms_total"] / n_serial * 1e-3
         roofs["pose"]["note"] = ("not an HBM kernel (the HBM figure is its algorithmic 12 B/pair): every transformed hi point (%.3g per step, %.0f G/s) "
-                                 "goes through a float32 occupancy-bitmap test, the ~1 in 8 that pass through the exact float64 cell search; "
-                                 "vector-ALU issue is the binding resource (valu_issue_share, SQ_INSTS_VALU of the profiled run)"
-                                 % (pts, pts / (groups["pose"]["ms_total"] / n_serial * 1e-3) / 1e9))
+                                 "goes through a float32 occupancy-bitmap test; vector-ALU issue is the binding resource (valu_issue_share, "
+                                 "SQ_INSTS_VALU of the profiled run)" % (pts, pts / t_pose / 1e9 if t_pose > 0 else 0.0))
         roof["others"] = {g: roofs[g] for g in roofs if g != dom_name}
 
-        cpu, agree, cpu_all = (None, None, None)
-        if world == 1 and not args.no_cpu_baseline:
-            cpu, agree = cpu_baseline(the_map, subs, cc, dist_thr, k, lib)
+        cpu, agree, cpu_all, agree_whole = (None, None, None, None)
+        if world == 1 and not emu and not args.no_cpu_baseline:
+            cpu, agree = cpu_baseline(the_map, subs[:4], cc, dist_thr, k, lib)
             n_host = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
             n_host = min(n_host, 16)      # a one-GPU box's CPU share
-            if n_host > 1:      # the same sample on the host cores of this box's share
-                cpu_all, agree_all = cpu_baseline(the_map, subs, cc, dist_thr, k, lib, threads=n_host)
-                agree = bool(agree and agree_all)
+            if n_host > 1:      # the FULL step (every anchor, both octaves) on the host cores of this box's share: also the top-k check of the line
+                cpu_all, agree_whole = cpu_baseline(the_map, subs[:4], cc, dist_thr, k, lib, threads=n_host, whole=True)
         refine_line = None
-        if world == 1:
+        if world == 1 and not emu:
             lib.timing_enable(True)
-            refine_line = refine_ccc_leg(lib, the_map, subs, tops, W)
+            refine_line = refine_ccc_leg(lib, the_map, subs[:4], tops[:4], W)
             lib.timing_enable(False)
+            roof["others"].update(refine_line.pop("roofline"))
 
+        n_ranks = emu if emu else world
         line = {
             "metric": "anchor-pair x rotation correlations/sec on 256^3 map; top-k pose agreement",
             "value": corr_total * args.steps / t_max,
             "unit": "correlations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * t_max / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "latency_ms_single_step": 1e3 * float(lat_all.item()),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "i8 (correlation, exact int32 accumulate) / f64 (binning, pose scoring)",
             "data": "synthetic",
             "config": {"workload": W["desc"], "map": "%d^3 @ %.1f A/voxel, %.0f A" % (W["N"], W["vs"], W["res"]),
-                       "subunits_per_gpu": W["n_sub"], "map_anchors": n_anchor_lo, "map_rows": rows_lo,
-                       "subunit_anchors": anchors_hi, "subunit_rows": rows_hi, "pairs_over_cc": pairs,
-                       "cc_threshold": cc, "top_k": k, "correlations_per_step_per_gpu": corr,
-                       "parallelism": "1 process per GPU, subunits sharded, RCCL all-gather of top-k" if world > 1 else "single GPU",
+                       "subunits": W["n_sub"], "subunits_this_rank": len(subs), "map_anchors": len(the_map.coords), "map_rows": rows_lo,
+                       "map_anchors_built_by_this_rank": n_anchor_lo, "map_rows_built_by_this_rank": rows_lo_built,
+                       "subunit_anchors_this_rank": anchors_hi, "subunit_rows_this_rank": rows_hi, "pairs_over_cc_this_rank": pairs,
+                       "cc_threshold": cc, "top_k": k, "correlations_per_step": corr_total, "correlations_per_step_this_rank": corr,
+                       "parallelism": ("1 process per GPU over RCCL: map anchors dealt round-robin (orient + describe), all-gather of the rows; "
+                                       "subunits dealt round-robin (correlate + pose + top-k), all-gather of the top-k poses") if world > 1 else "single GPU",
                        "pipelining": "%d steps in flight: the builds (and, with 3, the matches) of the next step are enqueued before the results of a step are awaited; every step does the full work" % args.in_flight,
-                       "topk_agrees_with_cpu_oracle": agree, "setup_s": t_setup,
+                       "latency_note": "latency_ms_single_step = one step submitted alone (lanes overlapped, nothing else in flight, result exchange included), median of %d; ms_per_step = throughput of identical steps, %d in flight" % (len(lat), args.in_flight),
+                       "topk_agrees_with_cpu_oracle": agree_whole if agree_whole is not None else agree,
+                       "topk_agrees_with_cpu_oracle_on": None if agree is None else ("every anchor of both octaves, all subunits (the full step) and the base-octave sample" if agree_whole is not None else "the base-octave sample"),
+                       "topk_agrees_on_sample": agree,
+                       "sharded_map_set_identical_to_unsharded": shard_check,
+                       "setup_s": t_setup,
                        "setup_detail_s": {k_: round(v, 4) for k_, v in SETUP_T.items()}},
             "roofline": roof,
             "cpu_baseline": cpu,
             "cpu_baseline_all_cores": cpu_all,
             "refine_ccc": refine_line,
+            "one_gpu_same_workload": one_gpu,
         }
+        if emu:
+            line["rehearsal"] = ("ESTIMATE, not a multi-GPU measurement: one GPU doing the per-step work of rank 0 of %d (its share of the map build, the "
+                                 "import of all %d shares, %d of %d subunits); value = that rank's correlations x %d / its time, without any link traffic"
+                                 % (n_ranks, n_ranks, len(subs), W["n_sub"], n_ranks))
+            line["value"] = corr * n_ranks * args.steps / t_max
+        if one_gpu is not None:
+            line["speedup_vs_one_gpu_same_workload"] = line["value"] / one_gpu["value"]
         print(json.dumps(line))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     lib.close()

@@ -216,6 +216,14 @@ int mad_match_topk_many_finish(mad_ctx *ctx);
  * diagnostics: the three give identical counts, so only this tells when a sizing change has demoted a workload.
  */
 int mad_last_pose_kernel(mad_ctx *ctx);
+/*
+ * How many pairs of the most recently COMPLETED match went through the exact search.  mad_match_topk* only report the k best
+ * pairs (MaD.py:480,502), so the pose search first brackets every pair's count with the occupancy bitmaps alone (lower bound =
+ * points certainly within dist, upper bound = those plus the points in the uncertain shell) and searches exactly only the pairs
+ * whose upper bound reaches the k-th largest lower bound; the k rows and their order are those of the full search.  Equal to
+ * n_pairs when nothing could be pruned.  mad_match_fetch(counts) / mad_match_results complete the other pairs on demand.
+ */
+int64_t mad_last_pose_selected(mad_ctx *ctx);
 /* After mad_match_topk: all pairs of that call (for MaD._match_dsc's full return value). */
 int mad_match_fetch(mad_ctx *ctx, int32_t *pair_hi, int32_t *pair_lo, double *pair_score,
                     int32_t *counts, int64_t cap);
@@ -283,6 +291,40 @@ int mad_match_shard_pairs(mad_ctx *ctx, const mad_set *hi, const mad_set *lo, in
 int mad_match_shard_topk(mad_ctx *ctx, const mad_set *hi, const mad_set *lo, const uint8_t *used_hi_all,
                          const uint8_t *used_lo_all, double dist, int64_t k, double *results, int64_t *pair_rank,
                          int32_t *counts, int64_t *n_out, int64_t *l_hi);
+
+/* ---- one structure's rows built in shares on several GPUs (stage A).  Orientation and description
+ *      are independent per anchor (Orientator.py:80-108, Descriptor.py:106-116): anchor a of the structure's list goes
+ *      to share a % n_shares (local position a / n_shares), every rank runs mad_set_build on its share, the shares
+ *      travel as fixed-size "wire images" (one all-gather, issued by the caller: mad_amd/dist.py) and every rank
+ *      assembles the full set, rows in the reference's order (anchor x main x sec, Orientator.py:90-106) -- bit for bit
+ *      the set mad_set_build makes from the whole list. ------------------------------------------------------------ */
+
+/* Bytes of a wire image with room for cap_rows rows of D counts (header + main / sec / local anchor / norm / int8 rows). */
+int64_t mad_set_wire_bytes(int D, int64_t cap_rows);
+/*
+ * Packs the rows of a built set into a wire image.  wire_on_device != 0: `wire` is device memory (e.g. the tensor
+ * handed to the all-gather) and the call is asynchronous on the set's lane (mad_set_stream); otherwise host memory
+ * and synchronous.  A share with more than cap_rows rows is sent as an empty image whose header carries its row count;
+ * the import then fails with MAD_ENOSPC at the first call that needs the set's size.
+ */
+int mad_set_export(mad_ctx *ctx, const mad_set *share, void *wire, int wire_on_device, int64_t cap_rows);
+/*
+ * Assembles `set` from n_shares wire images laid out back to back (share r at wires + r * mad_set_wire_bytes).  The
+ * anchors are those of the WHOLE structure in the reference's order; anc_coords may be NULL (an imported set is never
+ * described again).  Rfinal, inv(Rfinal), the int16 counts and the result metadata are re-derived on the importing
+ * GPU with the builder's own expressions.  wires_on_device as above (asynchronous on the set's lane).
+ */
+int mad_set_import(mad_ctx *ctx, mad_set *set, const void *wires, int wires_on_device, int n_shares, int64_t cap_rows,
+                   const int32_t *anc_coords, const int32_t *anc_octave, const double *anc_subv, const int32_t *anc_index,
+                   int n_anchors);
+/*
+ * The lane a set is built on, its HIP stream (for callers that order a collective against the export / import
+ * kernels: hipStreamWaitEvent or a torch ExternalStream), and a way to put two sets on one lane so that
+ * build -> export -> all-gather -> import is one in-order stream.  mad_set_bind_lane synchronises the ctx.
+ */
+int mad_set_lane(mad_ctx *ctx, const mad_set *set);
+void *mad_set_stream(mad_ctx *ctx, const mad_set *set);
+int mad_set_bind_lane(mad_ctx *ctx, mad_set *set, int lane);
 
 /*
  * a14-a16 for a batch of placed copies of one structure, on the device end to end: candidate c's atoms

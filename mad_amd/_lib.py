@@ -22,8 +22,9 @@ SYMBOLS = [
     "mad_set_eqsp", "mad_upload_field", "mad_upload_field_device", "mad_free_field",
     "mad_orient", "mad_describe", "mad_correlate", "mad_pose_score", "mad_topk",
     "mad_set_create", "mad_set_destroy", "mad_set_build", "mad_set_load", "mad_set_size", "mad_set_download",
-    "mad_match_topk", "mad_match_topk_many", "mad_match_topk_many_begin", "mad_match_topk_many_finish", "mad_last_pose_kernel", "mad_match_fetch", "mad_match_results", "mad_match_used",
+    "mad_match_topk", "mad_match_topk_many", "mad_match_topk_many_begin", "mad_match_topk_many_finish", "mad_last_pose_kernel", "mad_last_pose_selected", "mad_match_fetch", "mad_match_results", "mad_match_used",
     "mad_match_shard_pairs", "mad_match_shard_topk",
+    "mad_set_wire_bytes", "mad_set_export", "mad_set_import", "mad_set_lane", "mad_set_stream", "mad_set_bind_lane",
     "mad_upload_density", "mad_refine", "mad_structure_to_density", "mad_ccc", "mad_density_ccc", "mad_grid_overlap", "mad_overlap_matrix",
     "mad_space_create", "mad_space_destroy", "mad_space_build", "mad_space_info", "mad_space_download",
     "mad_space_peaks", "mad_space_patches",
@@ -37,6 +38,30 @@ class MadBackendError(RuntimeError):
 _dll = None
 
 
+def _share_torch_hip_runtime():
+    """PyTorch-ROCm ships its own libamdhip64 next to its extension modules.  Two HIP runtimes in one process do not share a
+    device: whichever is loaded second finds "no HIP GPUs".  So when torch is installed, its copy of the runtime is loaded first
+    and libmad_amd.so binds to that one (same soname), whatever the import order of torch and this package.  torch itself is
+    neither imported nor needed."""
+    import importlib.util
+    if os.environ.get("MAD_OWN_HIP_RUNTIME", "0") == "1":
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    for d in spec.submodule_search_locations:
+        path = os.path.join(d, "lib", "libamdhip64.so")
+        if os.path.exists(path):
+            try:
+                C.CDLL(path, mode=C.RTLD_GLOBAL)
+            except OSError:
+                pass
+            return
+
+
 def load_library():
     """dlopen the HIP library (works without a GPU; opening a device does not)."""
     global _dll
@@ -45,6 +70,7 @@ def load_library():
             raise MadBackendError(
                 "MaD> %s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "or `make -C mad_amd/csrc` (there is no CPU fallback)" % LIB_PATH)
+        _share_torch_hip_runtime()
         try:
             _dll = C.CDLL(LIB_PATH)
         except OSError as e:
@@ -55,6 +81,12 @@ def load_library():
         _dll.mad_stream.argtypes = [C.c_void_p]
         _dll.mad_last_ms.restype = C.c_double
         _dll.mad_last_ms.argtypes = [C.c_void_p, C.c_char_p]
+        _dll.mad_set_stream.restype = C.c_void_p
+        _dll.mad_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+        _dll.mad_last_pose_selected.restype = C.c_int64
+        _dll.mad_last_pose_selected.argtypes = [C.c_void_p]
+        _dll.mad_set_wire_bytes.restype = C.c_int64
+        _dll.mad_set_wire_bytes.argtypes = [C.c_int, C.c_int64]
         _dll.mad_destroy.restype = None
         _dll.mad_set_destroy.restype = None
         _dll.mad_space_destroy.restype = None
@@ -72,11 +104,24 @@ def _c(a, dt):
 class DeviceSet(object):
     """Device-resident oriented-anchor rows of one structure (mad_set)."""
 
-    def __init__(self, lib):
+    def __init__(self, lib, lane=None):
         self.lib = lib
         self.h = C.c_void_p()
         lib._chk(lib.dll.mad_set_create(lib.ctx, C.byref(self.h)))
         self.n_anchors = 0
+        if lane is not None:
+            self.bind_lane(lane)
+
+    def lane(self):
+        return int(self.lib.dll.mad_set_lane(self.lib.ctx, self.h))
+
+    def bind_lane(self, lane):
+        """Put the set on lane `lane` (0..7): sets of one lane run in order on one stream.  Synchronises the context."""
+        self.lib._chk(self.lib.dll.mad_set_bind_lane(self.lib.ctx, self.h, C.c_int(int(lane))))
+
+    def stream(self):
+        """The HIP stream (as an integer handle) the set's kernels are enqueued on."""
+        return self.lib.dll.mad_set_stream(self.lib.ctx, self.h)
 
     def size(self):
         n = C.c_int64(0)
@@ -416,6 +461,10 @@ class Lib(object):
         """0 k_pose_lds, 1 k_pose_lds32, 2 k_pose (global cell list): the kernel of the most recently enqueued match."""
         return int(self.dll.mad_last_pose_kernel(self.ctx))
 
+    def last_pose_selected(self):
+        """Pairs of the last completed match that went through the exact pose search (the rest were excluded by their bounds)."""
+        return int(self.dll.mad_last_pose_selected(self.ctx))
+
     def match_topk_many_begin(self, his, lo, cc, dist, k):
         """Enqueue every match and return a handle; `match_topk_many_finish(handle)` waits and unpacks.  In between
         the caller may build the sets of its next batch (not the ones this bracket reads)."""
@@ -461,6 +510,50 @@ class Lib(object):
                                                 _p(cnt), C.byref(n), C.byref(l_hi)))
         m = n.value
         return res[:m].copy(), cnt[:m].copy(), rank[:m].copy(), l_hi.value
+
+    # -- a structure's rows built in shares (SURVEY.md 8(e) stage A; the all-gather itself is mad_amd/dist.py's) --------
+    def set_wire_bytes(self, cap_rows, D=1024):
+        n = int(self.dll.mad_set_wire_bytes(C.c_int(int(D)), C.c_int64(int(cap_rows))))
+        if n < 0:
+            raise ValueError("set_wire_bytes(%r, %r)" % (cap_rows, D))
+        return n
+
+    def set_export(self, share, cap_rows, wire=None, device_ptr=None):
+        """Wire image of a built set.  device_ptr: address of device memory of set_wire_bytes(cap_rows) bytes (asynchronous
+        on the set's stream); otherwise a host uint8 array is filled (and returned)."""
+        if device_ptr is not None:
+            self._chk(self.dll.mad_set_export(self.ctx, share.h, C.c_void_p(int(device_ptr)), C.c_int(1), C.c_int64(int(cap_rows))))
+            return None
+        nbytes = self.set_wire_bytes(cap_rows)
+        if wire is None:
+            wire = np.zeros(nbytes, np.uint8)
+        if wire.dtype != np.uint8 or wire.size != nbytes or not wire.flags.c_contiguous:
+            raise ValueError("set_export: wire must be a contiguous uint8 array of %d bytes" % nbytes)
+        self._chk(self.dll.mad_set_export(self.ctx, share.h, _p(wire), C.c_int(0), C.c_int64(int(cap_rows))))
+        return wire
+
+    def set_import(self, n_shares, cap_rows, anc_coords, anc_octave, anc_subv, anc_index, wires=None, device_ptr=None, into=None):
+        """The full set of a structure from the wire images of its n_shares shares (anchor a was built in share a % n_shares).
+        wires: host uint8 array (n_shares x set_wire_bytes), or device_ptr: the same bytes in device memory (asynchronous)."""
+        s = into if into is not None else DeviceSet(self)
+        anc_octave = _c(anc_octave, np.int32)
+        anc_subv = _c(anc_subv, np.float64).reshape(-1, 3)
+        anc_index = _c(anc_index, np.int32)
+        anc_coords = None if anc_coords is None else _c(anc_coords, np.int32).reshape(-1, 3)
+        n = len(anc_octave)
+        if len(anc_subv) != n or len(anc_index) != n or (anc_coords is not None and len(anc_coords) != n):
+            raise ValueError("set_import: anchor arrays of different lengths")
+        if device_ptr is not None:
+            src, on_dev = C.c_void_p(int(device_ptr)), 1
+        else:
+            wires = np.ascontiguousarray(wires, dtype=np.uint8)
+            if wires.size != n_shares * self.set_wire_bytes(cap_rows):
+                raise ValueError("set_import: %d bytes for %d shares of %d" % (wires.size, n_shares, self.set_wire_bytes(cap_rows)))
+            src, on_dev = _p(wires), 0
+        s.n_anchors = n
+        self._chk(self.dll.mad_set_import(self.ctx, s.h, src, C.c_int(on_dev), C.c_int(int(n_shares)), C.c_int64(int(cap_rows)),
+                                          _p(anc_coords), _p(anc_octave), _p(anc_subv), _p(anc_index), C.c_int(n)))
+        return s
 
     def match_fetch(self, n_pairs):
         ph, pl = np.zeros(n_pairs, np.int32), np.zeros(n_pairs, np.int32)

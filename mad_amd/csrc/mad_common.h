@@ -121,6 +121,13 @@ struct MatchState {            // the most recent mad_match_topk call
     int64_t cap_c = 0;         // capacity hints carried from call to call (elements of the int32 score matrix,
     int64_t cap_pairs = 0;     // number of pairs); the device raises a flag when one is too small
     int lane = 0;              // scratch copy that holds this match's pairs and counts
+    // the pose search of that match was pruned by bounds: S_COUNTS holds exact counts only for the pairs that could reach the
+    // top k.  mad_match_fetch / mad_match_results complete it on demand (they need the two sets alive and the distance).
+    bool pruned = false, fits = true;
+    const void *hi = nullptr, *lo = nullptr;
+    double dist = 0;
+    int64_t cap_pairs_used = 0;
+    int64_t n_sel = 0;         // pairs that went through the exact search (= n_pairs when nothing was pruned)
     // the shard left in lane 0 by mad_match_shard_pairs, consumed by mad_match_shard_topk
     const void *shard_hi = nullptr, *shard_lo = nullptr;
     int64_t shard_begin = 0, shard_end = 0, shard_pairs = 0, shard_cap_pairs = 0;
@@ -156,6 +163,8 @@ struct mad_ctx {
     DensityDev dens;
     MatchState match;
     int last_pose_kernel = -1;               // 0 k_pose_lds, 1 k_pose_lds32, 2 k_pose (mad_last_pose_kernel)
+    bool lane_pruned[MAD_LANES] = {};        // whether the match last enqueued in a lane pruned its pose search
+    int64_t lane_sel_hint[MAD_LANES] = {};   // pairs the last pruned match of a lane sent to the exact search (sizes the next launch)
     void *many[2] = {nullptr, nullptr};      // open mad_match_topk_many_begin brackets (ManyState, mad_match.hip), by result slot
     int many_oldest = 0;                     // the slot _finish collects next when both are open
     bool timing = false;
@@ -350,6 +359,15 @@ __device__ __forceinline__ void mad_mat3_inv(const double *m, double *o) {      
     o[0] = c00 * id; o[1] = (m[2] * m[7] - m[1] * m[8]) * id; o[2] = (m[1] * m[5] - m[2] * m[4]) * id;
     o[3] = c01 * id; o[4] = (m[0] * m[8] - m[2] * m[6]) * id; o[5] = (m[2] * m[3] - m[0] * m[5]) * id;
     o[6] = c02 * id; o[7] = (m[1] * m[6] - m[0] * m[7]) * id; o[8] = (m[0] * m[4] - m[1] * m[3]) * id;
+}
+
+// Rfinal = adj_sec_mat @ to_dom_mat (Orientator.py:105) from the table matrices of (main bin, secondary bin).  One
+// expression, used by k_orient_rows and by the import of rows built on another GPU (mad_set_import), so that both
+// produce the same bits.
+__device__ __forceinline__ void mad_rfinal(const EqspDev *eq, int mb, int sb, double *o) {
+    const double *A = eq->adj_sec[sb], *B = eq->to_dom[mb];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) o[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
 }
 
 // Copies `bytes` (a multiple of 4) from 16-byte-aligned global memory to 16-byte-aligned LDS with the whole workgroup:

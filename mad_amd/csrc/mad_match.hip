@@ -22,7 +22,8 @@
 
 // status words of one match, on the device (int32)
 // [ST_NHI .. +3] and [ST_NLO .. +3] mirror the two sets' dev_n words {rows, range flag, border rejects, describe overflow}
-enum { ST_NPAIRS = 0, ST_LHI, ST_LLO, ST_NKEYS, ST_FLAG_C, ST_FLAG_PAIRS, ST_BAD, ST_PAD, ST_NHI = 8, ST_NLO = 12, ST_COUNT = 16 };
+// ST_NSEL: pairs whose exact count is computed when the pose search prunes by bounds (k_prune_select)
+enum { ST_NPAIRS = 0, ST_LHI, ST_LLO, ST_NKEYS, ST_FLAG_C, ST_FLAG_PAIRS, ST_BAD, ST_NSEL, ST_NHI = 8, ST_NLO = 12, ST_COUNT = 16 };
 
 // ---------------------------------------------------------------------------
 // per-row auxiliaries: int8 rows + norms, inverse rotations, result-row meta
@@ -417,8 +418,21 @@ struct PoseBits {
     int wz;      // words per z-row
 };
 
+// one launch marks up to four bitmaps (blockIdx.y): the two planes of the fine bitmap and of the coarse one (k_pose_bounds)
+struct PoseBitsJobs {
+    PoseBits B[4];
+    double rad[4];
+    int plane[4];
+    int planes[4];      // planes interleaved in the job's bitmap: 2 (fine: outer, inner) or 1 (coarse: outer only)
+    unsigned *bits[4];
+};
+
 __global__ __launch_bounds__(256) void k_pose_bits(const double *__restrict__ sorted, const int32_t *__restrict__ cell_start, int ncell,
-                                                   PoseBits B, double rad, int plane, unsigned *__restrict__ bits) {
+                                                   PoseBitsJobs J) {
+    const PoseBits B = J.B[blockIdx.y];
+    const double rad = J.rad[blockIdx.y];
+    const int plane = J.plane[blockIdx.y], planes = J.planes[blockIdx.y];
+    unsigned *__restrict__ bits = J.bits[blockIdx.y];
     const int l_lo = cell_start[ncell];
     const double inv_h = 1.0 / B.h, rad2 = rad * rad;
     for (int p = blockIdx.x; p < l_lo; p += gridDim.x) {
@@ -437,11 +451,11 @@ __global__ __launch_bounds__(256) void k_pose_bits(const double *__restrict__ so
             const int z0 = max(plane == 0 ? (int)floor((pz - sq) * inv_h - 0.5) : (int)ceil((pz - sq) * inv_h - 0.5 + 1e-9), 0);
             const int z1 = min(plane == 0 ? (int)ceil((pz + sq) * inv_h - 0.5) : (int)floor((pz + sq) * inv_h - 0.5 - 1e-9), B.dim[2] - 1);
             if (z1 < z0) continue;
-            unsigned *row = bits + 2 * ((size_t)kx * B.dim[1] + ky) * B.wz + plane;      // planes interleaved: [outer][inner] per word
+            unsigned *row = bits + planes * ((size_t)kx * B.dim[1] + ky) * B.wz + plane;      // planes interleaved: [outer][inner] per word
             for (int w = z0 >> 5; w <= (z1 >> 5); w++) {
                 const int lo = max(z0 - 32 * w, 0), hi = min(z1 - 32 * w, 31);
                 const unsigned m = (hi == 31 ? 0xffffffffu : ((1u << (hi + 1)) - 1u)) & ~((1u << lo) - 1u);
-                atomicOr(&row[2 * w], m);
+                atomicOr(&row[planes * w], m);
             }
         }
     }
@@ -533,6 +547,7 @@ __device__ __forceinline__ int pose_count_filtered(int l_hi, const PoseVox &V, c
 struct PosePair {
     double R[9];      // inv(lo.Rfinal) @ hi.Rfinal (MaD.py:438)
     double ph[3], pl[3];
+    PoseVox vf, vc;   // hi-cloud point -> voxel coordinates of the fine / of the coarse bitmap (float32; pose_vox_setup)
 };
 
 __global__ __launch_bounds__(256) void k_pose_prep(const int32_t *__restrict__ pair_hi, const int32_t *__restrict__ pair_lo,
@@ -540,7 +555,7 @@ __global__ __launch_bounds__(256) void k_pose_prep(const int32_t *__restrict__ p
                                                    const double *__restrict__ hi_p, const double *__restrict__ hi_R,
                                                    const double *__restrict__ lo_p, const double *__restrict__ lo_Rinv,
                                                    const int32_t *__restrict__ hi_row_anchor, const int32_t *__restrict__ lo_row_anchor,
-                                                   PosePair *__restrict__ rec) {
+                                                   PoseBits Bf, PoseBits Bc, PosePair *__restrict__ rec) {
     if (status[ST_FLAG_C] || status[ST_FLAG_PAIRS]) return;
     const int64_t n_pairs = min((int64_t)status[ST_NPAIRS], cap_pairs);
     for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < n_pairs; p += (int64_t)gridDim.x * 256) {
@@ -549,6 +564,9 @@ __global__ __launch_bounds__(256) void k_pose_prep(const int32_t *__restrict__ p
         mat3_mul(lo_Rinv + 9 * il, hi_R + 9 * ih, P.R);
         const int ah = hi_row_anchor ? hi_row_anchor[ih] : ih, al = lo_row_anchor ? lo_row_anchor[il] : il;
         for (int d = 0; d < 3; d++) { P.ph[d] = hi_p[3 * ah + d]; P.pl[d] = lo_p[3 * al + d]; }
+        // the float64 part of the bitmap maps here, one thread per pair, not once per wave in the search kernels
+        pose_vox_setup(P.R, P.ph[0], P.ph[1], P.ph[2], P.pl[0], P.pl[1], P.pl[2], Bf, &P.vf);
+        pose_vox_setup(P.R, P.ph[0], P.ph[1], P.ph[2], P.pl[0], P.pl[1], P.pl[2], Bc, &P.vc);
         rec[p] = P;
     }
 }
@@ -570,7 +588,8 @@ __global__ __launch_bounds__(POSE_LDS_THREADS) void k_pose_lds(const int32_t *__
                                                                const int32_t *__restrict__ cell_start,
                                                                const unsigned short *__restrict__ cell_start16, PoseGrid G, int l_hi_cap,
                                                                int l_lo_cap, float reach, double dd_lim, PoseBits B,
-                                                               const unsigned *__restrict__ bits, int32_t *__restrict__ counts) {
+                                                               const unsigned *__restrict__ bits, int32_t *__restrict__ counts,
+                                                               const int32_t *__restrict__ sel) {
     extern __shared__ __align__(16) unsigned char smem[];
     if (status[ST_FLAG_C] || status[ST_FLAG_PAIRS]) return;
     // LDS regions, each a multiple of 16 bytes (pose_device on the host mirrors this)
@@ -581,7 +600,8 @@ __global__ __launch_bounds__(POSE_LDS_THREADS) void k_pose_lds(const int32_t *__
     unsigned char *wave_lds = (unsigned char *)cs + pad16((size_t)(G.ncell + 1) * 2) + (threadIdx.x >> 6) * POSE_WAVE_LDS;
     unsigned short *ring = (unsigned short *)wave_lds;                               // this wave's survivor queue
     double *recs = (double *)(wave_lds + POSE_RING * 2);                             // this wave's two pair records, 16 doubles each
-    const int64_t n_pairs = min((int64_t)status[ST_NPAIRS], cap_pairs);
+    // sel != nullptr: only the pairs listed there (status[ST_NSEL] of them; the others keep the lower bound k_pose_bounds left in counts)
+    const int64_t n_pairs = sel ? (int64_t)status[ST_NSEL] : min((int64_t)status[ST_NPAIRS], cap_pairs);
     const int l_hi = status[ST_LHI];
     const int l_lo = cell_start[G.ncell];
     stage_lds(lp, lo_sorted, (size_t)l_lo * 24);
@@ -595,7 +615,7 @@ __global__ __launch_bounds__(POSE_LDS_THREADS) void k_pose_lds(const int32_t *__
     const int64_t wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (POSE_LDS_THREADS / MAD_WAVE) + (threadIdx.x >> 6)));
     const int64_t nwaves = (int64_t)gridDim.x * (POSE_LDS_THREADS / MAD_WAVE);
     PosePair cur;
-    if (wave < n_pairs) cur = rec[wave];
+    if (wave < n_pairs) cur = rec[sel ? sel[wave] : wave];
     const float mnx = (float)G.mn[0], mny = (float)G.mn[1], mnz = (float)G.mn[2];
 
     // the exact search for queue entry e = slot << 15 | hi point
@@ -658,11 +678,11 @@ __global__ __launch_bounds__(POSE_LDS_THREADS) void k_pose_lds(const int32_t *__
             if (old_left == 0 && lane == 0) counts[p_old] = cnt_old;      // the previous pair is complete
         }
     };
-    for (int64_t p = wave; p < n_pairs; p += nwaves) {
+    for (int64_t it = wave; it < n_pairs; it += nwaves) {
+        const int64_t p = sel ? sel[it] : it;
         PosePair nxt;      // requested now, needed one iteration later
-        if (p + nwaves < n_pairs) nxt = rec[p + nwaves];
-        PoseVox V;
-        pose_vox_setup(cur.R, cur.ph[0], cur.ph[1], cur.ph[2], cur.pl[0], cur.pl[1], cur.pl[2], B, &V);
+        if (it + nwaves < n_pairs) nxt = rec[sel ? sel[it + nwaves] : it + nwaves];
+        const PoseVox V = cur.vf;
         if (lane == 0) {      // this pair's transform for the exact search (the slot's previous user is complete by now)
             double *P = recs + 16 * slot;
             for (int i = 0; i < 9; i++) P[i] = cur.R[i];
@@ -742,13 +762,14 @@ __global__ __launch_bounds__(POSE_LDS_THREADS) void k_pose_lds32(const int32_t *
                                                                  const int32_t *__restrict__ cell_start,
                                                                  const unsigned short *__restrict__ cell_start16, PoseGrid G, int l_lo_cap, int l_hi_cap,
                                                                  float reach, double dd_lim, float lim_in, float lim_out, PoseBits B,
-                                                                 const unsigned *__restrict__ bits, int32_t *__restrict__ counts) {
+                                                                 const unsigned *__restrict__ bits, int32_t *__restrict__ counts,
+                                                                 const int32_t *__restrict__ sel) {
     extern __shared__ __align__(16) unsigned char smem[];
     if (status[ST_FLAG_C] || status[ST_FLAG_PAIRS]) return;
     float4 *lpf = (float4 *)smem;                                  // sorted lo cloud, float32 offsets from G.mn
     unsigned short *cs = (unsigned short *)(lpf + l_lo_cap + 1);   // cell offsets
     unsigned short *stack = (unsigned short *)((unsigned char *)cs + pad16((size_t)(G.ncell + 1) * 2)) + (threadIdx.x >> 6) * POSE_STACK;
-    const int64_t n_pairs = min((int64_t)status[ST_NPAIRS], cap_pairs);
+    const int64_t n_pairs = sel ? (int64_t)status[ST_NSEL] : min((int64_t)status[ST_NPAIRS], cap_pairs);      // as in k_pose_lds
     const int l_hi = status[ST_LHI];
     const int l_lo = cell_start[G.ncell];
     // HI_LDS: the hi cloud too, as float64 for the exact search and as float32 for the bitmap test (when it fits beside the lo cloud)
@@ -769,18 +790,19 @@ __global__ __launch_bounds__(POSE_LDS_THREADS) void k_pose_lds32(const int32_t *
     const int64_t wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (POSE_LDS_THREADS / MAD_WAVE) + (threadIdx.x >> 6)));
     const int64_t nwaves = (int64_t)gridDim.x * (POSE_LDS_THREADS / MAD_WAVE);
     PosePair cur;
-    if (wave < n_pairs) cur = rec[wave];
-    for (int64_t p = wave; p < n_pairs; p += nwaves) {
+    if (wave < n_pairs) cur = rec[sel ? sel[wave] : wave];
+    for (int64_t it = wave; it < n_pairs; it += nwaves) {
+        const int64_t p = sel ? sel[it] : it;
         PosePair nxt;      // requested now, needed one iteration later
-        if (p + nwaves < n_pairs) nxt = rec[p + nwaves];
+        if (it + nwaves < n_pairs) nxt = rec[sel ? sel[it + nwaves] : it + nwaves];
         const double *R = cur.R;
         const double ph0 = cur.ph[0], ph1 = cur.ph[1], ph2 = cur.ph[2], pl0 = cur.pl[0], pl1 = cur.pl[1], pl2 = cur.pl[2];
-        PoseVox V;
-        pose_vox_setup(R, ph0, ph1, ph2, pl0, pl1, pl2, B, &V);
+        const PoseVox V = cur.vf;
         auto cloud32 = [&](int a, float &cx, float &cy, float &cz) {
             if (HI_LDS) { const float4 c = clf[a]; cx = c.x; cy = c.y; cz = c.z; }
             else { cx = (float)hi_cloud[3 * a]; cy = (float)hi_cloud[3 * a + 1]; cz = (float)hi_cloud[3 * a + 2]; }
         };
+
         auto exact = [&](int a) -> bool {
             const double d0 = hc[3 * a] - ph0, d1 = hc[3 * a + 1] - ph1, d2 = hc[3 * a + 2] - ph2;
             const double x = (d0 * R[0] + d1 * R[1] + d2 * R[2]) + pl0;      // MaD.py:440-444
@@ -835,6 +857,161 @@ __global__ __launch_bounds__(POSE_LDS_THREADS) void k_pose_lds32(const int32_t *
         cnt = wave_sum_i32(cnt);
         if (lane == 0) counts[p] = cnt;
         cur = nxt;
+    }
+}
+
+// ---- pruning by bounds: the bitmap phase alone brackets a pair's count ------------------------------------------
+//
+// For one pair, the number of hi points whose voxel has the INNER bit set is a lower bound L of its match count, and L plus
+// the number of points in the shell (outer bit set, inner clear) an upper bound U.  A match only reports the k best pairs
+// (count descending, pair order ascending, MaD.py:480), so with T = the k-th largest L over all pairs, a pair with U < T
+// cannot be among them: at least k pairs have a count >= T.  k_pose_bounds brackets every pair (the bitmap phase of
+// k_pose_lds: float32, ~40 % of its instructions, and it needs neither the lo cloud nor float64 points in LDS);
+// k_prune_select lists the pairs with U >= T; the exact search then runs on those alone and overwrites their entry of
+// `counts`.  The others keep L <= count < T there, which the top-k selection ranks behind every listed pair exactly as
+// it would rank their true counts: the k rows and their order are those of the unpruned search.
+__device__ __forceinline__ int topk_threshold(const int32_t *__restrict__ hist, int nbins, int64_t k, int *wt, int *sh, int *need);
+__global__ __launch_bounds__(256) void k_count_hist(const int32_t *__restrict__ counts, const int32_t *__restrict__ status, int64_t cap_pairs,
+                                                    int32_t *__restrict__ hist, int nbins);
+
+#define PB_THREADS 1024
+struct PoseCoarse {
+    PoseBits B;
+    int n_words;
+};
+
+// NB x 64 >= l_hi: the point sets of one pair.  Per pair and wave:
+//   coarse phase : every hi point is mapped into the COARSE outer-plane bitmap, which sits in LDS (one LDS lookup per point);
+//                  a clear voxel proves that no lo point lies within dist -- 3 points in 4 end here.  The others are queued
+//                  (ballot compaction, per-wave queue in LDS);
+//   fine phase   : the queued points, now in full lanes, are mapped into the FINE two-plane bitmap in global memory (one
+//                  scattered L2 request per lane: what bounded the search when every point made one) and tallied:
+//                  inner bit = certainly within dist (lower bound), outer bit = possibly (upper bound).
+// Software-pipelined over pairs: the fine lookups of pair i are in flight while the coarse phase of pair i + 1 runs.
+template <int NB>
+__global__ __launch_bounds__(PB_THREADS) void k_pose_bounds(const int32_t *__restrict__ status, int64_t cap_pairs,
+                                                            const PosePair *__restrict__ rec, const double *__restrict__ hi_cloud,
+                                                            PoseBits B, const unsigned *__restrict__ bits, PoseCoarse C,
+                                                            const unsigned *__restrict__ bits_c, int32_t *__restrict__ lower,
+                                                            unsigned short *__restrict__ upper, int probe) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    if (status[ST_FLAG_C] || status[ST_FLAG_PAIRS]) return;
+    unsigned *lb = (unsigned *)smem;                                           // coarse bitmap
+    float4 *clf = (float4 *)(smem + pad16((size_t)C.n_words * 4));             // hi cloud, float32
+    const int64_t n_pairs = min((int64_t)status[ST_NPAIRS], cap_pairs);
+    const int l_hi = status[ST_LHI];
+    // one queue of NB x 64 point ids per wave (LDS operations of a wave execute in order: the lookups of a pair have read it
+    // before the next pair's filter writes it)
+    unsigned short *queue = (unsigned short *)(clf + ((l_hi + 3) & ~3)) + (threadIdx.x >> 6) * (NB * MAD_WAVE);
+    stage_lds(lb, bits_c, (size_t)C.n_words * 4);
+    for (int i = threadIdx.x; i < l_hi; i += PB_THREADS)
+        clf[i] = make_float4((float)hi_cloud[3 * i], (float)hi_cloud[3 * i + 1], (float)hi_cloud[3 * i + 2], 0.f);
+    __syncthreads();
+    const int lane = lane_id();
+    const int64_t wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (PB_THREADS / MAD_WAVE) + (threadIdx.x >> 6)));
+    const int64_t nwaves = (int64_t)gridDim.x * (PB_THREADS / MAD_WAVE);
+
+    // coarse phase of one pair -> number of queued points (wave-uniform)
+    auto filter = [&](const PoseVox &V, unsigned short *q) -> int {
+        int nq = 0;
+#pragma unroll
+        for (int u = 0; u < NB; u++) {
+            if (u * MAD_WAVE >= l_hi) break;      // wave-uniform
+            const int a = u * MAD_WAVE + lane;
+            const float4 c = clf[min(a, l_hi - 1)];
+            const float vx = fmaf(c.z, V.m[2], fmaf(c.y, V.m[1], fmaf(c.x, V.m[0], V.t[0])));
+            const float vy = fmaf(c.z, V.m[5], fmaf(c.y, V.m[4], fmaf(c.x, V.m[3], V.t[1])));
+            const float vz = fmaf(c.z, V.m[8], fmaf(c.y, V.m[7], fmaf(c.x, V.m[6], V.t[2])));
+            const int jx = cvt_floor(vx), jy = cvt_floor(vy), jz = cvt_floor(vz);
+            const bool in = (a < l_hi) & ((unsigned)jx < (unsigned)C.B.dim[0]) & ((unsigned)jy < (unsigned)C.B.dim[1]) & ((unsigned)jz < (unsigned)C.B.dim[2]);
+            const unsigned cw = lb[in ? mad_u24(mad_u24((unsigned)jx, (unsigned)C.B.dim[1], (unsigned)jy), (unsigned)C.B.wz, (unsigned)(jz >> 5)) : 0u];
+            const bool pass = in & (((cw >> (jz & 31)) & 1u) != 0u);
+            const unsigned long long bal = __ballot(pass);
+            // set bits below this lane: two instructions (v_mbcnt_lo / _hi) where a lane mask costs a 64-bit shift and two population counts
+            const int below = __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+            if (pass) q[nq + below] = (unsigned short)a;
+            nq += __popcll(bal);
+        }
+        return nq;
+    };
+    // fine phase, first half: the lookups of the queued points go out
+    auto lookup = [&](const PoseVox &V, const unsigned short *q, int nq, uint2 (&w)[NB], int (&bit)[NB]) {
+        __builtin_amdgcn_wave_barrier();      // the queue was written by this wave's own lanes
+#pragma unroll
+        for (int u = 0; u < NB; u++) {
+            w[u] = make_uint2(0u, 0u); bit[u] = 0;
+            if (u * MAD_WAVE >= nq) continue;      // wave-uniform
+            const int e = u * MAD_WAVE + lane;
+            const float4 c = clf[q[min(e, nq - 1)]];
+            const float vx = fmaf(c.z, V.m[2], fmaf(c.y, V.m[1], fmaf(c.x, V.m[0], V.t[0])));
+            const float vy = fmaf(c.z, V.m[5], fmaf(c.y, V.m[4], fmaf(c.x, V.m[3], V.t[1])));
+            const float vz = fmaf(c.z, V.m[8], fmaf(c.y, V.m[7], fmaf(c.x, V.m[6], V.t[2])));
+            const int ix = cvt_floor(vx), iy = cvt_floor(vy), iz = cvt_floor(vz);
+            bit[u] = iz & 31;
+            const bool in = (e < nq) & ((unsigned)ix < (unsigned)B.dim[0]) & ((unsigned)iy < (unsigned)B.dim[1]) & ((unsigned)iz < (unsigned)B.dim[2]);
+            unsigned fi = mad_u24(mad_u24((unsigned)ix, (unsigned)B.dim[1], (unsigned)iy), (unsigned)B.wz, (unsigned)(iz >> 5));
+            if (probe == 3) fi &= 1023u;      // timing probe (MAD_PB_PROBE=3): every lookup an L1 hit; the results are wrong
+            if (in) w[u] = ((const uint2 *)bits)[fi];
+        }
+    };
+    // second half: the inner ball lies inside the outer one, so L = the inner count (low half), U = the outer count (high half)
+    auto tally = [&](const uint2 (&w)[NB], const int (&bit)[NB], int nq) -> int {
+        int acc = 0;
+#pragma unroll
+        for (int u = 0; u < NB; u++) {
+            if (u * MAD_WAVE >= nq) break;      // wave-uniform
+            const unsigned in = (w[u].y >> bit[u]) & 1u, out = ((w[u].x | w[u].y) >> bit[u]) & 1u;
+            acc += (int)(in + (out << 16));
+        }
+        return wave_sum_i32(acc);
+    };
+
+    uint2 wA[NB], wB[NB];
+    int bitA[NB], bitB[NB];
+    int nqA = 0, nqB = 0;
+    auto put = [&](int64_t p, int acc) { if (lane == 0) { lower[p] = acc & 0xffff; upper[p] = (unsigned short)(acc >> 16); } };
+    int64_t p = wave;
+    if (p < n_pairs) {
+        nqA = filter(rec[p].vc, queue);
+        lookup(rec[p].vf, queue, nqA, wA, bitA);
+    }
+    while (p < n_pairs) {      // two pairs per trip (A, then B): the buffers swap roles without register copies
+        const int64_t pb = p + nwaves, pa = pb + nwaves;
+        if (pb < n_pairs) nqB = filter(rec[pb].vc, queue);      // while the lookups of pair p are in flight
+        put(p, tally(wA, bitA, nqA));
+        if (pb >= n_pairs) break;
+        lookup(rec[pb].vf, queue, nqB, wB, bitB);
+        if (pa < n_pairs) nqA = filter(rec[pa].vc, queue);
+        put(pb, tally(wB, bitB, nqB));
+        if (pa >= n_pairs) break;
+        lookup(rec[pa].vf, queue, nqA, wA, bitA);
+        p = pa;
+    }
+}
+
+// T = the k-th largest lower bound (from its histogram; 0 when there are fewer than k pairs), then the pairs whose upper bound
+// reaches it, in no particular order.  Every workgroup derives T for itself, as k_tie_chunks does.
+__global__ __launch_bounds__(256) void k_prune_select(const int32_t *__restrict__ status_in, int64_t cap_pairs, const int32_t *__restrict__ hist,
+                                                      int nbins, int64_t k, const unsigned short *__restrict__ upper, int32_t *__restrict__ sel,
+                                                      int32_t *__restrict__ n_sel, int32_t *__restrict__ thr_out) {
+    __shared__ int wt[5];
+    __shared__ int sh[3];
+    __shared__ int s_base;
+    const int64_t n = (status_in[ST_FLAG_C] || status_in[ST_FLAG_PAIRS]) ? 0 : min((int64_t)status_in[ST_NPAIRS], cap_pairs);
+    if (k > n) k = n;
+    int need;
+    const int cstar = topk_threshold(hist, nbins, k, wt, sh, &need);
+    const int T = max(cstar, 0);
+    if (blockIdx.x == 0 && threadIdx.x == 0) *thr_out = T;
+    for (int64_t i0 = (int64_t)blockIdx.x * 256; i0 < n; i0 += (int64_t)gridDim.x * 256) {
+        const int64_t i = i0 + threadIdx.x;
+        const bool take = i < n && (int)upper[i] >= T;
+        int tot;
+        const int pos = block_excl_scan(take ? 1 : 0, wt, &tot);      // one returning atomic per workgroup: 2 000 of them on one word cost 20 us
+        if (threadIdx.x == 0) s_base = tot ? atomicAdd(n_sel, tot) : 0;
+        __syncthreads();
+        if (take) sel[s_base + pos] = (int32_t)i;
+        __syncthreads();
     }
 }
 
@@ -1238,9 +1415,14 @@ static int pose_wgs_per_cu() {
 // Scores the pairs in S_PAIR_* into S_COUNTS.  The lo cloud is the set of points `d_cloud[0..n_cloud)` whose flag in
 // `d_cloud_used` is set (all when nullptr); `fallback` (cell = dist, built over the same points) is used when the clouds
 // do not fit LDS.
+// prune_k > 0 (with hist2 = l_hi_max + 1 zeroed ints, and status[ST_NSEL] zero): only the k best pairs will be asked for, so the
+// exact search runs on the pairs the bounds cannot exclude (k_pose_bounds, k_prune_select) and S_COUNTS holds lower bounds for
+// the rest.  *pruned (nullable) tells whether that happened (it needs the LDS path and both bitmap planes).
 static int pose_device(mad_ctx *ctx, const Side &hi, const Side &lo, int32_t *d_status, int64_t cap_pairs,
                        const double *d_hi_cloud, int l_hi_max, const double *d_cloud, int n_cloud, const uint8_t *d_cloud_used,
-                       const double bb_min[3], const double bb_max[3], const CellGrid *fallback, double dist) {
+                       const double bb_min[3], const double bb_max[3], const CellGrid *fallback, double dist, int64_t prune_k = 0,
+                       int32_t *hist2 = nullptr, bool *pruned = nullptr) {
+    if (pruned) *pruned = false;
     MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_COUNTS), (size_t)cap_pairs * 4));
     const double dd_lim = sqrt_limit(dist);
     const double reach = dist + 0.01;
@@ -1286,6 +1468,29 @@ static int pose_device(mad_ctx *ctx, const Side &hi, const Side &lo, int32_t *d_
     }
     const size_t lds = lds_base;
     const double bits_rad = dist + B.h * 0.8660254037844387 + slack, bits_rad_in = dist - B.h * 0.8660254037844387 - slack;
+    // The coarse outer-plane bitmap of the pruning pass (k_pose_bounds keeps it in LDS beside the float32 hi cloud): the finest voxel
+    // with which it fits.  A coarser voxel lets more points through to the global lookup, it never changes a count.
+    PoseCoarse PC;
+    double rad_c_out = 0;
+    {
+        PoseBits &Bc = PC.B;
+        // beside the bitmap: the float32 hi cloud and one queue of 2-byte point ids per wave
+        const int nb_sets = (l_hi_max + MAD_WAVE - 1) / MAD_WAVE;
+        const size_t budget = (size_t)150 * 1024 - pad16((size_t)(l_hi_max + 4) * 16) - (size_t)(PB_THREADS / MAD_WAVE) * ((nb_sets + 1) & ~1) * MAD_WAVE * 2 - 64;
+        size_t n_words_c = 0;
+        for (Bc.h = std::max(1.2, B.h);; Bc.h *= 1.05) {
+            const double guard = dist + Bc.h * 0.8660254037844387 + slack + Bc.h;
+            for (int d = 0; d < 3; d++) {
+                Bc.mn[d] = bb_min[d] - guard;
+                Bc.dim[d] = (int)ceil((bb_max[d] - bb_min[d] + 2.0 * guard) / Bc.h) + 1;
+            }
+            Bc.wz = (Bc.dim[2] + 31) / 32;
+            n_words_c = (size_t)Bc.dim[0] * Bc.dim[1] * Bc.wz;
+            if (n_words_c * 4 <= budget || Bc.h > 16.0) break;
+        }
+        PC.n_words = (int)n_words_c;
+        rad_c_out = dist + Bc.h * 0.8660254037844387 + slack;      // float32 voxel coordinates, as for the fine bitmap: same slack
+    }
     // float32 tier of k_pose_lds32: offsets from the grid origin are below M = extent + reach, each rounded once (error
     // <= ulp(M) / 2); a squared distance near dist^2 is then off by < 2 sqrt(3) (dist + 1) ulp(M) plus ~1e-5 of float32
     // arithmetic.  The band is 4 x that bound.
@@ -1312,36 +1517,84 @@ static int pose_device(mad_ctx *ctx, const Side &hi, const Side &lo, int32_t *d_
         hipLaunchKernelGGL(k_pose_grid_build, dim3(1), dim3(1024), (size_t)G.ncell * 4, ctx->stream, d_cloud, d_cloud_used, n_cloud, G,
                            scratch<int32_t>(ctx, S_PG_START), d_start16, scratch<double>(ctx, S_PG_PTS),
                            fits64 ? (float4 *)nullptr : scratch<float4>(ctx, S_PG_PTSF), d_status + ST_LLO);
-        MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_PG_BITS), n_words * 4 + 16));
+        static const bool no_prune = getenv("MAD_NO_PRUNE") != nullptr;      // diagnostic switch
+        const bool prune = prune_k > 0 && hist2 && bits_rad_in > 0.5 && PC.B.h <= 16.0 && l_hi_max <= 8 * MAD_WAVE && !no_prune;
+        // fine bitmap, then (when pruning) the coarse one, in one buffer: one zero fill, one launch marks all planes
+        const size_t fine_bytes = pad16(n_words * 4);
+        const size_t coarse_bytes = prune ? pad16((size_t)PC.n_words * 4) : 0;
+        MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_PG_BITS), fine_bytes + coarse_bytes + 16));
         unsigned *d_bits = scratch<unsigned>(ctx, S_PG_BITS);
-        mad_zero_words(ctx, d_bits, n_words * 4);
-        hipLaunchKernelGGL(k_pose_bits, dim3((unsigned)std::min(std::max(n_cloud, 1), ctx->n_cu * 8)), dim3(256), 0, ctx->stream,
-                           (const double *)scratch<double>(ctx, S_PG_PTS), (const int32_t *)scratch<int32_t>(ctx, S_PG_START), G.ncell, B,
-                           bits_rad, 0, d_bits);
-        if (bits_rad_in > 0.5)
-            hipLaunchKernelGGL(k_pose_bits, dim3((unsigned)std::min(std::max(n_cloud, 1), ctx->n_cu * 8)), dim3(256), 0, ctx->stream,
-                               (const double *)scratch<double>(ctx, S_PG_PTS), (const int32_t *)scratch<int32_t>(ctx, S_PG_START), G.ncell, B,
-                               bits_rad_in, 1, d_bits);
+        unsigned *d_bits_c = (unsigned *)(scratch<char>(ctx, S_PG_BITS) + fine_bytes);
+        mad_zero_words(ctx, d_bits, fine_bytes + coarse_bytes);
+        PoseBitsJobs J;
+        int n_jobs = 0;
+        auto job = [&](const PoseBits &b, double rad, int plane, int planes, unsigned *bits) {
+            J.B[n_jobs] = b; J.rad[n_jobs] = rad; J.plane[n_jobs] = plane; J.planes[n_jobs] = planes; J.bits[n_jobs] = bits; n_jobs++;
+        };
+        job(B, bits_rad, 0, 2, d_bits);
+        if (bits_rad_in > 0.5) job(B, bits_rad_in, 1, 2, d_bits);
+        if (prune) job(PC.B, rad_c_out, 0, 1, d_bits_c);
+        for (int j = n_jobs; j < 4; j++) { J.B[j] = B; J.rad[j] = 0; J.plane[j] = 0; J.planes[j] = 2; J.bits[j] = nullptr; }
+        hipLaunchKernelGGL(k_pose_bits, dim3((unsigned)std::min(std::max(n_cloud, 1), ctx->n_cu * 4), n_jobs), dim3(256), 0, ctx->stream,
+                           (const double *)scratch<double>(ctx, S_PG_PTS), (const int32_t *)scratch<int32_t>(ctx, S_PG_START), G.ncell, J);
         MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_PG_PAIRS), (size_t)cap_pairs * sizeof(PosePair)));
         PosePair *d_rec = scratch<PosePair>(ctx, S_PG_PAIRS);
         hipLaunchKernelGGL(k_pose_prep, dim3(ctx->n_cu * 8), dim3(256), 0, ctx->stream, scratch<int32_t>(ctx, S_PAIR_HI),
-                           scratch<int32_t>(ctx, S_PAIR_LO), d_status, cap_pairs, hi.p, hi.R, lo.p, lo.Rinv, hi.row_anchor, lo.row_anchor, d_rec);
+                           scratch<int32_t>(ctx, S_PAIR_LO), d_status, cap_pairs, hi.p, hi.R, lo.p, lo.Rinv, hi.row_anchor, lo.row_anchor, B, PC.B, d_rec);
         ctx->last_pose_kernel = fits64 ? 0 : 1;
-        mad_timer_begin(ctx, MAD_T_POSE);      // the search kernel alone: what the rocprofv3 summary lists as k_pose_lds
+        mad_timer_begin(ctx, MAD_T_POSE);      // the pose stage: bounds + selection (when pruning) + the exact search
+        const int32_t *d_sel = nullptr;
+        if (prune) {
+            MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_TMP_C), (size_t)cap_pairs * 2 + 64));
+            MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_TMP_D), (size_t)cap_pairs * 4 + 64));
+            const int nbins = l_hi_max + 1;
+            static bool attr_b = false;
+            if (!attr_b) {
+                MAD_HIP(hipFuncSetAttribute((const void *)k_pose_bounds<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                MAD_HIP(hipFuncSetAttribute((const void *)k_pose_bounds<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                MAD_HIP(hipFuncSetAttribute((const void *)k_pose_bounds<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                MAD_HIP(hipFuncSetAttribute((const void *)k_pose_bounds<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                attr_b = true;
+            }
+            static const int probe_mode = getenv("MAD_PB_PROBE") ? atoi(getenv("MAD_PB_PROBE")) : 0;
+            const int nb = (l_hi_max + MAD_WAVE - 1) / MAD_WAVE;      // point sets of 64 an entire hi cloud needs
+            const int nbv = nb <= 2 ? 2 : (nb <= 4 ? 4 : (nb <= 6 ? 6 : 8));
+            const size_t lds_b = pad16((size_t)PC.n_words * 4) + pad16((size_t)(l_hi_max + 4) * 16) + (size_t)(PB_THREADS / MAD_WAVE) * nbv * MAD_WAVE * 2 + 16;
+#define MAD_PB_LAUNCH(NBV)                                                                                                              \
+    hipLaunchKernelGGL(k_pose_bounds<NBV>, dim3(ctx->n_cu), dim3(PB_THREADS), lds_b, ctx->stream, d_status, cap_pairs, d_rec, d_hi_cloud, B, \
+                       d_bits, PC, d_bits_c, scratch<int32_t>(ctx, S_COUNTS), scratch<unsigned short>(ctx, S_TMP_C), probe_mode)
+            if (nbv == 2) MAD_PB_LAUNCH(2);
+            else if (nbv == 4) MAD_PB_LAUNCH(4);
+            else if (nbv == 6) MAD_PB_LAUNCH(6);
+            else MAD_PB_LAUNCH(8);
+#undef MAD_PB_LAUNCH
+            hipLaunchKernelGGL(k_count_hist, dim3(ctx->n_cu * 2), dim3(256), (size_t)nbins * 4, ctx->stream, scratch<int32_t>(ctx, S_COUNTS),
+                               d_status, cap_pairs, hist2, nbins);
+            hipLaunchKernelGGL(k_prune_select, dim3(ctx->n_cu / 2), dim3(256), 0, ctx->stream, d_status, cap_pairs, hist2, nbins, prune_k,
+                               scratch<unsigned short>(ctx, S_TMP_C), scratch<int32_t>(ctx, S_TMP_D), d_status + ST_NSEL, hist2 + nbins);
+            d_sel = scratch<int32_t>(ctx, S_TMP_D);
+            if (pruned) *pruned = true;
+        }
+        // the exact search of a pruned match sees a few hundred pairs: a grid sized from what the previous match in this lane
+        // selected (one pair per wave, 25 % spare) instead of one workgroup per CU staging both clouds for nothing.  A larger
+        // selection than expected is still searched completely, the kernels are persistent.
+        unsigned wgs_sel = (unsigned)ctx->n_cu;
+        if (d_sel && ctx->lane_sel_hint[ctx->lane] > 0)
+            wgs_sel = (unsigned)std::min<int64_t>(ctx->n_cu, std::max<int64_t>(16, (ctx->lane_sel_hint[ctx->lane] * 5 / 4) / (POSE_LDS_THREADS / MAD_WAVE) + 4));
         if (fits64)
-            hipLaunchKernelGGL(k_pose_lds, dim3(ctx->n_cu * (lds > 80 * 1024 ? 1 : pose_wgs_per_cu())), dim3(POSE_LDS_THREADS), lds, ctx->stream, d_status, cap_pairs, d_rec,
+            hipLaunchKernelGGL(k_pose_lds, dim3(d_sel ? wgs_sel : ctx->n_cu * (lds > 80 * 1024 ? 1 : pose_wgs_per_cu())), dim3(POSE_LDS_THREADS), lds, ctx->stream, d_status, cap_pairs, d_rec,
                                d_hi_cloud, scratch<double>(ctx, S_PG_PTS), scratch<int32_t>(ctx, S_PG_START), d_start16, G,
-                               l_hi_max, n_cloud, (float)reach, dd_lim, B, d_bits, scratch<int32_t>(ctx, S_COUNTS));
+                               l_hi_max, n_cloud, (float)reach, dd_lim, B, d_bits, scratch<int32_t>(ctx, S_COUNTS), d_sel);
         else if (hi_in_lds)
-            hipLaunchKernelGGL(k_pose_lds32<true>, dim3(ctx->n_cu), dim3(POSE_LDS_THREADS), lds32_hi, ctx->stream, d_status, cap_pairs, d_rec,
+            hipLaunchKernelGGL(k_pose_lds32<true>, dim3(d_sel ? wgs_sel : ctx->n_cu), dim3(POSE_LDS_THREADS), lds32_hi, ctx->stream, d_status, cap_pairs, d_rec,
                                d_hi_cloud, scratch<double>(ctx, S_PG_PTS), scratch<float4>(ctx, S_PG_PTSF),
                                scratch<int32_t>(ctx, S_PG_START), d_start16, G, n_cloud, l_hi_max, (float)reach, dd_lim, lim_in, lim_out, B, d_bits,
-                               scratch<int32_t>(ctx, S_COUNTS));
+                               scratch<int32_t>(ctx, S_COUNTS), d_sel);
         else
-            hipLaunchKernelGGL(k_pose_lds32<false>, dim3(ctx->n_cu), dim3(POSE_LDS_THREADS), lds32, ctx->stream, d_status, cap_pairs, d_rec,
+            hipLaunchKernelGGL(k_pose_lds32<false>, dim3(d_sel ? wgs_sel : ctx->n_cu), dim3(POSE_LDS_THREADS), lds32, ctx->stream, d_status, cap_pairs, d_rec,
                                d_hi_cloud, scratch<double>(ctx, S_PG_PTS), scratch<float4>(ctx, S_PG_PTSF),
                                scratch<int32_t>(ctx, S_PG_START), d_start16, G, n_cloud, l_hi_max, (float)reach, dd_lim, lim_in, lim_out, B, d_bits,
-                               scratch<int32_t>(ctx, S_COUNTS));
+                               scratch<int32_t>(ctx, S_COUNTS), d_sel);
         mad_timer_end(ctx, MAD_T_POSE);
         MAD_HIP(hipGetLastError());
         return MAD_OK;
@@ -1596,6 +1849,10 @@ static int set_rows(mad_ctx *ctx, const mad_set *cs, int64_t *n_rows) {
             MAD_HIP(hipMemcpyAsync(&ctx->pinned[s->pinned_slot], s->dev_n.p, 16, hipMemcpyDeviceToHost, ctx->stream));
             MAD_HIP(hipStreamSynchronize(ctx->stream));
         }
+        if (h[3] && s->last_r == 0) {      // an imported set (mad_set_import) that could not be completed
+            if (h[3] < 0) return mad_fail(ctx, MAD_EINVAL, "mad_set_import: malformed wire image (size, capacity or anchor ids do not match)");
+            return mad_fail(ctx, MAD_ENOSPC, "mad_set_import: a share has %d rows, more than the wire images hold; export again with a larger cap_rows", h[3]);
+        }
         s->n_rows_host = h[0];
         s->rows_hint = h[0];
         s->range_bad = h[1] != 0;
@@ -1806,20 +2063,26 @@ struct MatchPlan {
     int64_t cap_c, cap_pairs, k;
     bool fits;
     CellGrid G;
+    double dist;
 };
 
 // enqueue a11 + a12 + top-k (+ the result rows) of one (hi, lo) pair in the CURRENT lane; no host round trip.
-// layout of the zero region of a match: [status ST_COUNT int32][hist (n_hi_anchors + 17) int32][used flags]
+// layout of the zero region of a match: [status ST_COUNT int32][hist (n_hi_anchors + 17) int32: match counts, top-k selection]
+// [hist2 (n_hi_anchors + 17) int32: lower bounds, pose pruning][used flags of the hi anchors, padded to 32][of the lo anchors]
 static int32_t *zero_status(mad_ctx *ctx) { return scratch<int32_t>(ctx, S_ZERO); }
+static inline int32_t *zr_hist(int32_t *st) { return st + ST_COUNT; }
+static inline int32_t *zr_hist2(int32_t *st, int n_hi) { return st + ST_COUNT + n_hi + 17; }
+static inline uint8_t *zr_used_hi(int32_t *st, int n_hi) { return (uint8_t *)(st + ST_COUNT + 2 * (n_hi + 17)); }
+static inline uint8_t *zr_used_lo(int32_t *st, int n_hi) { return zr_used_hi(st, n_hi) + ((n_hi + 31) & ~31); }
 static size_t zero_bytes(const mad_set *hi, const mad_set *lo) {
-    return ((size_t)(ST_COUNT + hi->n_anchors + 17) * 4 + (size_t)hi->n_anchors + lo->n_anchors + 64 + 15) / 16 * 16;
+    return ((size_t)(ST_COUNT + 2 * (hi->n_anchors + 17)) * 4 + (size_t)hi->n_anchors + lo->n_anchors + 64 + 15) / 16 * 16;
 }
 static size_t tail_bytes(int64_t k) { return (size_t)k * (MAD_RESULT_COLS * 8 + 8) + ST_COUNT * 4; }
 
 static int match_enqueue(mad_ctx *ctx, const mad_set *hi, const mad_set *lo, double cc, double dist, const MatchPlan &P) {
     int32_t *st = zero_status(ctx);
-    int32_t *hist = st + ST_COUNT;
-    uint8_t *used_hi = (uint8_t *)(hist + hi->n_anchors + 17), *used_lo = used_hi + ((hi->n_anchors + 31) & ~31);
+    int32_t *hist = zr_hist(st);
+    uint8_t *used_hi = zr_used_hi(st, hi->n_anchors), *used_lo = zr_used_lo(st, hi->n_anchors);
     const Side H = side_of(hi), L = side_of(lo);
     // the sets may have been built on other lanes
     MAD_HIP(hipStreamWaitEvent(ctx->stream, hi->built, 0));
@@ -1832,8 +2095,10 @@ static int match_enqueue(mad_ctx *ctx, const mad_set *hi, const mad_set *lo, dou
                        (const int32_t *)lo->dev_n.p, st);
     CellGrid G = P.G;
     G.used = used_lo;
+    bool pruned = false;      // the caller gets k rows: pairs that cannot be among them need no exact count
     MAD_TRY(pose_device(ctx, H, L, st, P.cap_pairs, scratch<double>(ctx, S_HI_CLOUD), hi->n_anchors, (const double *)lo->anc_subv.p,
-                        lo->n_anchors, used_lo, lo->bb_min, lo->bb_max, P.fits ? nullptr : &G, dist));
+                        lo->n_anchors, used_lo, lo->bb_min, lo->bb_max, P.fits ? nullptr : &G, dist, P.k, zr_hist2(st, hi->n_anchors), &pruned));
+    ctx->lane_pruned[ctx->lane] = pruned;
     MAD_TRY(topk_device(ctx, scratch<int32_t>(ctx, S_COUNTS), st, P.cap_pairs, P.k, hi->n_anchors, scratch<int64_t>(ctx, S_SEL_OUT), hist));
     hipLaunchKernelGGL(k_results, dim3((unsigned)mad_ceil_div(P.k, 256)), dim3(256), 0, ctx->stream,
                        scratch<int64_t>(ctx, S_SEL_OUT), st + ST_NKEYS, P.k, scratch<int32_t>(ctx, S_PAIR_HI),
@@ -1850,6 +2115,7 @@ static int match_prepare(mad_ctx *ctx, const mad_set *hi, const mad_set *lo, dou
     if (hi->D != lo->D) return mad_fail(ctx, MAD_EINVAL, "mad_match_topk: descriptor lengths %d vs %d", hi->D, lo->D);
     if (!(dist > 0)) return mad_fail(ctx, MAD_EINVAL, "mad_match_topk: dist must be positive");
     P->k = k < 1 ? 1 : k;
+    P->dist = dist;
     MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_ZERO), zero_bytes(hi, lo)));
     MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_HI_CLOUD), (size_t)hi->n_anchors * 24 + 24));
     MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_SEL_OUT), (size_t)(P->k + 8) * 8));
@@ -1918,6 +2184,10 @@ static int match_finish(mad_ctx *ctx, int lane, const mad_set *hi, const mad_set
     ctx->match.lane = lane;
     ctx->match.n_hi_anchors = hi->n_anchors;
     ctx->match.n_lo_anchors = lo->n_anchors;
+    ctx->match.pruned = ctx->lane_pruned[lane];
+    ctx->match.n_sel = ctx->match.pruned ? hs[ST_NSEL] : hs[ST_NPAIRS];
+    ctx->lane_sel_hint[lane] = ctx->match.pruned ? std::max<int64_t>(hs[ST_NSEL], 1) : 0;
+    ctx->match.hi = hi; ctx->match.lo = lo; ctx->match.cap_pairs_used = P->cap_pairs; ctx->match.fits = P->fits; ctx->match.dist = P->dist;
     const_cast<mad_set *>(hi)->n_rows_host = hs[ST_NHI];
     const_cast<mad_set *>(lo)->n_rows_host = hs[ST_NLO];
     const_cast<mad_set *>(hi)->rows_hint = hs[ST_NHI];
@@ -2034,6 +2304,8 @@ extern "C" int mad_match_topk_many_begin(mad_ctx *ctx, int n, const mad_set *con
 
 extern "C" int mad_last_pose_kernel(mad_ctx *ctx) { return ctx ? ctx->last_pose_kernel : -1; }
 
+extern "C" int64_t mad_last_pose_selected(mad_ctx *ctx) { return ctx ? ctx->match.n_sel : -1; }
+
 extern "C" int mad_match_topk_many_finish(mad_ctx *ctx) {
     if (!ctx) return MAD_EINVAL;
     if (!ctx->many[0] && !ctx->many[1]) return mad_fail(ctx, MAD_EINVAL, "mad_match_topk_many_finish: nothing was begun");
@@ -2094,8 +2366,8 @@ extern "C" int mad_match_shard_pairs(mad_ctx *ctx, const mad_set *hi, const mad_
     const int64_t nb = lo_end - lo_begin;
     MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_ZERO), zero_bytes(hi, lo)));
     int32_t *st = zero_status(ctx);
-    int32_t *hist = st + ST_COUNT;
-    uint8_t *d_used_hi = (uint8_t *)(hist + hi->n_anchors + 17), *d_used_lo = d_used_hi + ((hi->n_anchors + 31) & ~31);
+    int32_t *hist = zr_hist(st);
+    uint8_t *d_used_hi = zr_used_hi(st, hi->n_anchors), *d_used_lo = zr_used_lo(st, hi->n_anchors);
     MAD_HIP(hipStreamWaitEvent(ctx->stream, hi->built, 0));
     MAD_HIP(hipStreamWaitEvent(ctx->stream, lo->built, 0));
     int64_t cap_pairs = std::max<int64_t>(ctx->match.cap_pairs, 1 << 16);
@@ -2144,13 +2416,14 @@ extern "C" int mad_match_shard_topk(mad_ctx *ctx, const mad_set *hi, const mad_s
     MAD_TRY(set_rows(ctx, lo, &n_lo));
     const int64_t np = ctx->match.shard_pairs, begin = ctx->match.shard_begin, nb = ctx->match.shard_end - begin;
     int32_t *st = zero_status(ctx);
-    int32_t *hist = st + ST_COUNT;
-    uint8_t *d_used_hi = (uint8_t *)(hist + hi->n_anchors + 17), *d_used_lo = d_used_hi + ((hi->n_anchors + 31) & ~31);
+    int32_t *hist = zr_hist(st);
+    uint8_t *d_used_hi = zr_used_hi(st, hi->n_anchors), *d_used_lo = zr_used_lo(st, hi->n_anchors);
     // the global flags replace the shard's own; the histogram of the top-k selection starts from zero
     MAD_HIP(hipMemcpyAsync(d_used_hi, used_hi_all, (size_t)hi->n_anchors, hipMemcpyHostToDevice, ctx->stream));
     MAD_HIP(hipMemcpyAsync(d_used_lo, used_lo_all, (size_t)lo->n_anchors, hipMemcpyHostToDevice, ctx->stream));
-    MAD_HIP(hipMemsetAsync(hist, 0, (size_t)(hi->n_anchors + 17) * 4, ctx->stream));
+    MAD_HIP(hipMemsetAsync(hist, 0, (size_t)(hi->n_anchors + 17) * 8, ctx->stream));      // hist and hist2
     MAD_HIP(hipMemsetAsync(st + ST_NKEYS, 0, 4, ctx->stream));
+    MAD_HIP(hipMemsetAsync(st + ST_NSEL, 0, 4, ctx->stream));
     MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_HI_CLOUD), (size_t)hi->n_anchors * 24 + 24));
     MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_SEL_OUT), (size_t)(k + 8) * 8));
     MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_RESULTS), (size_t)(k + 1) * MAD_RESULT_COLS * 8));
@@ -2173,7 +2446,7 @@ extern "C" int mad_match_shard_topk(mad_ctx *ctx, const mad_set *hi, const mad_s
             G.used = d_used_lo;
         }
         MAD_TRY(pose_device(ctx, H, L, st, cap_pairs, scratch<double>(ctx, S_HI_CLOUD), hi->n_anchors, (const double *)lo->anc_subv.p,
-                            lo->n_anchors, d_used_lo, lo->bb_min, lo->bb_max, fits ? nullptr : &G, dist));
+                            lo->n_anchors, d_used_lo, lo->bb_min, lo->bb_max, fits ? nullptr : &G, dist, k, zr_hist2(st, hi->n_anchors)));
         MAD_TRY(topk_device(ctx, scratch<int32_t>(ctx, S_COUNTS), st, cap_pairs, k, hi->n_anchors, scratch<int64_t>(ctx, S_SEL_OUT), hist));
         hipLaunchKernelGGL(k_results, dim3((unsigned)mad_ceil_div(k, 256)), dim3(256), 0, ctx->stream, scratch<int64_t>(ctx, S_SEL_OUT),
                            st + ST_NKEYS, k, scratch<int32_t>(ctx, S_PAIR_HI), scratch<int32_t>(ctx, S_PAIR_LO),
@@ -2205,9 +2478,28 @@ extern "C" int mad_match_shard_topk(mad_ctx *ctx, const mad_set *hi, const mad_s
     return MAD_OK;
 }
 
+// The match counts of ALL pairs of the last match: when its pose search was pruned by bounds (only the k best were asked for),
+// run the exact search over every pair now.  The pair list, the clouds' flags and the status words of that match are still in its
+// lane's scratch (the condition mad_match_fetch has always had); the two sets must still exist.
+static int complete_counts(mad_ctx *ctx) {
+    if (!ctx->match.pruned || ctx->match.n_pairs <= 0) return MAD_OK;
+    const mad_set *hi = (const mad_set *)ctx->match.hi, *lo = (const mad_set *)ctx->match.lo;
+    if (!hi || !lo) return mad_fail(ctx, MAD_EINVAL, "match counts: the sets of the last match are unknown");
+    mad_use_lane(ctx, ctx->match.lane);
+    int32_t *st = zero_status(ctx);
+    const Side H = side_of(hi), L = side_of(lo);
+    MAD_TRY(pose_device(ctx, H, L, st, ctx->match.cap_pairs_used, scratch<double>(ctx, S_HI_CLOUD), hi->n_anchors, (const double *)lo->anc_subv.p,
+                        lo->n_anchors, zr_used_lo(st, hi->n_anchors), lo->bb_min, lo->bb_max, nullptr, ctx->match.dist));
+    MAD_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->match.pruned = false;
+    ctx->lane_pruned[ctx->match.lane] = false;
+    return MAD_OK;
+}
+
 extern "C" int mad_match_fetch(mad_ctx *ctx, int32_t *pair_hi, int32_t *pair_lo, double *pair_score, int32_t *counts,
                                int64_t cap) {
     if (!ctx) return MAD_EINVAL;
+    if (counts) MAD_TRY(complete_counts(ctx));
     mad_use_lane(ctx, ctx->match.lane);
     const int64_t np = ctx->match.n_pairs;
     if (np > cap) return mad_fail(ctx, MAD_ENOSPC, "mad_match_fetch: %lld pairs, capacity %lld", (long long)np, (long long)cap);
@@ -2222,6 +2514,7 @@ extern "C" int mad_match_fetch(mad_ctx *ctx, int32_t *pair_hi, int32_t *pair_lo,
 
 extern "C" int mad_match_results(mad_ctx *ctx, const mad_set *hi, const mad_set *lo, double *results, int64_t cap) {
     if (!ctx || !hi || !lo || !results) return MAD_EINVAL;
+    MAD_TRY(complete_counts(ctx));
     mad_use_lane(ctx, ctx->match.lane);
     const int64_t np = ctx->match.n_pairs;
     if (np > cap) return mad_fail(ctx, MAD_ENOSPC, "mad_match_results: %lld pairs, capacity %lld", (long long)np, (long long)cap);
@@ -2246,9 +2539,249 @@ extern "C" int mad_match_used(mad_ctx *ctx, uint8_t *hi_used, int32_t n_hi_ancho
     if (n_hi_anchors != ctx->match.n_hi_anchors || n_lo_anchors != ctx->match.n_lo_anchors)
         return mad_fail(ctx, MAD_EINVAL, "mad_match_used: anchor counts do not match the last mad_match_topk call");
     mad_use_lane(ctx, ctx->match.lane);
-    const uint8_t *d_hi = (const uint8_t *)(zero_status(ctx) + ST_COUNT + n_hi_anchors + 17), *d_lo = d_hi + ((n_hi_anchors + 31) & ~31);
+    const uint8_t *d_hi = zr_used_hi(zero_status(ctx), n_hi_anchors), *d_lo = zr_used_lo(zero_status(ctx), n_hi_anchors);
     if (hi_used && n_hi_anchors > 0) MAD_HIP(hipMemcpyAsync(hi_used, d_hi, n_hi_anchors, hipMemcpyDeviceToHost, ctx->stream));
     if (lo_used && n_lo_anchors > 0) MAD_HIP(hipMemcpyAsync(lo_used, d_lo, n_lo_anchors, hipMemcpyDeviceToHost, ctx->stream));
     MAD_HIP(hipStreamSynchronize(ctx->stream));
+    return MAD_OK;
+}
+
+// ---------------------------------------------------------------------------
+// a structure's rows built in shares on several GPUs (stage A)
+// ---------------------------------------------------------------------------
+//
+// Orientation and description are independent per anchor (Orientator.py:80-108, Descriptor.py:106-116), so the anchors
+// of one structure are dealt round-robin to the ranks (anchor a -> share a % n_shares, local position a / n_shares), each
+// rank runs mad_set_build on its share, and the shares travel as "wire images" (what one all-gather moves):
+//   [header 64 B][main int32 C][sec int32 C][local anchor int32 C][norm double C][dsc8 int8 C x D],   C = cap_rows
+// every section padded to 16 bytes.  Rfinal, its inverse, the int16 descriptors and the result metadata are NOT sent:
+// the importer re-derives them with the expressions the builder used (mad_rfinal, mad_mat3_inv, a widening copy).
+// mad_set_import scatters the rows of all shares into the reference's order: anchor order x main x sec
+// (Orientator.py:90-106) -- a set bit-identical to the one mad_set_build makes from the whole anchor list.
+
+struct WireHeader {
+    int32_t n_rows, n_anchors, overflow, range_bad, rejects, D, cap_rows, magic;
+    int32_t pad[8];
+};
+static_assert(sizeof(WireHeader) == 64, "wire header is 64 bytes");
+#define MAD_WIRE_MAGIC 0x4d614431
+
+struct WireLayout {
+    size_t o_main, o_sec, o_anchor, o_norm, o_dsc8, total;
+};
+
+__host__ __device__ static inline WireLayout wire_layout(int D, int64_t C) {
+    WireLayout L;
+    L.o_main = 64;
+    L.o_sec = L.o_main + pad16((size_t)C * 4);
+    L.o_anchor = L.o_sec + pad16((size_t)C * 4);
+    L.o_norm = L.o_anchor + pad16((size_t)C * 4);
+    L.o_dsc8 = L.o_norm + pad16((size_t)C * 8);
+    L.total = L.o_dsc8 + pad16((size_t)C * D);
+    return L;
+}
+
+extern "C" int64_t mad_set_wire_bytes(int D, int64_t cap_rows) {
+    if (D <= 0 || cap_rows < 0) return -1;
+    return (int64_t)wire_layout(D, cap_rows > 0 ? cap_rows : 1).total;
+}
+
+extern "C" int mad_set_lane(mad_ctx *ctx, const mad_set *s) { return (ctx && s) ? s->lane : -1; }
+
+extern "C" void *mad_set_stream(mad_ctx *ctx, const mad_set *s) {
+    return (ctx && s) ? (void *)ctx->lane_stream[ctx->overlap ? s->lane : 0] : nullptr;
+}
+
+extern "C" int mad_set_bind_lane(mad_ctx *ctx, mad_set *s, int lane) {
+    if (!ctx || !s || lane < 0 || lane >= MAD_LANES) return MAD_EINVAL;
+    MAD_TRY(mad_synchronize(ctx));      // nothing of the set may be in flight on its old lane
+    s->lane = lane;
+    return MAD_OK;
+}
+
+__global__ __launch_bounds__(256) void k_set_export(const int32_t *__restrict__ dev_n, const int32_t *__restrict__ row_main,
+                                                    const int32_t *__restrict__ row_sec, const int32_t *__restrict__ row_anchor,
+                                                    const double *__restrict__ norm, const int8_t *__restrict__ dsc8, int D, int64_t C,
+                                                    int n_anchors, unsigned char *__restrict__ wire) {
+    const WireLayout L = wire_layout(D, C);
+    const int64_t n_all = dev_n[0];
+    const bool over = n_all > C || dev_n[3] != 0;      // more rows than the wire holds, or the share's own describe launch fell short
+    const int64_t n = over ? 0 : n_all;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        WireHeader h;
+        h.n_rows = (int32_t)n; h.n_anchors = n_anchors; h.overflow = over ? (int32_t)max(n_all, (int64_t)1) : 0; h.range_bad = dev_n[1];
+        h.rejects = dev_n[2]; h.D = D; h.cap_rows = (int32_t)C; h.magic = MAD_WIRE_MAGIC;
+        for (int i = 0; i < 8; i++) h.pad[i] = 0;
+        *(WireHeader *)wire = h;
+    }
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nt = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = tid; i < n; i += nt) {
+        ((int32_t *)(wire + L.o_main))[i] = row_main[i];
+        ((int32_t *)(wire + L.o_sec))[i] = row_sec[i];
+        ((int32_t *)(wire + L.o_anchor))[i] = row_anchor[i];
+        ((double *)(wire + L.o_norm))[i] = norm[i];
+    }
+    const int64_t n16 = n * D / 16;      // D is a multiple of 16
+    const uint4 *src = (const uint4 *)dsc8;
+    uint4 *dst = (uint4 *)(wire + L.o_dsc8);
+    for (int64_t i = tid; i < n16; i += nt) dst[i] = src[i];
+}
+
+// Packs the rows of `share` (built with mad_set_build) into a wire image of capacity cap_rows.  wire_on_device != 0:
+// `wire` is device memory and the call is asynchronous on the set's lane (mad_set_stream); otherwise host memory,
+// synchronous.  A share with more than cap_rows rows travels as an empty image whose header says how many it had.
+extern "C" int mad_set_export(mad_ctx *ctx, const mad_set *s, void *wire, int wire_on_device, int64_t cap_rows) {
+    if (!ctx || !s || !wire || cap_rows < 1) return MAD_EINVAL;
+    if (!s->dev_n.p || s->D <= 0 || (s->D % 16)) return mad_fail(ctx, MAD_EINVAL, "mad_set_export: the set has not been built");
+    mad_use_lane(ctx, s->lane);
+    const WireLayout L = wire_layout(s->D, cap_rows);
+    unsigned char *d_wire = (unsigned char *)wire;
+    if (!wire_on_device) {
+        MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_TMP_B), L.total));
+        d_wire = scratch<unsigned char>(ctx, S_TMP_B);
+    }
+    const int64_t work = std::max<int64_t>(std::min<int64_t>(s->cap_rows, cap_rows) * s->D / 16, 256);
+    hipLaunchKernelGGL(k_set_export, dim3((unsigned)std::min<int64_t>(mad_ceil_div(work, 256), (int64_t)ctx->n_cu * 8)), dim3(256), 0,
+                       ctx->stream, (const int32_t *)s->dev_n.p, (const int32_t *)s->row_main.p, (const int32_t *)s->row_sec.p,
+                       (const int32_t *)s->row_anchor.p, (const double *)s->norm.p, (const int8_t *)s->dsc8.p, s->D, cap_rows, s->n_anchors,
+                       d_wire);
+    MAD_HIP(hipGetLastError());
+    if (!wire_on_device) {
+        MAD_HIP(hipMemcpyAsync(wire, d_wire, L.total, hipMemcpyDeviceToHost, ctx->stream));
+        MAD_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return MAD_OK;
+}
+
+// rows per anchor of the whole structure (anchor = local anchor * n_shares + share), counted from the shares' row lists
+__global__ __launch_bounds__(256) void k_import_count(const unsigned char *__restrict__ wires, size_t wire_bytes, int n_shares, int D, int64_t C,
+                                                      int n_anchors, int32_t *__restrict__ cnt, int32_t *__restrict__ flags) {
+    const WireLayout L = wire_layout(D, C);
+    for (int r = blockIdx.y; r < n_shares; r += gridDim.y) {
+        const unsigned char *w = wires + (size_t)r * wire_bytes;
+        const WireHeader *h = (const WireHeader *)w;
+        const bool bad = h->magic != MAD_WIRE_MAGIC || h->D != D || h->cap_rows != (int32_t)C || h->n_rows < 0 || h->n_rows > C;
+        if (bad || h->overflow) {
+            if (blockIdx.x == 0 && threadIdx.x == 0) atomicMax(&flags[bad ? 1 : 0], bad ? 1 : h->overflow);
+            continue;
+        }
+        const int32_t *la = (const int32_t *)(w + L.o_anchor);
+        for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < h->n_rows; j += (int64_t)gridDim.x * blockDim.x) {
+            const int64_t a = (int64_t)la[j] * n_shares + r;
+            if (la[j] < 0 || a >= n_anchors) atomicMax(&flags[1], 1);
+            else atomicAdd(&cnt[a], 1);
+        }
+    }
+}
+
+// one wave per source row: its place in the reference's order, the copied and the re-derived fields
+__global__ __launch_bounds__(256) void k_import_rows(const unsigned char *__restrict__ wires, size_t wire_bytes, int n_shares, int D, int64_t C,
+                                                     const int32_t *__restrict__ row_off, int n_anchors, const int32_t *__restrict__ flags,
+                                                     const EqspDev *__restrict__ eq, const int32_t *__restrict__ anc_index,
+                                                     const int32_t *__restrict__ anc_octave, int32_t *__restrict__ dev_n,
+                                                     int32_t *__restrict__ row_anchor, int32_t *__restrict__ row_main, int32_t *__restrict__ row_sec,
+                                                     double *__restrict__ row_R, double *__restrict__ row_Rinv, int32_t *__restrict__ row_meta,
+                                                     int16_t *__restrict__ dsc, int8_t *__restrict__ dsc8, double *__restrict__ norm) {
+    const WireLayout L = wire_layout(D, C);
+    const bool failed = flags[0] != 0 || flags[1] != 0;
+    const int64_t total = failed ? 0 : row_off[n_anchors];
+    const int lane = lane_id();
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (int64_t)gridDim.x * 4;
+    if (wave == 0 && lane == 0) {
+        int32_t rej = 0, bad = 0;
+        for (int r = 0; r < n_shares; r++) {
+            const WireHeader *h = (const WireHeader *)(wires + (size_t)r * wire_bytes);
+            rej += h->rejects; bad |= h->range_bad;
+        }
+        // {rows, rows out of the int8 range, border rejects, incomplete}: an incomplete import reads as an empty set whose
+        // fourth word tells mad_set_size / the match calls why
+        dev_n[0] = (int32_t)total; dev_n[1] = bad; dev_n[2] = rej; dev_n[3] = failed ? (flags[1] ? -1 : flags[0]) : 0;
+    }
+    // rows up to the next multiple of 128 are zero: the GEMM reads whole tiles
+    const int64_t n_pad = (total + 127) / 128 * 128;
+    for (int64_t r = total + wave; r < n_pad; r += nw) {
+        for (int i = lane; i < D / 16; i += MAD_WAVE) ((uint4 *)(dsc8 + r * D))[i] = make_uint4(0, 0, 0, 0);
+        if (lane == 0) norm[r] = 0.0;
+    }
+    if (failed) return;
+    const int64_t slots = (int64_t)n_shares * C;
+    for (int64_t s = wave; s < slots; s += nw) {
+        const int r = (int)(s / C);
+        const int64_t j = s % C;
+        const unsigned char *w = wires + (size_t)r * wire_bytes;
+        if (j >= ((const WireHeader *)w)->n_rows) continue;
+        const int32_t *la = (const int32_t *)(w + L.o_anchor);
+        const int me = la[j];
+        int64_t first = j;      // rows of one anchor are consecutive in a share (at most lim_main x lim_sec of them)
+        while (first > 0 && la[first - 1] == me) first--;
+        const int a = me * n_shares + r;
+        const int64_t dst = (int64_t)row_off[a] + (j - first);
+        const uint4 *src8 = (const uint4 *)(w + L.o_dsc8 + (size_t)j * D);
+        for (int i = lane; i < D / 16; i += MAD_WAVE) {
+            const uint4 v = src8[i];
+            ((uint4 *)(dsc8 + dst * D))[i] = v;
+            // the int16 counts the builder also keeps (mad_set_download): a widening copy
+            const int8_t *b = (const int8_t *)&v;
+            short4 lo4[2], hi4[2];
+            lo4[0] = make_short4(b[0], b[1], b[2], b[3]); lo4[1] = make_short4(b[4], b[5], b[6], b[7]);
+            hi4[0] = make_short4(b[8], b[9], b[10], b[11]); hi4[1] = make_short4(b[12], b[13], b[14], b[15]);
+            short4 *o = (short4 *)(dsc + dst * D + 16 * i);
+            o[0] = lo4[0]; o[1] = lo4[1]; o[2] = hi4[0]; o[3] = hi4[1];
+        }
+        if (lane == 0) {
+            const int mb = ((const int32_t *)(w + L.o_main))[j], sb = ((const int32_t *)(w + L.o_sec))[j];
+            norm[dst] = ((const double *)(w + L.o_norm))[j];
+            row_anchor[dst] = a; row_main[dst] = mb; row_sec[dst] = sb;
+            double R[9];
+            mad_rfinal(eq, mb, sb, R);
+            for (int i = 0; i < 9; i++) row_R[9 * dst + i] = R[i];
+            mad_mat3_inv(R, row_Rinv + 9 * dst);
+            row_meta[3 * dst] = anc_index[a]; row_meta[3 * dst + 1] = anc_octave[a]; row_meta[3 * dst + 2] = mb;
+        }
+    }
+}
+
+// Assembles `s` from the wire images of n_shares shares (contiguous, share r at wires + r * mad_set_wire_bytes(D, cap_rows)).
+// The anchors are those of the WHOLE structure, in the reference's order (anc_coords may be NULL: an imported set is not
+// described again).  wires_on_device != 0: device memory, asynchronous on the set's lane; otherwise host memory.
+extern "C" int mad_set_import(mad_ctx *ctx, mad_set *s, const void *wires, int wires_on_device, int n_shares, int64_t cap_rows,
+                              const int32_t *anc_coords, const int32_t *anc_octave, const double *anc_subv, const int32_t *anc_index,
+                              int n_anchors) {
+    if (!ctx || !s || !wires || n_shares < 1 || cap_rows < 1) return MAD_EINVAL;
+    if (n_anchors > 0 && (!anc_octave || !anc_subv || !anc_index)) return mad_fail(ctx, MAD_EINVAL, "mad_set_import: NULL anchors");
+    if (n_anchors > 65536) return mad_fail(ctx, MAD_EINVAL, "mad_set_import: %d anchors exceed the single-launch scan", n_anchors);
+    if (!ctx->eq_set[0] || !ctx->eq_set[1]) return mad_fail(ctx, MAD_EINVAL, "mad_set_import: EQSP tables not set");
+    mad_use_lane(ctx, s->lane);
+    const int D = 64 * ctx->eq_host[1].Z;
+    const WireLayout L = wire_layout(D, cap_rows);
+    const unsigned char *d_wires = (const unsigned char *)wires;
+    if (!wires_on_device) {
+        MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_TMP_B), L.total * n_shares));
+        MAD_HIP(hipMemcpyAsync(mad_sb(ctx, S_TMP_B).p, wires, L.total * n_shares, hipMemcpyHostToDevice, ctx->stream));
+        d_wires = scratch<unsigned char>(ctx, S_TMP_B);
+    }
+    MAD_TRY(set_upload_anchors(ctx, s, anc_coords, anc_octave, anc_subv, anc_index, n_anchors));
+    s->D = D;
+    const int64_t cap_all = std::min<int64_t>((int64_t)n_shares * cap_rows, std::max<int64_t>((int64_t)n_anchors * 64, 1));
+    MAD_TRY(set_reserve_rows(ctx, s, cap_all));
+    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_SLOT_CNT), (size_t)(n_anchors + 8) * 4));
+    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_ROW_OFF), (size_t)(n_anchors + 8) * 4));
+    int32_t *cnt = scratch<int32_t>(ctx, S_SLOT_CNT), *off = scratch<int32_t>(ctx, S_ROW_OFF);
+    int32_t *flags = cnt + n_anchors;      // {overflow: rows the largest share had, malformed image}
+    mad_zero_words(ctx, cnt, (size_t)(n_anchors + 8) * 4);
+    const unsigned gx = (unsigned)std::min<int64_t>(mad_ceil_div(cap_rows, 256), 64);
+    hipLaunchKernelGGL(k_import_count, dim3(gx, (unsigned)std::min(n_shares, 64)), dim3(256), 0, ctx->stream, d_wires, L.total, n_shares, D,
+                       cap_rows, n_anchors, cnt, flags);
+    mad_scan_small(ctx, cnt, off, nullptr, nullptr, n_anchors);
+    hipLaunchKernelGGL(k_import_rows, dim3((unsigned)std::min<int64_t>(mad_ceil_div((int64_t)n_shares * cap_rows, 4) + 1, (int64_t)ctx->n_cu * 16)),
+                       dim3(256), 0, ctx->stream, d_wires, L.total, n_shares, D, cap_rows, off, n_anchors, flags, ctx->eq[0],
+                       (const int32_t *)s->anc_index.p, (const int32_t *)s->anc_octave.p, (int32_t *)s->dev_n.p, (int32_t *)s->row_anchor.p,
+                       (int32_t *)s->row_main.p, (int32_t *)s->row_sec.p, (double *)s->row_R.p, (double *)s->row_Rinv.p,
+                       (int32_t *)s->row_meta.p, (int16_t *)s->dsc.p, (int8_t *)s->dsc8.p, (double *)s->norm.p);
+    MAD_HIP(hipGetLastError());
+    s->last_r = 0;      // nothing to repeat locally: an incomplete import is the caller's to redo with larger images
+    s->n_rows_host = -1;
+    MAD_HIP(hipEventRecord(s->built, ctx->stream));
+    if (!wires_on_device) MAD_HIP(hipStreamSynchronize(ctx->stream));      // the host images may go away
     return MAD_OK;
 }

@@ -311,10 +311,8 @@ __global__ void k_orient_rows(const int32_t *slot_cnt, const int32_t *slot_main,
     row_anchor[row] = a;
     row_main[row] = mb;
     row_sec[row] = sb;
-    const double *A = eq->adj_sec[sb], *B = eq->to_dom[mb];
     double *o = row_R + 9 * row;
-    for (int i = 0; i < 3; i++)
-        for (int j = 0; j < 3; j++) o[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+    mad_rfinal(eq, mb, sb, o);
     if (row_count) {
         const int Z = eq->Z;
         const int32_t *h = slot_hist + ((size_t)a * lim_main + slot_hidx[(size_t)a * fan + s]) * Z;

@@ -1,6 +1,12 @@
 """Multi-GPU layer: one process per GPU, `torch.distributed` for the exchanges
 ("nccl" = RCCL over xGMI on the node, "gloo" in the CPU tests).
 
+Stage A of SURVEY.md section 8(e) -- a structure's orient + describe work split over the ranks -- is
+`ShardedSetBuild`: anchors dealt round-robin, every rank builds its share (mad_set_build), ONE all-gather of
+fixed-size wire images (int8 rows + norms + bin ids, ~1 KB per row; on RCCL straight out of and into device
+memory, ordered against the library's kernels on the set's own stream), and every rank assembles the full
+set in the reference's row order (mad_set_import) -- bit for bit the set one GPU builds from the whole list.
+
 The hot path shards by independent units: every subunit is docked
 against the same map, so subunits are dealt round-robin to the ranks and each rank runs
 orient / describe / correlate / pose / top-k for its own subunits with no data-path
@@ -51,7 +57,7 @@ class TopkExchange(object):
         mine = list(tops) + [np.zeros((0, RESULT_COLS))] * (self.per_rank - len(tops))
         block, valid = pack_topk(mine, k)
         self.work = None
-        if world == 1:
+        if world == 1 and not (dist.is_available() and dist.is_initialized()):
             self.local = (block, valid)
             return
         dev = device if device is not None else ("cuda" if dist.get_backend(group) == "nccl" else "cpu")
@@ -63,7 +69,7 @@ class TopkExchange(object):
     def finish(self):
         """-> list of n_items_total arrays (item order), identical on every rank."""
         k, per_rank = self.k, self.per_rank
-        if self.world == 1:
+        if self.work is None:
             block, valid = self.local
             return [block[i, :valid[i]] for i in range(self.n_items)]
         self.work.wait()
@@ -168,3 +174,133 @@ def or_reduce_flags(flags, group=None, device=None):
     t = torch.from_numpy(np.asarray(flags, dtype=np.int32).copy()).to(dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     return t.cpu().numpy().astype(np.uint8)
+
+
+def share_of(n_anchors, rank, world):
+    """Indices (into the structure's anchor list) of the anchors rank `rank` of `world` builds: a, a + world, ..."""
+    return np.arange(rank, n_anchors, world)
+
+
+class ShardedSetBuild(object):
+    """The rows of ONE structure (normally the map: MaD.py:143-150 describes it once, every subunit is matched against it)
+    built in shares over the ranks of a process group.  Orientation and description are independent per anchor
+    (Orientator.py:80-108, Descriptor.py:106-116); anchor a goes to rank a % world.
+
+        b = ShardedSetBuild(lib, slots, coords, octave, subv, index, rank, world)
+        full = b.enqueue()        # every step: build the share, export, all-gather, import -> the full device set
+
+    With the "nccl" backend (RCCL) nothing blocks the host: export, collective and import are ordered on the share's
+    stream (the full set is bound to the same lane).  The image capacity is sized once (a blocking first build + a MAX
+    all-reduce of the shares' row counts) and then carried from call to call; should a later build outgrow it, the
+    import reports MAD_ENOSPC at the first use of the set and `resize()` repeats the sizing.
+    With "gloo" (CPU tests, rehearsals on a box with fewer GPUs than ranks) the images travel through host memory.
+
+    `emulate=(world, rank)`: rehearsal of ONE rank of a larger job on a single GPU -- the other ranks' images are built
+    here once (untimed) and stay in the gather buffer; each call builds, exports and "receives" only this rank's share.
+    Whatever it reports is a per-rank cost estimate without link traffic, never a multi-GPU measurement."""
+
+    def __init__(self, lib, slots, coords, octave, subv, index, rank, world, group=None, emulate=None, force=False, r=8, lim_main=6, lim_sec=6):
+        from . import _lib
+        self.lib, self.slots, self.group = lib, slots, group
+        self.coords = np.ascontiguousarray(coords, np.int32).reshape(-1, 3)
+        self.octave = np.ascontiguousarray(octave, np.int32)
+        self.subv = np.ascontiguousarray(subv, np.float64).reshape(-1, 3)
+        self.index = np.ascontiguousarray(index, np.int32)
+        self.emulate = emulate
+        if emulate is not None:
+            world, rank = emulate
+        self.rank, self.world = rank, world
+        self.r, self.lim_main, self.lim_sec = r, lim_main, lim_sec
+        self.full = _lib.DeviceSet(lib)
+        self.share = self.wire = self.gathered = self.cap_rows = None
+        self.backend = None
+        self.host_s = dict(build_share=0.0, export=0.0, collective=0.0, **{"import": 0.0}, calls=0)      # host seconds spent enqueuing, by piece
+        self.sharded = world > 1 or bool(force)      # force: the export / all-gather / import path even for a single share
+        if self.sharded:
+            self.mine = share_of(len(self.octave), rank, world)
+            self.share = _lib.DeviceSet(lib, lane=self.full.lane())      # one lane: build -> export -> gather -> import in stream order
+            if emulate is None:
+                import torch.distributed as dist
+                self.backend = dist.get_backend(group)
+            else:
+                self.backend = "emulate"
+
+    # -- pieces ---------------------------------------------------------------------------------
+    def _build_share(self, rank=None, into=None):
+        sel = self.mine if rank is None else share_of(len(self.octave), rank, self.world)
+        return self.lib.set_build(self.slots, self.coords[sel], self.octave[sel], self.subv[sel], self.index[sel], self.r, self.lim_main,
+                                  self.lim_sec, into=self.share if into is None else into)
+
+    def resize(self):
+        """Blocking: builds the share, agrees on an image capacity for all ranks, (re)allocates the buffers."""
+        import torch
+        if not self.sharded:
+            return
+        self._build_share()
+        rows, _ = self.share.size()
+        if self.backend == "emulate":
+            from . import _lib
+            tmp = _lib.DeviceSet(self.lib)
+            counts = []
+            for rr in range(self.world):
+                self._build_share(rr, into=tmp)
+                counts.append(tmp.size()[0])
+            rows_max = max(counts)
+        else:
+            import torch.distributed as dist
+            dev = "cuda" if self.backend == "nccl" else "cpu"
+            t = torch.tensor([rows], dtype=torch.int64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+            rows_max = int(t.item())
+        self.cap_rows = rows_max + rows_max // 8 + 64
+        nbytes = self.lib.set_wire_bytes(self.cap_rows)
+        dev = "cpu" if self.backend == "gloo" else "cuda"
+        self.wire = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+        self.gathered = torch.zeros(self.world * nbytes, dtype=torch.uint8, device=dev)
+        if self.backend == "emulate":      # the other ranks' images, once
+            for rr in range(self.world):
+                self._build_share(rr, into=tmp)
+                self.lib.set_export(tmp, self.cap_rows, device_ptr=self.gathered.data_ptr() + rr * nbytes)
+            self.lib.synchronize()
+            tmp.close()
+
+    def enqueue(self):
+        """-> the full DeviceSet (asynchronous on RCCL; complete on return with gloo)."""
+        import torch
+        lib = self.lib
+        if not self.sharded:
+            return lib.set_build(self.slots, self.coords, self.octave, self.subv, self.index, self.r, self.lim_main, self.lim_sec, into=self.full)
+        if self.cap_rows is None:
+            self.resize()
+        import time
+        tb = time.perf_counter()
+        self._build_share()
+        nbytes = self.wire.numel()
+        if self.backend == "gloo":
+            import torch.distributed as dist
+            lib.set_export(self.share, self.cap_rows, wire=self.wire.numpy())
+            dist.all_gather_into_tensor(self.gathered, self.wire, group=self.group)
+            return lib.set_import(self.world, self.cap_rows, self.coords, self.octave, self.subv, self.index, wires=self.gathered.numpy(), into=self.full)
+        import time
+        T = self.host_s
+        t0 = time.perf_counter()
+        lib.set_export(self.share, self.cap_rows, device_ptr=self.wire.data_ptr())
+        t1 = time.perf_counter()
+        stream = torch.cuda.ExternalStream(self.share.stream())      # the library's stream of this lane (lane 0's when the lanes are serialised)
+        with torch.cuda.stream(stream):
+            if self.backend == "emulate":
+                self.gathered[self.rank * nbytes:(self.rank + 1) * nbytes].copy_(self.wire, non_blocking=True)
+            else:
+                import torch.distributed as dist
+                # the collective starts behind the export kernel and the import behind the collective, all in stream order
+                dist.all_gather_into_tensor(self.gathered, self.wire, group=self.group, async_op=True).wait()
+        t2 = time.perf_counter()
+        out = lib.set_import(self.world, self.cap_rows, self.coords, self.octave, self.subv, self.index, device_ptr=self.gathered.data_ptr(), into=self.full)
+        t3 = time.perf_counter()
+        T["export"] += t1 - t0; T["collective"] += t2 - t1; T["import"] += t3 - t2; T["build_share"] += t0 - tb; T["calls"] += 1
+        return out
+
+    def close(self):
+        self.full.close()
+        if self.share is not None:
+            self.share.close()

@@ -156,3 +156,82 @@ def test_sharded_match_two_ranks(tmp_path):
         np.testing.assert_array_equal(o["cnt"], ref.cnt_all[order])
         np.testing.assert_array_equal(o["rows"], ref.rows_all[order])
         np.testing.assert_array_equal(o["flags"], np.concatenate([uh, ul]))
+
+
+class _FakeBuildLib(object):
+    """Stand-in for Lib in the host logic of ShardedSetBuild: a "set" is the list of (anchor position, fan-out) rows its
+    anchors produce; a wire image is [n_rows, rows...] as int64 in uint8 clothing."""
+
+    class _Set(object):
+        def __init__(self):
+            self.rows = np.zeros((0, 2), np.int64)
+
+        def size(self):
+            return len(self.rows), 0
+
+        def lane(self):
+            return 0
+
+        def close(self):
+            pass
+
+    def set_build(self, slots, coords, octave, subv, index, r, lim_main, lim_sec, into=None):
+        s = into if into is not None else self._Set()
+        rows = [(int(i), j) for i in index for j in range(int(i) % 4)]      # anchor "index" makes index % 4 rows
+        s.rows = np.array(rows, np.int64).reshape(-1, 2)
+        return s
+
+    def set_wire_bytes(self, cap_rows, D=1024):
+        return 8 * (1 + 2 * cap_rows)
+
+    def set_export(self, share, cap_rows, wire=None, device_ptr=None):
+        img = np.zeros(1 + 2 * cap_rows, np.int64)
+        img[0] = len(share.rows)
+        img[1:1 + 2 * len(share.rows)] = share.rows.reshape(-1)
+        wire[...] = img.view(np.uint8)
+        return wire
+
+    def set_import(self, n_shares, cap_rows, coords, octave, subv, index, wires=None, device_ptr=None, into=None):
+        img = np.ascontiguousarray(wires).view(np.int64).reshape(n_shares, 1 + 2 * cap_rows)
+        parts = [img[r, 1:1 + 2 * img[r, 0]].reshape(-1, 2) for r in range(n_shares)]
+        rows = np.concatenate(parts)
+        into.rows = rows[np.lexsort((rows[:, 1], rows[:, 0]))]      # the reference's order: anchor, then row within the anchor
+        return into
+
+
+def _share_worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+    from mad_amd import _lib
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    fake = _FakeBuildLib()
+    real_set = _lib.DeviceSet
+    _lib.DeviceSet = lambda lib, lane=None: _FakeBuildLib._Set()      # no GPU here: the builder only needs size() / lane()
+    try:
+        n = 23
+        b = mdist.ShardedSetBuild(fake, [0, 1], np.zeros((n, 3)), np.ones(n), np.zeros((n, 3)), np.arange(n), rank, world)
+        outs = [b.enqueue().rows.copy() for _ in range(2)]      # sized by the first call, reused by the second
+    finally:
+        _lib.DeviceSet = real_set
+    np.savez(os.path.join(out_dir, "full%d.npz" % rank), a=outs[0], b=outs[1], cap=b.cap_rows, mine=b.mine)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_set_build_two_ranks(tmp_path):
+    """Stage A over gloo: anchors dealt round-robin, the image capacity agreed by a MAX all-reduce, one all-gather of the
+    images, every rank ends up with the rows of the whole list in the reference's order."""
+    import torch.multiprocessing as mp
+    world = 2
+    mp.spawn(_share_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    want = np.array([(i, j) for i in range(23) for j in range(i % 4)], np.int64)
+    seen = []
+    for r in range(world):
+        o = np.load(os.path.join(str(tmp_path), "full%d.npz" % r))
+        np.testing.assert_array_equal(o["a"], want)
+        np.testing.assert_array_equal(o["b"], want)
+        np.testing.assert_array_equal(o["mine"], np.arange(r, 23, world))
+        seen.append(int(o["cap"]))
+    per_rank = [sum(i % 4 for i in range(r, 23, world)) for r in range(world)]
+    assert seen[0] == seen[1] == max(per_rank) + max(per_rank) // 8 + 64

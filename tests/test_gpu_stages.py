@@ -546,3 +546,94 @@ def test_sharded_match_equals_unsharded(lib, world):
     for s_ in sets:
         s_.close()
     lib.free_field(slot)
+
+
+@pytest.mark.parametrize("n_shares", [1, 2, 3, 8])
+def test_set_built_in_shares_equals_unsharded(lib, fields, n_shares):
+    """SURVEY.md 8(e) stage A on one GPU: the anchors of a structure (both octaves, border rejects included) dealt round-robin
+    to n_shares shares, each built on its own (mad_set_build), exported as a wire image and imported into one set
+    (mad_set_import): rows, bins, Rfinal, descriptors and the match against it are those of the set built from the whole list,
+    bit for bit.  Host images and device images (what the RCCL all-gather moves) both."""
+    import torch
+    from mad_amd import dist as mdist
+    f0, f1 = fields[0], fields[1]
+    a0, a1 = _anchors(f0["shape"], 0, 40, 21), _anchors(f1["shape"], 1, 50, 22)
+    coords = np.concatenate([a0, a1]).astype(np.int32)
+    octave = np.concatenate([np.zeros(len(a0), np.int32), np.ones(len(a1), np.int32)])
+    rng = np.random.default_rng(5)
+    subv = coords * np.where(octave[:, None] == 0, 0.75, 1.5) + rng.normal(scale=0.2, size=coords.shape)
+    subv[7] = subv[3]      # two anchors on one position: one point of a cloud (anc_canon must survive the import)
+    index = np.arange(len(coords), dtype=np.int32) + 100
+    slots = [f0["slot"], f1["slot"]]
+    ref = lib.set_build(slots, coords, octave, subv, index)
+    want = ref.download()
+    n_ref = ref.size()[0]
+    assert n_ref > 150 and len(np.unique(want["anchor"])) < len(coords)      # some anchors are rejected
+    shares = []
+    for r in range(n_shares):
+        sel = mdist.share_of(len(coords), r, n_shares)
+        shares.append(lib.set_build(slots, coords[sel], octave[sel], subv[sel], index[sel]))
+    cap = max(s.size()[0] for s in shares) + 3
+    nbytes = lib.set_wire_bytes(cap)
+    host = np.concatenate([lib.set_export(s, cap) for s in shares])
+    dev = torch.zeros(n_shares * nbytes, dtype=torch.uint8, device="cuda")
+    for r, s in enumerate(shares):
+        lib.set_export(s, cap, device_ptr=dev.data_ptr() + r * nbytes)
+    lib.synchronize()      # (the images agree up to the unused tail of every section, which is not defined)
+    # a subunit to match against the assembled set
+    hi_c = _anchors(f1["shape"], 1, 30, 23)
+    hi = lib.set_build([-1, f1["slot"]], hi_c, np.ones(len(hi_c), np.int32), hi_c * 1.5 + 0.1, np.arange(len(hi_c)))
+    top_ref, idx_ref, st_ref = lib.match_topk(hi, ref, 0.3, 4.0, 30)
+    assert st_ref["n_pairs"] > 50
+    for kind in ("host", "device"):
+        if kind == "host":
+            full = lib.set_import(n_shares, cap, coords, octave, subv, index, wires=host)
+        else:
+            full = lib.set_import(n_shares, cap, None, octave, subv, index, device_ptr=dev.data_ptr())
+        assert full.size() == (n_ref, len(coords))
+        got = full.download()
+        for key in ("anchor", "main", "sec", "R", "dsc"):
+            np.testing.assert_array_equal(got[key], want[key], err_msg="%s (%s images)" % (key, kind))
+        top, idx, st = lib.match_topk(hi, full, 0.3, 4.0, 30)
+        assert st == st_ref
+        np.testing.assert_array_equal(idx, idx_ref)
+        np.testing.assert_array_equal(top, top_ref)
+        # rebuilt in place from the same images: still the same set
+        full = lib.set_import(n_shares, cap, coords, octave, subv, index, wires=host, into=full)
+        np.testing.assert_array_equal(full.download()["dsc"], want["dsc"])
+        full.close()
+    # images too small for the largest share: the import says so when the set is first used
+    small = max(s.size()[0] for s in shares) - 1
+    from mad_amd._lib import MadBackendError
+    bad = lib.set_import(n_shares, small, coords, octave, subv, index, wires=np.concatenate([lib.set_export(s, small) for s in shares]))
+    with pytest.raises(MadBackendError, match="ENOSPC"):
+        bad.size()
+    host2 = host.copy()
+    host2[28:32] = 0      # magic word of share 0
+    bad = lib.set_import(n_shares, cap, coords, octave, subv, index, wires=host2, into=bad)
+    with pytest.raises(MadBackendError, match="EINVAL"):
+        bad.size()
+    for s in shares + [ref, hi, bad]:
+        s.close()
+
+
+def test_sharded_set_build_object_on_one_rank(lib, fields):
+    """mad_amd.dist.ShardedSetBuild in rehearsal mode (rank 0 of 4 on one GPU, the other shares built once): every call
+    returns the set of the whole anchor list, through device images and the library's own stream."""
+    from mad_amd import dist as mdist
+    f1 = fields[1]
+    coords = _anchors(f1["shape"], 1, 60, 31)
+    n = len(coords)
+    octave, subv, index = np.ones(n, np.int32), coords * 1.5 + 0.25, np.arange(n, dtype=np.int32)
+    ref = lib.set_build([-1, f1["slot"]], coords, octave, subv, index)
+    want = ref.download()
+    b = mdist.ShardedSetBuild(lib, [-1, f1["slot"]], coords, octave, subv, index, 0, 1, emulate=(4, 0))
+    for overlap in (True, False, True):
+        lib.set_overlap(overlap)
+        for _ in range(2):
+            got = b.enqueue().download()
+            for key in ("anchor", "main", "sec", "R", "dsc"):
+                np.testing.assert_array_equal(got[key], want[key])
+    assert b.share.size()[0] < ref.size()[0]
+    b.close()
+    ref.close()
