@@ -306,8 +306,13 @@ class MaD(object):
     def _match_filter_refine(self, pdbfile, n_copies, k, cc_threshold, weight_threshold, n_samples):
         n_samples_sub = int(n_samples * n_copies)
         print("MaD> Matching descriptors (%s vs. %s) (cc = %.2f)..." % (self.map_name, k, cc_threshold))
-        hi_list = self._load_descriptors(self.dsc_dict[k]) if isinstance(self.dsc_dict[k], str) else self.dsc_dict[k]
+        from_cache = isinstance(self.dsc_dict[k], str)
+        hi_list = self._load_descriptors(self.dsc_dict[k]) if from_cache else self.dsc_dict[k]
         top, map_anchors, comp_anchors = self._match_dsc_topk(self.map_dsc, hi_list, n_samples_sub, cc_threshold=cc_threshold)
+        if from_cache:      # an ensemble frame re-loaded for this match (MaD.py:158-162, 379-380): one frame resident at a time
+            hit = self._rowsets.pop(id(hi_list), None)
+            if hit is not None:
+                hit[1].dev.close()
         if not len(top):
             print("MaD> No descriptor pair above the threshold for %s" % k)
             return []

@@ -182,6 +182,8 @@ struct mad_set {
     DevBuf anc_coords, anc_octave, anc_subv, anc_index, anc_canon;      // views into anc_blob
     void *host_stage = nullptr;
     size_t host_stage_cap = 0;
+    int staged_n = -1;                  // what the staging buffer (and the device blob) hold: anchor count, with / without voxel coordinates
+    bool staged_coords = false;
     hipEvent_t uploaded = nullptr;      // recorded behind the staging copy: the buffer may be rewritten after it
     int lane = 0;                       // the lane (stream + scratch) this set is built on
     hipEvent_t built = nullptr;         // recorded behind the last kernel of a build / load: consumers on other lanes wait for it

@@ -1877,16 +1877,31 @@ static int set_upload_anchors(mad_ctx *ctx, mad_set *s, const int32_t *anc_coord
         const size_t want = total + total / 2;
         if (hipHostMalloc(&s->host_stage, want) != hipSuccess) return mad_fail(ctx, MAD_ENOMEM, "pinned anchor staging of %zu bytes", want);
         s->host_stage_cap = want;
+        s->staged_n = -1;      // a fresh buffer holds nothing
     } else {
         MAD_HIP(hipEventSynchronize(s->uploaded));      // the previous copy out of the staging buffer has finished
     }
+    const void *blob_before = s->anc_blob.p;
     MAD_TRY(mad_reserve(ctx, s->anc_blob, total));
     char *h = (char *)s->host_stage, *d = (char *)s->anc_blob.p;
     s->dev_n.p = d;
     s->anc_subv.p = d + o_subv; s->anc_coords.p = d + o_coords; s->anc_octave.p = d + o_oct; s->anc_index.p = d + o_idx;
     s->anc_canon.p = d + o_canon;
+    // The same anchors as last time (a set rebuilt in place, step after step): the staging buffer and the device copy already
+    // hold them -- only the counters are reset.  Decided by comparing the bytes, not by trusting the caller.
+    const bool same = n > 0 && s->staged_n == n && s->staged_coords == (anc_coords != nullptr) && blob_before == s->anc_blob.p &&
+                      memcmp(h + o_subv, anc_subv, (size_t)n * 24) == 0 && (!anc_coords || memcmp(h + o_coords, anc_coords, (size_t)n * 12) == 0) &&
+                      memcmp(h + o_oct, anc_octave, (size_t)n * 4) == 0 && memcmp(h + o_idx, anc_index, (size_t)n * 4) == 0;
     memset(h, 0, 64);      // the device counters start from zero
     ((int32_t *)h)[0] = rows0;
+    if (same) {
+        mad_copy_words(ctx, d, h, 64);
+        MAD_HIP(hipGetLastError());
+        MAD_HIP(hipEventRecord(s->uploaded, ctx->stream));
+        s->n_rows_host = -1;
+        return MAD_OK;
+    }
+    s->staged_n = n; s->staged_coords = anc_coords != nullptr;
     if (n > 0) {
         memcpy(h + o_subv, anc_subv, (size_t)n * 24);
         if (anc_coords) memcpy(h + o_coords, anc_coords, (size_t)n * 12);

@@ -140,29 +140,43 @@ __global__ __launch_bounds__(ORI_THREADS) void k_orient(OrientArgs A) {
 
     // step01: fetch, normalise (float32, Orientator.py:139-147), keep weighted voxels only
     const float cutoff = 1e-5f;
-    for (int m0 = 0; m0 < A.nmask; m0 += ORI_THREADS) {      // uniform trip count: the ballot below needs whole waves
-        const int m = m0 + tid;
-        bool keep = false;
-        float gx = 0.f, gy = 0.f, gz = 0.f;
-        if (m < A.nmask) {
-            const int packed = ((const int *)A.mask_off)[m];      // {dx, dy, dz, 0} as one load
-            const int dx = (int)(int8_t)(packed & 0xff), dy = (int)(int8_t)((packed >> 8) & 0xff), dz = (int)(int8_t)((packed >> 16) & 0xff);
+    // All texels of a thread are requested before the first one is looked at (the box has ceil(nmask / 512) <= ORI_TRIPS of
+    // them per thread): a trip that waits for its mask offset, then for its texel, then compacts, costs two memory round trips,
+    // and five such trips in a row were a quarter of the anchor's time.
+    constexpr int ORI_TRIPS = 5;      // r = 8: 2 517 voxels in the sphere; larger boxes take the loop below more than once
+    for (int m00 = 0; m00 < A.nmask; m00 += ORI_TRIPS * ORI_THREADS) {
+        int packed[ORI_TRIPS];
+        float4 tx[ORI_TRIPS];
+#pragma unroll
+        for (int k = 0; k < ORI_TRIPS; k++) {
+            const int m = m00 + k * ORI_THREADS + tid;
+            packed[k] = ((const int *)A.mask_off)[min(m, A.nmask - 1)];      // {dx, dy, dz, 0} as one load
+        }
+#pragma unroll
+        for (int k = 0; k < ORI_TRIPS; k++) {
+            const int dx = (int)(int8_t)(packed[k] & 0xff), dy = (int)(int8_t)((packed[k] >> 8) & 0xff), dz = (int)(int8_t)((packed[k] >> 16) & 0xff);
             // 24-bit multiplies (full rate): nx ny < 2^24 is checked on the host, the sum stays below 2^32 texels
             const unsigned src = __umul24(__umul24((unsigned)(x + __mul24(dx, stride)), (unsigned)F.ny) + (unsigned)(y + __mul24(dy, stride)), (unsigned)F.nz) +
                                  (unsigned)(z + __mul24(dz, stride));
-            const float4 t = F.tex[src];
-            keep = !(t.w < cutoff);
-            gx = t.x; gy = t.y; gz = t.z;
-            if (t.w > cutoff) { gx = __fdiv_rn(gx, t.w); gy = __fdiv_rn(gy, t.w); gz = __fdiv_rn(gz, t.w); }
+            tx[k] = F.tex[src];
         }
-        // one LDS atomic per wave instead of one per voxel (they all hit the same word)
-        const unsigned long long bal = __ballot(keep);
-        int base = 0;
-        if (lane_id() == 0 && bal) base = atomicAdd(&s_nvox, __popcll(bal));
-        base = __shfl(base, 0, MAD_WAVE);
-        if (keep) {
-            const int slot = base + __popcll(bal & lanemask_lt());
-            vx[slot] = gx; vy[slot] = gy; vz[slot] = gz;
+#pragma unroll
+        for (int k = 0; k < ORI_TRIPS; k++) {
+            if (m00 + k * ORI_THREADS >= A.nmask) break;      // workgroup-uniform: the ballot below needs whole waves
+            const int m = m00 + k * ORI_THREADS + tid;
+            const float4 t = tx[k];
+            const bool keep = m < A.nmask && !(t.w < cutoff);
+            float gx = t.x, gy = t.y, gz = t.z;
+            if (t.w > cutoff) { gx = __fdiv_rn(gx, t.w); gy = __fdiv_rn(gy, t.w); gz = __fdiv_rn(gz, t.w); }
+            // one LDS atomic per wave instead of one per voxel (they all hit the same word)
+            const unsigned long long bal = __ballot(keep);
+            int base = 0;
+            if (lane_id() == 0 && bal) base = atomicAdd(&s_nvox, __popcll(bal));
+            base = __shfl(base, 0, MAD_WAVE);
+            if (keep) {
+                const int slot = base + __popcll(bal & lanemask_lt());
+                vx[slot] = gx; vy[slot] = gy; vz[slot] = gz;
+            }
         }
     }
     __syncthreads();

@@ -8,20 +8,40 @@ single launch (one workgroup each).  `move_structure` / `move_copy_structure` ar
 bookkeeping; `get_overlap` (assembly building) counts on the
 device through `mad_grid_overlap`.
 """
+import zlib
+
 import numpy as np
 
 from . import _lib
 from .math_utils import euler_rod_mat
 from .PDB import PDB
 
-_uploaded = {"key": None}
+# What the device holds as "the map candidates are refined in": the context and the grid OBJECT (strong references, so neither
+# id can be recycled for another map while this entry lives), its placement, and a fingerprint of its contents.
+_uploaded = {"lib": None, "grid": None, "where": None, "print": None}
+
+
+def _fingerprint(grid):
+    """Cheap token of a grid's contents: shape, dtype and the CRC of a strided sample of ~64k voxels (thresholding,
+    normalisation, masking and re-loading all change it; a single-voxel edit between two calls may not --
+    `invalidate_density()` is there for that)."""
+    flat = grid.reshape(-1)
+    step = max(1, flat.size // 65536)
+    return (grid.shape, str(grid.dtype), zlib.crc32(np.ascontiguousarray(flat[::step]).tobytes()))
+
+
+def invalidate_density():
+    """Forget which map is on the device: the next refinement / CCC call uploads again."""
+    _uploaded.update(lib=None, grid=None, where=None, print=None)
 
 
 def _ensure_density(lib, dmap):
-    key = (id(lib), id(dmap), id(dmap.grid3d), dmap.xi, dmap.yi, dmap.zi, dmap.voxsp)
-    if _uploaded["key"] != key:
-        lib.upload_density(dmap.grid3d, (dmap.xi, dmap.yi, dmap.zi), dmap.voxsp)
-        _uploaded["key"] = key
+    where = (float(dmap.xi), float(dmap.yi), float(dmap.zi), float(dmap.voxsp))
+    fp = _fingerprint(dmap.grid3d)
+    if _uploaded["lib"] is lib and lib.ctx and _uploaded["grid"] is dmap.grid3d and _uploaded["where"] == where and _uploaded["print"] == fp:
+        return
+    lib.upload_density(dmap.grid3d, (dmap.xi, dmap.yi, dmap.zi), dmap.voxsp)
+    _uploaded.update(lib=lib, grid=dmap.grid3d, where=where, print=fp)
 
 
 def _rmsd_before_after(pdb, before, after):
@@ -60,7 +80,9 @@ def ccc_many(dmap, coords, masses, resolution, isovalue=0):
     lib = _lib.get_lib()
     _ensure_density(lib, dmap)
     out = lib.density_ccc(np.asarray(coords, dtype=np.float64), masses, resolution, 0.0, isovalue)
-    dmap.grid3d[dmap.grid3d < isovalue] = 0
+    if np.any(dmap.grid3d < isovalue):
+        dmap.grid3d[dmap.grid3d < isovalue] = 0
+        invalidate_density()      # the host copy changed: the device copy is re-made from it next time
     return out
 
 

@@ -20,10 +20,13 @@ _i64p = np.ctypeslib.ndpointer(np.int64, flags="C_CONTIGUOUS")
 
 
 def build(force=False):
-    so = os.path.join(_HERE, "libmad_oracle.so")
+    """-> path of the oracle library.  MAD_ORACLE_SANITIZE=1 selects the AddressSanitizer + UBSan build (`make asan`): the
+    interpreter must then run with libasan preloaded (tests/test_oracle_sanitized.py does that in a child process)."""
+    asan = os.environ.get("MAD_ORACLE_SANITIZE", "0") == "1"
+    so = os.path.join(_HERE, "libmad_oracle_asan.so" if asan else "libmad_oracle.so")
     src = os.path.join(_HERE, "mad_oracle.c")
     if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []) + (["asan"] if asan else []))
     return so
 
 

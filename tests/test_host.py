@@ -294,3 +294,46 @@ def test_check_localize_against_the_reference():
             np.testing.assert_array_equal(np.array([float(v) for v in got_s]), sc)
             n_good += bool(ok)
         assert n_good >= 40
+
+
+def test_density_upload_cache_follows_the_grid_object_and_its_contents():
+    """structure_utils keeps ONE map on the device for refinement / CCC.  It must be re-uploaded when another grid object
+    comes along (even one that recycles an id), when the same object is edited in place, or when its placement changes --
+    and only then."""
+    from mad_amd import structure_utils as su
+
+    class FakeLib(object):
+        ctx = 1
+
+        def __init__(self):
+            self.uploads = 0
+
+        def upload_density(self, grid, origin, voxsp):
+            self.uploads += 1
+
+    class FakeMap(object):
+        def __init__(self, grid):
+            self.grid3d, self.xi, self.yi, self.zi, self.voxsp = grid, 1.0, 2.0, 3.0, 1.5
+
+    rng = np.random.default_rng(0)
+    lib, m = FakeLib(), FakeMap(rng.random((40, 41, 42)).astype(np.float32))
+    su.invalidate_density()
+    su._ensure_density(lib, m)
+    su._ensure_density(lib, m)
+    assert lib.uploads == 1
+    m.grid3d[m.grid3d < 0.5] = 0      # thresholded in place
+    su._ensure_density(lib, m)
+    assert lib.uploads == 2
+    m.grid3d *= 0.5                   # normalised in place
+    su._ensure_density(lib, m)
+    assert lib.uploads == 3
+    m2 = FakeMap(m.grid3d.copy())     # another object with the same contents and placement
+    su._ensure_density(lib, m2)
+    assert lib.uploads == 4
+    m2.xi += 1.5
+    su._ensure_density(lib, m2)
+    assert lib.uploads == 5
+    su._ensure_density(FakeLib(), m2)      # another context: nothing of this one is valid there
+    su._ensure_density(lib, m2)
+    assert lib.uploads == 6
+    su.invalidate_density()

@@ -45,8 +45,13 @@ def main():
                     res[n][c + "_avg"] = sum(v) / len(v)
                     if c in ("FETCH_SIZE", "WRITE_SIZE"):
                         res[n][c.lower() + "_bytes_avg"] = 1024.0 * sum(v) / len(v)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench      # source_fingerprint(): which build of the kernels these counters belong to (bench.py checks it before quoting them)
+    doc = {"_meta": {"source_fingerprint": bench.source_fingerprint(), "git": os.environ.get("MAD_GIT_HEAD"),
+                     "command": "rocprofv3 --kernel-trace --stats / --pmc ... -- python3 bench.py --serial (tools/profile_round.sh)"}}
+    doc.update({k: res[k] for k in sorted(res, key=lambda k: -res[k].get("total_us", 0))})
     with open(out, "w") as fh:
-        json.dump({k: res[k] for k in sorted(res, key=lambda k: -res[k].get("total_us", 0))}, fh, indent=1)
+        json.dump(doc, fh, indent=1)
     for k in sorted(res, key=lambda k: -res[k].get("total_us", 0))[:12]:
         print(k, {a: round(b, 1) for a, b in res[k].items()})
 
