@@ -101,13 +101,13 @@ def test_full_size_properties(lib, workload):
             st_.ms.release_device()
 
 
-@pytest.mark.parametrize("workload", ["c2", "c3", pytest.param("c5", marks=pytest.mark.skipif(
-    os.environ.get("MAD_TEST_C5_ORACLE", "0") == "0", reason="512^3 against the oracle takes minutes: MAD_TEST_C5_ORACLE=1"))])
+@pytest.mark.parametrize("workload", ["c2", "c3", "c5"])
 def test_whole_workload_equals_the_oracle(lib, workload):
     """The benchmark's own workload (c3: 256^3 map, 4 subunits, every anchor of both octaves) through the CPU oracle on
     the host threads and through the device path: rows, descriptors, pair lists, match counts and top-k must be
-    identical (~10 s on 16 threads).  c5 (512^3, its first 4 subunits; the pose search then runs in k_pose_lds32) is the
-    same comparison at the largest size, run on request."""
+    identical (~10 s on 16 threads).  c5 is the same comparison at the largest size: the whole 512^3 map (~30 000 rows,
+    5 400 anchors: the pose search runs in k_pose_lds32) against its first 2 subunits (70 s, most of it the oracle);
+    MAD_TEST_C5_ORACLE=n takes the first n of the 12."""
     import bench
     from mad_amd.eqsp import EQSP_Sphere
     from mad_amd.orient_tables import orientation_matrices
@@ -119,8 +119,8 @@ def test_whole_workload_equals_the_oracle(lib, workload):
     cc, dist, k = 0.6, 4.0, 60
     threads = min(16, os.cpu_count() or 1)
     the_map, subs, _ = bench.build_inputs(lib, bench.WORKLOADS[workload], 0)
-    n_subs = int(os.environ.get("MAD_TEST_C5_ORACLE", "0"))      # c5: 1 = its first 4 subunits, n > 1 = its first n
-    subs = subs[:n_subs if n_subs > 1 else 4]
+    n_subs = int(os.environ.get("MAD_TEST_C5_ORACLE", "0"))
+    subs = subs[:4] if workload != "c5" else subs[:max(n_subs, 2)]
 
     def described(st):
         parts = []
@@ -161,6 +161,8 @@ def test_whole_workload_equals_the_oracle(lib, workload):
         top, idx, st = lib.match_topk(hi_d, lo_d, cc, dist, k)
         assert st["n_pairs"] == len(ph) > (10000 if workload != "c2" else 100)
         assert lib.last_pose_kernel() == (1 if workload == "c5" else 0)
+        n_sel = lib.last_pose_selected()      # the top-k above comes from the search pruned by bounds; the counts below are completed on demand
+        assert 0 < n_sel <= st["n_pairs"] and (workload == "c2" or n_sel < st["n_pairs"] // 4)
         gph, gpl, gps, gcnt = lib.match_fetch(st["n_pairs"])
         assert np.array_equal(gph, ph) and np.array_equal(gpl, pl)
         assert np.array_equal(gcnt, cnt)

@@ -637,3 +637,64 @@ def test_sharded_set_build_object_on_one_rank(lib, fields):
     assert b.share.size()[0] < ref.size()[0]
     b.close()
     ref.close()
+
+
+@pytest.mark.parametrize("k", [1, 7, 60, 400, 5000])
+def test_pruned_pose_search_returns_the_rows_of_the_full_search(lib, k):
+    """mad_match_topk only reports k pairs, so the pose search brackets every pair's count with the occupancy bitmaps and
+    searches exactly only the pairs whose upper bound reaches the k-th largest lower bound.  On clouds made to produce ties
+    en masse at the k-th place (a planted pose that a third of the rows share, rows duplicated, lo points exactly at the
+    distance threshold) the k rows and their order must be those of python's stable sort over the EXACT counts of all pairs
+    (MaD.py:480), which mad_match_fetch delivers afterwards."""
+    rng = np.random.default_rng(11)
+    n_lo_a, n_hi_a = 260, 90
+    lo_p = rng.uniform(0, 110, size=(n_lo_a, 3))
+    Q = synth.random_rotation(rng)
+    shift = np.array([7.0, -3.0, 5.0])
+    hi_p = np.zeros((n_hi_a, 3))
+    # 60 hi anchors are rigid images of lo anchors (the planted pose), half of them displaced by exactly 4 A or a hair less / more
+    src = rng.choice(n_lo_a, 60, replace=False)
+    d = np.zeros((60, 3))
+    d[20:40, 0] = 4.0
+    d[40:50, 1] = 4.0 - 1e-9
+    d[50:60, 2] = 4.0 + 1e-9
+    hi_p[:60] = (lo_p[src] + d - shift) @ Q      # so that (x - p_hi) @ R.T + p_lo with R = Q.T-ish brings them back
+    hi_p[60:] = rng.uniform(0, 110, size=(n_hi_a - 60, 3))
+    D = 1024
+    base = rng.integers(0, 12, size=(8, D)).astype(np.int16)      # 8 descriptor prototypes: rows of the same one correlate perfectly
+
+    def rows_for(n_anchor, per_anchor, seed, planted_R):
+        r = np.random.default_rng(seed)
+        anchor = np.repeat(np.arange(n_anchor), per_anchor)
+        n = len(anchor)
+        R = np.stack([synth.random_rotation(r) for _ in range(n)])
+        R[::3] = planted_R      # every third row carries the planted frame: pairs of such rows give the same pose
+        dsc = base[r.integers(0, 8, size=n)]
+        return anchor.astype(np.int32), R, dsc
+
+    la, lR, ldsc = rows_for(n_lo_a, 3, 1, np.eye(3))
+    ha, hR, hdsc = rows_for(n_hi_a, 3, 2, Q.T)
+    lo = lib.set_load(la, np.zeros(len(la), np.int32), lR, ldsc, lo_p, np.arange(n_lo_a), np.ones(n_lo_a, np.int32))
+    hi = lib.set_load(ha, np.zeros(len(ha), np.int32), hR, hdsc, hi_p, np.arange(n_hi_a), np.ones(n_hi_a, np.int32))
+    top, idx, st = lib.match_topk(hi, lo, 0.9, 4.0, k)
+    n_sel = lib.last_pose_selected()
+    assert st["n_pairs"] > 20000
+    ph, pl, ps, cnt = lib.match_fetch(st["n_pairs"])      # exact counts of ALL pairs (completes what the pruning skipped)
+    order = np.lexsort((np.arange(len(cnt)), -cnt.astype(np.int64)))[:k]
+    np.testing.assert_array_equal(idx, order)
+    np.testing.assert_array_equal(top[:, 1], 100.0 * cnt[order] / st["l_hi"])
+    assert len(np.unique(cnt[order])) < len(order) or k == 1      # ties inside the selection ...
+    if k < len(cnt):
+        assert cnt[order[-1]] == np.sort(cnt)[::-1][k - 1]
+    if k <= 400:
+        assert np.sum(cnt == cnt[order[-1]]) > np.sum(cnt[order] == cnt[order[-1]]) or k == 1      # ... and across its edge
+        assert 0 < n_sel < st["n_pairs"]      # the bounds did exclude pairs
+    # the same call again (hints warmed, a pruned match behind it) and the all-pairs rows of the drop-in _match_dsc
+    top2, idx2, _ = lib.match_topk(hi, lo, 0.9, 4.0, k)
+    np.testing.assert_array_equal(idx2, idx)
+    np.testing.assert_array_equal(top2, top)
+    res = lib.match_results(hi, lo, st["n_pairs"])
+    np.testing.assert_array_equal(res[:, 1], 100.0 * cnt / st["l_hi"])
+    np.testing.assert_array_equal(res[order], top)
+    hi.close()
+    lo.close()
