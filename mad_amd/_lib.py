@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmad_amd.so")
+# MAD_LIB_PATH: another build of the same library (diagnostic builds with other compiler flags; tools/build_variant.sh)
+LIB_PATH = os.environ.get("MAD_LIB_PATH") or os.path.join(_HERE, "libmad_amd.so")
 RESULT_COLS = 23
 
 ERRORS = {-22: "EINVAL", -12: "ENOMEM", -28: "ENOSPC", -19: "ENODEV", -33: "EDOM", -5: "EHIP"}

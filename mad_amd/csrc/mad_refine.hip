@@ -74,6 +74,10 @@ struct RefineArgs {
     int n_steps;
     double max_step, min_step;
     int32_t *converged, *last_step;
+    // a candidate's atoms split over G workgroups (G > 1): per-candidate arrival counter and two slots of G x 8 partial sums
+    int G;
+    unsigned long long *arrive;      // n_cand, zeroed before the launch
+    double *partial;                 // n_cand x 2 x G x 8
 };
 
 // fixed-order block reduction of NV doubles per thread (sum or max); result valid in all threads
@@ -94,6 +98,39 @@ __device__ __forceinline__ void block_reduce(double *v, double *lds /* RF_WAVES 
             lds[RF_WAVES * NV + i] = a;
         }
     }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NV; i++) v[i] = lds[RF_WAVES * NV + i];
+}
+
+// The same reduction over the G workgroups that share one candidate (G = 1: the workgroup's own).  Every workgroup publishes
+// its partial result, arrives on the candidate's counter and waits for the others; each then combines the G partials in the same
+// fixed order, so all of them continue with bit-identical values and take the same branches.  Hand-off by 8-byte agent-scope
+// atomics on both sides (MI355X_MICROARCH.md, inter-workgroup visibility); two slots, used alternately, because a workgroup may
+// publish epoch e + 1 while a slower one still reads epoch e -- never further ahead, it cannot leave e + 1 before that one arrives.
+// All G x n_cand workgroups are resident at once (mad_refine sizes G for that), so the wait cannot starve.
+template <int NV, bool IS_MAX>
+__device__ __forceinline__ void group_reduce(double *v, double *lds, const RefineArgs &A, int cand, int g, unsigned &epoch) {
+    block_reduce<NV, IS_MAX>(v, lds);
+    if (A.G == 1) return;
+    __syncthreads();      // everybody has read the block result out of lds before thread 0 reuses it
+    if (threadIdx.x == 0) {
+        double *slot = A.partial + ((size_t)(cand * 2 + (epoch & 1)) * A.G) * 8;
+        for (int i = 0; i < NV; i++) __hip_atomic_store(slot + g * 8 + i, v[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(A.arrive + cand, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long want = (unsigned long long)A.G * (epoch + 1);
+        while (__hip_atomic_load(A.arrive + cand, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) __builtin_amdgcn_s_sleep(2);
+        for (int i = 0; i < NV; i++) {
+            double a = __hip_atomic_load(slot + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int k = 1; k < A.G; k++) {
+                const double b = __hip_atomic_load(slot + k * 8 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                a = IS_MAX ? fmax(a, b) : a + b;
+            }
+            lds[RF_WAVES * NV + i] = a;
+        }
+    }
+    epoch++;
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < NV; i++) v[i] = lds[RF_WAVES * NV + i];
@@ -122,8 +159,10 @@ __global__ __launch_bounds__(RF_THREADS) void k_refine(RefineArgs A) {
     __shared__ double s_rot[9], s_trans[3], s_upd[12];      // s_upd: step translation (3) or step rotation (9) + centre
     __shared__ double s_step;
     __shared__ int s_flag;      // 1 = NaN abort, 2 = converged
-    const int cand = blockIdx.x;
+    const int cand = blockIdx.x / A.G, grp = blockIdx.x % A.G;
     const int tid = threadIdx.x;
+    const int64_t first = (int64_t)grp * RF_THREADS + tid, stride = (int64_t)A.G * RF_THREADS;      // this thread's atoms: first, first + stride, ...
+    unsigned epoch = 0;
     const int64_t n = A.n_atoms;
     double *cur = A.coords + (size_t)cand * n * 3;
     double *ini = A.init + (size_t)cand * n * 3;
@@ -132,20 +171,20 @@ __global__ __launch_bounds__(RF_THREADS) void k_refine(RefineArgs A) {
     // structure_utils.py:65-67: start copy, centroid, farthest atom
     double v[7];
     v[0] = v[1] = v[2] = 0;
-    for (int64_t i = tid; i < n; i += RF_THREADS) {
+    for (int64_t i = first; i < n; i += stride) {
         const double x = cur[3 * i], y = cur[3 * i + 1], z = cur[3 * i + 2];
         ini[3 * i] = x; ini[3 * i + 1] = y; ini[3 * i + 2] = z;
         prv[3 * i] = x; prv[3 * i + 1] = y; prv[3 * i + 2] = z;
         v[0] += x; v[1] += y; v[2] += z;
     }
-    block_reduce<3, false>(v, red);
+    group_reduce<3, false>(v, red, A, cand, grp, epoch);
     const double cen0 = v[0] / (double)n, cen1 = v[1] / (double)n, cen2 = v[2] / (double)n;
     v[0] = 0;
-    for (int64_t i = tid; i < n; i += RF_THREADS) {
+    for (int64_t i = first; i < n; i += stride) {
         const double a = ini[3 * i] - cen0, b = ini[3 * i + 1] - cen1, c = ini[3 * i + 2] - cen2;
         v[0] = fmax(v[0], sqrt(a * a + b * b + c * c));
     }
-    block_reduce<1, true>(v, red);
+    group_reduce<1, true>(v, red, A, cand, grp, epoch);
     const double maxd = v[0];
     if (tid == 0) {
         for (int i = 0; i < 9; i++) s_rot[i] = (i % 4 == 0) ? 1.0 : 0.0;
@@ -162,7 +201,7 @@ __global__ __launch_bounds__(RF_THREADS) void k_refine(RefineArgs A) {
         const double ct0 = cen0 + s_trans[0], ct1 = cen1 + s_trans[1], ct2 = cen2 + s_trans[2];
         const double step_size = s_step;
         for (int i = 0; i < 7; i++) v[i] = 0;
-        for (int64_t i = tid; i < n; i += RF_THREADS) {
+        for (int64_t i = first; i < n; i += stride) {
             // :91-96 re-apply the accumulated transform to the start coordinates
             const double a = ini[3 * i] - cen0, b = ini[3 * i + 1] - cen1, c = ini[3 * i + 2] - cen2;
             const double p0 = (a * r0 + b * r3 + c * r6) + ct0;
@@ -212,9 +251,9 @@ __global__ __launch_bounds__(RF_THREADS) void k_refine(RefineArgs A) {
             v[4] += g[2] * c0 - g[0] * c2;
             v[5] += g[0] * c1 - g[1] * c0;
         }
-        block_reduce<7, false>(v, red);
+        group_reduce<7, false>(v, red, A, cand, grp, epoch);
         if (v[6] != 0.0) {      // :97-98
-            if (tid == 0) { A.converged[cand] = 0; A.last_step[cand] = step; }
+            if (tid == 0 && grp == 0) { A.converged[cand] = 0; A.last_step[cand] = step; }
             return;
         }
         const bool is_trans = (step % 2) == 0;
@@ -239,7 +278,7 @@ __global__ __launch_bounds__(RF_THREADS) void k_refine(RefineArgs A) {
         double mn = 0;
         if (is_trans) {
             const double u0 = s_upd[0], u1 = s_upd[1], u2 = s_upd[2];
-            for (int64_t i = tid; i < n; i += RF_THREADS) {
+            for (int64_t i = first; i < n; i += stride) {
                 const double x = cur[3 * i] + u0, yv = cur[3 * i + 1] + u1, z = cur[3 * i + 2] + u2;
                 cur[3 * i] = x; cur[3 * i + 1] = yv; cur[3 * i + 2] = z;
                 if (batch_end) {
@@ -252,7 +291,7 @@ __global__ __launch_bounds__(RF_THREADS) void k_refine(RefineArgs A) {
             const double m0 = s_upd[0], m1 = s_upd[1], m2 = s_upd[2], m3 = s_upd[3], m4 = s_upd[4], m5 = s_upd[5],
                          m6 = s_upd[6], m7 = s_upd[7], m8 = s_upd[8];
             const double n0 = -1 * cen0 - s_trans[0], n1 = -1 * cen1 - s_trans[1], n2 = -1 * cen2 - s_trans[2];
-            for (int64_t i = tid; i < n; i += RF_THREADS) {
+            for (int64_t i = first; i < n; i += stride) {
                 const double a = cur[3 * i] + n0, b = cur[3 * i + 1] + n1, c = cur[3 * i + 2] + n2;
                 const double x = (a * m0 + b * m3 + c * m6) + ct0;
                 const double yv = (a * m1 + b * m4 + c * m7) + ct1;
@@ -267,7 +306,7 @@ __global__ __launch_bounds__(RF_THREADS) void k_refine(RefineArgs A) {
         }
         if (batch_end) {      // :141-147
             double mv[1] = {mn};
-            block_reduce<1, true>(mv, red);
+            group_reduce<1, true>(mv, red, A, cand, grp, epoch);
             if (tid == 0 && mv[0] < s_step) s_step *= 0.5;
             batch = 0;
         }
@@ -275,7 +314,7 @@ __global__ __launch_bounds__(RF_THREADS) void k_refine(RefineArgs A) {
         if (s_step < A.min_step) { conv = 1; break; }      // :150-152
     }
     if (step == A.n_steps) step = A.n_steps - 1;
-    if (tid == 0) { A.converged[cand] = conv; A.last_step[cand] = step; }
+    if (tid == 0 && grp == 0) { A.converged[cand] = conv; A.last_step[cand] = step; }
 }
 
 extern "C" int mad_refine(mad_ctx *ctx, double *coords, int n_cand, int64_t n_atoms, int n_steps, double max_step,
@@ -304,8 +343,20 @@ extern "C" int mad_refine(mad_ctx *ctx, double *coords, int n_cand, int64_t n_at
     A.n_atoms = n_atoms; A.n_steps = n_steps; A.max_step = max_step; A.min_step = min_step;
     A.converged = scratch<int32_t>(ctx, S_MISC) + 64;
     A.last_step = A.converged + n_cand;
+    // A candidate is a chain of <= 500 dependent steps, and a batch of them is tens of workgroups on 256 CUs: split each
+    // candidate's atoms over G workgroups that meet once per reduction (group_reduce).  G is such that ALL workgroups are
+    // resident together even at one per CU -- the wait inside group_reduce relies on it -- and a workgroup keeps >= 2 atoms
+    // per thread.  MAD_REFINE_SPLIT=1 forces the one-workgroup form (the summation order, hence the last bits, depend on G).
+    static const int split_cap = getenv("MAD_REFINE_SPLIT") ? atoi(getenv("MAD_REFINE_SPLIT")) : 8;
+    int G = std::max(1, std::min(std::min(split_cap, 8), ctx->n_cu / n_cand));
+    while (G > 1 && n_atoms < (int64_t)G * RF_THREADS * 2) G--;
+    A.G = G;
+    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_TMP_I), (size_t)n_cand * 8 + (size_t)n_cand * 2 * G * 64 + 64));
+    A.arrive = scratch<unsigned long long>(ctx, S_TMP_I);
+    A.partial = (double *)(A.arrive + ((n_cand + 1) & ~1));
+    MAD_HIP(hipMemsetAsync(A.arrive, 0, (size_t)n_cand * 8 + 16, ctx->stream));
     mad_timer_begin(ctx, MAD_T_REFINE);
-    hipLaunchKernelGGL(k_refine, dim3(n_cand), dim3(RF_THREADS), 0, ctx->stream, A);
+    hipLaunchKernelGGL(k_refine, dim3(n_cand * G), dim3(RF_THREADS), 0, ctx->stream, A);
     mad_timer_end(ctx, MAD_T_REFINE);
     MAD_HIP(hipGetLastError());
     MAD_HIP(hipMemcpyAsync(coords, A.coords, bytes, hipMemcpyDeviceToHost, ctx->stream));

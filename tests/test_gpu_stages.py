@@ -352,6 +352,33 @@ def test_refine_batch_of_candidates(lib):
         np.testing.assert_allclose(got[i], ref, rtol=0, atol=1e-7)
 
 
+def test_refine_split_over_workgroups(lib):
+    """Large structures in small batches: mad_refine splits each candidate's atoms over several workgroups that meet at every
+    reduction (group_reduce: agent-scope hand-off of the partial sums).  Same trajectory as the oracle: converged / last step
+    identical, coordinates to 1e-6 A after up to 500 dependent steps (the summation order differs in the last bits)."""
+    coords, names, elems = synth.random_globule(9000, 30.0, 6)
+    m = synth.masses(elems)
+    grid, x0, y0, z0 = O.structure_to_density(coords, m, 8.0, 1.5)
+    grid = np.pad(grid, 8)
+    origin = np.array([x0, y0, z0]) - 8 * 1.5
+    from mad_amd.math_utils import euler_rod_mat
+    starts = []
+    for ang, sh in ((0.08, (1.0, -0.8, 0.5)), (0.15, (-1.5, 0.3, 1.1)), (0.02, (40.0, 40.0, 40.0))):      # the last one mostly outside the map
+        R = euler_rod_mat(np.array([0.3, -0.5, 0.81]) / np.linalg.norm([0.3, -0.5, 0.81]), ang)
+        starts.append((coords - coords.mean(0)) @ R + coords.mean(0) + np.array(sh))
+    starts = np.stack(starts)
+    lib.upload_density(grid, origin, 1.5)
+    for n_steps in (3, 500):
+        got, conv, last = lib.refine(starts, n_steps=n_steps, max_step=1.0, min_step=0.1)
+        for i in range(len(starts)):
+            ref, rconv, rlast, _ = O.refine(grid, origin, 1.5, starts[i], n_steps=n_steps, max_step=1.0, min_step=0.1)
+            assert (bool(conv[i]), int(last[i])) == (rconv, rlast)
+            np.testing.assert_allclose(got[i], ref, rtol=0, atol=1e-6)
+    again, conv2, last2 = lib.refine(starts, n_steps=500, max_step=1.0, min_step=0.1)      # reproducible run to run
+    np.testing.assert_array_equal(again, got)
+    assert np.sqrt(((got[0] - coords) ** 2).sum(1).mean()) < 0.6 * np.sqrt(((starts[0] - coords) ** 2).sum(1).mean())
+
+
 def test_density_and_ccc_match_oracle(lib):
     coords, names, elems = synth.random_globule(500, 15.0, 8)
     m = synth.masses(elems)
