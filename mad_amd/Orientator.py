@@ -34,9 +34,10 @@ class Orientator(object):
             print("MaD> ERROR: radius %i invalid, must be even. Setting %i instead." % (ori_radius, ori_radius - 1))
             ori_radius -= 1
         self.ori_radius = ori_radius // 2
-        if gw_sig or magn_weighted:
-            raise NotImplementedError("MaD> only the default orientation window (gw_sig=0, magn_weighted=False) is implemented")
+        if gw_sig:
+            raise NotImplementedError("MaD> only the default orientation window (gw_sig=0) is implemented")
         self.gw_sig = gw_sig
+        # the reference stores this flag and never reads it again (Orientator.py:33 is its only use): accepted, without effect
         self.magn_weighted = magn_weighted
         # sphere mask of Orientator.py:38-47, kept for inspection (the device builds the same one)
         dr = self.ori_radius

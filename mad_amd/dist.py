@@ -45,9 +45,28 @@ def pack_topk(tops, k):
 
 
 class TopkExchange(object):
-    """One in-flight all-gather of top-k rows: the constructor enqueues it (asynchronously for world > 1, on
-    the collective library's own stream, so it overlaps the kernels of the next step); `finish` waits and
-    unpacks."""
+    """One in-flight all-gather of top-k rows: the constructor enqueues it (asynchronously, on the collective library's
+    own stream, so it overlaps the kernels of the next step); `finish` waits and unpacks.
+
+    On RCCL the payload goes host -> device and the gathered block device -> host through PINNED staging tensors with
+    non-blocking copies on a side stream, so neither call blocks the host on anything but the collective itself; the
+    staging sets are reused round-robin (at most three exchanges are ever in flight)."""
+
+    _pool = {}      # (bytes of one payload, world, device) -> [next set, [staging sets]]
+
+    @classmethod
+    def _staging(cls, n, world, dev):
+        import torch
+        key = (n, world, str(dev))
+        slot = cls._pool.setdefault(key, [0, []])
+        if len(slot[1]) < 3:
+            pin = dev != "cpu"
+            slot[1].append(dict(h_in=torch.empty(n, dtype=torch.float64, pin_memory=pin), h_out=torch.empty(world * n, dtype=torch.float64, pin_memory=pin),
+                                d_in=torch.empty(n, dtype=torch.float64, device=dev), d_out=torch.empty(world * n, dtype=torch.float64, device=dev),
+                                stream=torch.cuda.Stream() if pin else None, done=torch.cuda.Event() if pin else None))
+            return slot[1][-1]
+        slot[0] = (slot[0] + 1) % 3
+        return slot[1][slot[0]]
 
     def __init__(self, tops, k, n_items_total, rank, world, group=None, device=None):
         import torch
@@ -61,10 +80,21 @@ class TopkExchange(object):
             self.local = (block, valid)
             return
         dev = device if device is not None else ("cuda" if dist.get_backend(group) == "nccl" else "cpu")
-        self.payload = torch.from_numpy(np.concatenate([block.reshape(-1), valid.astype(np.float64)])).to(dev)
-        self.out = torch.empty(world * self.payload.numel(), dtype=torch.float64, device=dev)
-        # flat output: accepted by gloo and by RCCL
-        self.work = dist.all_gather_into_tensor(self.out, self.payload, group=group, async_op=True)
+        n = block.size + valid.size
+        st = self.st = self._staging(n, world, dev)
+        h = st["h_in"].numpy()
+        h[:block.size] = block.reshape(-1)
+        h[block.size:] = valid
+        self.n = n
+        if dev == "cpu":      # gloo: flat tensors in host memory
+            self.work = dist.all_gather_into_tensor(st["h_out"], st["h_in"], group=group, async_op=True)
+            return
+        with torch.cuda.stream(st["stream"]):      # copy in, gather, copy out: one chain on a side stream, nothing waits on the host
+            st["d_in"].copy_(st["h_in"], non_blocking=True)
+            self.work = dist.all_gather_into_tensor(st["d_out"], st["d_in"], group=group, async_op=True)
+            self.work.wait()      # orders the copy-out behind the collective on this stream (no host wait)
+            st["h_out"].copy_(st["d_out"], non_blocking=True)
+            st["done"].record()
 
     def finish(self):
         """-> list of n_items_total arrays (item order), identical on every rank."""
@@ -72,8 +102,11 @@ class TopkExchange(object):
         if self.work is None:
             block, valid = self.local
             return [block[i, :valid[i]] for i in range(self.n_items)]
-        self.work.wait()
-        out = self.out.view(self.world, self.payload.numel()).cpu().numpy()
+        if self.st["done"] is not None:
+            self.st["done"].synchronize()
+        else:
+            self.work.wait()
+        out = self.st["h_out"].numpy().reshape(self.world, self.n)
         res = []
         for item in range(self.n_items):
             r, slot = owner_of(item, self.world), item // self.world
