@@ -411,10 +411,12 @@ def main():
             os.environ.setdefault("MASTER_PORT", "29533")
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
+        import datetime
+        patience = datetime.timedelta(seconds=int(os.environ.get("MAD_DIST_TIMEOUT_S", "300")))      # a rank that died must not hold the others for the default 10 minutes
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local), timeout=patience)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=patience)
 
     from mad_amd import _lib
     from mad_amd import dist as mdist

@@ -23,7 +23,8 @@
 // status words of one match, on the device (int32)
 // [ST_NHI .. +3] and [ST_NLO .. +3] mirror the two sets' dev_n words {rows, range flag, border rejects, describe overflow}
 // ST_NSEL: pairs whose exact count is computed when the pose search prunes by bounds (k_prune_select)
-enum { ST_NPAIRS = 0, ST_LHI, ST_LLO, ST_NKEYS, ST_FLAG_C, ST_FLAG_PAIRS, ST_BAD, ST_NSEL, ST_NHI = 8, ST_NLO = 12, ST_COUNT = 16 };
+// ST_FLAG_SEL: more pairs were selected than the one-workgroup top-k over the selection holds (the match is repeated with the general one)
+enum { ST_NPAIRS = 0, ST_LHI, ST_LLO, ST_NKEYS, ST_FLAG_C, ST_FLAG_PAIRS, ST_BAD, ST_NSEL, ST_NHI = 8, ST_NLO = 12, ST_FLAG_SEL = 16, ST_COUNT = 20 };
 
 // ---------------------------------------------------------------------------
 // per-row auxiliaries: int8 rows + norms, inverse rotations, result-row meta
@@ -303,31 +304,42 @@ __global__ __launch_bounds__(256) void k_pair_emit(const int32_t *__restrict__ C
 // pose scoring
 // ---------------------------------------------------------------------------
 
-// compact the used anchors' coordinates (order immaterial for the count)
-__global__ __launch_bounds__(1024) void k_compact_cloud(const double *__restrict__ subv, const uint8_t *__restrict__ used,
-                                                        int n, double *__restrict__ cloud, int32_t *__restrict__ count,
-                                                        const int32_t *__restrict__ hi_words, const int32_t *__restrict__ lo_words,
-                                                        int32_t *__restrict__ status) {
-    __shared__ int wt[17];
-    __shared__ int s_base;
-    if (threadIdx.x == 0) s_base = 0;
-    if (hi_words && threadIdx.x < 4) status[ST_NHI + threadIdx.x] = hi_words[threadIdx.x];      // for the host's read-back
-    if (lo_words && threadIdx.x >= 4 && threadIdx.x < 8) status[ST_NLO + threadIdx.x - 4] = lo_words[threadIdx.x - 4];
+// compact the used anchors' coordinates (order immaterial for the count); one workgroup of 1024 threads
+struct CloudJob {
+    const double *subv;          // n x 3 sub-voxel coordinates of the hi anchors; nullptr = nothing to do
+    const uint8_t *used;
+    int n;
+    double *cloud;               // out: the used ones
+    int32_t *count;              // out: how many (status[ST_LHI])
+    const int32_t *hi_words, *lo_words;      // the two sets' dev_n words, mirrored into status for the host's read-back
+    int32_t *status;
+};
+
+__device__ __forceinline__ void compact_cloud_block(const CloudJob &J, int *wt /* 17 */, int *s_base) {
+    if (threadIdx.x == 0) *s_base = 0;
+    if (J.hi_words && threadIdx.x < 4) J.status[ST_NHI + threadIdx.x] = J.hi_words[threadIdx.x];      // for the host's read-back
+    if (J.lo_words && threadIdx.x >= 4 && threadIdx.x < 8) J.status[ST_NLO + threadIdx.x - 4] = J.lo_words[threadIdx.x - 4];
     __syncthreads();
-    for (int b = 0; b < n; b += 1024) {
+    for (int b = 0; b < J.n; b += 1024) {
         const int i = b + threadIdx.x;
-        const bool p = i < n && (!used || used[i]);
+        const bool p = i < J.n && (!J.used || J.used[i]);
         int tot;
         const int pos = block_excl_scan(p ? 1 : 0, wt, &tot);
         if (p) {
-            const int o = s_base + pos;
-            cloud[3 * o] = subv[3 * i]; cloud[3 * o + 1] = subv[3 * i + 1]; cloud[3 * o + 2] = subv[3 * i + 2];
+            const int o = *s_base + pos;
+            J.cloud[3 * o] = J.subv[3 * i]; J.cloud[3 * o + 1] = J.subv[3 * i + 1]; J.cloud[3 * o + 2] = J.subv[3 * i + 2];
         }
         __syncthreads();
-        if (threadIdx.x == 0) s_base += tot;
+        if (threadIdx.x == 0) *s_base += tot;
         __syncthreads();
     }
-    if (threadIdx.x == 0) *count = s_base;
+    if (threadIdx.x == 0) *J.count = *s_base;
+}
+
+__global__ __launch_bounds__(1024) void k_compact_cloud(CloudJob J) {
+    __shared__ int wt[17];
+    __shared__ int s_base;
+    compact_cloud_block(J, wt, &s_base);
 }
 
 __global__ void k_count_flags(const uint8_t *__restrict__ used, int n, int32_t *__restrict__ count) {
@@ -357,11 +369,15 @@ __device__ __forceinline__ int pg_cell(double v, double mn, double inv, int dim)
 __global__ __launch_bounds__(1024) void k_pose_grid_build(const double *__restrict__ pts, const uint8_t *__restrict__ used, int n,
                                                           PoseGrid G, int32_t *__restrict__ cell_start,
                                                           unsigned short *__restrict__ cell_start16, double *__restrict__ sorted,
-                                                          float4 *__restrict__ sorted_f, int32_t *__restrict__ n_used) {
+                                                          float4 *__restrict__ sorted_f, int32_t *__restrict__ n_used, CloudJob J) {
     extern __shared__ __align__(16) unsigned char smem[];
     int *cnt = (int *)smem;
     __shared__ int wt[17];
     __shared__ int carry;
+    if (J.subv) {      // the hi cloud of the same match, compacted by this workgroup too: one launch fewer on the match's critical path
+        compact_cloud_block(J, wt, &carry);
+        __syncthreads();
+    }
     for (int c = threadIdx.x; c < G.ncell; c += 1024) cnt[c] = 0;
     if (threadIdx.x == 0) carry = 0;
     __syncthreads();
@@ -893,16 +909,19 @@ __global__ __launch_bounds__(PB_THREADS) void k_pose_bounds(const int32_t *__res
                                                             const PosePair *__restrict__ rec, const double *__restrict__ hi_cloud,
                                                             PoseBits B, const unsigned *__restrict__ bits, PoseCoarse C,
                                                             const unsigned *__restrict__ bits_c, int32_t *__restrict__ lower,
-                                                            unsigned short *__restrict__ upper, int probe) {
+                                                            unsigned short *__restrict__ upper, int32_t *__restrict__ hist, int nbins, int probe) {
     extern __shared__ __align__(16) unsigned char smem[];
     if (status[ST_FLAG_C] || status[ST_FLAG_PAIRS]) return;
     unsigned *lb = (unsigned *)smem;                                           // coarse bitmap
     float4 *clf = (float4 *)(smem + pad16((size_t)C.n_words * 4));             // hi cloud, float32
     const int64_t n_pairs = min((int64_t)status[ST_NPAIRS], cap_pairs);
     const int l_hi = status[ST_LHI];
+    // histogram of the lower bounds (k_prune_select takes its threshold from it): per workgroup in LDS, flushed once at the end
+    int *lh = (int *)(smem + pad16((size_t)C.n_words * 4) + pad16((size_t)(l_hi + 4) * 16) + (size_t)(PB_THREADS / MAD_WAVE) * (NB * MAD_WAVE) * 2);
+    for (int i = threadIdx.x; i < nbins; i += PB_THREADS) lh[i] = 0;
     // one queue of NB x 64 point ids per wave (LDS operations of a wave execute in order: the lookups of a pair have read it
     // before the next pair's filter writes it)
-    unsigned short *queue = (unsigned short *)(clf + ((l_hi + 3) & ~3)) + (threadIdx.x >> 6) * (NB * MAD_WAVE);
+    unsigned short *queue = (unsigned short *)(smem + pad16((size_t)C.n_words * 4) + pad16((size_t)(l_hi + 4) * 16)) + (threadIdx.x >> 6) * (NB * MAD_WAVE);
     stage_lds(lb, bits_c, (size_t)C.n_words * 4);
     for (int i = threadIdx.x; i < l_hi; i += PB_THREADS)
         clf[i] = make_float4((float)hi_cloud[3 * i], (float)hi_cloud[3 * i + 1], (float)hi_cloud[3 * i + 2], 0.f);
@@ -969,7 +988,9 @@ __global__ __launch_bounds__(PB_THREADS) void k_pose_bounds(const int32_t *__res
     uint2 wA[NB], wB[NB];
     int bitA[NB], bitB[NB];
     int nqA = 0, nqB = 0;
-    auto put = [&](int64_t p, int acc) { if (lane == 0) { lower[p] = acc & 0xffff; upper[p] = (unsigned short)(acc >> 16); } };
+    auto put = [&](int64_t p, int acc) {
+        if (lane == 0) { lower[p] = acc & 0xffff; upper[p] = (unsigned short)(acc >> 16); atomicAdd(&lh[min(acc & 0xffff, nbins - 1)], 1); }
+    };
     int64_t p = wave;
     if (p < n_pairs) {
         nqA = filter(rec[p].vc, queue);
@@ -987,6 +1008,9 @@ __global__ __launch_bounds__(PB_THREADS) void k_pose_bounds(const int32_t *__res
         lookup(rec[pa].vf, queue, nqA, wA, bitA);
         p = pa;
     }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nbins; i += PB_THREADS)
+        if (lh[i]) atomicAdd(&hist[i], lh[i]);
 }
 
 // T = the k-th largest lower bound (from its histogram; 0 when there are fewer than k pairs), then the pairs whose upper bound
@@ -1244,6 +1268,46 @@ __global__ __launch_bounds__(1024) void k_topk_sort(const unsigned long long *__
     for (int i = threadIdx.x; i < n; i += 1024) order[i] = (int64_t)(s[i] & ((1ull << 40) - 1));
 }
 
+// The k best of the pairs a pruned pose search has LISTED (sel[0 .. status[ST_NSEL])): every pair that is not listed has a count
+// strictly below the k-th best (k_prune_select), so the first k of the stable order (count descending, pair index ascending,
+// MaD.py:480) over the list are those over all pairs.  One workgroup: keys (maxc - count) << 40 | pair, bitonic sort in LDS over
+// the next power of two >= the list length, the first k out.  A list longer than TKS_CAP raises ST_FLAG_SEL instead.
+#define TKS_CAP 8192
+__global__ __launch_bounds__(1024) void k_topk_selected(const int32_t *__restrict__ counts, const int32_t *__restrict__ sel,
+                                                        int32_t *__restrict__ status, int64_t k, int maxc, int64_t *__restrict__ order) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    unsigned long long *s = (unsigned long long *)smem;
+    const bool failed = status[ST_FLAG_C] || status[ST_FLAG_PAIRS];
+    const int n = failed ? 0 : status[ST_NSEL];
+    if (n > TKS_CAP) {
+        if (threadIdx.x == 0) { status[ST_FLAG_SEL] = 1; status[ST_NKEYS] = 0; }
+        return;
+    }
+    int cap = 64;
+    while (cap < n) cap <<= 1;
+    for (int i = threadIdx.x; i < cap; i += 1024) {
+        unsigned long long key = ~0ull;
+        if (i < n) { const int p = sel[i]; key = ((unsigned long long)(maxc - counts[p]) << 40) | (unsigned long long)p; }
+        s[i] = key;
+    }
+    __syncthreads();
+    for (int kk = 2; kk <= cap; kk <<= 1)
+        for (int j = kk >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < cap; i += 1024) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const unsigned long long a = s[i], b = s[ixj];
+                    const bool up = (i & kk) == 0;
+                    if ((a > b) == up) { s[i] = b; s[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    const int n_out = (int)min((int64_t)n, k);
+    for (int i = threadIdx.x; i < n_out; i += 1024) order[i] = (int64_t)(s[i] & ((1ull << 40) - 1));
+    if (threadIdx.x == 0) status[ST_NKEYS] = n_out;
+}
+
 // Selects the first k pairs of the (count desc, index asc) order into d_order (sorted); their number goes to
 // status[ST_NKEYS].  Everything is enqueued; nothing is read back.
 static int topk_device(mad_ctx *ctx, const int32_t *d_counts, int32_t *d_status, int64_t cap_pairs, int64_t k, int maxc,
@@ -1421,8 +1485,9 @@ static int pose_wgs_per_cu() {
 static int pose_device(mad_ctx *ctx, const Side &hi, const Side &lo, int32_t *d_status, int64_t cap_pairs,
                        const double *d_hi_cloud, int l_hi_max, const double *d_cloud, int n_cloud, const uint8_t *d_cloud_used,
                        const double bb_min[3], const double bb_max[3], const CellGrid *fallback, double dist, int64_t prune_k = 0,
-                       int32_t *hist2 = nullptr, bool *pruned = nullptr) {
+                       int32_t *hist2 = nullptr, bool *pruned = nullptr, const CloudJob *job = nullptr) {
     if (pruned) *pruned = false;
+    const CloudJob no_job = {nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr};
     MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_COUNTS), (size_t)cap_pairs * 4));
     const double dd_lim = sqrt_limit(dist);
     const double reach = dist + 0.01;
@@ -1476,7 +1541,7 @@ static int pose_device(mad_ctx *ctx, const Side &hi, const Side &lo, int32_t *d_
         PoseBits &Bc = PC.B;
         // beside the bitmap: the float32 hi cloud and one queue of 2-byte point ids per wave
         const int nb_sets = (l_hi_max + MAD_WAVE - 1) / MAD_WAVE;
-        const size_t budget = (size_t)150 * 1024 - pad16((size_t)(l_hi_max + 4) * 16) - (size_t)(PB_THREADS / MAD_WAVE) * ((nb_sets + 1) & ~1) * MAD_WAVE * 2 - 64;
+        const size_t budget = (size_t)150 * 1024 - pad16((size_t)(l_hi_max + 4) * 16) - (size_t)(PB_THREADS / MAD_WAVE) * ((nb_sets + 1) & ~1) * MAD_WAVE * 2 - pad16((size_t)(l_hi_max + 1) * 4) - 64;
         size_t n_words_c = 0;
         for (Bc.h = std::max(1.2, B.h);; Bc.h *= 1.05) {
             const double guard = dist + Bc.h * 0.8660254037844387 + slack + Bc.h;
@@ -1516,7 +1581,7 @@ static int pose_device(mad_ctx *ctx, const Side &hi, const Side &lo, int32_t *d_
         }
         hipLaunchKernelGGL(k_pose_grid_build, dim3(1), dim3(1024), (size_t)G.ncell * 4, ctx->stream, d_cloud, d_cloud_used, n_cloud, G,
                            scratch<int32_t>(ctx, S_PG_START), d_start16, scratch<double>(ctx, S_PG_PTS),
-                           fits64 ? (float4 *)nullptr : scratch<float4>(ctx, S_PG_PTSF), d_status + ST_LLO);
+                           fits64 ? (float4 *)nullptr : scratch<float4>(ctx, S_PG_PTSF), d_status + ST_LLO, job ? *job : no_job);
         static const bool no_prune = getenv("MAD_NO_PRUNE") != nullptr;      // diagnostic switch
         const bool prune = prune_k > 0 && hist2 && bits_rad_in > 0.5 && PC.B.h <= 16.0 && l_hi_max <= 8 * MAD_WAVE && !no_prune;
         // fine bitmap, then (when pruning) the coarse one, in one buffer: one zero fill, one launch marks all planes
@@ -1559,17 +1624,16 @@ static int pose_device(mad_ctx *ctx, const Side &hi, const Side &lo, int32_t *d_
             static const int probe_mode = getenv("MAD_PB_PROBE") ? atoi(getenv("MAD_PB_PROBE")) : 0;
             const int nb = (l_hi_max + MAD_WAVE - 1) / MAD_WAVE;      // point sets of 64 an entire hi cloud needs
             const int nbv = nb <= 2 ? 2 : (nb <= 4 ? 4 : (nb <= 6 ? 6 : 8));
-            const size_t lds_b = pad16((size_t)PC.n_words * 4) + pad16((size_t)(l_hi_max + 4) * 16) + (size_t)(PB_THREADS / MAD_WAVE) * nbv * MAD_WAVE * 2 + 16;
+            const size_t lds_b = pad16((size_t)PC.n_words * 4) + pad16((size_t)(l_hi_max + 4) * 16) + (size_t)(PB_THREADS / MAD_WAVE) * nbv * MAD_WAVE * 2 +
+                                 pad16((size_t)nbins * 4) + 16;
 #define MAD_PB_LAUNCH(NBV)                                                                                                              \
     hipLaunchKernelGGL(k_pose_bounds<NBV>, dim3(ctx->n_cu), dim3(PB_THREADS), lds_b, ctx->stream, d_status, cap_pairs, d_rec, d_hi_cloud, B, \
-                       d_bits, PC, d_bits_c, scratch<int32_t>(ctx, S_COUNTS), scratch<unsigned short>(ctx, S_TMP_C), probe_mode)
+                       d_bits, PC, d_bits_c, scratch<int32_t>(ctx, S_COUNTS), scratch<unsigned short>(ctx, S_TMP_C), hist2, nbins, probe_mode)
             if (nbv == 2) MAD_PB_LAUNCH(2);
             else if (nbv == 4) MAD_PB_LAUNCH(4);
             else if (nbv == 6) MAD_PB_LAUNCH(6);
             else MAD_PB_LAUNCH(8);
 #undef MAD_PB_LAUNCH
-            hipLaunchKernelGGL(k_count_hist, dim3(ctx->n_cu * 2), dim3(256), (size_t)nbins * 4, ctx->stream, scratch<int32_t>(ctx, S_COUNTS),
-                               d_status, cap_pairs, hist2, nbins);
             hipLaunchKernelGGL(k_prune_select, dim3(ctx->n_cu / 2), dim3(256), 0, ctx->stream, d_status, cap_pairs, hist2, nbins, prune_k,
                                scratch<unsigned short>(ctx, S_TMP_C), scratch<int32_t>(ctx, S_TMP_D), d_status + ST_NSEL, hist2 + nbins);
             d_sel = scratch<int32_t>(ctx, S_TMP_D);
@@ -1600,6 +1664,7 @@ static int pose_device(mad_ctx *ctx, const Side &hi, const Side &lo, int32_t *d_
         return MAD_OK;
     }
     if (!fallback) return mad_fail(ctx, MAD_EINVAL, "pose: clouds of %d + %d points need the global cell list", l_hi_max, n_cloud);
+    if (job) hipLaunchKernelGGL(k_compact_cloud, dim3(1), dim3(1024), 0, ctx->stream, *job);
     const size_t lds2 = (size_t)l_hi_max * 24;
     if (lds2 > 150 * 1024) return mad_fail(ctx, MAD_EINVAL, "pose: hi cloud of %d anchors does not fit LDS", l_hi_max);
     MAD_HIP(hipFuncSetAttribute((const void *)k_pose, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -2079,6 +2144,7 @@ struct MatchPlan {
     bool fits;
     CellGrid G;
     double dist;
+    bool no_small;      // the one-workgroup top-k over the pruned selection overflowed: use the general selection
 };
 
 // enqueue a11 + a12 + top-k (+ the result rows) of one (hi, lo) pair in the CURRENT lane; no host round trip.
@@ -2105,16 +2171,31 @@ static int match_enqueue(mad_ctx *ctx, const mad_set *hi, const mad_set *lo, dou
     mad_zero_words(ctx, st, zero_bytes(hi, lo));      // status, histogram and flags in one launch
     MAD_TRY(correlate_device(ctx, H, L, hi->D, cc, st, P.cap_c, P.cap_pairs, used_hi, used_lo));
     // clouds: anchors that take part in at least one pair (MaD.py:427-428)
-    hipLaunchKernelGGL(k_compact_cloud, dim3(1), dim3(1024), 0, ctx->stream, (const double *)hi->anc_subv.p, used_hi,
-                       hi->n_anchors, scratch<double>(ctx, S_HI_CLOUD), st + ST_LHI, (const int32_t *)hi->dev_n.p,
-                       (const int32_t *)lo->dev_n.p, st);
+    const CloudJob job = {(const double *)hi->anc_subv.p, used_hi, hi->n_anchors, scratch<double>(ctx, S_HI_CLOUD), st + ST_LHI,
+                          (const int32_t *)hi->dev_n.p, (const int32_t *)lo->dev_n.p, st};      // compacted by the first pose kernel
     CellGrid G = P.G;
     G.used = used_lo;
     bool pruned = false;      // the caller gets k rows: pairs that cannot be among them need no exact count
     MAD_TRY(pose_device(ctx, H, L, st, P.cap_pairs, scratch<double>(ctx, S_HI_CLOUD), hi->n_anchors, (const double *)lo->anc_subv.p,
-                        lo->n_anchors, used_lo, lo->bb_min, lo->bb_max, P.fits ? nullptr : &G, dist, P.k, zr_hist2(st, hi->n_anchors), &pruned));
+                        lo->n_anchors, used_lo, lo->bb_min, lo->bb_max, P.fits ? nullptr : &G, dist, P.k, zr_hist2(st, hi->n_anchors), &pruned, &job));
     ctx->lane_pruned[ctx->lane] = pruned;
-    MAD_TRY(topk_device(ctx, scratch<int32_t>(ctx, S_COUNTS), st, P.cap_pairs, P.k, hi->n_anchors, scratch<int64_t>(ctx, S_SEL_OUT), hist));
+    // A pruned search has listed every pair that can be among the k best (all others lie strictly below the k-th count): when the
+    // previous match of this lane listed few enough, the k best are taken from that list by ONE workgroup instead of four
+    // launches over all pairs.  Should the list outgrow the kernel (ST_FLAG_SEL), the match is repeated with the general selection.
+    const int64_t hint = ctx->lane_sel_hint[ctx->lane];
+    if (pruned && !P.no_small && hint > 0 && hint <= TKS_CAP / 2 && P.k <= TKS_CAP) {
+        mad_timer_begin(ctx, MAD_T_TOPK);
+        static bool attr_t = false;
+        if (!attr_t) {
+            MAD_HIP(hipFuncSetAttribute((const void *)k_topk_selected, hipFuncAttributeMaxDynamicSharedMemorySize, TKS_CAP * 8));
+            attr_t = true;
+        }
+        hipLaunchKernelGGL(k_topk_selected, dim3(1), dim3(1024), (size_t)TKS_CAP * 8, ctx->stream, scratch<int32_t>(ctx, S_COUNTS),
+                           scratch<int32_t>(ctx, S_TMP_D), st, P.k, hi->n_anchors, scratch<int64_t>(ctx, S_SEL_OUT));
+        mad_timer_end(ctx, MAD_T_TOPK);
+    } else {
+        MAD_TRY(topk_device(ctx, scratch<int32_t>(ctx, S_COUNTS), st, P.cap_pairs, P.k, hi->n_anchors, scratch<int64_t>(ctx, S_SEL_OUT), hist));
+    }
     hipLaunchKernelGGL(k_results, dim3((unsigned)mad_ceil_div(P.k, 256)), dim3(256), 0, ctx->stream,
                        scratch<int64_t>(ctx, S_SEL_OUT), st + ST_NKEYS, P.k, scratch<int32_t>(ctx, S_PAIR_HI),
                        scratch<int32_t>(ctx, S_PAIR_LO), scratch<double>(ctx, S_PAIR_SCORE), scratch<int32_t>(ctx, S_COUNTS),
@@ -2131,6 +2212,7 @@ static int match_prepare(mad_ctx *ctx, const mad_set *hi, const mad_set *lo, dou
     if (!(dist > 0)) return mad_fail(ctx, MAD_EINVAL, "mad_match_topk: dist must be positive");
     P->k = k < 1 ? 1 : k;
     P->dist = dist;
+    P->no_small = false;
     MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_ZERO), zero_bytes(hi, lo)));
     MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_HI_CLOUD), (size_t)hi->n_anchors * 24 + 24));
     MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_SEL_OUT), (size_t)(P->k + 8) * 8));
@@ -2189,6 +2271,11 @@ static int match_finish(mad_ctx *ctx, int lane, const mad_set *hi, const mad_set
     }
     if (hs[ST_FLAG_PAIRS]) {
         P->cap_pairs = (int64_t)hs[ST_NPAIRS] + hs[ST_NPAIRS] / 8 + 1024;
+        return 1;
+    }
+    if (hs[ST_FLAG_SEL]) {
+        P->no_small = true;
+        ctx->lane_sel_hint[lane] = 0;
         return 1;
     }
     ctx->match.cap_c = std::max(ctx->match.cap_c, P->cap_c);
@@ -2442,8 +2529,8 @@ extern "C" int mad_match_shard_topk(mad_ctx *ctx, const mad_set *hi, const mad_s
     MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_HI_CLOUD), (size_t)hi->n_anchors * 24 + 24));
     MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_SEL_OUT), (size_t)(k + 8) * 8));
     MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_RESULTS), (size_t)(k + 1) * MAD_RESULT_COLS * 8));
-    hipLaunchKernelGGL(k_compact_cloud, dim3(1), dim3(1024), 0, ctx->stream, (const double *)hi->anc_subv.p, d_used_hi, hi->n_anchors,
-                       scratch<double>(ctx, S_HI_CLOUD), st + ST_LHI, (const int32_t *)nullptr, (const int32_t *)nullptr, st);
+    hipLaunchKernelGGL(k_compact_cloud, dim3(1), dim3(1024), 0, ctx->stream,
+                       CloudJob{(const double *)hi->anc_subv.p, d_used_hi, hi->n_anchors, scratch<double>(ctx, S_HI_CLOUD), st + ST_LHI, nullptr, nullptr, st});
     MAD_HIP(hipGetLastError());
     if (np > 0) {
         const Side H = side_of(hi), L = side_block(lo, begin, st + ST_NLO, nb);
