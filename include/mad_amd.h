@@ -108,6 +108,14 @@ int mad_free_field(mad_ctx *ctx, int slot);
  * row_count (nullable): Z quantised zone counts per row (DensityFeature.ar_count).
  * n_reject (nullable): anchors refused by the border test (Orientator.py:131-135).
  */
+/*
+ * Orientator(gw_sig = sigma) (Orientator.py:49-54): a Gaussian window exp(-d^2 / (2 sigma^2)) on the orientation histogram,
+ * d = a voxel's offset from the anchor in voxels of the box.  0 (the default, and what MaD.run uses) = no window.  Applies
+ * to mad_orient and mad_set_build from the next call on.  The reference truncates each zone's float64 weight sum to
+ * int32 before it quantises; the kernel sums the weights in 2^-50 fixed point (deterministic, |error| < 1.2e-12 per
+ * sum), so a zone count can differ from the reference's only where its weight sum lies that close to an integer.
+ */
+int mad_set_orient_window(mad_ctx *ctx, double gw_sig);
 int mad_orient(mad_ctx *ctx, int slot, int octave, const int32_t *coords, int n, int r,
                int lim_main, int lim_sec,
                int32_t *row_anchor, int32_t *row_main, int32_t *row_sec, double *row_R,
@@ -122,6 +130,13 @@ int mad_orient(mad_ctx *ctx, int slot, int octave, const int32_t *coords, int n,
  */
 int mad_describe(mad_ctx *ctx, int slot, int octave, const int32_t *coords, const double *R,
                  int64_t n_rows, int r, int16_t *dsc);
+/*
+ * The same with another partition of the sample cube, Descriptor(dsc_size = 64 | 27 | 8 | 1) (Descriptor.py:44-93):
+ * dsc is n_rows x (dsc_size * Zd), sub-regions in the order of the reference's sub_slices lists.  MaD.run never selects
+ * them (it constructs Descriptor(dsc_radius=patch_size) only, MaD.py:362); 27, 8 and 1 exist for r = 8.
+ */
+int mad_describe_sized(mad_ctx *ctx, int slot, int octave, const int32_t *coords, const double *R,
+                       int64_t n_rows, int r, int dsc_size, int16_t *dsc);
 
 /* ---- a11: MaD._match_dsc part 1 (MaD.py:416-424) ----------------------------- */
 

@@ -31,8 +31,10 @@ class Descriptor(object):
         if dsc_size not in (64, 27, 8, 1):
             print("MaD>> ERROR: invalid dsc size %i" % dsc_size)
             sys.exit(1)
-        if dsc_size != 64 or subeqsp_size != 16:
-            raise NotImplementedError("MaD> the device descriptor is 64 sub-cubes x 16 zones (the reference's only used layout)")
+        if subeqsp_size != 16:
+            raise NotImplementedError("MaD> the device descriptor has 16 zones per sub-region (the only descriptor table the reference ships)")
+        if dsc_size != 64 and self.dsc_radius != 8:
+            raise NotImplementedError("MaD> dsc_size 27, 8 and 1 are built for the default dsc_radius (16) only")
         dr = self.dsc_radius
         # sample lattices (Descriptor.py:34-35), kept for inspection
         self.dsc_layout = {
@@ -58,7 +60,7 @@ class Descriptor(object):
             R = np.array([df_list[i].Rfinal for i in ids], dtype=np.float64).reshape(-1, 9)
             slot = slots[octave] if len(ms.grad_list) > 1 else slots[0]
             lattice = octave if len(ms.grad_list) > 1 else (1 if ms.oct_mode == "base" else 0)
-            dsc = lib.describe(slot, lattice, coords, R, r=self.dsc_radius, Zd=self.subeqsp_size)
+            dsc = lib.describe(slot, lattice, coords, R, r=self.dsc_radius, Zd=self.subeqsp_size, dsc_size=self.dsc_size)
             for j, i in enumerate(ids):
                 df = df_list[i]
                 df.set_descriptor_info(self.subeqsp_size, self.dsc_radius)

@@ -34,8 +34,6 @@ class Orientator(object):
             print("MaD> ERROR: radius %i invalid, must be even. Setting %i instead." % (ori_radius, ori_radius - 1))
             ori_radius -= 1
         self.ori_radius = ori_radius // 2
-        if gw_sig:
-            raise NotImplementedError("MaD> only the default orientation window (gw_sig=0) is implemented")
         self.gw_sig = gw_sig
         # the reference stores this flag and never reads it again (Orientator.py:33 is its only use): accepted, without effect
         self.magn_weighted = magn_weighted
@@ -43,7 +41,8 @@ class Orientator(object):
         dr = self.ori_radius
         g = np.mgrid[-dr:dr + 1, -dr:dr + 1, -dr:dr + 1]
         self.sphere_mask_ori_dict = (np.sqrt(np.sum(g * g, 0)) <= dr * 1.05).astype(int)
-        self.gauss_weight_ori_dict = self.sphere_mask_ori_dict.copy()
+        # Orientator.py:49-54: Gaussian window times the mask (ones times the mask when gw_sig is 0), kept for inspection
+        self.gauss_weight_ori_dict = (np.exp(-1 * np.divide(np.sum(g * g, 0), 2 * (gw_sig) ** 2)) if gw_sig else np.ones_like(np.sum(g * g, 0))) * self.sphere_mask_ori_dict
         self.to_dom_table, self.adj_sec_table = orientation_matrices(self.eqsp)
         self.step1_reject = 0
         self.time1 = self.time2 = self.time3 = self.time4 = self.time5 = 0
@@ -53,6 +52,7 @@ class Orientator(object):
         if lib._eq_loaded.get(0) != key:
             lib.set_eqsp(0, self.eqsp.sphere_eqsp, self.to_dom_table, self.adj_sec_table)
             lib._eq_loaded[0] = key
+        lib.set_orient_window(self.gw_sig)
 
     def assign_orientations(self, ms, df_list):
         print("MaD> Orienting %i anchors..." % (len(df_list)))

@@ -21,7 +21,7 @@ SYMBOLS = [
     "mad_init", "mad_destroy", "mad_last_error", "mad_synchronize", "mad_stream", "mad_set_overlap",
     "mad_timing_enable", "mad_timing_reset", "mad_timing_get", "mad_last_ms",
     "mad_set_eqsp", "mad_upload_field", "mad_upload_field_device", "mad_free_field",
-    "mad_orient", "mad_describe", "mad_correlate", "mad_pose_score", "mad_topk",
+    "mad_set_orient_window", "mad_orient", "mad_describe", "mad_describe_sized", "mad_correlate", "mad_pose_score", "mad_topk",
     "mad_set_create", "mad_set_destroy", "mad_set_build", "mad_set_load", "mad_set_size", "mad_set_download",
     "mad_match_topk", "mad_match_topk_many", "mad_match_topk_many_begin", "mad_match_topk_many_finish", "mad_last_pose_kernel", "mad_last_pose_selected", "mad_match_fetch", "mad_match_results", "mad_match_used",
     "mad_match_shard_pairs", "mad_match_shard_topk",
@@ -100,6 +100,17 @@ def _p(a):
 
 def _c(a, dt):
     return np.ascontiguousarray(a, dtype=dt)
+
+
+def _pad_rows(dsc, to=128):
+    """Descriptor rows zero-padded to a multiple of 128 counts: the correlation kernel consumes K in steps of 128 bytes, and zeros
+    change neither a dot product nor a norm (row lengths 432 and 16 of Descriptor(dsc_size=27 | 1))."""
+    d = dsc.shape[1] if dsc.ndim == 2 else 0
+    if d == 0 or d % to == 0:
+        return dsc
+    out = np.zeros((dsc.shape[0], (d + to - 1) // to * to), dsc.dtype)
+    out[:, :d] = dsc
+    return out
 
 
 class DeviceSet(object):
@@ -300,6 +311,12 @@ class Lib(object):
         adj_sec = None if adj_sec is None else _c(adj_sec, np.float64)
         self._chk(self.dll.mad_set_eqsp(self.ctx, C.c_int(which), C.c_int(len(bounds)), _p(bounds), _p(to_dom), _p(adj_sec)))
 
+    def set_orient_window(self, gw_sig=0.0):
+        """Orientator(gw_sig): Gaussian window on the orientation histogram for the following orient / set_build calls (0 = none)."""
+        if getattr(self, "_gw_sig", 0.0) != float(gw_sig):
+            self._chk(self.dll.mad_set_orient_window(self.ctx, C.c_double(float(gw_sig))))
+            self._gw_sig = float(gw_sig)
+
     def new_slot(self):
         if self._free_slots:
             return self._free_slots.pop()
@@ -348,16 +365,17 @@ class Lib(object):
         return dict(anchor=ra[:k].copy(), main=rm[:k].copy(), sec=rs[:k].copy(), R=R[:k].reshape(k, 3, 3).copy(),
                     counts=None if cnt is None else cnt[:k].copy(), n_reject=nrej.value)
 
-    def describe(self, slot, octave, coords, R, r=8, Zd=16):
+    def describe(self, slot, octave, coords, R, r=8, Zd=16, dsc_size=64):
         coords = _c(coords, np.int32).reshape(-1, 3)
         R = _c(R, np.float64).reshape(-1, 9)
         n = len(coords)
-        out = np.zeros((n, 64 * Zd), np.int16)
-        self._chk(self.dll.mad_describe(self.ctx, C.c_int(slot), C.c_int(octave), _p(coords), _p(R), C.c_int64(n), C.c_int(r), _p(out)))
+        out = np.zeros((n, dsc_size * Zd), np.int16)
+        self._chk(self.dll.mad_describe_sized(self.ctx, C.c_int(slot), C.c_int(octave), _p(coords), _p(R), C.c_int64(n), C.c_int(r),
+                                              C.c_int(dsc_size), _p(out)))
         return out
 
     def correlate(self, hi, lo, cc):
-        hi, lo = _c(hi, np.int16), _c(lo, np.int16)
+        hi, lo = _pad_rows(_c(hi, np.int16)), _pad_rows(_c(lo, np.int16))
         n_hi, D = hi.shape
         n_lo = lo.shape[0]
         npairs = C.c_int64(0)
@@ -421,6 +439,7 @@ class Lib(object):
         dsc = _c(dsc, np.int16)
         if dsc.ndim != 2:
             dsc = dsc.reshape(len(row_anchor), -1)
+        dsc = _pad_rows(dsc)
         anc_subv = _c(anc_subv, np.float64).reshape(-1, 3)
         anc_index, anc_octave = _c(anc_index, np.int32), _c(anc_octave, np.int32)
         s.n_anchors = len(anc_index)

@@ -145,6 +145,9 @@ struct mad_ctx {
     EqspDev *eq[2] = {nullptr, nullptr};     // device copies
     EqspDev eq_host[2];
     bool eq_set[2] = {false, false};
+    double gw_sig = 0.0, gw_built = 0.0;     // Orientator(gw_sig): Gaussian window on the orientation histogram (0 = none); the table's sigma
+    unsigned long long *gw_tab = nullptr;    // device: its weights by squared offset, 2^-50 fixed point, for box size gw_r
+    int gw_r = -1;
     int8_t *mask_off = nullptr;              // sphere-mask offsets for the current r
     int mask_r = -1;
     int mask_n = 0;
@@ -256,7 +259,7 @@ int mad_orient_device(mad_ctx *ctx, FieldDev f0, FieldDev f1, const int32_t *d_c
 int mad_describe_device(mad_ctx *ctx, FieldDev f0, FieldDev f1, const int32_t *d_anc_coords, const int32_t *d_anc_octave,
                         int uniform_octave, const int32_t *d_row_anchor, const double *d_row_R, const double *d_row_Rinv,
                         const int32_t *d_n_rows, int64_t grid_rows, int32_t *d_overflow, int r, int16_t *d_dsc, int8_t *d_dsc8 = nullptr,
-                        double *d_norm = nullptr);
+                        double *d_norm = nullptr, int dsc_size = 64);
 void mad_many_abandon(mad_ctx *ctx);
 void mad_zero_words(mad_ctx *ctx, void *p, size_t bytes);              // one-launch zero fill (bytes rounded up to 16)
 void mad_copy_words(mad_ctx *ctx, void *dst, const void *src, size_t bytes);      // kernel copy, e.g. out of pinned host memory

@@ -98,6 +98,7 @@ extern "C" void mad_destroy(mad_ctx *ctx) {
     if (ctx->eq[0]) (void)hipFree(ctx->eq[0]);
     if (ctx->eq[1]) (void)hipFree(ctx->eq[1]);
     if (ctx->mask_off) (void)hipFree(ctx->mask_off);
+    if (ctx->gw_tab) (void)hipFree(ctx->gw_tab);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->dens.grid) (void)hipFree(ctx->dens.grid);
     if (ctx->dens.grad) (void)hipFree(ctx->dens.grad);

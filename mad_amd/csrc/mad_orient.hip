@@ -70,14 +70,24 @@ struct OrientArgs {
     int32_t *slot_sec;             // n x fan
     int32_t *slot_hist;            // n x lim_main x Z quantised counts per accepted main bin (or nullptr)
     int32_t *slot_hidx;            // n x fan: which of the anchor's hist rows a slot uses
+    // Orientator(gw_sig != 0): weight of a voxel at squared offset d2 from the anchor, exp(-d2 / (2 sigma^2)) in 2^-50 units
+    // (Orientator.py:49-54); nullptr = every voxel of the sphere counts 1
+    const unsigned long long *wfix;
 };
+#define ORI_WFIX_BITS 50
 
 // Quantise `hist` (Z counts in LDS) to 0..50 of its max (Orientator.py:336-340) into q.
 // Executed by wave 0 only; returns the max (0 = nothing counted, q left = hist).
-__device__ __forceinline__ int quantise_wave0(const int *hist, int *q, int Z) {
+// A weighted histogram holds fixed-point sums; the reference stores a zone's float64 sum into an int32 array
+// (DensityFeature.py:50, Orientator.py:334), i.e. truncates it, before anything else looks at it.
+__device__ __forceinline__ int hist_count(int v) { return v; }
+__device__ __forceinline__ int hist_count(unsigned long long v) { return (int)(v >> ORI_WFIX_BITS); }
+
+template <class H>
+__device__ __forceinline__ int quantise_wave0(const H *hist, int *q, int Z) {
     const int lane = lane_id();
-    const int c0 = lane < Z ? hist[lane] : 0;
-    const int c1 = lane + 64 < Z ? hist[lane + 64] : 0;
+    const int c0 = lane < Z ? hist_count(hist[lane]) : 0;
+    const int c1 = lane + 64 < Z ? hist_count(hist[lane + 64]) : 0;
     const int mx = wave_max_i32(max(c0, c1));
     if (lane < Z) q[lane] = mx ? (int)((double)c0 / (double)mx * 50.0) : c0;
     if (lane + 64 < Z) q[lane + 64] = mx ? (int)((double)c1 / (double)mx * 50.0) : c1;
@@ -96,13 +106,18 @@ __device__ __forceinline__ void classify_exact64(const EqspFastLds *eq, double r
     eqsp_classify_lds(eq, th, sth, ph, f);
 }
 
+template <bool GW>
 __global__ __launch_bounds__(ORI_THREADS) void k_orient(OrientArgs A) {
     extern __shared__ __align__(16) unsigned char smem[];
     float *vx = (float *)smem;
     float *vy = vx + A.nmask;
     float *vz = vy + A.nmask;
     int *queue = (int *)(vz + A.nmask);                 // (voxel | candidate << 16) the fast classifier could not decide
-    __shared__ int hist[ORI_MAX_MAIN + 1][MAD_MAX_Z];   // [0]: first pass; [1 + c]: main-bin candidate c
+    // GW (Gaussian window): the kept voxels' squared offsets and the weight table, behind the queue
+    unsigned short *vw = (unsigned short *)(queue + A.nmask);
+    unsigned long long *wl = (unsigned long long *)(smem + (((size_t)A.nmask * 18 + 15) & ~(size_t)15));
+    using H = typename std::conditional<GW, unsigned long long, int>::type;
+    __shared__ H hist[ORI_MAX_MAIN + 1][MAD_MAX_Z];     // [0]: first pass; [1 + c]: main-bin candidate c
     __shared__ int qz[ORI_MAX_MAIN + 1][MAD_MAX_Z];     // quantised counts, same indexing
     __shared__ int main_list[MAD_MAX_Z];
     __shared__ int sec_list[ORI_MAX_MAIN][ORI_MAX_FAN];
@@ -135,7 +150,14 @@ __global__ __launch_bounds__(ORI_THREADS) void k_orient(OrientArgs A) {
     }
     if (tid == 0) { s_nvox = 0; s_nq = 0; }
     for (int i = tid; i < (ORI_MAX_MAIN + 1) * MAD_MAX_Z; i += ORI_THREADS) (&hist[0][0])[i] = 0;
+    if (GW)
+        for (int i = tid; i <= 3 * r * r; i += ORI_THREADS) wl[i] = A.wfix[i];
     eqsp_fast_stage(A.eq, &fast);
+    // one count (or one weight) of voxel v for zone zn of histogram h
+    auto tally = [&](int h, int zn, int v) {
+        if (GW) atomicAdd(&hist[h][zn], (H)wl[vw[v]]);
+        else atomicAdd(&hist[h][zn], (H)1);
+    };
     __syncthreads();
 
     // step01: fetch, normalise (float32, Orientator.py:139-147), keep weighted voxels only
@@ -176,6 +198,10 @@ __global__ __launch_bounds__(ORI_THREADS) void k_orient(OrientArgs A) {
             if (keep) {
                 const int slot = base + __popcll(bal & lanemask_lt());
                 vx[slot] = gx; vy[slot] = gy; vz[slot] = gz;
+                if (GW) {
+                    const int dx = (int)(int8_t)(packed[k] & 0xff), dy = (int)(int8_t)((packed[k] >> 8) & 0xff), dz = (int)(int8_t)((packed[k] >> 16) & 0xff);
+                    vw[slot] = (unsigned short)(dx * dx + dy * dy + dz * dz);
+                }
             }
         }
     }
@@ -186,7 +212,7 @@ __global__ __launch_bounds__(ORI_THREADS) void k_orient(OrientArgs A) {
     // take the guard-banded float32 path; the few near a bound are queued for the exact test.
     for (int v = tid; v < nvox; v += ORI_THREADS) {
         const int zn = eqsp_fast32<true>(&fast, vx[v], vy[v], vz[v]);
-        if (zn >= 0) atomicAdd(&hist[0][zn], 1);
+        if (zn >= 0) tally(0, zn, v);
         else queue[atomicAdd(&s_nq, 1)] = v;
     }
     __syncthreads();
@@ -195,14 +221,14 @@ __global__ __launch_bounds__(ORI_THREADS) void k_orient(OrientArgs A) {
         const int nq = s_nq;
         for (int qi = tid; qi < nq; qi += ORI_THREADS) {      // the reference's float32 arithmetic
             const int v = queue[qi];
-            if (eqsp_tier2(&fast, (double)vx[v], (double)vy[v], (double)vz[v], true, [&](int zn) { atomicAdd(&hist[0][zn], 1); })) continue;
+            if (eqsp_tier2(&fast, (double)vx[v], (double)vy[v], (double)vz[v], true, [&](int zn) { tally(0, zn, v); })) continue;
             float th = (float)atan2((double)vy[v], (double)vx[v]);
             if (th < 0.0f) th = __fadd_rn(th, two_pi_f);
             const float sth = __fadd_rn(th, two_pi_f);
             double cz = (double)vz[v];
             cz = cz > 1.0 ? 1.0 : (cz < -1.0 ? -1.0 : cz);
             const float ph = (float)acos(cz);
-            eqsp_classify_lds(&fast, (double)th, (double)sth, (double)ph, [&](int zn) { atomicAdd(&hist[0][zn], 1); });
+            eqsp_classify_lds(&fast, (double)th, (double)sth, (double)ph, [&](int zn) { tally(0, zn, v); });
         }
     }
     __syncthreads();
@@ -241,14 +267,14 @@ __global__ __launch_bounds__(ORI_THREADS) void k_orient(OrientArgs A) {
             const float ry = g0 * d[3] + g1 * d[4] + g2 * d[5];
             const float rz = g0 * d[6] + g1 * d[7] + g2 * d[8];
             const int zn = eqsp_fast32<true>(&fast, rx, ry, rz);
-            if (zn >= 0) { atomicAdd(&hist[1 + c][zn], 1); continue; }
+            if (zn >= 0) { tally(1 + c, zn, v); continue; }
             const int slot = atomicAdd(&s_nq, 1);
             if (slot < A.nmask) { queue[slot] = v | (c << 16); continue; }
             // queue full (only if nearly every direction sat on a bound): exact test in place
             const double *dd = s_dom[c];
             const double e0 = g0, e1 = g1, e2 = g2;
             classify_exact64(&fast, e0 * dd[0] + e1 * dd[1] + e2 * dd[2], e0 * dd[3] + e1 * dd[4] + e2 * dd[5],
-                             e0 * dd[6] + e1 * dd[7] + e2 * dd[8], [&](int z2) { atomicAdd(&hist[1 + c][z2], 1); });
+                             e0 * dd[6] + e1 * dd[7] + e2 * dd[8], [&](int z2) { tally(1 + c, z2, v); });
         }
     }
     __syncthreads();
@@ -261,7 +287,7 @@ __global__ __launch_bounds__(ORI_THREADS) void k_orient(OrientArgs A) {
             const double rx = g0 * d[0] + g1 * d[1] + g2 * d[2];
             const double ry = g0 * d[3] + g1 * d[4] + g2 * d[5];
             const double rz = g0 * d[6] + g1 * d[7] + g2 * d[8];
-            classify_exact64(&fast, rx, ry, rz, [&](int zn) { atomicAdd(&hist[1 + c][zn], 1); });
+            classify_exact64(&fast, rx, ry, rz, [&](int zn) { tally(1 + c, zn, v); });
         }
     }
     __syncthreads();
@@ -374,9 +400,23 @@ int mad_orient_device(mad_ctx *ctx, FieldDev f0, FieldDev f1, const int32_t *d_c
     A.slot_hidx = scratch<int32_t>(ctx, S_TMP_A);
     if (out.d_n_reject && !out.counters_zeroed) MAD_HIP(hipMemsetAsync(out.d_n_reject, 0, 4, ctx->stream));
 
+    A.wfix = nullptr;
+    if (ctx->gw_sig != 0.0) {      // Orientator(gw_sig): the window's weights for this box size, as 2^-50 fixed point
+        if (ctx->gw_r != r || ctx->gw_built != ctx->gw_sig) {
+            unsigned long long tab[3 * 10 * 10 + 1];
+            for (int d2 = 0; d2 <= 3 * r * r; d2++)
+                tab[d2] = (unsigned long long)llround(ldexp(exp(-1.0 * ((double)d2 / (2.0 * (ctx->gw_sig * ctx->gw_sig)))), ORI_WFIX_BITS));
+            if (!ctx->gw_tab && hipMalloc((void **)&ctx->gw_tab, sizeof(tab)) != hipSuccess) return mad_fail(ctx, MAD_ENOMEM, "orientation window table");
+            MAD_HIP(hipMemcpy(ctx->gw_tab, tab, sizeof(unsigned long long) * (3 * r * r + 1), hipMemcpyHostToDevice));
+            ctx->gw_r = r; ctx->gw_built = ctx->gw_sig;
+        }
+        A.wfix = ctx->gw_tab;
+    }
     mad_timer_begin(ctx, MAD_T_ORIENT);
-    const size_t lds = (size_t)ctx->mask_n * 4 * sizeof(float);      // unit gradients (SoA) + the undecided-voxel queue
-    hipLaunchKernelGGL(k_orient, dim3(n), dim3(ORI_THREADS), lds, ctx->stream, A);
+    // unit gradients (SoA) + the undecided-voxel queue; with a window also the voxels' squared offsets and the weight table
+    const size_t lds = A.wfix ? ((((size_t)ctx->mask_n * 18 + 15) & ~(size_t)15) + (size_t)(3 * r * r + 1) * 8) : (size_t)ctx->mask_n * 4 * sizeof(float);
+    if (A.wfix) hipLaunchKernelGGL(k_orient<true>, dim3(n), dim3(ORI_THREADS), lds, ctx->stream, A);
+    else hipLaunchKernelGGL(k_orient<false>, dim3(n), dim3(ORI_THREADS), lds, ctx->stream, A);
     mad_timer_end(ctx, MAD_T_ORIENT);
     int32_t *row_off = scratch<int32_t>(ctx, S_ROW_OFF);
     if (n <= 65536) {
@@ -391,6 +431,14 @@ int mad_orient_device(mad_ctx *ctx, FieldDev f0, FieldDev f1, const int32_t *d_c
                        out.row_anchor, out.row_main, out.row_sec, out.row_R, out.row_count, out.row_Rinv, out.row_meta,
                        out.anc_index, out.anc_octave);
     MAD_HIP(hipGetLastError());
+    return MAD_OK;
+}
+
+extern "C" int mad_set_orient_window(mad_ctx *ctx, double gw_sig) {
+    if (!ctx) return MAD_EINVAL;
+    if (!(gw_sig >= 0.0) || !(gw_sig < 1e6)) return mad_fail(ctx, MAD_EINVAL, "mad_set_orient_window: gw_sig = %g", gw_sig);
+    MAD_TRY(mad_synchronize(ctx));      // the table may be in use
+    ctx->gw_sig = gw_sig;
     return MAD_OK;
 }
 
@@ -497,10 +545,32 @@ __device__ __forceinline__ unsigned lattice_index_exact(double l0, double l1, do
     return (unsigned)(((size_t)a0i * F.ny + a1i) * F.nz + a2i);
 }
 
+// Descriptor.py:44-93: the sub-region of lattice point (i, j, k) among NSUB, split into the part a thread's (j, k) column fixes
+// and the part its sample index i adds.  Order of the reference's sub_slices lists: 64 and 27 -- third axis fastest, then the
+// first, then the second; 8 -- its own order ((s1,s1,s2) first); 1 -- the whole cube.
+template <int S, int NSUB> __device__ __forceinline__ int sub_blk(int x) {
+    if (NSUB == 64) return x / (S / 4);
+    if (NSUB == 27) return x < S / 3 ? 0 : (x < 2 * S / 3 ? 1 : 2);
+    if (NSUB == 8) return x < S / 2 ? 0 : 1;
+    return 0;
+}
+template <int S, int NSUB> __device__ __forceinline__ int sub_of_jk(int j, int k) {
+    if (NSUB == 64) return sub_blk<S, NSUB>(j) * 16 + sub_blk<S, NSUB>(k);
+    if (NSUB == 27) return sub_blk<S, NSUB>(j) * 9 + sub_blk<S, NSUB>(k);
+    if (NSUB == 8) return sub_blk<S, NSUB>(j) * 2 + (1 - sub_blk<S, NSUB>(k));
+    return 0;
+}
+template <int S, int NSUB> __device__ __forceinline__ int sub_of_i(int i) {
+    if (NSUB == 64) return sub_blk<S, NSUB>(i) * 4;
+    if (NSUB == 27) return sub_blk<S, NSUB>(i) * 3;
+    if (NSUB == 8) return sub_blk<S, NSUB>(i) * 4;
+    return 0;
+}
+
 #define DSC_CHUNK 8
-template <int S>
+template <int S, int NSUB = 64>
 __global__ __launch_bounds__(DSC_THREADS, 4) void k_describe(DescribeArgs A) {
-    __shared__ int hist[64 * 16];
+    __shared__ int hist[NSUB * 16];
     __shared__ int s_oob, s_nq;
     __shared__ double sInv[9];
     __shared__ EqspFastLds fast;
@@ -519,7 +589,7 @@ __global__ __launch_bounds__(DSC_THREADS, 4) void k_describe(DescribeArgs A) {
     }
     if (A.dsc8) {      // zero rows up to the next multiple of 128: the GEMM reads whole tiles
         const int64_t n_pad = (n_rows + 127) / 128 * 128;
-        const int Dp = 64 * A.eq->Z;
+        const int Dp = NSUB * A.eq->Z;
         for (int64_t r = n_rows + blockIdx.x; r < n_pad; r += gridDim.x) {
             for (int i = tid; i < Dp / 4; i += DSC_THREADS) ((int32_t *)(A.dsc8 + r * Dp))[i] = 0;
             if (tid == 0) A.norm[r] = 0.0;
@@ -532,8 +602,7 @@ __global__ __launch_bounds__(DSC_THREADS, 4) void k_describe(DescribeArgs A) {
     const int oct = A.anc_octave ? A.anc_octave[a] : A.uniform_octave;
     const FieldDev F = A.f[oct == 1 ? 1 : 0];
     const int Z = A.eq->Z;
-    constexpr int q4 = S / 4;          // S = 2 r samples per axis (16)
-    const int D = 64 * Z;
+    const int D = NSUB * Z;            // S = 2 r samples per axis (16), NSUB sub-regions of Z zones each
 
     // Rfinal and its inverse (np.linalg.inv, Descriptor.py:132; cofactors): the row is uniform over the workgroup, so these
     // are scalar loads; nobody waits for a thread 0 to publish them through LDS
@@ -623,7 +692,7 @@ __global__ __launch_bounds__(DSC_THREADS, 4) void k_describe(DescribeArgs A) {
         // overlap; then the histogram updates.  The few points the fast classifier declines (~2 per row) are collected in
         // a bit mask and handed to the exact path afterwards.
         unsigned undecided = 0;
-        const int sub_jk = (j / q4) * 16 + (k / q4);      // Descriptor.py:44-64
+        const int sub_jk = sub_of_jk<S, NSUB>(j, k);      // Descriptor.py:44-93
 #pragma unroll
         for (int i0 = 0; i0 < S; i0 += DSC_CHUNK) {
             int zone[DSC_CHUNK];
@@ -640,7 +709,7 @@ __global__ __launch_bounds__(DSC_THREADS, 4) void k_describe(DescribeArgs A) {
             }
 #pragma unroll
             for (int u = 0; u < DSC_CHUNK; u++) {
-                if (zone[u] >= 0) atomicAdd(&hist[(sub_jk + ((i0 + u) / q4) * 4) * Z + zone[u]], 1);
+                if (zone[u] >= 0) atomicAdd(&hist[(sub_jk + sub_of_i<S, NSUB>(i0 + u)) * Z + zone[u]], 1);
                 undecided |= zone[u] == -1 ? (1u << (i0 + u)) : 0u;
             }
         }
@@ -649,7 +718,7 @@ __global__ __launch_bounds__(DSC_THREADS, 4) void k_describe(DescribeArgs A) {
             for (int i = 0; i < S; i++)
                 if (undecided & (1u << i)) {
                     const int slot = atomicAdd(&s_nq, 1);
-                    if (slot < DSC_QUEUE) { qv[slot] = t[i]; qsub[slot] = sub_jk + (i / q4) * 4; }
+                    if (slot < DSC_QUEUE) { qv[slot] = t[i]; qsub[slot] = sub_jk + sub_of_i<S, NSUB>(i); }
                 }
         }
     }
@@ -664,7 +733,7 @@ __global__ __launch_bounds__(DSC_THREADS, 4) void k_describe(DescribeArgs A) {
                 bool none = false;
                 const float4 tx = F.tex[lattice_index_exact(lbase + lstep * i, l1, l2, sInv, c0, c1, c2, F, &none)];
                 if (tx.w < 1e-5f) continue;
-                atomicAdd(&hist[((j / q4) * 16 + (i / q4) * 4 + (k / q4)) * Z + describe_exact(&fast, tx, Rrow)], 1);
+                atomicAdd(&hist[(sub_of_jk<S, NSUB>(j, k) + sub_of_i<S, NSUB>(i)) * Z + describe_exact(&fast, tx, Rrow)], 1);
             }
     } else {
         const int nq = s_nq;
@@ -693,8 +762,11 @@ __global__ __launch_bounds__(DSC_THREADS, 4) void k_describe(DescribeArgs A) {
 
 int mad_describe_device(mad_ctx *ctx, FieldDev f0, FieldDev f1, const int32_t *d_anc_coords, const int32_t *d_anc_octave,
                         int uniform_octave, const int32_t *d_row_anchor, const double *d_row_R, const double *d_row_Rinv,
-                        const int32_t *d_n_rows, int64_t grid_rows, int32_t *d_overflow, int r, int16_t *d_dsc, int8_t *d_dsc8, double *d_norm) {
+                        const int32_t *d_n_rows, int64_t grid_rows, int32_t *d_overflow, int r, int16_t *d_dsc, int8_t *d_dsc8, double *d_norm,
+                        int dsc_size) {
     const int64_t cap_rows = grid_rows;
+    if (dsc_size != 64 && (2 * r != 16 || (dsc_size != 27 && dsc_size != 8 && dsc_size != 1)))
+        return mad_fail(ctx, MAD_EINVAL, "mad_describe: dsc_size %d (27, 8 and 1 are built for the default dsc_radius 16 only; 64 for 4 ... 16)", dsc_size);
     if (!ctx->eq_set[1]) return mad_fail(ctx, MAD_EINVAL, "mad_describe: descriptor EQSP table not set");
     if (ctx->eq_host[1].Z != 16) return mad_fail(ctx, MAD_EINVAL, "mad_describe: kernel is built for 16 descriptor zones");
     if (r < 2 || r > 8 || (r % 2)) return mad_fail(ctx, MAD_EINVAL, "mad_describe: dsc radius %d must be 2, 4, 6 or 8", r);
@@ -711,10 +783,13 @@ int mad_describe_device(mad_ctx *ctx, FieldDev f0, FieldDev f1, const int32_t *d
     mad_timer_begin(ctx, MAD_T_DESCRIBE);
     // enough workgroups to fill the chip a few times over, never more than one per possible row
     const unsigned nblk = (unsigned)(((cap_rows + 7) / 8) * 8 + 8);      // one workgroup per possible row
-    switch (2 * r) {
+    switch (dsc_size == 64 ? 2 * r : -dsc_size) {
         case 4: hipLaunchKernelGGL(k_describe<4>, dim3(nblk), dim3(DSC_THREADS), 0, ctx->stream, A); break;
         case 8: hipLaunchKernelGGL(k_describe<8>, dim3(nblk), dim3(DSC_THREADS), 0, ctx->stream, A); break;
         case 12: hipLaunchKernelGGL(k_describe<12>, dim3(nblk), dim3(DSC_THREADS), 0, ctx->stream, A); break;
+        case -27: hipLaunchKernelGGL((k_describe<16, 27>), dim3(nblk), dim3(DSC_THREADS), 0, ctx->stream, A); break;
+        case -8: hipLaunchKernelGGL((k_describe<16, 8>), dim3(nblk), dim3(DSC_THREADS), 0, ctx->stream, A); break;
+        case -1: hipLaunchKernelGGL((k_describe<16, 1>), dim3(nblk), dim3(DSC_THREADS), 0, ctx->stream, A); break;
         default: hipLaunchKernelGGL(k_describe<16>, dim3(nblk), dim3(DSC_THREADS), 0, ctx->stream, A); break;
     }
     mad_timer_end(ctx, MAD_T_DESCRIBE);
@@ -724,6 +799,11 @@ int mad_describe_device(mad_ctx *ctx, FieldDev f0, FieldDev f1, const int32_t *d
 
 extern "C" int mad_describe(mad_ctx *ctx, int slot, int octave, const int32_t *coords, const double *R, int64_t n_rows,
                             int r, int16_t *dsc) {
+    return mad_describe_sized(ctx, slot, octave, coords, R, n_rows, r, 64, dsc);
+}
+
+extern "C" int mad_describe_sized(mad_ctx *ctx, int slot, int octave, const int32_t *coords, const double *R, int64_t n_rows,
+                                  int r, int dsc_size, int16_t *dsc) {
     if (ctx) mad_use_lane(ctx, 0);
     if (!ctx) return MAD_EINVAL;
     if (slot < 0 || slot >= MAD_MAX_FIELDS || !ctx->fields[slot].tex)
@@ -731,7 +811,8 @@ extern "C" int mad_describe(mad_ctx *ctx, int slot, int octave, const int32_t *c
     if (octave != 0 && octave != 1) return mad_fail(ctx, MAD_EINVAL, "mad_describe: octave %d", octave);
     if (n_rows <= 0) return MAD_OK;
     if (!coords || !R || !dsc) return mad_fail(ctx, MAD_EINVAL, "mad_describe: NULL argument");
-    const int D = 64 * ctx->eq_host[1].Z;
+    if (dsc_size != 64 && dsc_size != 27 && dsc_size != 8 && dsc_size != 1) return mad_fail(ctx, MAD_EINVAL, "mad_describe: invalid dsc size %d", dsc_size);
+    const int D = dsc_size * ctx->eq_host[1].Z;
     MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_ROW_COORDS), (size_t)n_rows * 12));
     MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_ROW_R), (size_t)n_rows * 72));
     MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_DSC), (size_t)n_rows * D * 2));
@@ -743,7 +824,7 @@ extern "C" int mad_describe(mad_ctx *ctx, int slot, int octave, const int32_t *c
     const int32_t n32 = (int32_t)n_rows;
     MAD_HIP(hipMemcpyAsync(d_n, &n32, 4, hipMemcpyHostToDevice, ctx->stream));
     MAD_TRY(mad_describe_device(ctx, f, f, scratch<int32_t>(ctx, S_ROW_COORDS), nullptr, octave, nullptr,
-                                scratch<double>(ctx, S_ROW_R), nullptr, d_n, n_rows, d_n + 1, r, scratch<int16_t>(ctx, S_DSC)));
+                                scratch<double>(ctx, S_ROW_R), nullptr, d_n, n_rows, d_n + 1, r, scratch<int16_t>(ctx, S_DSC), nullptr, nullptr, dsc_size));
     MAD_HIP(hipMemcpyAsync(dsc, mad_sb(ctx, S_DSC).p, (size_t)n_rows * D * 2, hipMemcpyDeviceToHost, ctx->stream));
     MAD_HIP(hipStreamSynchronize(ctx->stream));
     return MAD_OK;

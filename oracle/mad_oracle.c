@@ -281,6 +281,152 @@ int orc_orient(const float *gx, const float *gy, const float *gz, int nx, int ny
     return rows > cap ? -1 : 0;
 }
 
+/* ---- the same with Orientator(gw_sig != 0): a Gaussian window on the orientation histogram (Orientator.py:49-54).  The zone
+ * counts are then float64 sums of the weights of the voxels in each zone: df.weight_mask[area_mask] selects them in C order
+ * (all voxels of the box, weight 0 included) and np.sum adds them pairwise (first element + numpy's blocked pairwise sum of the
+ * rest), which orc_np_sum restates. ---- */
+static double orc_pairwise(const double *a, int n) {
+    if (n < 8) { double res = 0.0; for (int i = 0; i < n; i++) res += a[i]; return res; }
+    if (n <= 128) {
+        double r[8];
+        int i;
+        for (int j = 0; j < 8; j++) r[j] = a[j];
+        for (i = 8; i < n - (n % 8); i += 8) for (int j = 0; j < 8; j++) r[j] += a[i + j];
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; i++) res += a[i];
+        return res;
+    }
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    return orc_pairwise(a, n2) + orc_pairwise(a + n2, n - n2);
+}
+static double orc_np_sum(const double *a, int n) { return n <= 0 ? 0.0 : a[0] + orc_pairwise(a + 1, n - 1); }
+
+static void orc_list_zones(double th, double sth, double ph, const double *bounds, int Z, double w, double *lists, int *ln, int stride) {
+    for (int a = 0; a < Z; a++) {
+        const double *b = bounds + 4 * a;
+        int thm = (th < b[2]) && (th > b[0]);
+        int sthm = (sth < b[2]) && (sth > b[0]);
+        int phm = (ph < b[3]) && (ph > b[1]);
+        if ((thm || sthm) && phm) lists[(size_t)a * stride + ln[a]++] = w;
+    }
+}
+
+int orc_orient_gw(const float *gx, const float *gy, const float *gz, int nx, int ny, int nz,
+               int octave, const int32_t *coords, int n, int r, int lim_main, int lim_sec,
+               const double *bounds, const double *centers, int Z,
+               int32_t *row_anchor, int32_t *row_main, int32_t *row_sec, double *row_R,
+               int32_t *row_count, int64_t *n_rows, int64_t cap, int32_t *n_reject, double gw_sig) {
+    const int B = 2 * r + 1, nv = B * B * B;
+    const int stride = (octave == 1) ? 1 : 2;
+    float *box = (float *)malloc(sizeof(float) * 3 * nv);
+    double *w = (double *)malloc(sizeof(double) * nv);
+    double *lists = (double *)malloc(sizeof(double) * (size_t)Z * nv);
+    int ln[ORC_MAX_Z];
+    int64_t rows = 0;
+    int32_t rejects = 0;
+    const float two_pi_f = (float)ORC_TWO_PI;
+    const float cutoff = 1e-5f;
+
+    /* Orientator.py:38-47: sphere mask, weight 1 where |offset| <= 1.05 r */
+    /* :49-54 Gaussian window exp(-d^2 / (2 sigma^2)) times the sphere mask (ones when gw_sig == 0) */
+    double *mask = (double *)malloc(sizeof(double) * nv);
+    for (int i = 0; i < B; i++) for (int j = 0; j < B; j++) for (int k = 0; k < B; k++) {
+        int sq = (i - r) * (i - r) + (j - r) * (j - r) + (k - r) * (k - r);
+        double gwt = gw_sig != 0.0 ? exp(-1.0 * ((double)sq / (2.0 * (gw_sig * gw_sig)))) : 1.0;
+        mask[(i * B + j) * B + k] = (sqrt((double)sq) <= r * 1.05) ? gwt : 0.0;
+    }
+
+    for (int a = 0; a < n; a++) {
+        int x = coords[3 * a], y = coords[3 * a + 1], z = coords[3 * a + 2];
+        /* step01, Orientator.py:128-135 / 149-155 */
+        int xm = x - r * stride, ym = y - r * stride, zm = z - r * stride;
+        int xp = x + r * stride + 1, yp = y + r * stride + 1, zp = z + r * stride + 1;
+        if (xm < 0 || ym < 0 || zm < 0 || xp > nx - 1 || yp > ny - 1 || zp > nz - 1) { rejects++; continue; }
+        for (int i = 0; i < B; i++) for (int j = 0; j < B; j++) for (int k = 0; k < B; k++) {
+            size_t src = ((size_t)(xm + i * stride) * ny + (size_t)(ym + j * stride)) * nz + (size_t)(zm + k * stride);
+            int v = (i * B + j) * B + k;
+            float fx = gx[src], fy = gy[src], fz = gz[src];
+            /* Orientator.py:139: float32 sqrt(sum(square)) */
+            volatile float sx = fx * fx, sy = fy * fy, sz = fz * fz;
+            volatile float s1 = sx + sy;
+            volatile float s2 = s1 + sz;
+            float magn = sqrtf(s2);
+            if (magn > cutoff) { fx = fx / magn; fy = fy / magn; fz = fz / magn; } /* :142-143 */
+            box[3 * v] = fx; box[3 * v + 1] = fy; box[3 * v + 2] = fz;
+            w[v] = (magn < cutoff) ? 0.0 : mask[v];                                  /* :146-147 */
+        }
+        /* step02: process_df_gradient on the float32 box, Orientator.py:305-340 */
+        int32_t cnt[ORC_MAX_Z], q[ORC_MAX_Z];
+        memset(ln, 0, sizeof(ln));
+        for (int v = 0; v < nv; v++) {
+            float th = (float)atan2((double)box[3 * v + 1], (double)box[3 * v]);
+            if (th < 0.0f) th = th + two_pi_f;
+            float sth = th + two_pi_f;
+            float ph = (float)acos(orc_clamp1((double)box[3 * v + 2]));
+            orc_list_zones((double)th, (double)sth, (double)ph, bounds, Z, w[v], lists, ln, nv);
+        }
+        /* :334 df.ar_count is an int32 array (DensityFeature.py:50): the float64 sum is truncated when it is stored */
+        for (int zz = 0; zz < Z; zz++) cnt[zz] = (int32_t)orc_np_sum(lists + (size_t)zz * nv, ln[zz]);
+        if (!orc_quantise(cnt, Z, q)) continue;   /* no bins > 0.8*0 -> no rows */
+        /* Orientator.py:181-184 */
+        int mains[ORC_MAX_Z], nmain = 0;
+        for (int i = 0; i < Z; i++) if ((double)q[i] > 50 * 0.8) mains[nmain++] = i;
+        if (nmain > lim_main) continue;
+
+        for (int mi = 0; mi < nmain; mi++) {
+            int mb = mains[mi];
+            double dom[9];
+            int32_t q1[ORC_MAX_Z];
+            orc_to_dom_mat(centers, mb, dom);
+            if (mb != 0) {
+                /* step03: rotate the float32 box by dom (-> float64) and re-bin, :204-206, :303 */
+                int32_t c1[ORC_MAX_Z];
+                memset(ln, 0, sizeof(ln));
+                for (int v = 0; v < nv; v++) {
+                    double g0 = box[3 * v], g1 = box[3 * v + 1], g2 = box[3 * v + 2];
+                    double rx = g0 * dom[0] + g1 * dom[1] + g2 * dom[2];
+                    double ry = g0 * dom[3] + g1 * dom[4] + g2 * dom[5];
+                    double rz = g0 * dom[6] + g1 * dom[7] + g2 * dom[8];
+                    double th = atan2(ry, rx);
+                    if (th < 0) th += ORC_TWO_PI;
+                    double sth = th + ORC_TWO_PI;
+                    double ph = acos(orc_clamp1(rz));
+                    orc_list_zones(th, sth, ph, bounds, Z, w[v], lists, ln, nv);
+                }
+                for (int zz = 0; zz < Z; zz++) c1[zz] = (int32_t)orc_np_sum(lists + (size_t)zz * nv, ln[zz]);
+                if (!orc_quantise(c1, Z, q1)) memcpy(q1, c1, sizeof(int32_t) * Z);
+            } else {
+                memcpy(q1, q, sizeof(int32_t) * Z);   /* :211 no re-binning for the pole */
+            }
+            /* step04, Orientator.py:228-239 */
+            int32_t mx = 0;
+            for (int i = 1; i < Z - 1; i++) if (q1[i] > mx) mx = q1[i];
+            if (mx == 0) continue;
+            int secs[ORC_MAX_Z], nsec = 0;
+            for (int i = 1; i < Z - 1; i++) {
+                int32_t q2 = (int32_t)((double)q1[i] / (double)mx * 50.0);
+                if ((double)q2 > 50 * 0.8) secs[nsec++] = i;
+            }
+            if (nsec > lim_sec) continue;
+            for (int si = 0; si < nsec; si++) {
+                if (rows < cap) {
+                    double adj[9];
+                    orc_adj_sec_mat(bounds, centers, Z, secs[si], adj);
+                    row_anchor[rows] = a; row_main[rows] = mb; row_sec[rows] = secs[si];
+                    orc_mat3_mul(adj, dom, row_R + 9 * rows);                  /* :105 */
+                    if (row_count) memcpy(row_count + (size_t)Z * rows, q1, sizeof(int32_t) * Z);
+                }
+                rows++;
+            }
+        }
+    }
+    free(box); free(w); free(mask); free(lists);
+    *n_rows = rows;
+    if (n_reject) *n_reject = rejects;
+    return rows > cap ? -1 : 0;
+}
+
 /* ------------------------------------------------------------------ */
 /* a9-a10: descriptor generation                                       */
 /* ------------------------------------------------------------------ */
@@ -291,11 +437,40 @@ int orc_orient(const float *gx, const float *gy, const float *gz, int nx, int ny
  * R = Rfinal.  dsc[n][64*Z] int16, sub-cube id j*16+i*4+k (Descriptor.py:44-64),
  * zone fastest.  S = 2r samples per axis (16).
  */
+/* Descriptor.py:44-93: which of the dsc_size sub-regions holds lattice point (i, j, k) (indices along axes 0, 1, 2 of the
+ * S^3 sample cube), in the order of the reference's sub_slices lists: the third axis runs fastest, then the first, then the
+ * second (64 and 27); the 8-region list has its own order; 1 = the whole cube. */
+static int orc_sub_region(int i, int j, int k, int S, int dsc_size) {
+    if (dsc_size == 64) { const int q = S / 4; return (j / q) * 16 + (i / q) * 4 + (k / q); }
+    if (dsc_size == 27) {
+        const int a = S / 3, b = 2 * S / 3;      /* fl//3, 2*fl//3 with fl = 2*dr = S */
+        const int bi = i < a ? 0 : (i < b ? 1 : 2), bj = j < a ? 0 : (j < b ? 1 : 2), bk = k < a ? 0 : (k < b ? 1 : 2);
+        return bj * 9 + bi * 3 + bk;
+    }
+    if (dsc_size == 8) {
+        const int h = S / 2;
+        const int bi = i < h ? 0 : 1, bj = j < h ? 0 : 1, bk = k < h ? 0 : 1;
+        return bi * 4 + bj * 2 + (1 - bk);      /* (s1,s1,s2), (s1,s1,s1), (s1,s2,s2), (s1,s2,s1), (s2,...) */
+    }
+    return 0;
+}
+
+int orc_describe_sized(const float *gx, const float *gy, const float *gz, int nx, int ny, int nz,
+                       int octave, const int32_t *coords, const double *R, int64_t n, int r,
+                       const double *bounds, int Z, int dsc_size, int16_t *dsc);
+
 int orc_describe(const float *gx, const float *gy, const float *gz, int nx, int ny, int nz,
                  int octave, const int32_t *coords, const double *R, int64_t n, int r,
                  const double *bounds, int Z, int16_t *dsc) {
-    const int S = 2 * r, q4 = S / 4;
-    const int D = 64 * Z;
+    return orc_describe_sized(gx, gy, gz, nx, ny, nz, octave, coords, R, n, r, bounds, Z, 64, dsc);
+}
+
+int orc_describe_sized(const float *gx, const float *gy, const float *gz, int nx, int ny, int nz,
+                       int octave, const int32_t *coords, const double *R, int64_t n, int r,
+                       const double *bounds, int Z, int dsc_size, int16_t *dsc) {
+    const int S = 2 * r;
+    const int D = dsc_size * Z;
+    if (dsc_size != 64 && dsc_size != 27 && dsc_size != 8 && dsc_size != 1) return -2;
     const float cut_norm = 1e-12f, cut_zero = 1e-5f;
     int *zone = (int *)malloc(sizeof(int) * S * S * S);
     for (int64_t row = 0; row < n; row++) {
@@ -350,7 +525,7 @@ int orc_describe(const float *gx, const float *gy, const float *gz, int nx, int 
         for (int i = 0; i < S; i++) for (int j = 0; j < S; j++) for (int k = 0; k < S; k++) {
             int zn = zone[(i * S + j) * S + k];
             if (zn < 0) continue;
-            int sub = (j / q4) * 16 + (i / q4) * 4 + (k / q4);
+            int sub = orc_sub_region(i, j, k, S, dsc_size);
             out[sub * Z + zn]++;
         }
     }

@@ -111,7 +111,7 @@ def matrix_tables(bounds, centers):
     return _tables[key]
 
 
-def orient(gx, gy, gz, octave, coords, bounds, centers, r=8, lim_main=6, lim_sec=6, want_counts=True):
+def orient(gx, gy, gz, octave, coords, bounds, centers, r=8, lim_main=6, lim_sec=6, want_counts=True, gw_sig=0.0):
     gx, gy, gz = _c(gx, np.float32), _c(gy, np.float32), _c(gz, np.float32)
     coords = _c(coords, np.int32).reshape(-1, 3)
     bounds, centers = _c(bounds, np.float64), _c(centers, np.float64)
@@ -126,27 +126,28 @@ def orient(gx, gy, gz, octave, coords, bounds, centers, r=8, lim_main=6, lim_sec
     nx, ny, nz = gx.shape
     dom, adj = matrix_tables(bounds, centers)
     lib().orc_set_matrix_tables(_opt(dom), _opt(adj), C.c_int(Z))
-    rc = lib().orc_orient(_opt(gx), _opt(gy), _opt(gz), C.c_int(nx), C.c_int(ny), C.c_int(nz), C.c_int(octave),
-                          _opt(coords), C.c_int(n), C.c_int(r), C.c_int(lim_main), C.c_int(lim_sec),
-                          _opt(bounds), _opt(centers), C.c_int(Z),
-                          _opt(ra), _opt(rm), _opt(rs), _opt(R), _opt(cnt), C.byref(nrows), C.c_int64(cap), C.byref(nrej))
+    args = (_opt(gx), _opt(gy), _opt(gz), C.c_int(nx), C.c_int(ny), C.c_int(nz), C.c_int(octave),
+            _opt(coords), C.c_int(n), C.c_int(r), C.c_int(lim_main), C.c_int(lim_sec),
+            _opt(bounds), _opt(centers), C.c_int(Z),
+            _opt(ra), _opt(rm), _opt(rs), _opt(R), _opt(cnt), C.byref(nrows), C.c_int64(cap), C.byref(nrej))
+    rc = lib().orc_orient_gw(*args, C.c_double(gw_sig)) if gw_sig else lib().orc_orient(*args)
     assert rc == 0
     k = nrows.value
     return dict(anchor=ra[:k].copy(), main=rm[:k].copy(), sec=rs[:k].copy(), R=R[:k].reshape(k, 3, 3).copy(),
                 counts=None if cnt is None else cnt[:k].copy(), n_reject=nrej.value)
 
 
-def describe(gx, gy, gz, octave, coords, R, bounds, r=8):
+def describe(gx, gy, gz, octave, coords, R, bounds, r=8, dsc_size=64):
     gx, gy, gz = _c(gx, np.float32), _c(gy, np.float32), _c(gz, np.float32)
     coords = _c(coords, np.int32).reshape(-1, 3)
     R = _c(R, np.float64).reshape(-1, 9)
     bounds = _c(bounds, np.float64)
     Z = len(bounds)
     n = len(coords)
-    out = np.zeros((n, 64 * Z), np.int16)
+    out = np.zeros((n, dsc_size * Z), np.int16)
     nx, ny, nz = gx.shape
-    rc = lib().orc_describe(_opt(gx), _opt(gy), _opt(gz), C.c_int(nx), C.c_int(ny), C.c_int(nz), C.c_int(octave),
-                            _opt(coords), _opt(R), C.c_int64(n), C.c_int(r), _opt(bounds), C.c_int(Z), _opt(out))
+    rc = lib().orc_describe_sized(_opt(gx), _opt(gy), _opt(gz), C.c_int(nx), C.c_int(ny), C.c_int(nz), C.c_int(octave),
+                                  _opt(coords), _opt(R), C.c_int64(n), C.c_int(r), _opt(bounds), C.c_int(Z), C.c_int(dsc_size), _opt(out))
     assert rc == 0
     return out
 

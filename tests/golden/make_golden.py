@@ -16,7 +16,7 @@ Fixtures hold inputs and the reference's outputs only (numpy arrays).  Everythin
 seeded; re-running this script reproduces the files bit for bit on the same numpy /
 scipy build.
 
-Usage:  cd /root/repo && python tests/golden/make_golden.py [--only-g9 | --only-g10 | --only-g11 | --only-g12 | --only-g13 | --only-g14 | --only-g15 | --only-g16]
+Usage:  cd /root/repo && python tests/golden/make_golden.py [--only-g9 | --only-g10 | --only-g11 | --only-g12 | --only-g13 | --only-g14 | --only-g15 | --only-g16 | --only-g17]
 """
 import hashlib
 import os
@@ -408,6 +408,54 @@ def make_g16(R, synth):
     np.savez_compressed(os.path.join(OUT, "g16_localize.npz"), **g16)
 
 
+def make_g17(R, synth):
+    """G17: the stage options MaD.run never selects but the constructors take: Orientator(gw_sig=...) -- a
+    Gaussian window on the orientation histogram, Orientator.py:49-54 -- and Descriptor(dsc_size=27 | 8 | 1) -- other partitions
+    of the sample cube, Descriptor.py:66-93 -- by the reference, on a smooth field, both octaves."""
+    from scipy.interpolate import RegularGridInterpolator as RGI
+    g17 = {}
+    for octave, shape, seed, margin in ((1, (44, 46, 48), 171, 10), (0, (62, 60, 64), 172, 18)):
+        vol = synth.blob_volume(shape, 50, seed, sigma=(1.5, 3.5), hollow=0.2)
+        grad = synth.gradient_field(vol).astype(np.float32)      # (X, Y, Z, 3)
+        lists = [grad, grad] if octave == 1 else [grad, grad]
+        ms = types.SimpleNamespace(grad_list=lists, rgi_space=[RGI(points=[np.arange(s_) for s_ in shape], values=grad, method="nearest")] * 2)
+        coords = synth.interior_anchors(shape, 26, margin, seed + 1)
+        tag = "o%d_" % octave
+        g17[tag + "field"] = np.ascontiguousarray(np.moveaxis(grad, -1, 0))
+        g17[tag + "coords"] = coords
+
+        def fresh(extra=None):
+            out = []
+            for i, c in enumerate(coords):
+                df = R.DF.DensityFeature()
+                df.set_detector_info(i, octave, [int(c[0]), int(c[1]), int(c[2])], np.zeros(3), np.zeros(3), 1.0)
+                if extra is not None:
+                    df.Rfinal = extra[i].copy()
+                out.append(df)
+            return out
+
+        for gw in (2.0, 4.5):
+            ori = R.Ori.Orientator(gw_sig=gw)
+            ori.step1_reject = 0
+            rows = ori.assign_orientations(ms, fresh())
+            k = tag + "gw%g_" % gw
+            g17[k + "anchor"] = np.array([r.index for r in rows], np.int32)
+            g17[k + "main"] = np.array([r.main_bin for r in rows], np.int32)
+            g17[k + "sec"] = np.array([r.sec_bin for r in rows], np.int32)
+            g17[k + "count"] = np.array([r.ar_count for r in rows], np.int32)
+            g17[k + "R"] = np.array([r.Rfinal for r in rows])
+            print("g17 octave", octave, "gw_sig", gw, "rows", len(rows))
+        rr = np.random.default_rng(seed + 2)
+        Rm = np.stack([np.identity(3)] * 4 + [synth.random_rotation(rr) for _ in range(len(coords) - 4)])
+        g17[tag + "dsc_R"] = Rm
+        for size in (27, 8, 1):
+            dd = fresh(Rm)
+            R.Dsc.Descriptor(dsc_size=size).generate_descriptors(ms, dd)
+            g17[tag + "dsc%d" % size] = np.array([d.lin_ar_subeqsp for d in dd], np.int16)
+            print("g17 octave", octave, "dsc_size", size, "row length", g17[tag + "dsc%d" % size].shape[1], "sum", int(g17[tag + "dsc%d" % size].sum()))
+    np.savez_compressed(os.path.join(OUT, "g17_options.npz"), **g17)
+
+
 def main():
     from scipy.interpolate import RegularGridInterpolator as RGI
     R = import_reference()
@@ -438,6 +486,9 @@ def main():
         return
     if "--only-g16" in sys.argv:
         make_g16(R, synth)
+        return
+    if "--only-g17" in sys.argv:
+        make_g17(R, synth)
         return
 
     # ---- G1: EQSP tables -----------------------------------------------------------

@@ -258,3 +258,57 @@ def test_g11_pose_count_at_the_distance_threshold(lib):
                               g["hi_cloud"], g["lo_cloud"], dist=4.0)
     np.testing.assert_array_equal(cnt, want_cnt)
     np.testing.assert_allclose(res, ref, rtol=0, atol=1e-12)
+
+
+def test_stage_options_of_the_constructors(default_lib):
+    """Orientator(gw_sig=...), Orientator(magn_weighted=True) and Descriptor(dsc_size=27 | 8 | 1) through the drop-in classes
+    against the reference's own outputs (g17): rows, bins, quantised 112-zone histograms and descriptors identical; and the
+    shorter descriptor rows go through the correlation kernel while their counts fit its int8 operands (rows padded to its K step)."""
+    from mad_amd.Descriptor import Descriptor
+    from mad_amd.Orientator import Orientator
+    g = load("g17_options.npz")
+    lib = default_lib
+    for octave in (1, 0):
+        field = np.ascontiguousarray(np.moveaxis(g["o%d_field" % octave], 0, -1))
+        ms = types.SimpleNamespace(grad_list=[field, field], oct_mode="both", name="g17")
+        slot = lib.new_slot()
+        lib.upload_field(slot, field)
+        ms.device_slots = lambda lib_, s=slot: [s, s]
+        coords = g["o%d_coords" % octave]
+        for gw in (2.0, 4.5):
+            k = "o%d_gw%g_" % (octave, gw)
+            rows = Orientator(gw_sig=gw, magn_weighted=True).assign_orientations(ms, _anchors(coords, octave))
+            np.testing.assert_array_equal([r.index for r in rows], g[k + "anchor"])
+            np.testing.assert_array_equal([r.main_bin for r in rows], g[k + "main"])
+            np.testing.assert_array_equal([r.sec_bin for r in rows], g[k + "sec"])
+            np.testing.assert_array_equal([r.ar_count for r in rows], g[k + "count"])
+            np.testing.assert_allclose([r.Rfinal for r in rows], g[k + "R"], rtol=0, atol=1e-14)
+        plain = Orientator().assign_orientations(ms, _anchors(coords, octave))      # the window is off again afterwards
+        assert len(plain) != len(g["o%d_gw2_anchor" % octave]) or [r.main_bin for r in plain] != list(g["o%d_gw2_main" % octave])
+        for size in (27, 8, 1):
+            drows = []
+            for c, R in zip(coords, g["o%d_dsc_R" % octave]):
+                df = DensityFeature()
+                df.set_detector_info(0, octave, [int(v) for v in c], np.zeros(3), np.zeros(3), 1.0)
+                df.Rfinal = R
+                drows.append(df)
+            Descriptor(dsc_size=size).generate_descriptors(ms, drows)
+            got = np.array([r.lin_ar_subeqsp for r in drows])
+            np.testing.assert_array_equal(got, g["o%d_dsc%d" % (octave, size)])
+            # Correlation of such rows.  The int8 MFMA contraction holds counts up to 127 -- every count of the 64-region layout
+            # MaD.run uses (<= 64 samples per region) -- and refuses larger ones loudly rather than wrapping them.
+            if got.max() > 127:
+                from mad_amd._lib import MadBackendError
+                with pytest.raises(MadBackendError, match="EDOM"):
+                    lib.correlate(got, got, 0.95)
+                continue
+            ph, pl, ps = lib.correlate(got, got, 0.95)      # exact integer dot products over the zero-padded length
+            d = got.astype(np.float64)
+            nrm = np.sqrt((d * d).sum(1))
+            nrm[nrm == 0] = 1.0
+            ref = (d @ d.T) / np.outer(nrm, nrm)
+            wh, wl = np.nonzero(ref > 0.95)
+            np.testing.assert_array_equal(ph, wh)
+            np.testing.assert_array_equal(pl, wl)
+            np.testing.assert_allclose(ps, ref[wh, wl], rtol=1e-12, atol=0)
+        lib.free_field(slot)

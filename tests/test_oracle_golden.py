@@ -172,3 +172,28 @@ def test_g11_pose_count_at_the_distance_threshold():
                             g["hi_cloud"], g["lo_cloud"], dist=4.0)
     np.testing.assert_array_equal(cnt, want_cnt)
     np.testing.assert_allclose(res, ref, rtol=0, atol=1e-12)
+
+
+def test_g17_stage_options_of_the_constructors():
+    """Orientator(gw_sig=...) and Descriptor(dsc_size=27 | 8 | 1) -- options MaD.run never selects (tests/golden/make_golden.py::
+    make_g17): the oracle on the reference's own outputs, both octaves.  With a window the reference stores each zone's float64
+    weight sum into an int32 array, i.e. truncates it (DensityFeature.py:50): rows, bins and quantised histograms identical."""
+    from mad_amd.eqsp import EQSP_Sphere
+    from oracle import oracle as O
+    g = load("g17_options.npz")
+    e112, e16 = EQSP_Sphere(112), EQSP_Sphere(16)
+    for octave in (1, 0):
+        f, coords = g["o%d_field" % octave], g["o%d_coords" % octave]
+        for gw in (2.0, 4.5):
+            k = "o%d_gw%g_" % (octave, gw)
+            rows = O.orient(f[0], f[1], f[2], octave, coords, e112.sphere_eqsp, e112.p_centers_eqsp, gw_sig=gw)
+            assert len(g[k + "anchor"]) > 60
+            np.testing.assert_array_equal(rows["anchor"], g[k + "anchor"])
+            np.testing.assert_array_equal(rows["main"], g[k + "main"])
+            np.testing.assert_array_equal(rows["sec"], g[k + "sec"])
+            np.testing.assert_array_equal(rows["counts"], g[k + "count"])
+            np.testing.assert_allclose(rows["R"], g[k + "R"], rtol=0, atol=1e-14)
+        for size in (27, 8, 1):
+            want = g["o%d_dsc%d" % (octave, size)]
+            assert want.shape[1] == size * 16 and want.sum() > 30000
+            np.testing.assert_array_equal(O.describe(f[0], f[1], f[2], octave, coords, g["o%d_dsc_R" % octave], e16.sphere_eqsp, dsc_size=size), want)
