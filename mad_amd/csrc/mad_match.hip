@@ -588,6 +588,7 @@ __global__ __launch_bounds__(256) void k_pose_prep(const int32_t *__restrict__ p
 }
 
 #define POSE_LDS_THREADS 1024
+#define POSE_PARTS 4                        // waves that share one listed pair of a pruned search
 #define POSE_RING 256                       // survivor queue of a wave (entries), a power of two >= 2 x 64
 #define POSE_WAVE_LDS (POSE_RING * 2 + 256) // bytes per wave: the queue + two pair records of 128 bytes
 
@@ -616,8 +617,11 @@ __global__ __launch_bounds__(POSE_LDS_THREADS) void k_pose_lds(const int32_t *__
     unsigned char *wave_lds = (unsigned char *)cs + pad16((size_t)(G.ncell + 1) * 2) + (threadIdx.x >> 6) * POSE_WAVE_LDS;
     unsigned short *ring = (unsigned short *)wave_lds;                               // this wave's survivor queue
     double *recs = (double *)(wave_lds + POSE_RING * 2);                             // this wave's two pair records, 16 doubles each
-    // sel != nullptr: only the pairs listed there (status[ST_NSEL] of them; the others keep the lower bound k_pose_bounds left in counts)
-    const int64_t n_pairs = sel ? (int64_t)status[ST_NSEL] : min((int64_t)status[ST_NPAIRS], cap_pairs);
+    // sel != nullptr: only the pairs listed there (status[ST_NSEL] of them; the others keep the lower bound k_pose_bounds left in
+    // counts).  The listed pairs are few (hundreds) and heavy (good poses: most hi points reach the exact search), so each is cut
+    // into POSE_PARTS runs of hi points, one wave each, whose counts add up atomically in counts[pair] (zeroed by k_prune_select).
+    const int parts = sel ? POSE_PARTS : 1;
+    const int64_t n_pairs = sel ? (int64_t)status[ST_NSEL] * parts : min((int64_t)status[ST_NPAIRS], cap_pairs);      // work items
     const int l_hi = status[ST_LHI];
     const int l_lo = cell_start[G.ncell];
     stage_lds(lp, lo_sorted, (size_t)l_lo * 24);
@@ -631,8 +635,13 @@ __global__ __launch_bounds__(POSE_LDS_THREADS) void k_pose_lds(const int32_t *__
     const int64_t wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (POSE_LDS_THREADS / MAD_WAVE) + (threadIdx.x >> 6)));
     const int64_t nwaves = (int64_t)gridDim.x * (POSE_LDS_THREADS / MAD_WAVE);
     PosePair cur;
-    if (wave < n_pairs) cur = rec[sel ? sel[wave] : wave];
+    if (wave < n_pairs) cur = rec[sel ? sel[wave / parts] : wave];
     const float mnx = (float)G.mn[0], mny = (float)G.mn[1], mnz = (float)G.mn[2];
+    const int part_len = (l_hi + parts - 1) / parts;
+    auto emit = [&](int64_t p, int c) {      // a pair's (partial) count
+        if (sel) atomicAdd(&counts[p], c);
+        else counts[p] = c;
+    };
 
     // the exact search for queue entry e = slot << 15 | hi point
     auto exact = [&](int e) -> bool {
@@ -691,23 +700,24 @@ __global__ __launch_bounds__(POSE_LDS_THREADS) void k_pose_lds(const int32_t *__
         count -= n_take;
         if (old_left > 0) {
             old_left = max(old_left - n_take, 0);
-            if (old_left == 0 && lane == 0) counts[p_old] = cnt_old;      // the previous pair is complete
+            if (old_left == 0 && lane == 0) emit(p_old, cnt_old);      // the previous pair is complete
         }
     };
     for (int64_t it = wave; it < n_pairs; it += nwaves) {
-        const int64_t p = sel ? sel[it] : it;
+        const int64_t p = sel ? sel[it / parts] : it;
+        const int a_begin = sel ? (int)(it % parts) * part_len : 0, a_end = sel ? min(a_begin + part_len, l_hi) : l_hi;      // this item's hi points
         PosePair nxt;      // requested now, needed one iteration later
-        if (it + nwaves < n_pairs) nxt = rec[sel ? sel[it + nwaves] : it + nwaves];
+        if (it + nwaves < n_pairs) nxt = rec[sel ? sel[(it + nwaves) / parts] : it + nwaves];
         const PoseVox V = cur.vf;
         if (lane == 0) {      // this pair's transform for the exact search (the slot's previous user is complete by now)
             double *P = recs + 16 * slot;
             for (int i = 0; i < 9; i++) P[i] = cur.R[i];
             for (int i = 0; i < 3; i++) { P[9 + i] = cur.ph[i]; P[12 + i] = cur.pl[i]; }
         }
-        for (int a0 = 0; a0 < l_hi; a0 += MAD_WAVE * POSE_BATCH) {
+        for (int a0 = a_begin; a0 < a_end; a0 += MAD_WAVE * POSE_BATCH) {
             uint2 word[POSE_BATCH];
             int bit[POSE_BATCH];
-            if (a0 + MAD_WAVE * POSE_BATCH <= l_hi) {      // wave-uniform: a full batch, in straight-line code -- the four LDS reads and transforms overlap
+            if (a0 + MAD_WAVE * POSE_BATCH <= a_end) {      // wave-uniform: a full batch, in straight-line code -- the four LDS reads and transforms overlap
                 unsigned idx[POSE_BATCH];
                 bool in[POSE_BATCH];
 #pragma unroll
@@ -731,7 +741,7 @@ __global__ __launch_bounds__(POSE_LDS_THREADS) void k_pose_lds(const int32_t *__
                 for (int u = 0; u < POSE_BATCH; u++) {      // the bitmap words of 4 x 64 points are requested before any is looked at
                     const int a = a0 + u * MAD_WAVE + lane;
                     word[u] = make_uint2(0u, 0u); bit[u] = 0;
-                    if (a < l_hi) {
+                    if (a < a_end) {
                         const float4 c = clf[a];
                         pose_vox_fetch(V, c.x, c.y, c.z, B, bits, &word[u], &bit[u]);
                     }
@@ -739,7 +749,7 @@ __global__ __launch_bounds__(POSE_LDS_THREADS) void k_pose_lds(const int32_t *__
             }
 #pragma unroll
             for (int u = 0; u < POSE_BATCH; u++) {
-                if (a0 + u * MAD_WAVE >= l_hi) break;      // wave-uniform
+                if (a0 + u * MAD_WAVE >= a_end) break;      // wave-uniform
                 const bool certain = (word[u].y >> bit[u]) & 1u;      // inner plane: a lo point within dist for certain
                 cnt_cur += __popcll(__ballot(certain));
                 const bool sv = ((word[u].x >> bit[u]) & 1u) && !certain;
@@ -754,7 +764,7 @@ __global__ __launch_bounds__(POSE_LDS_THREADS) void k_pose_lds(const int32_t *__
         if (old_left > 0) round(count);      // rare: too few survivors to reach the previous pair's leftovers; take everything
         // this pair becomes the previous one; what it left in the queue waits for company
         p_old = p; cnt_old = cnt_cur; cnt_cur = 0; old_left = count;
-        if (old_left == 0 && lane == 0) counts[p] = cnt_old;
+        if (old_left == 0 && lane == 0) emit(p, cnt_old);
         slot ^= 1;
         cur = nxt;
     }
@@ -1017,7 +1027,7 @@ __global__ __launch_bounds__(PB_THREADS) void k_pose_bounds(const int32_t *__res
 // reaches it, in no particular order.  Every workgroup derives T for itself, as k_tie_chunks does.
 __global__ __launch_bounds__(256) void k_prune_select(const int32_t *__restrict__ status_in, int64_t cap_pairs, const int32_t *__restrict__ hist,
                                                       int nbins, int64_t k, const unsigned short *__restrict__ upper, int32_t *__restrict__ sel,
-                                                      int32_t *__restrict__ n_sel, int32_t *__restrict__ thr_out) {
+                                                      int32_t *__restrict__ n_sel, int32_t *__restrict__ thr_out, int32_t *__restrict__ zero_counts) {
     __shared__ int wt[5];
     __shared__ int sh[3];
     __shared__ int s_base;
@@ -1034,7 +1044,7 @@ __global__ __launch_bounds__(256) void k_prune_select(const int32_t *__restrict_
         const int pos = block_excl_scan(take ? 1 : 0, wt, &tot);      // one returning atomic per workgroup: 2 000 of them on one word cost 20 us
         if (threadIdx.x == 0) s_base = tot ? atomicAdd(n_sel, tot) : 0;
         __syncthreads();
-        if (take) sel[s_base + pos] = (int32_t)i;
+        if (take) { sel[s_base + pos] = (int32_t)i; if (zero_counts) zero_counts[i] = 0; }
         __syncthreads();
     }
 }
@@ -1291,6 +1301,19 @@ __global__ __launch_bounds__(1024) void k_topk_selected(const int32_t *__restric
         s[i] = key;
     }
     __syncthreads();
+    if (n <= 1024) {
+        // a short list (the usual case: a few hundred pairs): every key is distinct, so a key's place in the order is the number
+        // of smaller keys -- n comparisons per thread against ~50 barrier-separated passes of the sorting network
+        const int n_out = (int)min((int64_t)n, k);
+        if ((int)threadIdx.x < n) {
+            const unsigned long long mine = s[threadIdx.x];
+            int rank = 0;
+            for (int j = 0; j < n; j++) rank += s[j] < mine ? 1 : 0;
+            if (rank < n_out) order[rank] = (int64_t)(mine & ((1ull << 40) - 1));
+        }
+        if (threadIdx.x == 0) status[ST_NKEYS] = n_out;
+        return;
+    }
     for (int kk = 2; kk <= cap; kk <<= 1)
         for (int j = kk >> 1; j > 0; j >>= 1) {
             for (int i = threadIdx.x; i < cap; i += 1024) {
@@ -1635,7 +1658,8 @@ static int pose_device(mad_ctx *ctx, const Side &hi, const Side &lo, int32_t *d_
             else MAD_PB_LAUNCH(8);
 #undef MAD_PB_LAUNCH
             hipLaunchKernelGGL(k_prune_select, dim3(ctx->n_cu / 2), dim3(256), 0, ctx->stream, d_status, cap_pairs, hist2, nbins, prune_k,
-                               scratch<unsigned short>(ctx, S_TMP_C), scratch<int32_t>(ctx, S_TMP_D), d_status + ST_NSEL, hist2 + nbins);
+                               scratch<unsigned short>(ctx, S_TMP_C), scratch<int32_t>(ctx, S_TMP_D), d_status + ST_NSEL, hist2 + nbins,
+                               fits64 ? scratch<int32_t>(ctx, S_COUNTS) : (int32_t *)nullptr);      // k_pose_lds adds up partial counts
             d_sel = scratch<int32_t>(ctx, S_TMP_D);
             if (pruned) *pruned = true;
         }
@@ -1644,7 +1668,7 @@ static int pose_device(mad_ctx *ctx, const Side &hi, const Side &lo, int32_t *d_
         // selection than expected is still searched completely, the kernels are persistent.
         unsigned wgs_sel = (unsigned)ctx->n_cu;
         if (d_sel && ctx->lane_sel_hint[ctx->lane] > 0)
-            wgs_sel = (unsigned)std::min<int64_t>(ctx->n_cu, std::max<int64_t>(16, (ctx->lane_sel_hint[ctx->lane] * 5 / 4) / (POSE_LDS_THREADS / MAD_WAVE) + 4));
+            wgs_sel = (unsigned)std::min<int64_t>(ctx->n_cu, std::max<int64_t>(16, (ctx->lane_sel_hint[ctx->lane] * (fits64 ? POSE_PARTS : 1) * 5 / 4) / (POSE_LDS_THREADS / MAD_WAVE) + 4));
         if (fits64)
             hipLaunchKernelGGL(k_pose_lds, dim3(d_sel ? wgs_sel : ctx->n_cu * (lds > 80 * 1024 ? 1 : pose_wgs_per_cu())), dim3(POSE_LDS_THREADS), lds, ctx->stream, d_status, cap_pairs, d_rec,
                                d_hi_cloud, scratch<double>(ctx, S_PG_PTS), scratch<int32_t>(ctx, S_PG_START), d_start16, G,
