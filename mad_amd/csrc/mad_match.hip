@@ -182,7 +182,16 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_corr_gemm(const int8_t *__rest
             }
         }
         // C/D layout of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg
+        // Epilogue.  Per entry: int -> float, one product, one compare (the compare IS the ballot).  Everything else is per ballot
+        // and on the scalar unit: a candidate store only where a ballot is non-zero (23 % of them), and the eight mask words of a
+        // row group cut out of the four ballots with scalar shifts and handed to lanes 0..7 with v_writelane -- the earlier form,
+        // which indexed the ballots by lane, compiled into 224 v_cndmask per tile.  Offsets are 32-bit from a per-tile base.
         const int64_t ldm = lp / 32;
+        int32_t *Ct = C + row0 * lp + col0;                                   // uniform
+        uint32_t *Mt = mask + row0 * ldm + col0 / 32;                         // uniform
+        const unsigned lp32 = (unsigned)lp, ldm32 = (unsigned)ldm;
+        const unsigned voff = mad_u24((unsigned)(wm * 64 + (lane >> 4) * 4), lp32, (unsigned)(wn * 64 + (lane & 15)));      // < 2^24: 128 rows x lp
+        const unsigned moff = mad_u24((unsigned)(wm * 64 + (lane & 3) * 4), ldm32, (unsigned)(wn * 2 + (lane >> 2)));        // lanes 0..7: row group, word
         float tl[4];
 #pragma unroll
         for (int n = 0; n < 4; n++) {      // cc |l| moved towards "candidate" by the margin (|h| > 0, so the product moves with it)
@@ -193,25 +202,26 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_corr_gemm(const int8_t *__rest
         for (int m = 0; m < 4; m++)
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                const int64_t r = row0 + wm * 64 + m * 16 + (lane >> 4) * 4 + j;
                 const float th = sT[wm * 64 + m * 16 + (lane >> 4) * 4 + j];
                 unsigned long long bal[4];
 #pragma unroll
                 for (int n = 0; n < 4; n++) {
-                    const int64_t c = col0 + wn * 64 + n * 16 + (lane & 15);
                     const int d = acc[m][n][j];
                     const bool cand = (float)d > th * tl[n];
-                    if (cand) C[r * lp + c] = d;      // only candidates are ever read back (k_pair_count / k_pair_emit): ~0.4 % of the entries
                     bal[n] = __ballot(cand);
+                    if (bal[n] != 0ull) {      // wave-uniform: only candidates are ever read back (k_pair_count / k_pair_emit), ~0.4 % of the entries
+                        if (cand) Ct[voff + (unsigned)(m * 16 + j) * lp32 + (unsigned)(n * 16)] = d;
+                    }
                 }
-                // bits 16 g .. 16 g + 15 of a ballot = row group g (= lane >> 4), columns n * 16 ..: lanes 0..7 write
-                // the two 32-bit words of the four rows (lane & 3 = row group, lane >> 2 = word)
-                if (lane < 8) {
-                    const int g = lane & 3, h = lane >> 2;
-                    const unsigned lo16 = (unsigned)(bal[2 * h] >> (16 * g)) & 0xffffu, hi16 = (unsigned)(bal[2 * h + 1] >> (16 * g)) & 0xffffu;
-                    const int64_t rr = row0 + wm * 64 + m * 16 + g * 4 + j;
-                    mask[rr * ldm + (col0 + wn * 64) / 32 + h] = lo16 | (hi16 << 16);
-                }
+                // bits 16 g .. 16 g + 15 of a ballot = row group g (= lane >> 4), columns n * 16 ..: word (g, h) = columns 32 h .. 32 h + 31
+                int w = 0;
+#define MAD_MASK_WORD(G, Hh) (((unsigned)(bal[2 * (Hh)] >> (16 * (G))) & 0xffffu) | (((unsigned)(bal[2 * (Hh) + 1] >> (16 * (G))) & 0xffffu) << 16))
+#define MAD_WRITELANE(G, Hh, LANE) asm volatile("v_writelane_b32 %0, %1, " #LANE : "+v"(w) : "s"(MAD_MASK_WORD(G, Hh)))
+                MAD_WRITELANE(0, 0, 0); MAD_WRITELANE(1, 0, 1); MAD_WRITELANE(2, 0, 2); MAD_WRITELANE(3, 0, 3);
+                MAD_WRITELANE(0, 1, 4); MAD_WRITELANE(1, 1, 5); MAD_WRITELANE(2, 1, 6); MAD_WRITELANE(3, 1, 7);
+#undef MAD_WRITELANE
+#undef MAD_MASK_WORD
+                if (lane < 8) Mt[moff + (unsigned)(m * 16 + j) * ldm32] = (unsigned)w;
             }
         __syncthreads();
     }
