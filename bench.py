@@ -162,15 +162,41 @@ def build_inputs(lib, W, rank=0, world=1):
 HOST_T = {}
 
 
+_BATCHES = {}
+
+
 def enqueue_builds(lib, the_map, subs, sets):
     """orient + describe of the map and of every subunit into `sets` (device-resident, rebuilt in place); asynchronous.
-    sets[0] is the map's DeviceSet, or a dist.ShardedSetBuild when the map's rows are built in shares over the ranks."""
+    sets[0] is the map's DeviceSet, or a dist.ShardedSetBuild when the map's rows are built in shares over the ranks.
+    All structures of the step go out in ONE batch (one launch per stage, `mad_set_build_many`); MAD_BUILD_PER_SET=1 builds
+    them one `mad_set_build` each, as round 1 did (for comparison)."""
     t0 = time.perf_counter()
-    if hasattr(sets[0], "enqueue"):
-        lo = sets[0].enqueue()
+    shared = hasattr(sets[0], "enqueue")
+    if os.environ.get("MAD_BUILD_PER_SET", "0") == "1":
+        if shared:
+            lo = sets[0].enqueue()
+        else:
+            lo = lib.set_build(the_map.slots, the_map.coords, the_map.octave, the_map.subv, the_map.index, into=sets[0])
+        his = [lib.set_build(s.slots, s.coords, s.octave, s.subv, s.index, into=d) for s, d in zip(subs, sets[1:])]
     else:
-        lo = lib.set_build(the_map.slots, the_map.coords, the_map.octave, the_map.subv, the_map.index, into=sets[0])
-    his = [lib.set_build(s.slots, s.coords, s.octave, s.subv, s.index, into=d) for s, d in zip(subs, sets[1:])]
+        ent = _BATCHES.get(id(sets))
+        if ent is None or ent[1] is not sets:
+            first = sets[0].build_job() if shared else (the_map.slots, the_map.coords, the_map.octave, the_map.subv, the_map.index, sets[0])
+            jobs = [first] + [(s.slots, s.coords, s.octave, s.subv, s.index, d) for s, d in zip(subs, sets[1:])]
+            # MAD_BUILD_GROUPS batches, each on the lane of its first set (they overlap); the structures are dealt largest first
+            # to the batch with the fewest anchors so far
+            n_groups = max(1, min(int(os.environ.get("MAD_BUILD_GROUPS", "1")), len(jobs)))
+            groups = [[] for _ in range(n_groups)]
+            for i in sorted(range(len(jobs)), key=lambda i: -len(jobs[i][2])):
+                min(groups, key=lambda g: sum(len(jobs[j][2]) for j in g)).append(i)
+            groups = [sorted(g) for g in groups if g]
+            ent = _BATCHES[id(sets)] = ([(lib.prepare_build_many([jobs[i] for i in g]), g) for g in groups], sets)      # made once per group of sets
+        built = [None] * len(sets)
+        for batch, g in ent[0]:
+            for i, d in zip(g, batch.run()):
+                built[i] = d
+        lo = sets[0].finish() if shared else built[0]
+        his = built[1:]
     HOST_T["build_enqueue"] = HOST_T.get("build_enqueue", 0.0) + time.perf_counter() - t0
     return lo, his
 

@@ -188,6 +188,15 @@ void mad_set_destroy(mad_ctx *ctx, mad_set *set);
 int mad_set_build(mad_ctx *ctx, mad_set *set, const int *slot_of_octave,
                   const int32_t *anc_coords, const int32_t *anc_octave, const double *anc_subv,
                   const int32_t *anc_index, int n_anchors, int r, int lim_main, int lim_sec);
+/* The same for n_sets structures at once -- the map and the subunits of a MaD.run step, which the reference describes one
+ * after the other (MaD._describe_struct, MaD.py:358-368, called per structure from get_descriptors, MaD.py:116-163): ONE k_orient grid, one
+ * scan, one row expansion and ONE k_describe grid over the anchors / rows of all of them, so that small structures do not each
+ * pay a launch that cannot fill 256 CUs.  Arrays of n_sets entries; slot_of_octave has 2 per set.  Each set comes out exactly as
+ * mad_set_build would have made it.  Asynchronous, on the lane of sets[0]; every set's consumers wait for its own event. */
+int mad_set_build_many(mad_ctx *ctx, int n_sets, mad_set *const *sets, const int *slot_of_octave,
+                       const int32_t *const *anc_coords, const int32_t *const *anc_octave,
+                       const double *const *anc_subv, const int32_t *const *anc_index, const int *n_anchors,
+                       int r, int lim_main, int lim_sec);
 /* Load rows computed earlier (descriptor cache, MaD.py:861-875): anchor = row -> anchor id. */
 int mad_set_load(mad_ctx *ctx, mad_set *set, int64_t n_rows, const int32_t *row_anchor,
                  const int32_t *row_main, const double *row_R, const int16_t *dsc, int D,

@@ -22,7 +22,7 @@ SYMBOLS = [
     "mad_timing_enable", "mad_timing_reset", "mad_timing_get", "mad_last_ms",
     "mad_set_eqsp", "mad_upload_field", "mad_upload_field_device", "mad_free_field",
     "mad_set_orient_window", "mad_orient", "mad_describe", "mad_describe_sized", "mad_correlate", "mad_pose_score", "mad_topk",
-    "mad_set_create", "mad_set_destroy", "mad_set_build", "mad_set_load", "mad_set_size", "mad_set_download",
+    "mad_set_create", "mad_set_destroy", "mad_set_build", "mad_set_build_many", "mad_set_load", "mad_set_size", "mad_set_download",
     "mad_match_topk", "mad_match_topk_many", "mad_match_topk_many_begin", "mad_match_topk_many_finish", "mad_last_pose_kernel", "mad_last_pose_selected", "mad_match_fetch", "mad_match_results", "mad_match_used",
     "mad_match_shard_pairs", "mad_match_shard_topk",
     "mad_set_wire_bytes", "mad_set_export", "mad_set_import", "mad_set_lane", "mad_set_stream", "mad_set_bind_lane",
@@ -111,6 +111,42 @@ def _pad_rows(dsc, to=128):
     out = np.zeros((dsc.shape[0], (d + to - 1) // to * to), dsc.dtype)
     out[:, :d] = dsc
     return out
+
+
+class BuildBatch(object):
+    """The argument tables of one `mad_set_build_many` call (several structures, one launch per stage), kept alive between steps."""
+
+    def __init__(self, lib, jobs, r, lim_main, lim_sec):
+        self.lib, self.r, self.lim_main, self.lim_sec = lib, int(r), int(lim_main), int(lim_sec)
+        n = len(jobs)
+        self.sets = [job[5] if len(job) > 5 and job[5] is not None else DeviceSet(lib) for job in jobs]
+        self._keep = []
+        coords, octave, subv, index, counts, slots = [], [], [], [], [], []
+        for job in jobs:
+            c, o = _c(job[1], np.int32).reshape(-1, 3), _c(job[2], np.int32)
+            v, i = _c(job[3], np.float64).reshape(-1, 3), _c(job[4], np.int32)
+            if not (len(c) == len(o) == len(v) == len(i)):
+                raise ValueError("set_build_many: anchor arrays of different lengths")
+            self._keep += [c, o, v, i]
+            coords.append(c.ctypes.data); octave.append(o.ctypes.data); subv.append(v.ctypes.data); index.append(i.ctypes.data)
+            counts.append(len(o))
+            slots += [int(job[0][0]), int(job[0][1])]
+        self.counts = counts
+        self._h = (C.c_void_p * max(n, 1))(*[s.h.value for s in self.sets])
+        self._slots = (C.c_int * max(2 * n, 1))(*slots)
+        self._coords = (C.c_void_p * max(n, 1))(*coords)
+        self._octave = (C.c_void_p * max(n, 1))(*octave)
+        self._subv = (C.c_void_p * max(n, 1))(*subv)
+        self._index = (C.c_void_p * max(n, 1))(*index)
+        self._n = (C.c_int * max(n, 1))(*counts)
+
+    def run(self):
+        for s, n in zip(self.sets, self.counts):
+            s.n_anchors = n
+        self.lib._chk(self.lib.dll.mad_set_build_many(self.lib.ctx, C.c_int(len(self.sets)), self._h, self._slots, self._coords, self._octave,
+                                                      self._subv, self._index, self._n, C.c_int(self.r), C.c_int(self.lim_main),
+                                                      C.c_int(self.lim_sec)))
+        return self.sets
 
 
 class DeviceSet(object):
@@ -431,6 +467,15 @@ class Lib(object):
         self._chk(self.dll.mad_set_build(self.ctx, s.h, slots, _p(anc_coords), _p(anc_octave), _p(anc_subv), _p(anc_index),
                                          C.c_int(len(anc_octave)), C.c_int(r), C.c_int(lim_main), C.c_int(lim_sec)))
         return s
+
+    def prepare_build_many(self, jobs, r=8, lim_main=6, lim_sec=6):
+        """jobs: [(slots, anc_coords, anc_octave, anc_subv, anc_index, into-or-None), ...] -> a BuildBatch whose `run()` enqueues
+        orientation + description of all of them with one launch per stage (`mad_set_build_many`) and returns the sets.
+        Prepared once, run every step: the argument arrays are converted and pinned down here."""
+        return BuildBatch(self, jobs, r, lim_main, lim_sec)
+
+    def set_build_many(self, jobs, r=8, lim_main=6, lim_sec=6):
+        return self.prepare_build_many(jobs, r, lim_main, lim_sec).run()
 
     def set_load(self, row_anchor, row_main, row_R, dsc, anc_subv, anc_index, anc_octave):
         s = DeviceSet(self)

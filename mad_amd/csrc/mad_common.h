@@ -139,6 +139,7 @@ struct mad_ctx {
     hipStream_t lane_stream[MAD_LANES] = {};      // [0] is the stream mad_stream() reports
     int next_set_lane = 0;
     bool overlap = true;                      // false: every lane enqueues on lane_stream[0] (kernels run one at a time)
+    bool spatial_order = true;                // the build kernels take anchors / rows in Morton order (MAD_NO_SPATIAL_ORDER: list order)
     char err[512] = {0};
     FieldDev fields[MAD_MAX_FIELDS];
     void *field_mem[MAD_MAX_FIELDS];
@@ -183,6 +184,8 @@ struct mad_set {
     // copy from the pinned staging buffer fills (a copy from pageable memory would block the host on the stream)
     DevBuf anc_blob;
     DevBuf anc_coords, anc_octave, anc_subv, anc_index, anc_canon;      // views into anc_blob
+    DevBuf anc_order;            // view: the anchors in spatial (octave, Morton) order -- the order the build kernels WORK in, so that
+                                 // workgroups running side by side sample neighbouring texels (the rows keep the reference's order)
     void *host_stage = nullptr;
     size_t host_stage_cap = 0;
     int staged_n = -1;                  // what the staging buffer (and the device blob) hold: anchor count, with / without voxel coordinates
@@ -192,6 +195,7 @@ struct mad_set {
     hipEvent_t built = nullptr;         // recorded behind the last kernel of a build / load: consumers on other lanes wait for it
     // per row
     DevBuf row_anchor, row_main, row_sec, row_R, row_Rinv, row_meta, dsc, dsc8, norm;
+    DevBuf row_perm;             // k-th row in working order (rows of spatially neighbouring anchors next to each other)
     DevBuf dev_n;                // view: int32[4] on the device = {rows, rows out of int8 range, rejects, describe overflow}
     int64_t n_rows_host = -1;    // host copy of dev_n[0]; -1 until the asynchronous read-back has been waited for
     bool range_bad = false;      // a loaded row held a count outside the int8 range
@@ -199,8 +203,9 @@ struct mad_set {
     // what mad_set_build needs to repeat the describe stage when the hint was too small
     FieldDev last_f[2];
     int last_r = 0;
+    bool last_perm = false;
     int pinned_slot = 0;
-    hipEvent_t ready = nullptr;  // recorded behind the read-back of dev_n
+    hipEvent_t ready = nullptr;  // recorded behind mad_set_export: a rebuild on another lane (mad_set_build_many) waits for that read
     // cell list over ALL anchors (cell = dist), only built when a cloud does not fit LDS
     DevBuf cell_start, cell_pts, cell_ids;
     double cell_min[3] = {0, 0, 0};
@@ -218,7 +223,7 @@ enum {
     S_PAIR_HI, S_PAIR_LO, S_PAIR_SCORE, S_COUNTS, S_USED_HI, S_USED_LO, S_HI_CLOUD, S_MISC,
     S_HIST, S_SEL, S_RESULTS, S_TMP_A, S_TMP_B, S_TMP_C, S_TMP_D, S_TMP_E, S_TMP_F, S_TMP_G,
     S_TIE_FLAG, S_TIE_OFF, S_SEL_OUT, S_TMP_H, S_TMP_I, S_TMP_J,
-    S_CELL_START, S_CELL_PTS, S_CELL_IDS, S_PG_START, S_PG_PTS, S_PG_PTSF, S_ZERO, S_CMASK, S_PG_BITS, S_PG_PAIRS, S_N_SLOTS
+    S_CELL_START, S_CELL_PTS, S_CELL_IDS, S_PG_START, S_PG_PTS, S_PG_PTSF, S_ZERO, S_CMASK, S_PG_BITS, S_PG_PAIRS, S_PERM_OFF, S_N_SLOTS
 };
 static_assert(S_N_SLOTS <= 64, "grow mad_ctx::scratch");
 
@@ -250,12 +255,40 @@ struct OrientOut {
     double *row_Rinv = nullptr;
     int32_t *row_meta = nullptr;
     const int32_t *anc_index = nullptr, *anc_octave = nullptr;
+    // nullable: the anchors in working order (a permutation of 0 .. n-1) and, written with the rows, the rows in that order
+    const int32_t *anc_order = nullptr;
+    int32_t *row_perm = nullptr;
     bool counters_zeroed = false;      // the caller has already enqueued the zeroing of d_n_rows / d_n_reject
     int32_t *d_n_rows;       // device: number of rows produced
     int32_t *d_n_reject;     // device, nullable: anchors refused at the border
 };
 int mad_orient_device(mad_ctx *ctx, FieldDev f0, FieldDev f1, const int32_t *d_coords, const int32_t *d_octave,
                       int uniform_octave, int n, int r, int lim_main, int lim_sec, OrientOut out);
+// The same for the anchor lists of several structures in one k_orient grid (+ one scan, one row expansion), and their
+// descriptors in one k_describe grid: a step's structures fill the chip together instead of one small launch each.
+struct OrientJob {
+    FieldDev f[2];
+    const int32_t *d_coords, *d_octave;
+    int uniform_octave;
+    int n;
+    OrientOut out;
+};
+struct DescribeJob {
+    FieldDev f[2];
+    const int32_t *d_anc_coords, *d_anc_octave;
+    int uniform_octave;
+    const int32_t *d_row_anchor;
+    const double *d_row_R, *d_row_Rinv;
+    const int32_t *d_row_perm = nullptr;      // nullable: workgroup k describes row d_row_perm[k]
+    const int32_t *d_n_rows;
+    int64_t grid_rows;
+    int32_t *d_overflow;
+    int16_t *d_dsc;
+    int8_t *d_dsc8;
+    double *d_norm;
+};
+int mad_orient_device_many(mad_ctx *ctx, int n_jobs, const OrientJob *jobs, int r, int lim_main, int lim_sec);
+int mad_describe_device_many(mad_ctx *ctx, int n_jobs, const DescribeJob *jobs, int r, int dsc_size = 64);
 int mad_describe_device(mad_ctx *ctx, FieldDev f0, FieldDev f1, const int32_t *d_anc_coords, const int32_t *d_anc_octave,
                         int uniform_octave, const int32_t *d_row_anchor, const double *d_row_R, const double *d_row_Rinv,
                         const int32_t *d_n_rows, int64_t grid_rows, int32_t *d_overflow, int r, int16_t *d_dsc, int8_t *d_dsc8 = nullptr,

@@ -59,6 +59,7 @@ extern "C" int mad_init(int device, mad_ctx **out) {
         return mad_fail(nullptr, MAD_ENODEV, "mad_init: device %d is %s; this library is built for gfx950 only", device,
                         prop.gcnArchName);
     mad_ctx *ctx = new mad_ctx();
+    ctx->spatial_order = getenv("MAD_NO_SPATIAL_ORDER") == nullptr;      // diagnostic switch: build in list order
     ctx->device = device;
     ctx->n_cu = prop.multiProcessorCount;
     for (int i = 0; i < MAD_MAX_FIELDS; i++) {

@@ -1917,7 +1917,7 @@ extern "C" void mad_set_destroy(mad_ctx *ctx, mad_set *s) {
     if (!s) return;
     if (ctx) (void)mad_synchronize(ctx);
     DevBuf *bufs[] = {&s->anc_blob, &s->row_anchor, &s->row_main, &s->row_sec, &s->row_R, &s->row_Rinv, &s->row_meta, &s->dsc,
-                      &s->dsc8, &s->norm, &s->cell_start, &s->cell_pts, &s->cell_ids};      // anc_* and dev_n are views
+                      &s->dsc8, &s->norm, &s->row_perm, &s->cell_start, &s->cell_pts, &s->cell_ids};      // anc_* and dev_n are views
     for (DevBuf *b : bufs) mad_release(*b);
     if (s->host_stage) (void)hipHostFree(s->host_stage);
     if (s->ready) (void)hipEventDestroy(s->ready);
@@ -1934,16 +1934,20 @@ static int set_rows(mad_ctx *ctx, const mad_set *cs, int64_t *n_rows) {
         const int lane_before = ctx->lane;
         mad_use_lane(ctx, s->lane);
         struct Back { mad_ctx *c; int l; ~Back() { mad_use_lane(c, l); } } back{ctx, lane_before};
+        MAD_HIP(hipStreamWaitEvent(ctx->stream, s->built, 0));      // a batched build runs on the lane of the batch's first set
         const int32_t *h = (const int32_t *)&ctx->pinned[s->pinned_slot];
         MAD_HIP(hipMemcpyAsync(&ctx->pinned[s->pinned_slot], s->dev_n.p, 16, hipMemcpyDeviceToHost, ctx->stream));
         MAD_HIP(hipStreamSynchronize(ctx->stream));
         if (h[3] && s->last_r > 0) {
             MAD_HIP(hipMemsetAsync((int32_t *)s->dev_n.p + 3, 0, 4, ctx->stream));
-            MAD_TRY(mad_describe_device(ctx, s->last_f[0], s->last_f[1], (const int32_t *)s->anc_coords.p,
-                                        (const int32_t *)s->anc_octave.p, 0, (const int32_t *)s->row_anchor.p,
-                                        (const double *)s->row_R.p, (const double *)s->row_Rinv.p, (const int32_t *)s->dev_n.p, s->cap_rows,
-                                        (int32_t *)s->dev_n.p + 3, s->last_r, (int16_t *)s->dsc.p, (int8_t *)s->dsc8.p,
-                                        (double *)s->norm.p));
+            DescribeJob J;
+            J.f[0] = s->last_f[0]; J.f[1] = s->last_f[1];
+            J.d_anc_coords = (const int32_t *)s->anc_coords.p; J.d_anc_octave = (const int32_t *)s->anc_octave.p; J.uniform_octave = 0;
+            J.d_row_anchor = (const int32_t *)s->row_anchor.p; J.d_row_R = (const double *)s->row_R.p; J.d_row_Rinv = (const double *)s->row_Rinv.p;
+            J.d_row_perm = s->last_perm ? (const int32_t *)s->row_perm.p : nullptr;
+            J.d_n_rows = (const int32_t *)s->dev_n.p; J.grid_rows = s->cap_rows; J.d_overflow = (int32_t *)s->dev_n.p + 3;
+            J.d_dsc = (int16_t *)s->dsc.p; J.d_dsc8 = (int8_t *)s->dsc8.p; J.d_norm = (double *)s->norm.p;
+            MAD_TRY(mad_describe_device_many(ctx, 1, &J, s->last_r));
             MAD_HIP(hipEventRecord(s->built, ctx->stream));
             MAD_HIP(hipMemcpyAsync(&ctx->pinned[s->pinned_slot], s->dev_n.p, 16, hipMemcpyDeviceToHost, ctx->stream));
             MAD_HIP(hipStreamSynchronize(ctx->stream));
@@ -1965,7 +1969,7 @@ static int set_upload_anchors(mad_ctx *ctx, mad_set *s, const int32_t *anc_coord
     s->n_anchors = n;
     const size_t m = (size_t)(n > 0 ? n : 1);
     const size_t o_subv = 64, o_coords = o_subv + m * 24, o_oct = o_coords + m * 12, o_idx = o_oct + m * 4, o_canon = o_idx + m * 4,
-                 total = (o_canon + m * 4 + 15) / 16 * 16;
+                 o_order = o_canon + m * 4, total = (o_order + m * 4 + 15) / 16 * 16;
     if (s->host_stage_cap < total) {
         if (s->host_stage) {
             MAD_HIP(hipEventSynchronize(s->uploaded));
@@ -1985,7 +1989,7 @@ static int set_upload_anchors(mad_ctx *ctx, mad_set *s, const int32_t *anc_coord
     char *h = (char *)s->host_stage, *d = (char *)s->anc_blob.p;
     s->dev_n.p = d;
     s->anc_subv.p = d + o_subv; s->anc_coords.p = d + o_coords; s->anc_octave.p = d + o_oct; s->anc_index.p = d + o_idx;
-    s->anc_canon.p = d + o_canon;
+    s->anc_canon.p = d + o_canon; s->anc_order.p = d + o_order;
     // The same anchors as last time (a set rebuilt in place, step after step): the staging buffer and the device copy already
     // hold them -- only the counters are reset.  Decided by comparing the bytes, not by trusting the caller.
     const bool same = n > 0 && s->staged_n == n && s->staged_coords == (anc_coords != nullptr) && blob_before == s->anc_blob.p &&
@@ -2020,6 +2024,27 @@ static int set_upload_anchors(mad_ctx *ctx, mad_set *s, const int32_t *anc_coord
         });
         for (int i = 0; i < n; i++)
             canon[order[i]] = (i > 0 && memcmp(anc_subv + 3 * order[i], anc_subv + 3 * order[i - 1], 24) == 0) ? canon[order[i - 1]] : order[i];
+        // The order the build kernels work in: by octave (one texture each), then along a Morton curve through the voxel
+        // coordinates.  The reference lists anchors by detector response; workgroups that run side by side then sample balls
+        // all over a 1-2 GB texture.  In Morton order they sample overlapping balls and meet in the XCD's L2.
+        int32_t *work = (int32_t *)(h + o_order);
+        for (int i = 0; i < n; i++) work[i] = i;
+        if (anc_coords) {
+            std::vector<uint64_t> key(n);
+            auto spread = [](uint64_t v) {      // 21 bits -> every third bit
+                v &= 0x1fffff;
+                v = (v | v << 32) & 0x1f00000000ffffull; v = (v | v << 16) & 0x1f0000ff0000ffull; v = (v | v << 8) & 0x100f00f00f00f00full;
+                v = (v | v << 4) & 0x10c30c30c30c30c3ull; v = (v | v << 2) & 0x1249249249249249ull;
+                return v;
+            };
+            for (int i = 0; i < n; i++) {
+                const int sh = anc_octave[i] == 0 ? 1 : 0;      // the same physical cell size in both octaves
+                const uint64_t x = (uint64_t)std::max(anc_coords[3 * i], 0) >> sh, y = (uint64_t)std::max(anc_coords[3 * i + 1], 0) >> sh,
+                               z = (uint64_t)std::max(anc_coords[3 * i + 2], 0) >> sh;
+                key[i] = ((uint64_t)(anc_octave[i] != 0) << 63) | spread(x) << 2 | spread(y) << 1 | spread(z);
+            }
+            std::sort(work, work + n, [&](int32_t a, int32_t b) { return key[a] != key[b] ? key[a] < key[b] : a < b; });
+        }
     }
     // a kernel reads the pinned buffer directly: in stream order, without the copy engine's start-up latency
     mad_copy_words(ctx, d, h, n > 0 ? total : 64);
@@ -2048,6 +2073,7 @@ static int set_reserve_rows(mad_ctx *ctx, mad_set *s, int64_t cap) {
     MAD_TRY(mad_reserve(ctx, s->dsc, (size_t)cap_pad * s->D * 2));
     MAD_TRY(mad_reserve(ctx, s->dsc8, (size_t)cap_pad * s->D));
     MAD_TRY(mad_reserve(ctx, s->norm, (size_t)cap_pad * 8));
+    MAD_TRY(mad_reserve(ctx, s->row_perm, (size_t)cap_pad * 4));
     return MAD_OK;
 }
 
@@ -2068,47 +2094,85 @@ static int set_finish_rows(mad_ctx *ctx, mad_set *s) {
     return MAD_OK;
 }
 
+// Orientation + description of the anchors of n_sets structures, each into its own set, with ONE launch per stage for all of
+// them (k_orient, scan, row expansion, k_describe): the structures of a step fill the chip together.  Everything is enqueued
+// on the lane of the first set; every set's `built` event is recorded behind the last launch.
+extern "C" int mad_set_build_many(mad_ctx *ctx, int n_sets, mad_set *const *sets, const int *slot_of_octave,
+                                  const int32_t *const *anc_coords, const int32_t *const *anc_octave, const double *const *anc_subv,
+                                  const int32_t *const *anc_index, const int *n_anchors, int r, int lim_main, int lim_sec) {
+    if (!ctx || n_sets < 0 || (n_sets > 0 && (!sets || !slot_of_octave || !anc_coords || !anc_octave || !anc_subv || !anc_index || !n_anchors)))
+        return MAD_EINVAL;
+    if (n_sets == 0) return MAD_OK;
+    for (int i = 0; i < n_sets; i++) {
+        if (!sets[i]) return mad_fail(ctx, MAD_EINVAL, "mad_set_build: set %d is NULL", i);
+        for (int k = 0; k < i; k++)
+            if (sets[k] == sets[i]) return mad_fail(ctx, MAD_EINVAL, "mad_set_build: set %d is listed twice", i);
+    }
+    mad_use_lane(ctx, sets[0]->lane);
+    if (lim_main < 1 || lim_sec < 1 || lim_main * lim_sec > 64) return mad_fail(ctx, MAD_EINVAL, "mad_set_build: lim_main=%d lim_sec=%d", lim_main, lim_sec);
+    for (int i = 1; i < n_sets; i++)      // an export still reading a set on its own lane
+        if (sets[i]->lane != sets[0]->lane) MAD_HIP(hipStreamWaitEvent(ctx->stream, sets[i]->ready, 0));
+    std::vector<OrientJob> oj(n_sets);
+    std::vector<DescribeJob> dj(n_sets);
+    for (int i = 0; i < n_sets; i++) {
+        const int n = n_anchors[i];
+        if (n > 0 && (!anc_coords[i] || !anc_octave[i] || !anc_subv[i] || !anc_index[i])) return mad_fail(ctx, MAD_EINVAL, "mad_set_build: NULL anchors");
+        FieldDev *f = oj[i].f;
+        f[0] = f[1] = FieldDev{nullptr, 0, 0, 0};
+        for (int o = 0; o < 2; o++) {
+            const int sl = slot_of_octave[2 * i + o];
+            if (sl >= 0) {
+                if (sl >= MAD_MAX_FIELDS || !ctx->fields[sl].tex) return mad_fail(ctx, MAD_EINVAL, "mad_set_build: field slot %d is empty", sl);
+                f[o] = ctx->fields[sl];
+            }
+        }
+        for (int a = 0; a < n; a++) {
+            const int o = anc_octave[i][a];
+            if ((o != 0 && o != 1) || !f[o].tex) return mad_fail(ctx, MAD_EINVAL, "mad_set_build: anchor %d has octave %d without a field", a, o);
+        }
+    }
+    for (int i = 0; i < n_sets; i++) {
+        mad_set *s = sets[i];
+        const int n = n_anchors[i];
+        MAD_TRY(set_upload_anchors(ctx, s, anc_coords[i], anc_octave[i], anc_subv[i], anc_index[i], n));
+        s->D = 64 * ctx->eq_host[1].Z;
+        MAD_TRY(set_reserve_rows(ctx, s, (int64_t)n * lim_main * lim_sec));
+        OrientJob &J = oj[i];
+        J.d_coords = (const int32_t *)s->anc_coords.p; J.d_octave = (const int32_t *)s->anc_octave.p; J.uniform_octave = 0; J.n = n;
+        OrientOut &out = J.out;
+        out.row_anchor = (int32_t *)s->row_anchor.p; out.row_main = (int32_t *)s->row_main.p; out.row_sec = (int32_t *)s->row_sec.p;
+        out.row_R = (double *)s->row_R.p; out.row_count = nullptr;
+        out.d_n_rows = (int32_t *)s->dev_n.p; out.d_n_reject = (int32_t *)s->dev_n.p + 2;
+        out.row_Rinv = (double *)s->row_Rinv.p; out.row_meta = (int32_t *)s->row_meta.p;
+        out.anc_index = (const int32_t *)s->anc_index.p; out.anc_octave = (const int32_t *)s->anc_octave.p;
+        out.anc_order = ctx->spatial_order ? (const int32_t *)s->anc_order.p : nullptr;
+        out.row_perm = ctx->spatial_order ? (int32_t *)s->row_perm.p : nullptr;
+        out.counters_zeroed = true;
+        DescribeJob &Q = dj[i];
+        Q.f[0] = J.f[0]; Q.f[1] = J.f[1];
+        Q.d_anc_coords = J.d_coords; Q.d_anc_octave = J.d_octave; Q.uniform_octave = 0;
+        Q.d_row_anchor = out.row_anchor; Q.d_row_R = out.row_R; Q.d_row_Rinv = out.row_Rinv; Q.d_row_perm = out.row_perm; Q.d_n_rows = out.d_n_rows;
+        s->last_perm = out.row_perm != nullptr;
+        // the describe launch is sized from the row count of this set's previous build when there is one
+        Q.grid_rows = n <= 0 ? 0 : (s->rows_hint > 0 ? std::min<int64_t>(s->cap_rows, s->rows_hint + s->rows_hint / 8 + 64) : s->cap_rows);
+        Q.d_overflow = (int32_t *)s->dev_n.p + 3;
+        Q.d_dsc = (int16_t *)s->dsc.p; Q.d_dsc8 = (int8_t *)s->dsc8.p; Q.d_norm = (double *)s->norm.p;      // int8 copy + norms included: counts are <= 64 by construction
+        s->last_f[0] = J.f[0]; s->last_f[1] = J.f[1]; s->last_r = r;
+        s->n_rows_host = -1;
+    }
+    MAD_TRY(mad_orient_device_many(ctx, n_sets, oj.data(), r, lim_main, lim_sec));
+    MAD_TRY(mad_describe_device_many(ctx, n_sets, dj.data(), r));
+    for (int i = 0; i < n_sets; i++) {
+        MAD_HIP(hipEventRecord(sets[i]->built, ctx->stream));
+    }
+    return MAD_OK;
+}
+
 extern "C" int mad_set_build(mad_ctx *ctx, mad_set *s, const int *slot_of_octave, const int32_t *anc_coords,
                              const int32_t *anc_octave, const double *anc_subv, const int32_t *anc_index, int n, int r,
                              int lim_main, int lim_sec) {
     if (!ctx || !s || !slot_of_octave) return MAD_EINVAL;
-    mad_use_lane(ctx, s->lane);
-    if (n > 0 && (!anc_coords || !anc_octave || !anc_subv || !anc_index)) return mad_fail(ctx, MAD_EINVAL, "mad_set_build: NULL anchors");
-    if (lim_main < 1 || lim_sec < 1 || lim_main * lim_sec > 64) return mad_fail(ctx, MAD_EINVAL, "mad_set_build: lim_main=%d lim_sec=%d", lim_main, lim_sec);
-    FieldDev f[2] = {FieldDev{nullptr, 0, 0, 0}, FieldDev{nullptr, 0, 0, 0}};
-    for (int o = 0; o < 2; o++) {
-        const int sl = slot_of_octave[o];
-        if (sl >= 0) {
-            if (sl >= MAD_MAX_FIELDS || !ctx->fields[sl].tex) return mad_fail(ctx, MAD_EINVAL, "mad_set_build: field slot %d is empty", sl);
-            f[o] = ctx->fields[sl];
-        }
-    }
-    for (int i = 0; i < n; i++) {
-        const int o = anc_octave[i];
-        if ((o != 0 && o != 1) || !f[o].tex) return mad_fail(ctx, MAD_EINVAL, "mad_set_build: anchor %d has octave %d without a field", i, o);
-    }
-    MAD_TRY(set_upload_anchors(ctx, s, anc_coords, anc_octave, anc_subv, anc_index, n));
-    s->D = 64 * ctx->eq_host[1].Z;
-    MAD_TRY(set_reserve_rows(ctx, s, (int64_t)n * lim_main * lim_sec));
-    OrientOut out;
-    out.row_anchor = (int32_t *)s->row_anchor.p; out.row_main = (int32_t *)s->row_main.p; out.row_sec = (int32_t *)s->row_sec.p;
-    out.row_R = (double *)s->row_R.p; out.row_count = nullptr;
-    out.d_n_rows = (int32_t *)s->dev_n.p; out.d_n_reject = (int32_t *)s->dev_n.p + 2;
-    out.row_Rinv = (double *)s->row_Rinv.p; out.row_meta = (int32_t *)s->row_meta.p;
-    out.anc_index = (const int32_t *)s->anc_index.p; out.anc_octave = (const int32_t *)s->anc_octave.p;
-    out.counters_zeroed = true;
-    MAD_TRY(mad_orient_device(ctx, f[0], f[1], (const int32_t *)s->anc_coords.p, (const int32_t *)s->anc_octave.p, 0, n, r,
-                              lim_main, lim_sec, out));
-    // the describe launch is sized from the row count of this set's previous build when there is one
-    const int64_t grid_rows = s->rows_hint > 0 ? std::min<int64_t>(s->cap_rows, s->rows_hint + s->rows_hint / 8 + 64) : s->cap_rows;
-    MAD_TRY(mad_describe_device(ctx, f[0], f[1], (const int32_t *)s->anc_coords.p, (const int32_t *)s->anc_octave.p, 0,
-                                (const int32_t *)s->row_anchor.p, (const double *)s->row_R.p, (const double *)s->row_Rinv.p,
-                                (const int32_t *)s->dev_n.p, grid_rows, (int32_t *)s->dev_n.p + 3, r, (int16_t *)s->dsc.p, (int8_t *)s->dsc8.p,
-                                (double *)s->norm.p));      // int8 copy + norms included: counts are <= 64 by construction
-    s->last_f[0] = f[0]; s->last_f[1] = f[1]; s->last_r = r;
-    s->n_rows_host = -1;
-    MAD_HIP(hipEventRecord(s->built, ctx->stream));
-    return MAD_OK;
+    return mad_set_build_many(ctx, 1, &s, slot_of_octave, &anc_coords, &anc_octave, &anc_subv, &anc_index, &n, r, lim_main, lim_sec);
 }
 
 extern "C" int mad_set_load(mad_ctx *ctx, mad_set *s, int64_t n_rows, const int32_t *row_anchor, const int32_t *row_main,
@@ -2152,7 +2216,7 @@ extern "C" int mad_set_download(mad_ctx *ctx, const mad_set *s, int32_t *row_anc
     if (!ctx || !s) return MAD_EINVAL;
     mad_use_lane(ctx, s->lane);
     int64_t n = 0;
-    MAD_TRY(set_rows(ctx, s, &n));
+    MAD_TRY(set_rows(ctx, s, &n));      // waits for the build, on whichever lane it ran
     if (n <= 0) return MAD_OK;
     if (row_anchor) MAD_HIP(hipMemcpyAsync(row_anchor, s->row_anchor.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
     if (row_main) MAD_HIP(hipMemcpyAsync(row_main, s->row_main.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -2770,6 +2834,7 @@ extern "C" int mad_set_export(mad_ctx *ctx, const mad_set *s, void *wire, int wi
     if (!ctx || !s || !wire || cap_rows < 1) return MAD_EINVAL;
     if (!s->dev_n.p || s->D <= 0 || (s->D % 16)) return mad_fail(ctx, MAD_EINVAL, "mad_set_export: the set has not been built");
     mad_use_lane(ctx, s->lane);
+    MAD_HIP(hipStreamWaitEvent(ctx->stream, s->built, 0));      // the build may have run on another lane (mad_set_build_many)
     const WireLayout L = wire_layout(s->D, cap_rows);
     unsigned char *d_wire = (unsigned char *)wire;
     if (!wire_on_device) {
@@ -2782,6 +2847,7 @@ extern "C" int mad_set_export(mad_ctx *ctx, const mad_set *s, void *wire, int wi
                        (const int32_t *)s->row_anchor.p, (const double *)s->norm.p, (const int8_t *)s->dsc8.p, s->D, cap_rows, s->n_anchors,
                        d_wire);
     MAD_HIP(hipGetLastError());
+    MAD_HIP(hipEventRecord(s->ready, ctx->stream));      // a later build of this set on another lane waits for this read
     if (!wire_on_device) {
         MAD_HIP(hipMemcpyAsync(wire, d_wire, L.total, hipMemcpyDeviceToHost, ctx->stream));
         MAD_HIP(hipStreamSynchronize(ctx->stream));

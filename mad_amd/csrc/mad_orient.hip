@@ -55,6 +55,7 @@ static int ensure_mask(mad_ctx *ctx, int r) {
 struct OrientArgs {
     FieldDev f[2];                 // octave 0 (upsampled, stride 2) and 1 (base, stride 1)
     const int32_t *coords;         // n x 3
+    const int32_t *order;          // nullable: workgroup k takes anchor order[k] (spatial order: neighbours share texels in L2)
     const int32_t *octave;         // n, or nullptr -> uniform_octave
     int uniform_octave;
     int n;
@@ -75,6 +76,21 @@ struct OrientArgs {
     const unsigned long long *wfix;
 };
 #define ORI_WFIX_BITS 50
+
+// Several jobs (the anchor lists of several structures) in ONE grid: job j owns the workgroups first[j] .. first[j + 1] - 1.
+// The tables travel in the kernel arguments, so a workgroup finds its job with a few scalar compares and reads that job's
+// arguments with scalar loads.
+#define MAD_BATCH_MAX 16
+template <class Args> struct Batch {
+    int n_jobs;
+    int first[MAD_BATCH_MAX + 1];
+    Args job[MAD_BATCH_MAX];
+};
+template <class Args> __device__ __forceinline__ int batch_job(const Batch<Args> &B, int block) {
+    int j = 0;
+    while (j + 1 < B.n_jobs && block >= B.first[j + 1]) j++;
+    return j;
+}
 
 // Quantise `hist` (Z counts in LDS) to 0..50 of its max (Orientator.py:336-340) into q.
 // Executed by wave 0 only; returns the max (0 = nothing counted, q left = hist).
@@ -107,7 +123,9 @@ __device__ __forceinline__ void classify_exact64(const EqspFastLds *eq, double r
 }
 
 template <bool GW>
-__global__ __launch_bounds__(ORI_THREADS) void k_orient(OrientArgs A) {
+__global__ __launch_bounds__(ORI_THREADS) void k_orient(Batch<OrientArgs> B) {
+    const int job = batch_job(B, (int)blockIdx.x);
+    const OrientArgs &A = B.job[job];
     extern __shared__ __align__(16) unsigned char smem[];
     float *vx = (float *)smem;
     float *vy = vx + A.nmask;
@@ -127,7 +145,7 @@ __global__ __launch_bounds__(ORI_THREADS) void k_orient(OrientArgs A) {
     __shared__ float s_domf[ORI_MAX_MAIN][9];
     __shared__ EqspFastLds fast;
 
-    const int a = blockIdx.x;
+    const int a = A.order ? A.order[(int)blockIdx.x - B.first[job]] : (int)blockIdx.x - B.first[job];
     const int tid = threadIdx.x;
     const int oct = A.octave ? A.octave[a] : A.uniform_octave;
     const FieldDev F = A.f[oct == 1 ? 1 : 0];
@@ -335,103 +353,194 @@ __global__ __launch_bounds__(ORI_THREADS) void k_orient(OrientArgs A) {
     if (tid == 0) A.slot_cnt[a] = produced;
 }
 
-// expand the per-anchor slots into the compact row list; Rfinal = adj_sec @ to_dom (Orientator.py:105)
-__global__ void k_orient_rows(const int32_t *slot_cnt, const int32_t *slot_main, const int32_t *slot_sec,
-                              const int32_t *slot_hist, const int32_t *slot_hidx, const int32_t *row_off, int n, int fan,
-                              int lim_main, const EqspDev *eq, int32_t *row_anchor, int32_t *row_main, int32_t *row_sec,
-                              double *row_R, int32_t *row_count, double *row_Rinv, int32_t *row_meta,
-                              const int32_t *anc_index, const int32_t *anc_octave) {
-    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int a = (int)(gid / fan), s = (int)(gid % fan);
-    if (a >= n) return;
-    const int c = slot_cnt[a];
-    if (s >= c) return;
-    const int64_t row = (int64_t)row_off[a] + s;
-    const int mb = slot_main[(size_t)a * fan + s], sb = slot_sec[(size_t)a * fan + s];
-    row_anchor[row] = a;
-    row_main[row] = mb;
-    row_sec[row] = sb;
-    double *o = row_R + 9 * row;
-    mad_rfinal(eq, mb, sb, o);
-    if (row_count) {
-        const int Z = eq->Z;
-        const int32_t *h = slot_hist + ((size_t)a * lim_main + slot_hidx[(size_t)a * fan + s]) * Z;
-        for (int i = 0; i < Z; i++) row_count[row * Z + i] = h[i];
+// per job: where the per-anchor slots of k_orient lie and where the job's rows go
+struct RowsArgs {
+    const int32_t *slot_cnt, *slot_main, *slot_sec, *slot_hist, *slot_hidx;
+    int32_t *row_off;              // n + 1
+    int n;
+    int32_t *row_anchor, *row_main, *row_sec;
+    double *row_R;
+    int32_t *row_count;
+    double *row_Rinv;
+    int32_t *row_meta;
+    const int32_t *anc_index, *anc_octave;
+    int32_t *n_rows;               // device: the job's row count
+    const int32_t *order;          // nullable: anchors in working order
+    int32_t *perm_off;             // with order: n + 1 row offsets in working order
+    int32_t *row_perm;             // with order: the rows in working order
+};
+
+// row offsets of every job: exclusive scan of its anchors' row counts, one workgroup per job
+__global__ __launch_bounds__(1024) void k_orient_scan(Batch<RowsArgs> B) {
+    __shared__ int wt[1024 / MAD_WAVE + 1];
+    __shared__ int carry;
+    const RowsArgs &A = B.job[blockIdx.x];
+    const int n = A.n;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + threadIdx.x;
+        const int v = (i < n) ? A.slot_cnt[i] : 0;
+        int tot;
+        const int ex = block_excl_scan(v, wt, &tot);
+        if (i < n) A.row_off[i] = carry + ex;
+        __syncthreads();
+        if (threadIdx.x == 0) carry += tot;
+        __syncthreads();
     }
-    if (row_Rinv) mad_mat3_inv(o, row_Rinv + 9 * row);      // inv(lo.Rfinal) of MaD.py:438, once per row
-    if (row_meta) { row_meta[3 * row] = anc_index[a]; row_meta[3 * row + 1] = anc_octave[a]; row_meta[3 * row + 2] = mb; }
+    if (threadIdx.x == 0) {
+        A.row_off[n] = carry;
+        *A.n_rows = carry;
+    }
+    if (!A.order) return;
+    __syncthreads();
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024) {      // the same in working order
+        const int i = base + threadIdx.x;
+        const int v = (i < n) ? A.slot_cnt[A.order[i]] : 0;
+        int tot;
+        const int ex = block_excl_scan(v, wt, &tot);
+        if (i < n) A.perm_off[i] = carry + ex;
+        __syncthreads();
+        if (threadIdx.x == 0) carry += tot;
+        __syncthreads();
+    }
 }
 
-// Runs a1-a8 for n anchors whose coordinates (and octaves) are already on the device and writes the rows to
-// `out` (capacity n * lim_main * lim_sec rows).  Asynchronous: the row count stays on the device.
-int mad_orient_device(mad_ctx *ctx, FieldDev f0, FieldDev f1, const int32_t *d_coords, const int32_t *d_octave,
-                      int uniform_octave, int n, int r, int lim_main, int lim_sec, OrientOut out) {
+
+// expand the per-anchor slots into the compact row list; Rfinal = adj_sec @ to_dom (Orientator.py:105)
+__global__ __launch_bounds__(256) void k_orient_rows(Batch<RowsArgs> B, int fan, int lim_main, const EqspDev *eq) {
+    const int job = batch_job(B, (int)blockIdx.x);
+    const RowsArgs &A = B.job[job];
+    const int64_t gid = (int64_t)((int)blockIdx.x - B.first[job]) * 256 + threadIdx.x;
+    const int p = (int)(gid / fan), s = (int)(gid % fan);
+    if (p >= A.n) return;
+    const int a = A.order ? A.order[p] : p;
+    const int c = A.slot_cnt[a];
+    if (s >= c) return;
+    const int64_t row = (int64_t)A.row_off[a] + s;
+    if (A.order) A.row_perm[A.perm_off[p] + s] = (int32_t)row;
+    const int mb = A.slot_main[(size_t)a * fan + s], sb = A.slot_sec[(size_t)a * fan + s];
+    A.row_anchor[row] = a;
+    A.row_main[row] = mb;
+    A.row_sec[row] = sb;
+    double *o = A.row_R + 9 * row;
+    mad_rfinal(eq, mb, sb, o);
+    if (A.row_count) {
+        const int Z = eq->Z;
+        const int32_t *h = A.slot_hist + ((size_t)a * lim_main + A.slot_hidx[(size_t)a * fan + s]) * Z;
+        for (int i = 0; i < Z; i++) A.row_count[row * Z + i] = h[i];
+    }
+    if (A.row_Rinv) mad_mat3_inv(o, A.row_Rinv + 9 * row);      // inv(lo.Rfinal) of MaD.py:438, once per row
+    if (A.row_meta) { A.row_meta[3 * row] = A.anc_index[a]; A.row_meta[3 * row + 1] = A.anc_octave[a]; A.row_meta[3 * row + 2] = mb; }
+}
+
+// Runs a1-a8 for the anchor lists of n_jobs structures (coordinates and octaves already on the device) in one k_orient
+// grid, one scan and one row-expansion launch, and writes each job's rows to its `out` (capacity n * lim_main * lim_sec rows).
+// Asynchronous: the row counts stay on the device.
+static int orient_batch(mad_ctx *ctx, int n_jobs, const OrientJob *jobs, int r, int lim_main, int lim_sec) {
+    const int Z = ctx->eq_host[0].Z;
+    const int fan = lim_main * lim_sec;
+    int64_t total = 0;
+    bool want_hist = false;
+    for (int j = 0; j < n_jobs; j++) { total += jobs[j].n; want_hist |= jobs[j].out.row_count != nullptr; }
+    if (total > (int64_t)INT32_MAX / (fan * 4)) return mad_fail(ctx, MAD_EINVAL, "mad_orient: %lld anchors in one batch", (long long)total);
+    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_SLOT_CNT), (size_t)(total + 4) * 4));
+    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_SLOT_MAIN), (size_t)total * fan * 4));
+    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_SLOT_SEC), (size_t)total * fan * 4));
+    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_TMP_A), (size_t)total * fan * 4));
+    if (want_hist) MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_SLOT_HIST), (size_t)total * lim_main * Z * 4));
+    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_ROW_OFF), (size_t)(total + n_jobs + 2) * 4));
+    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_PERM_OFF), (size_t)(total + n_jobs + 2) * 4));
+
+    Batch<OrientArgs> B;
+    Batch<RowsArgs> R;
+    B.n_jobs = R.n_jobs = n_jobs;
+    int64_t a0 = 0, blk = 0;
+    for (int j = 0; j < n_jobs; j++) {
+        const OrientJob &J = jobs[j];
+        OrientArgs &A = B.job[j];
+        A.f[0] = J.f[0]; A.f[1] = J.f[1];
+        A.coords = J.d_coords; A.octave = J.d_octave; A.uniform_octave = J.uniform_octave;
+        A.order = J.out.row_perm ? J.out.anc_order : nullptr;
+        A.n = J.n; A.r = r; A.nmask = ctx->mask_n; A.mask_off = ctx->mask_off; A.eq = ctx->eq[0];
+        A.lim_main = lim_main; A.lim_sec = lim_sec; A.fan = fan;
+        A.slot_cnt = scratch<int32_t>(ctx, S_SLOT_CNT) + a0;
+        A.n_reject = J.out.d_n_reject;
+        A.slot_main = scratch<int32_t>(ctx, S_SLOT_MAIN) + a0 * fan;
+        A.slot_sec = scratch<int32_t>(ctx, S_SLOT_SEC) + a0 * fan;
+        A.slot_hist = J.out.row_count ? scratch<int32_t>(ctx, S_SLOT_HIST) + a0 * lim_main * Z : nullptr;
+        A.slot_hidx = scratch<int32_t>(ctx, S_TMP_A) + a0 * fan;
+        A.wfix = ctx->gw_sig != 0.0 ? ctx->gw_tab : nullptr;
+        B.first[j] = (int)a0;
+        RowsArgs &Q = R.job[j];
+        Q.slot_cnt = A.slot_cnt; Q.slot_main = A.slot_main; Q.slot_sec = A.slot_sec; Q.slot_hist = A.slot_hist; Q.slot_hidx = A.slot_hidx;
+        Q.row_off = scratch<int32_t>(ctx, S_ROW_OFF) + a0 + j;
+        Q.n = J.n;
+        Q.row_anchor = J.out.row_anchor; Q.row_main = J.out.row_main; Q.row_sec = J.out.row_sec; Q.row_R = J.out.row_R;
+        Q.row_count = J.out.row_count; Q.row_Rinv = J.out.row_Rinv; Q.row_meta = J.out.row_meta;
+        Q.anc_index = J.out.anc_index; Q.anc_octave = J.out.anc_octave;
+        Q.n_rows = J.out.d_n_rows;
+        Q.order = A.order; Q.perm_off = scratch<int32_t>(ctx, S_PERM_OFF) + a0 + j; Q.row_perm = J.out.row_perm;
+        R.first[j] = (int)blk;
+        a0 += J.n;
+        blk += mad_ceil_div((int64_t)J.n * fan, 256);
+        if (J.out.d_n_reject && !J.out.counters_zeroed) MAD_HIP(hipMemsetAsync(J.out.d_n_reject, 0, 4, ctx->stream));
+    }
+    B.first[n_jobs] = (int)a0;
+    R.first[n_jobs] = (int)blk;
+    mad_timer_begin(ctx, MAD_T_ORIENT);
+    // unit gradients (SoA) + the undecided-voxel queue; with a window also the voxels' squared offsets and the weight table
+    const bool gw = ctx->gw_sig != 0.0;
+    const size_t lds = gw ? ((((size_t)ctx->mask_n * 18 + 15) & ~(size_t)15) + (size_t)(3 * r * r + 1) * 8) : (size_t)ctx->mask_n * 4 * sizeof(float);
+    if (gw) hipLaunchKernelGGL(k_orient<true>, dim3((unsigned)a0), dim3(ORI_THREADS), lds, ctx->stream, B);
+    else hipLaunchKernelGGL(k_orient<false>, dim3((unsigned)a0), dim3(ORI_THREADS), lds, ctx->stream, B);
+    mad_timer_end(ctx, MAD_T_ORIENT);
+    hipLaunchKernelGGL(k_orient_scan, dim3(n_jobs), dim3(1024), 0, ctx->stream, R);
+    hipLaunchKernelGGL(k_orient_rows, dim3((unsigned)blk), dim3(256), 0, ctx->stream, R, fan, lim_main, ctx->eq[0]);
+    MAD_HIP(hipGetLastError());
+    return MAD_OK;
+}
+
+int mad_orient_device_many(mad_ctx *ctx, int n_jobs, const OrientJob *jobs, int r, int lim_main, int lim_sec) {
     if (!ctx->eq_set[0]) return mad_fail(ctx, MAD_EINVAL, "mad_orient: orientation EQSP table not set");
     if (r < 1 || r > 10) return mad_fail(ctx, MAD_EINVAL, "mad_orient: box_side %d outside 1..10", r);
     if (lim_main < 1 || lim_main > ORI_MAX_MAIN || lim_sec < 1 || lim_main * lim_sec > ORI_MAX_FAN)
         return mad_fail(ctx, MAD_EINVAL, "mad_orient: lim_main=%d lim_sec=%d unsupported", lim_main, lim_sec);
-    if (n <= 0) {
-        if (out.counters_zeroed) return MAD_OK;
-        MAD_HIP(hipMemsetAsync(out.d_n_rows, 0, 4, ctx->stream));
-        if (out.d_n_reject) MAD_HIP(hipMemsetAsync(out.d_n_reject, 0, 4, ctx->stream));
-        return MAD_OK;
-    }
     MAD_TRY(ensure_mask(ctx, r));
-    const int Z = ctx->eq_host[0].Z;
-    const int fan = lim_main * lim_sec;
-    const bool want_hist = out.row_count != nullptr;
-    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_SLOT_CNT), (size_t)(n + 4) * 4));
-    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_SLOT_MAIN), (size_t)n * fan * 4));
-    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_SLOT_SEC), (size_t)n * fan * 4));
-    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_TMP_A), (size_t)n * fan * 4));
-    if (want_hist) MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_SLOT_HIST), (size_t)n * lim_main * Z * 4));
-    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_ROW_OFF), (size_t)(n + 2) * 4));
-
-    OrientArgs A;
-    A.f[0] = f0; A.f[1] = f1;
-    A.coords = d_coords; A.octave = d_octave; A.uniform_octave = uniform_octave;
-    A.n = n; A.r = r; A.nmask = ctx->mask_n; A.mask_off = ctx->mask_off; A.eq = ctx->eq[0];
-    A.lim_main = lim_main; A.lim_sec = lim_sec; A.fan = fan;
-    A.slot_cnt = scratch<int32_t>(ctx, S_SLOT_CNT);
-    A.n_reject = out.d_n_reject;
-    A.slot_main = scratch<int32_t>(ctx, S_SLOT_MAIN);
-    A.slot_sec = scratch<int32_t>(ctx, S_SLOT_SEC);
-    A.slot_hist = want_hist ? scratch<int32_t>(ctx, S_SLOT_HIST) : nullptr;
-    A.slot_hidx = scratch<int32_t>(ctx, S_TMP_A);
-    if (out.d_n_reject && !out.counters_zeroed) MAD_HIP(hipMemsetAsync(out.d_n_reject, 0, 4, ctx->stream));
-
-    A.wfix = nullptr;
-    if (ctx->gw_sig != 0.0) {      // Orientator(gw_sig): the window's weights for this box size, as 2^-50 fixed point
-        if (ctx->gw_r != r || ctx->gw_built != ctx->gw_sig) {
-            unsigned long long tab[3 * 10 * 10 + 1];
-            for (int d2 = 0; d2 <= 3 * r * r; d2++)
-                tab[d2] = (unsigned long long)llround(ldexp(exp(-1.0 * ((double)d2 / (2.0 * (ctx->gw_sig * ctx->gw_sig)))), ORI_WFIX_BITS));
-            if (!ctx->gw_tab && hipMalloc((void **)&ctx->gw_tab, sizeof(tab)) != hipSuccess) return mad_fail(ctx, MAD_ENOMEM, "orientation window table");
-            MAD_HIP(hipMemcpy(ctx->gw_tab, tab, sizeof(unsigned long long) * (3 * r * r + 1), hipMemcpyHostToDevice));
-            ctx->gw_r = r; ctx->gw_built = ctx->gw_sig;
+    if (ctx->gw_sig != 0.0 && (ctx->gw_r != r || ctx->gw_built != ctx->gw_sig)) {
+        // Orientator(gw_sig): the window's weights for this box size, as 2^-50 fixed point
+        unsigned long long tab[3 * 10 * 10 + 1];
+        for (int d2 = 0; d2 <= 3 * r * r; d2++)
+            tab[d2] = (unsigned long long)llround(ldexp(exp(-1.0 * ((double)d2 / (2.0 * (ctx->gw_sig * ctx->gw_sig)))), ORI_WFIX_BITS));
+        if (!ctx->gw_tab && hipMalloc((void **)&ctx->gw_tab, sizeof(tab)) != hipSuccess) return mad_fail(ctx, MAD_ENOMEM, "orientation window table");
+        MAD_HIP(hipMemcpy(ctx->gw_tab, tab, sizeof(unsigned long long) * (3 * r * r + 1), hipMemcpyHostToDevice));
+        ctx->gw_r = r; ctx->gw_built = ctx->gw_sig;
+    }
+    // jobs without anchors only have their counters reset; the others go out in batches of MAD_BATCH_MAX
+    OrientJob live[MAD_BATCH_MAX];
+    int n_live = 0;
+    for (int j = 0; j < n_jobs; j++) {
+        if (jobs[j].n <= 0) {
+            if (!jobs[j].out.counters_zeroed) {
+                MAD_HIP(hipMemsetAsync(jobs[j].out.d_n_rows, 0, 4, ctx->stream));
+                if (jobs[j].out.d_n_reject) MAD_HIP(hipMemsetAsync(jobs[j].out.d_n_reject, 0, 4, ctx->stream));
+            }
+            continue;
         }
-        A.wfix = ctx->gw_tab;
+        live[n_live++] = jobs[j];
+        if (n_live == MAD_BATCH_MAX) { MAD_TRY(orient_batch(ctx, n_live, live, r, lim_main, lim_sec)); n_live = 0; }
     }
-    mad_timer_begin(ctx, MAD_T_ORIENT);
-    // unit gradients (SoA) + the undecided-voxel queue; with a window also the voxels' squared offsets and the weight table
-    const size_t lds = A.wfix ? ((((size_t)ctx->mask_n * 18 + 15) & ~(size_t)15) + (size_t)(3 * r * r + 1) * 8) : (size_t)ctx->mask_n * 4 * sizeof(float);
-    if (A.wfix) hipLaunchKernelGGL(k_orient<true>, dim3(n), dim3(ORI_THREADS), lds, ctx->stream, A);
-    else hipLaunchKernelGGL(k_orient<false>, dim3(n), dim3(ORI_THREADS), lds, ctx->stream, A);
-    mad_timer_end(ctx, MAD_T_ORIENT);
-    int32_t *row_off = scratch<int32_t>(ctx, S_ROW_OFF);
-    if (n <= 65536) {
-        mad_scan_small(ctx, A.slot_cnt, row_off, nullptr, out.d_n_rows, n);
-    } else {
-        MAD_TRY(mad_scan_i32(ctx, A.slot_cnt, row_off, n));
-        MAD_HIP(hipMemcpyAsync(out.d_n_rows, row_off + n, 4, hipMemcpyDeviceToDevice, ctx->stream));
-    }
-    const int64_t total = (int64_t)n * fan;
-    hipLaunchKernelGGL(k_orient_rows, dim3((unsigned)mad_ceil_div(total, 256)), dim3(256), 0, ctx->stream, A.slot_cnt,
-                       A.slot_main, A.slot_sec, A.slot_hist, A.slot_hidx, row_off, n, fan, lim_main, ctx->eq[0],
-                       out.row_anchor, out.row_main, out.row_sec, out.row_R, out.row_count, out.row_Rinv, out.row_meta,
-                       out.anc_index, out.anc_octave);
-    MAD_HIP(hipGetLastError());
+    if (n_live) MAD_TRY(orient_batch(ctx, n_live, live, r, lim_main, lim_sec));
     return MAD_OK;
+}
+
+int mad_orient_device(mad_ctx *ctx, FieldDev f0, FieldDev f1, const int32_t *d_coords, const int32_t *d_octave,
+                      int uniform_octave, int n, int r, int lim_main, int lim_sec, OrientOut out) {
+    OrientJob J;
+    J.f[0] = f0; J.f[1] = f1; J.d_coords = d_coords; J.d_octave = d_octave; J.uniform_octave = uniform_octave; J.n = n; J.out = out;
+    return mad_orient_device_many(ctx, 1, &J, r, lim_main, lim_sec);
 }
 
 extern "C" int mad_set_orient_window(mad_ctx *ctx, double gw_sig) {
@@ -503,6 +612,7 @@ struct DescribeArgs {
     const int32_t *row_anchor;     // row -> anchor, or nullptr (identity)
     const double *row_R;           // n_rows x 9
     const double *row_Rinv;        // n_rows x 9: inv(Rfinal) by cofactors (mad_mat3_inv), or nullptr -> formed here
+    const int32_t *row_perm;       // nullable: the k-th workgroup takes row row_perm[k] (rows of neighbouring anchors side by side)
     const int32_t *n_rows;         // device: number of rows
     int32_t *overflow;             // device: set when the grid was too small for *n_rows
     int r;
@@ -569,7 +679,10 @@ template <int S, int NSUB> __device__ __forceinline__ int sub_of_i(int i) {
 
 #define DSC_CHUNK 8
 template <int S, int NSUB = 64>
-__global__ __launch_bounds__(DSC_THREADS, 4) void k_describe(DescribeArgs A) {
+__global__ __launch_bounds__(DSC_THREADS, 4) void k_describe(Batch<DescribeArgs> B) {
+    const int job = batch_job(B, (int)blockIdx.x);
+    const DescribeArgs &A = B.job[job];
+    const int bid = (int)blockIdx.x - B.first[job], gdim = B.first[job + 1] - B.first[job];      // this job's part of the grid (multiples of 8)
     __shared__ int hist[NSUB * 16];
     __shared__ int s_oob, s_nq;
     __shared__ double sInv[9];
@@ -583,20 +696,21 @@ __global__ __launch_bounds__(DSC_THREADS, 4) void k_describe(DescribeArgs A) {
     const int64_t n_rows = *A.n_rows;
     const int64_t chunk = (n_rows + 7) / 8;
     const int tid = threadIdx.x;
-    if (8 * chunk > (int64_t)gridDim.x) {      // the launch was sized from a stale hint: tell the host
-        if (blockIdx.x == 0 && tid == 0) *A.overflow = 1;
+    if (8 * chunk > (int64_t)gdim) {      // the launch was sized from a stale hint: tell the host
+        if (bid == 0 && tid == 0) *A.overflow = 1;
         return;
     }
     if (A.dsc8) {      // zero rows up to the next multiple of 128: the GEMM reads whole tiles
         const int64_t n_pad = (n_rows + 127) / 128 * 128;
         const int Dp = NSUB * A.eq->Z;
-        for (int64_t r = n_rows + blockIdx.x; r < n_pad; r += gridDim.x) {
+        for (int64_t r = n_rows + bid; r < n_pad; r += gdim) {
             for (int i = tid; i < Dp / 4; i += DSC_THREADS) ((int32_t *)(A.dsc8 + r * Dp))[i] = 0;
             if (tid == 0) A.norm[r] = 0.0;
         }
     }
-    const int64_t row = (int64_t)(blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
-    if ((int64_t)(blockIdx.x >> 3) >= chunk || row >= n_rows) return;
+    const int64_t work = (int64_t)(bid & 7) * chunk + (bid >> 3);
+    if ((int64_t)(bid >> 3) >= chunk || work >= n_rows) return;
+    const int64_t row = A.row_perm ? (int64_t)A.row_perm[work] : work;
     eqsp_fast_stage(A.eq, &fast);
     const int a = A.row_anchor ? A.row_anchor[row] : (int)row;
     const int oct = A.anc_octave ? A.anc_octave[a] : A.uniform_octave;
@@ -760,41 +874,61 @@ __global__ __launch_bounds__(DSC_THREADS, 4) void k_describe(DescribeArgs A) {
     }
 }
 
-int mad_describe_device(mad_ctx *ctx, FieldDev f0, FieldDev f1, const int32_t *d_anc_coords, const int32_t *d_anc_octave,
-                        int uniform_octave, const int32_t *d_row_anchor, const double *d_row_R, const double *d_row_Rinv,
-                        const int32_t *d_n_rows, int64_t grid_rows, int32_t *d_overflow, int r, int16_t *d_dsc, int8_t *d_dsc8, double *d_norm,
-                        int dsc_size) {
-    const int64_t cap_rows = grid_rows;
+int mad_describe_device_many(mad_ctx *ctx, int n_jobs, const DescribeJob *jobs, int r, int dsc_size) {
     if (dsc_size != 64 && (2 * r != 16 || (dsc_size != 27 && dsc_size != 8 && dsc_size != 1)))
         return mad_fail(ctx, MAD_EINVAL, "mad_describe: dsc_size %d (27, 8 and 1 are built for the default dsc_radius 16 only; 64 for 4 ... 16)", dsc_size);
     if (!ctx->eq_set[1]) return mad_fail(ctx, MAD_EINVAL, "mad_describe: descriptor EQSP table not set");
     if (ctx->eq_host[1].Z != 16) return mad_fail(ctx, MAD_EINVAL, "mad_describe: kernel is built for 16 descriptor zones");
     if (r < 2 || r > 8 || (r % 2)) return mad_fail(ctx, MAD_EINVAL, "mad_describe: dsc radius %d must be 2, 4, 6 or 8", r);
-    if (cap_rows <= 0) return MAD_OK;
-    for (int o = 0; o < 2; o++) {
-        const FieldDev &f = o ? f1 : f0;
-        if (f.tex && ((size_t)f.nx * f.ny * f.nz >= (size_t)1 << 32 || (size_t)f.nx * f.ny >= (size_t)1 << 24 || f.nz >= 1 << 24))
-            return mad_fail(ctx, MAD_EINVAL, "mad_describe: field of %dx%dx%d texels exceeds 2^32 (or 2^24 per x-y plane)", f.nx, f.ny, f.nz);
+    for (int j0 = 0; j0 < n_jobs; j0 += MAD_BATCH_MAX) {
+        Batch<DescribeArgs> B;
+        B.n_jobs = 0;
+        int64_t blk = 0;
+        for (int j = j0; j < n_jobs && j < j0 + MAD_BATCH_MAX; j++) {
+            const DescribeJob &J = jobs[j];
+            if (J.grid_rows <= 0) continue;
+            for (int o = 0; o < 2; o++) {
+                const FieldDev &f = J.f[o];
+                if (f.tex && ((size_t)f.nx * f.ny * f.nz >= (size_t)1 << 32 || (size_t)f.nx * f.ny >= (size_t)1 << 24 || f.nz >= 1 << 24))
+                    return mad_fail(ctx, MAD_EINVAL, "mad_describe: field of %dx%dx%d texels exceeds 2^32 (or 2^24 per x-y plane)", f.nx, f.ny, f.nz);
+            }
+            DescribeArgs &A = B.job[B.n_jobs];
+            A.f[0] = J.f[0]; A.f[1] = J.f[1];
+            A.anc_coords = J.d_anc_coords; A.anc_octave = J.d_anc_octave; A.uniform_octave = J.uniform_octave;
+            A.row_anchor = J.d_row_anchor; A.row_R = J.d_row_R; A.row_Rinv = J.d_row_Rinv; A.row_perm = J.d_row_perm; A.n_rows = J.d_n_rows; A.overflow = J.d_overflow;
+            A.r = r; A.eq = ctx->eq[1]; A.dsc = J.d_dsc; A.dsc8 = J.d_dsc8; A.norm = J.d_norm;
+            B.first[B.n_jobs++] = (int)blk;
+            blk += ((J.grid_rows + 7) / 8) * 8 + 8;      // one workgroup per possible row, a multiple of 8 per job (one share per XCD)
+            if (blk > INT32_MAX) return mad_fail(ctx, MAD_EINVAL, "mad_describe: %lld rows in one batch", (long long)blk);
+        }
+        if (B.n_jobs == 0) continue;
+        B.first[B.n_jobs] = (int)blk;
+        const unsigned nblk = (unsigned)blk;
+        mad_timer_begin(ctx, MAD_T_DESCRIBE);
+        switch (dsc_size == 64 ? 2 * r : -dsc_size) {
+            case 4: hipLaunchKernelGGL(k_describe<4>, dim3(nblk), dim3(DSC_THREADS), 0, ctx->stream, B); break;
+            case 8: hipLaunchKernelGGL(k_describe<8>, dim3(nblk), dim3(DSC_THREADS), 0, ctx->stream, B); break;
+            case 12: hipLaunchKernelGGL(k_describe<12>, dim3(nblk), dim3(DSC_THREADS), 0, ctx->stream, B); break;
+            case -27: hipLaunchKernelGGL((k_describe<16, 27>), dim3(nblk), dim3(DSC_THREADS), 0, ctx->stream, B); break;
+            case -8: hipLaunchKernelGGL((k_describe<16, 8>), dim3(nblk), dim3(DSC_THREADS), 0, ctx->stream, B); break;
+            case -1: hipLaunchKernelGGL((k_describe<16, 1>), dim3(nblk), dim3(DSC_THREADS), 0, ctx->stream, B); break;
+            default: hipLaunchKernelGGL(k_describe<16>, dim3(nblk), dim3(DSC_THREADS), 0, ctx->stream, B); break;
+        }
+        mad_timer_end(ctx, MAD_T_DESCRIBE);
+        MAD_HIP(hipGetLastError());
     }
-    DescribeArgs A;
-    A.f[0] = f0; A.f[1] = f1;
-    A.anc_coords = d_anc_coords; A.anc_octave = d_anc_octave; A.uniform_octave = uniform_octave;
-    A.row_anchor = d_row_anchor; A.row_R = d_row_R; A.row_Rinv = d_row_Rinv; A.n_rows = d_n_rows; A.overflow = d_overflow; A.r = r; A.eq = ctx->eq[1]; A.dsc = d_dsc; A.dsc8 = d_dsc8; A.norm = d_norm;
-    mad_timer_begin(ctx, MAD_T_DESCRIBE);
-    // enough workgroups to fill the chip a few times over, never more than one per possible row
-    const unsigned nblk = (unsigned)(((cap_rows + 7) / 8) * 8 + 8);      // one workgroup per possible row
-    switch (dsc_size == 64 ? 2 * r : -dsc_size) {
-        case 4: hipLaunchKernelGGL(k_describe<4>, dim3(nblk), dim3(DSC_THREADS), 0, ctx->stream, A); break;
-        case 8: hipLaunchKernelGGL(k_describe<8>, dim3(nblk), dim3(DSC_THREADS), 0, ctx->stream, A); break;
-        case 12: hipLaunchKernelGGL(k_describe<12>, dim3(nblk), dim3(DSC_THREADS), 0, ctx->stream, A); break;
-        case -27: hipLaunchKernelGGL((k_describe<16, 27>), dim3(nblk), dim3(DSC_THREADS), 0, ctx->stream, A); break;
-        case -8: hipLaunchKernelGGL((k_describe<16, 8>), dim3(nblk), dim3(DSC_THREADS), 0, ctx->stream, A); break;
-        case -1: hipLaunchKernelGGL((k_describe<16, 1>), dim3(nblk), dim3(DSC_THREADS), 0, ctx->stream, A); break;
-        default: hipLaunchKernelGGL(k_describe<16>, dim3(nblk), dim3(DSC_THREADS), 0, ctx->stream, A); break;
-    }
-    mad_timer_end(ctx, MAD_T_DESCRIBE);
-    MAD_HIP(hipGetLastError());
     return MAD_OK;
+}
+
+int mad_describe_device(mad_ctx *ctx, FieldDev f0, FieldDev f1, const int32_t *d_anc_coords, const int32_t *d_anc_octave,
+                        int uniform_octave, const int32_t *d_row_anchor, const double *d_row_R, const double *d_row_Rinv,
+                        const int32_t *d_n_rows, int64_t grid_rows, int32_t *d_overflow, int r, int16_t *d_dsc, int8_t *d_dsc8, double *d_norm,
+                        int dsc_size) {
+    DescribeJob J;
+    J.f[0] = f0; J.f[1] = f1; J.d_anc_coords = d_anc_coords; J.d_anc_octave = d_anc_octave; J.uniform_octave = uniform_octave;
+    J.d_row_anchor = d_row_anchor; J.d_row_R = d_row_R; J.d_row_Rinv = d_row_Rinv; J.d_n_rows = d_n_rows; J.grid_rows = grid_rows;
+    J.d_overflow = d_overflow; J.d_dsc = d_dsc; J.d_dsc8 = d_dsc8; J.d_norm = d_norm;
+    return mad_describe_device_many(ctx, 1, &J, r, dsc_size);
 }
 
 extern "C" int mad_describe(mad_ctx *ctx, int slot, int octave, const int32_t *coords, const double *R, int64_t n_rows,

@@ -297,9 +297,18 @@ class ShardedSetBuild(object):
             self.lib.synchronize()
             tmp.close()
 
+    def build_job(self):
+        """The (slots, coords, octave, subv, index, into) of this rank's part, for `lib.prepare_build_many`: the caller builds
+        it in one batch with its other structures and then calls `finish()`."""
+        if not self.sharded:
+            return (self.slots, self.coords, self.octave, self.subv, self.index, self.full)
+        if self.cap_rows is None:
+            self.resize()
+        sel = self.mine
+        return (self.slots, self.coords[sel], self.octave[sel], self.subv[sel], self.index[sel], self.share)
+
     def enqueue(self):
         """-> the full DeviceSet (asynchronous on RCCL; complete on return with gloo)."""
-        import torch
         lib = self.lib
         if not self.sharded:
             return lib.set_build(self.slots, self.coords, self.octave, self.subv, self.index, self.r, self.lim_main, self.lim_sec, into=self.full)
@@ -308,6 +317,15 @@ class ShardedSetBuild(object):
         import time
         tb = time.perf_counter()
         self._build_share()
+        self.host_s["build_share"] += time.perf_counter() - tb
+        return self.finish()
+
+    def finish(self):
+        """What follows the build of the share: export, all-gather, import -> the full DeviceSet."""
+        import torch
+        lib = self.lib
+        if not self.sharded:
+            return self.full
         nbytes = self.wire.numel()
         if self.backend == "gloo":
             import torch.distributed as dist
@@ -330,7 +348,7 @@ class ShardedSetBuild(object):
         t2 = time.perf_counter()
         out = lib.set_import(self.world, self.cap_rows, self.coords, self.octave, self.subv, self.index, device_ptr=self.gathered.data_ptr(), into=self.full)
         t3 = time.perf_counter()
-        T["export"] += t1 - t0; T["collective"] += t2 - t1; T["import"] += t3 - t2; T["build_share"] += t0 - tb; T["calls"] += 1
+        T["export"] += t1 - t0; T["collective"] += t2 - t1; T["import"] += t3 - t2; T["calls"] += 1
         return out
 
     def close(self):

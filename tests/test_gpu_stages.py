@@ -575,6 +575,66 @@ def test_sharded_match_equals_unsharded(lib, world):
     lib.free_field(slot)
 
 
+@pytest.mark.parametrize("n_sets", [1, 5, 19])
+def test_sets_built_in_one_batch_equal_sets_built_one_by_one(lib, fields, n_sets):
+    """mad_set_build_many: the anchors of several structures (different fields, one or both octaves, an empty list, border
+    rejects) through ONE k_orient / scan / row-expansion / k_describe launch each: every set is bit for bit the set mad_set_build
+    makes on its own, also when the batch is rebuilt in place with other anchors (stale launch-size hints) and when there are
+    more structures than one batch of kernel arguments holds (19 > 16)."""
+    f0, f1 = fields[0], fields[1]
+    rng = np.random.default_rng(40 + n_sets)
+
+    def job(i, shrink=0):
+        kind = i % 4
+        a0 = _anchors(f0["shape"], 0, 24 + 3 * (i % 5) - shrink, 100 + i)
+        a1 = _anchors(f1["shape"], 1, 30 + 2 * (i % 7) - shrink, 200 + i)
+        if kind == 1:
+            a0 = a0[:0]
+        if kind == 2:
+            a1 = a1[:0]
+        if kind == 3 and i > 3:
+            a0, a1 = a0[:0], a1[:0]      # a structure without anchors
+        coords = np.concatenate([a0, a1]).astype(np.int32)
+        octave = np.concatenate([np.zeros(len(a0), np.int32), np.ones(len(a1), np.int32)])
+        subv = coords * np.where(octave[:, None] == 0, 0.75, 1.5) + rng.normal(scale=0.2, size=coords.shape)
+        slots = [f0["slot"] if kind != 1 else -1, f1["slot"] if kind != 2 else -1]
+        return (slots, coords, octave, subv, np.arange(len(coords), dtype=np.int32) + 10 * i)
+
+    jobs = [job(i) for i in range(n_sets)]
+    batch = lib.set_build_many(jobs)
+    assert len(batch) == n_sets
+    total = 0
+    for i, (j, got) in enumerate(zip(jobs, batch)):
+        one = lib.set_build(*j)
+        assert got.size() == one.size(), "set %d" % i
+        total += one.size()[0]
+        a, b = got.download(), one.download()
+        for key in ("anchor", "main", "sec", "R", "dsc"):
+            np.testing.assert_array_equal(a[key], b[key], err_msg="set %d: %s" % (i, key))
+        one.close()
+    assert total > 40 * n_sets
+    # the same sets rebuilt in place, with fewer / other anchors (and set 0 matched against set 1 afterwards)
+    jobs2 = [job(i + 1, shrink=6) for i in range(n_sets)]
+    again = lib.set_build_many([j + (d,) for j, d in zip(jobs2, batch)])
+    for i, (j, got) in enumerate(zip(jobs2, again)):
+        one = lib.set_build(*j)
+        assert got.size() == one.size(), "rebuilt set %d" % i
+        a, b = got.download(), one.download()
+        for key in ("anchor", "main", "sec", "R", "dsc"):
+            np.testing.assert_array_equal(a[key], b[key], err_msg="rebuilt set %d: %s" % (i, key))
+        if i == 1 and n_sets > 1:
+            top_a = lib.match_topk(again[0], got, 0.3, 4.0, 20)
+            ref0 = lib.set_build(*jobs2[0])
+            top_b = lib.match_topk(ref0, one, 0.3, 4.0, 20)
+            np.testing.assert_array_equal(top_a[0], top_b[0])
+            np.testing.assert_array_equal(top_a[1], top_b[1])
+            assert top_a[2] == top_b[2]
+            ref0.close()
+        one.close()
+    for s_ in again:
+        s_.close()
+
+
 @pytest.mark.parametrize("n_shares", [1, 2, 3, 8])
 def test_set_built_in_shares_equals_unsharded(lib, fields, n_shares):
     """SURVEY.md 8(e) stage A on one GPU: the anchors of a structure (both octaves, border rejects included) dealt round-robin
