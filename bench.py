@@ -163,16 +163,18 @@ HOST_T = {}
 
 
 _BATCHES = {}
+BATCHED = {"on": os.environ.get("MAD_BUILD_BATCH", "0") == "1"}
 
 
 def enqueue_builds(lib, the_map, subs, sets):
     """orient + describe of the map and of every subunit into `sets` (device-resident, rebuilt in place); asynchronous.
     sets[0] is the map's DeviceSet, or a dist.ShardedSetBuild when the map's rows are built in shares over the ranks.
-    All structures of the step go out in ONE batch (one launch per stage, `mad_set_build_many`); MAD_BUILD_PER_SET=1 builds
-    them one `mad_set_build` each, as round 1 did (for comparison)."""
+    One `mad_set_build` per structure, each on its own lane (the default: the launches of different structures overlap and every
+    match starts as soon as its own sets are ready), or -- BATCHED (`--batched`, MAD_BUILD_BATCH=1) -- all structures of the step
+    in one `mad_set_build_many` (one launch per stage: less device time, but one long dependency chain per step)."""
     t0 = time.perf_counter()
     shared = hasattr(sets[0], "enqueue")
-    if os.environ.get("MAD_BUILD_PER_SET", "0") == "1":
+    if not BATCHED["on"]:
         if shared:
             lo = sets[0].enqueue()
         else:
@@ -407,6 +409,8 @@ def main():
     ap.add_argument("--in-flight", type=int, default=3, choices=(2, 3), help="steps in flight (groups of device sets)")
     ap.add_argument("--serial", action="store_true", help="lanes serialised for the whole run: the mode the rocprofv3 summaries in profiles/ are "
                     "taken in, so that a kernel's average duration there is the one the roofline pass measures")
+    ap.add_argument("--batched", action="store_true", help="one launch per stage for all structures of a step (mad_set_build_many) and one GEMM "
+                    "grid for all its matches (mad_set_batching): less device time per step, longer dependency chains")
     ap.add_argument("--emulate-rank-of", type=int, default=0, metavar="N", help="REHEARSAL on one GPU: do the per-step work of rank 0 of an N-rank "
                     "job (its share of the map build, the import of all N shares, its subunits); the other ranks' map rows are built once, untimed.  "
                     "The line is labelled as an estimate and is not a multi-GPU measurement")
@@ -493,6 +497,10 @@ def main():
     sets = set_groups[0]
     if args.serial:
         lib.set_overlap(False)
+    if args.batched:
+        BATCHED["on"] = True
+    if BATCHED["on"]:
+        lib.set_batching(True)
     # Setup, not a step: all groups of device sets are created, sized and given their launch-size hints here (a set sizes
     # its describe grid and a match its pair capacity from what the previous use of the same objects needed; the wire images
     # of a sharded map build are sized by a blocking first build), the way an allocator is warmed before a run.  The W
@@ -711,6 +719,8 @@ def main():
                        "parallelism": ("1 process per GPU over RCCL: map anchors dealt round-robin (orient + describe), all-gather of the rows; "
                                        "subunits dealt round-robin (correlate + pose + top-k), all-gather of the top-k poses") if world > 1 else "single GPU",
                        "pipelining": "%d steps in flight: the builds (and, with 3, the matches) of the next step are enqueued before the results of a step are awaited; every step does the full work" % args.in_flight,
+                       "launches": ("batched: one launch per stage for all structures of a step, one GEMM grid for all its matches" if BATCHED["on"]
+                                    else "one mad_set_build per structure and one GEMM per match, each on its own lane (batched alternative: --batched)"),
                        "latency_note": "latency_ms_single_step = one step submitted alone (lanes overlapped, nothing else in flight, result exchange included), median of %d; ms_per_step = throughput of identical steps, %d in flight" % (len(lat), args.in_flight),
                        "topk_agrees_with_cpu_oracle": agree_whole if agree_whole is not None else agree,
                        "topk_agrees_with_cpu_oracle_on": None if agree is None else ("every anchor of both octaves, all subunits (the full step) and the base-octave sample" if agree_whole is not None else "the base-octave sample"),

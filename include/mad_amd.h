@@ -233,6 +233,11 @@ int mad_match_topk_many(mad_ctx *ctx, int n, const mad_set *const *hi, const mad
 int mad_match_topk_many_begin(mad_ctx *ctx, int n, const mad_set *const *hi, const mad_set *lo, double cc, double dist,
                               int64_t k, double *results, int64_t *pair_index, int64_t *n_out, int64_t *stats);
 int mad_match_topk_many_finish(mad_ctx *ctx);
+/* on != 0: mad_match_topk_many(_begin) computes the score tiles of all matches of a bracket (first match of every lane) in ONE
+ * GEMM grid -- fewer, fuller launches (C3: 0.151 -> 0.106 ms of device time per step) at the price of every match waiting for
+ * the slowest set; off (default): one GEMM per match, each on its own lane, which overlaps better when several lanes are busy
+ * (1.07 against 1.21 ms per overlapped C3 step).  Results are identical either way. */
+int mad_set_batching(mad_ctx *ctx, int on);
 
 /*
  * Which pose-scoring kernel the most recently enqueued match used: 0 = k_pose_lds (both clouds in LDS as float64),

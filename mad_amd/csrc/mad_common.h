@@ -139,6 +139,7 @@ struct mad_ctx {
     hipStream_t lane_stream[MAD_LANES] = {};      // [0] is the stream mad_stream() reports
     int next_set_lane = 0;
     bool overlap = true;                      // false: every lane enqueues on lane_stream[0] (kernels run one at a time)
+    bool batch_gemm = false;                  // mad_match_topk_many: the GEMMs of a bracket's matches in one launch (mad_set_batching)
     bool spatial_order = true;                // the build kernels take anchors / rows in Morton order (MAD_NO_SPATIAL_ORDER: list order)
     char err[512] = {0};
     FieldDev fields[MAD_MAX_FIELDS];
@@ -158,6 +159,8 @@ struct mad_ctx {
     // two result slots per lane: one per open mad_match_topk_many bracket, so that a second batch of matches can be enqueued
     // (and deliver into its own pinned staging) before the first one has been collected
     hipEvent_t lane_done[2][MAD_LANES]; // recorded behind the last operation a bracket enqueued in each lane
+    hipEvent_t lane_pre[MAD_LANES];     // mad_match_topk_many: a lane is ready for the bracket's common GEMM
+    hipEvent_t gemm_done[2];            // ... and that GEMM has been enqueued (per open bracket)
     void *host_res[2][MAD_LANES] = {};   // pinned staging of a match's results / indices / status
     size_t host_res_cap[2][MAD_LANES] = {};
     int res_slot = 0;                    // the slot the match calls below read and write
@@ -214,6 +217,21 @@ struct mad_set {
     int cell_dim[3] = {0, 0, 0};
     bool cells_ready = false;
 };
+
+// Several jobs (the anchor lists of several structures) in ONE grid: job j owns the workgroups first[j] .. first[j + 1] - 1.
+// The tables travel in the kernel arguments, so a workgroup finds its job with a few scalar compares and reads that job's
+// arguments with scalar loads.
+#define MAD_BATCH_MAX 16
+template <class Args> struct Batch {
+    int n_jobs;
+    int first[MAD_BATCH_MAX + 1];
+    Args job[MAD_BATCH_MAX];
+};
+template <class Args> __device__ __forceinline__ int batch_job(const Batch<Args> &B, int block) {
+    int j = 0;
+    while (j + 1 < B.n_jobs && block >= B.first[j + 1]) j++;
+    return j;
+}
 
 // scratch slots
 enum {

@@ -60,6 +60,7 @@ extern "C" int mad_init(int device, mad_ctx **out) {
                         prop.gcnArchName);
     mad_ctx *ctx = new mad_ctx();
     ctx->spatial_order = getenv("MAD_NO_SPATIAL_ORDER") == nullptr;      // diagnostic switch: build in list order
+    ctx->batch_gemm = getenv("MAD_GEMM_BATCH") != nullptr;
     ctx->device = device;
     ctx->n_cu = prop.multiProcessorCount;
     for (int i = 0; i < MAD_MAX_FIELDS; i++) {
@@ -84,6 +85,8 @@ extern "C" int mad_init(int device, mad_ctx **out) {
         }
     for (int r = 0; r < 2; r++)
         for (int l = 0; l < MAD_LANES; l++) (void)hipEventCreateWithFlags(&ctx->lane_done[r][l], hipEventDisableTiming);
+    for (int l = 0; l < MAD_LANES; l++) (void)hipEventCreateWithFlags(&ctx->lane_pre[l], hipEventDisableTiming);
+    for (int r = 0; r < 2; r++) (void)hipEventCreateWithFlags(&ctx->gemm_done[r], hipEventDisableTiming);
     *out = ctx;
     return MAD_OK;
 }
@@ -108,7 +111,9 @@ extern "C" void mad_destroy(mad_ctx *ctx) {
             (void)hipEventDestroy(ctx->timers[g].start[i]);
             (void)hipEventDestroy(ctx->timers[g].stop[i]);
         }
+    for (int r = 0; r < 2; r++) (void)hipEventDestroy(ctx->gemm_done[r]);
     for (int l = 0; l < MAD_LANES; l++) {
+        (void)hipEventDestroy(ctx->lane_pre[l]);
         for (int r = 0; r < 2; r++) {
             (void)hipEventDestroy(ctx->lane_done[r][l]);
             if (ctx->host_res[r][l]) (void)hipHostFree(ctx->host_res[r][l]);

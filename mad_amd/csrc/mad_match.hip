@@ -96,6 +96,10 @@ __global__ void k_row_aux(const double *__restrict__ row_R, const int32_t *__res
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 
+// the low (ll) / high (hh) 16 bits of two scalar words side by side: one scalar instruction each
+__device__ __forceinline__ unsigned s_pack_ll(unsigned a, unsigned b) { unsigned r; asm("s_pack_ll_b32_b16 %0, %1, %2" : "=s"(r) : "s"(a), "s"(b)); return r; }
+__device__ __forceinline__ unsigned s_pack_hh(unsigned a, unsigned b) { unsigned r; asm("s_pack_hh_b32_b16 %0, %1, %2" : "=s"(r) : "s"(a), "s"(b)); return r; }
+
 // persistent over 128 x 128 tiles; the row counts (hence the tile grid and ldc) are read on the device
 //
 // Epilogue: besides the int32 dot products, every tile leaves one bit per correlation in `mask` ([row][ldc / 32]
@@ -214,8 +218,10 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_corr_gemm(const int8_t *__rest
                     }
                 }
                 // bits 16 g .. 16 g + 15 of a ballot = row group g (= lane >> 4), columns n * 16 ..: word (g, h) = columns 32 h .. 32 h + 31
+                // = the g-th 16-bit piece of ballot 2 h beside that of ballot 2 h + 1: one s_pack each
                 int w = 0;
-#define MAD_MASK_WORD(G, Hh) (((unsigned)(bal[2 * (Hh)] >> (16 * (G))) & 0xffffu) | (((unsigned)(bal[2 * (Hh) + 1] >> (16 * (G))) & 0xffffu) << 16))
+#define MAD_MASK_WORD(G, Hh) ((G) & 1 ? s_pack_hh((unsigned)(bal[2 * (Hh)] >> (32 * ((G) >> 1))), (unsigned)(bal[2 * (Hh) + 1] >> (32 * ((G) >> 1)))) \
+                                      : s_pack_ll((unsigned)(bal[2 * (Hh)] >> (32 * ((G) >> 1))), (unsigned)(bal[2 * (Hh) + 1] >> (32 * ((G) >> 1)))))
 #define MAD_WRITELANE(G, Hh, LANE) asm volatile("v_writelane_b32 %0, %1, " #LANE : "+v"(w) : "s"(MAD_MASK_WORD(G, Hh)))
                 MAD_WRITELANE(0, 0, 0); MAD_WRITELANE(1, 0, 1); MAD_WRITELANE(2, 0, 2); MAD_WRITELANE(3, 0, 3);
                 MAD_WRITELANE(0, 1, 4); MAD_WRITELANE(1, 1, 5); MAD_WRITELANE(2, 1, 6); MAD_WRITELANE(3, 1, 7);
@@ -224,6 +230,200 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_corr_gemm(const int8_t *__rest
                 if (lane < 8) Mt[moff + (unsigned)(m * 16 + j) * ldm32] = (unsigned)w;
             }
         __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------
+// The same contraction, second form: 256 x 128 tiles (a wave owns 128 x 64: 12 fragment reads per 32 MFMAs instead of 8 per
+// 16), operands staged global -> LDS by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write pass), three
+// stages of 64 bytes of K in a ring with ONE barrier per stage and the loads of two stages in flight across it, and the tiles of
+// SEVERAL matches (jobs) in one persistent grid: the matches of a step share the lo (map) rows, and the ~570 tiles of one
+// match do not divide over 512 resident workgroups, the ~2 300 of four do.
+//
+// LDS image of a stage: 24 blocks of 16 rows x 64 B (16 of A, 8 of B), each written by one wave-instruction (lane l: row
+// l / 4, 16-byte position l % 4) and read back as one MFMA fragment (lane L: row L % 16, K chunk L / 16).  Rows are 64 B
+// apart, so rows r and r + 4 share banks: the chunk is stored at position chunk ^ (row / 4 % 4) -- applied to the SOURCE
+// address, because the LDS side of an LDS-DMA is lane-linear -- which makes every quarter-wave of a read hit all 64 banks once.
+// ---------------------------------------------------------------------------
+
+#define G2_BM 256
+#define G2_BN 128
+#define G2_BK 64
+#define G2_NSTAGE 3
+#define G2_STAGE ((G2_BM + G2_BN) * G2_BK)
+#define G2_LDS (G2_NSTAGE * G2_STAGE + (G2_BM + G2_BN) * 4)
+
+struct GemmJob {
+    const int8_t *A, *B;           // hi rows, lo rows (int8, K bytes each, zero-padded to multiples of 128 rows)
+    int32_t *C;
+    const int32_t *n_hi, *n_lo;    // device: row counts
+    int64_t cap_c;
+    int32_t *status;
+    const double *hn, *ln;
+    uint32_t *mask;
+};
+struct GemmBatch {
+    int n_jobs;
+    int K;
+    double cc;
+    GemmJob job[MAD_BATCH_MAX];
+};
+
+__device__ __forceinline__ void glds16(const int8_t *g, int8_t *l) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g, (__attribute__((address_space(3))) void *)l, 16, 0, 0);
+}
+
+#ifdef MAD_PROBE_STAMPS      // diagnostic build: s_memtime at the phases of each workgroup's first tile (tools/probe_gemm.py)
+__device__ long long g2_stamps[1024 * 8];
+#define G2_STAMP(k) do { if (tid == 0 && first_tile) g2_stamps[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+extern "C" int mad_debug_g2_stamps(long long *out, int n) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g2_stamps), (size_t)n * 8) == hipSuccess ? 0 : -1;
+}
+#else
+#define G2_STAMP(k) do { } while (0)
+#endif
+
+__global__ __launch_bounds__(GEMM_THREADS, 2) void k_corr_gemm2(GemmBatch G) {
+    extern __shared__ __align__(16) int8_t g2_smem[];      // the stages and, behind them, the norms of the tile: ONE object
+    float *sT = (float *)(g2_smem + G2_NSTAGE * G2_STAGE);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wm = w >> 1, wn = w & 1;
+    const int K = G.K, n_k = K / G2_BK;
+    const int xcd = blockIdx.x & 7;
+    const int64_t nslot = gridDim.x >> 3;
+    int64_t t = blockIdx.x >> 3, base = 0;
+#ifdef MAD_PROBE_STAMPS
+    bool first_tile = true;
+#endif
+    G2_STAMP(0);
+    const int ld_row = lane >> 2, ld_chunk = ((lane & 3) ^ ((lane >> 4) & 3)) * 16;
+    const int rd_off = (lane & 15) * 64 + ((((lane >> 4) ^ ((lane & 15) >> 2)) & 3) * 16);
+    for (int j = 0; j < G.n_jobs; j++) {
+        const GemmJob &J = G.job[j];
+        const int64_t hp = ((int64_t)*J.n_hi + 127) / 128 * 128, lp = ((int64_t)*J.n_lo + 127) / 128 * 128;
+        if (hp * lp > J.cap_c) {
+            if (blockIdx.x == 0 && tid == 0) J.status[ST_FLAG_C] = 1;
+            continue;
+        }
+        // XCD x takes a contiguous run of the job's tiles in column-major order: ~1/8 of the lo rows against all hi rows, for
+        // every job of the batch in turn -- the lo slice stays in its L2 from one match to the next
+        const int64_t tiles_m = (hp + G2_BM - 1) / G2_BM, tiles = tiles_m * (lp / G2_BN), per_xcd = (tiles + 7) / 8;
+        const int64_t begin = per_xcd * xcd, end = begin + per_xcd < tiles ? begin + per_xcd : tiles;
+        const int64_t cnt = end > begin ? end - begin : 0;
+        const int64_t ldm = lp / 32;
+        for (; t < base + cnt; t += nslot) {
+            const int64_t tile = begin + (t - base);
+            const int64_t row0 = (tile % tiles_m) * G2_BM, col0 = (tile / tiles_m) * G2_BN;
+            G2_STAMP(1);
+            // |h| per row, cc |l| per column (zero rows count as norm 1, MaD.py:416).  Plain loads, before any LDS-DMA is in
+            // flight: the compiler drains the vector-memory counter completely at their first use.
+            {
+                const int64_t r = row0 + tid < hp ? row0 + tid : hp - 1;
+                const double v = J.hn[r];
+                sT[tid] = (float)(v > 0 ? v : 1.0);
+                if (tid < G2_BN) {
+                    const double u = J.ln[col0 + tid];
+                    sT[G2_BM + tid] = (float)(G.cc * (u > 0 ? u : 1.0));
+                }
+            }
+            // this lane's source rows: blocks w, w + 4, w + 8, w + 12 of A (rows past the last 128-row block of a set with an
+            // odd number of them are read from its last row and never stored), blocks w, w + 4 of B
+            const int8_t *src[6];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int64_t r = row0 + (w + 4 * i) * 16 + ld_row;
+                src[i] = J.A + (r < hp ? r : hp - 1) * K + ld_chunk;
+            }
+#pragma unroll
+            for (int i = 0; i < 2; i++) src[4 + i] = J.B + (col0 + (w + 4 * i) * 16 + ld_row) * K + ld_chunk;
+            auto issue = [&](int s) {
+                int8_t *slot = g2_smem + (s % G2_NSTAGE) * G2_STAGE;
+                const int k0 = s * G2_BK;
+#pragma unroll
+                for (int i = 0; i < 4; i++) glds16(src[i] + k0, slot + (w + 4 * i) * 1024);
+#pragma unroll
+                for (int i = 0; i < 2; i++) glds16(src[4 + i] + k0, slot + (16 + w + 4 * i) * 1024);
+            };
+            v4i acc[8][4];
+#pragma unroll
+            for (int m = 0; m < 8; m++)
+#pragma unroll
+                for (int n = 0; n < 4; n++) acc[m][n] = (v4i){0, 0, 0, 0};
+            G2_STAMP(2);
+            issue(0);
+            if (n_k > 1) issue(1);
+            for (int s = 0; s < n_k; s++) {
+                if (s == 1) G2_STAMP(3);
+                // stage s has landed (this wave's part: six instructions per stage, the next stage's six may stay in flight)
+                if (s + 1 < n_k) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();      // ... and everybody's; and everybody has read stage s - 1, whose slot is filled next
+                if (s + 2 < n_k) issue(s + 2);
+                const int8_t *slot = g2_smem + (s % G2_NSTAGE) * G2_STAGE;
+                v4i fa[8], fb[4];
+#pragma unroll
+                for (int n = 0; n < 4; n++) fb[n] = *(const v4i *)(slot + (16 + wn * 4 + n) * 1024 + rd_off);
+#pragma unroll
+                for (int m = 0; m < 8; m++) fa[m] = *(const v4i *)(slot + (wm * 8 + m) * 1024 + rd_off);
+#pragma unroll
+                for (int m = 0; m < 8; m++)
+#pragma unroll
+                    for (int n = 0; n < 4; n++)
+                        acc[m][n] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[m], fb[n], acc[m][n], 0, 0, 0);
+            }
+            G2_STAMP(4);
+            // Epilogue, as in k_corr_gemm: a candidate bit per entry (float32 test with a margin: a superset of the reference's
+            // float64 test), the int32 dot product stored for candidates only, mask words assembled on the scalar unit.
+            if (row0 + wm * 128 < hp) {
+                int32_t *Ct = J.C + row0 * lp + col0;
+                uint32_t *Mt = J.mask + row0 * ldm + col0 / 32;
+                const unsigned lp32 = (unsigned)lp, ldm32 = (unsigned)ldm;
+                // byte offsets from the tile's (uniform) base, 32-bit: a tile spans 256 rows of at most 2^20 columns
+                const unsigned voff = ((unsigned)(wm * 128 + (lane >> 4) * 4) * lp32 + (unsigned)(wn * 64 + (lane & 15))) * 4u;
+                const unsigned moff = ((unsigned)(wm * 128 + (lane & 3) * 4) * ldm32 + (unsigned)(wn * 2 + (lane >> 2))) * 4u;      // lanes 0..7: row group, word
+                float tl[4];
+#pragma unroll
+                for (int n = 0; n < 4; n++) {      // cc |l| moved towards "candidate" by the margin (|h| > 0, so the product moves with it)
+                    const float v = sT[G2_BM + wn * 64 + n * 16 + (lane & 15)];
+                    tl[n] = v - fabsf(v) * 4e-6f;
+                }
+#pragma unroll
+                for (int m = 0; m < 8; m++)
+#pragma unroll
+                    for (int jj = 0; jj < 4; jj++) {
+                        const float th = sT[wm * 128 + m * 16 + (lane >> 4) * 4 + jj];
+                        unsigned long long bal[4];
+                        // the row's offsets are formed here, on the scalar unit, and not hoisted: 64 precomputed addresses spill
+                        unsigned rc = (unsigned)(m * 16 + jj) * lp32 * 4u, rm = (unsigned)(m * 16 + jj) * ldm32 * 4u;
+                        asm volatile("" : "+s"(rc), "+s"(rm));
+                        char *crow = (char *)Ct + (voff + rc);
+#pragma unroll
+                        for (int n = 0; n < 4; n++) {
+                            const int d = acc[m][n][jj];
+                            const bool cand = (float)d > th * tl[n];
+                            bal[n] = __ballot(cand);
+                            if (bal[n] != 0ull) {
+                                if (cand) *(int32_t *)(crow + n * 64) = d;
+                            }
+                        }
+                        int wd = 0;
+#define MAD_MASK_WORD(Gg, Hh) ((Gg) & 1 ? s_pack_hh((unsigned)(bal[2 * (Hh)] >> (32 * ((Gg) >> 1))), (unsigned)(bal[2 * (Hh) + 1] >> (32 * ((Gg) >> 1)))) \
+                                        : s_pack_ll((unsigned)(bal[2 * (Hh)] >> (32 * ((Gg) >> 1))), (unsigned)(bal[2 * (Hh) + 1] >> (32 * ((Gg) >> 1)))))
+#define MAD_WRITELANE(Gg, Hh, LANE) asm volatile("v_writelane_b32 %0, %1, " #LANE : "+v"(wd) : "s"(MAD_MASK_WORD(Gg, Hh)))
+                        MAD_WRITELANE(0, 0, 0); MAD_WRITELANE(1, 0, 1); MAD_WRITELANE(2, 0, 2); MAD_WRITELANE(3, 0, 3);
+                        MAD_WRITELANE(0, 1, 4); MAD_WRITELANE(1, 1, 5); MAD_WRITELANE(2, 1, 6); MAD_WRITELANE(3, 1, 7);
+#undef MAD_WRITELANE
+#undef MAD_MASK_WORD
+                        if (lane < 8) *(uint32_t *)((char *)Mt + (moff + rm)) = (unsigned)wd;
+                    }
+            }
+            G2_STAMP(5);
+            __syncthreads();      // the norms and the last stages have been read: the next tile may overwrite them
+            G2_STAMP(6);
+#ifdef MAD_PROBE_STAMPS
+            first_tile = false;
+#endif
+        }
+        base += cnt;
     }
 }
 
@@ -1470,8 +1670,20 @@ struct Side {      // one side of a match, all device pointers
 };
 
 // correlate + compact: fills S_PAIR_*; status[ST_NPAIRS]; used flags (nullable)
-static int correlate_device(mad_ctx *ctx, const Side &hi, const Side &lo, int D, double cc, int32_t *d_status, int64_t cap_c,
-                            int64_t cap_pairs, uint8_t *d_used_hi, uint8_t *d_used_lo) {
+static int gemm2_launch(mad_ctx *ctx, const GemmBatch &G) {
+    static bool attr = false;
+    if (!attr) {
+        MAD_HIP(hipFuncSetAttribute((const void *)k_corr_gemm2, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS));
+        attr = true;
+    }
+    hipLaunchKernelGGL(k_corr_gemm2, dim3(ctx->n_cu * 2), dim3(GEMM_THREADS), G2_LDS, ctx->stream, G);      // persistent: two per CU
+    return MAD_OK;
+}
+
+// The correlation stage in three pieces, so that the GEMMs of several matches can go out as ONE launch (mad_match_topk_many):
+// the scratch of this lane sized and the GEMM's arguments filled in; the GEMM; threshold + ordered compaction of the pairs.
+static int correlate_reserve(mad_ctx *ctx, const Side &hi, const Side &lo, int D, double cc, int32_t *d_status, int64_t cap_c,
+                             int64_t cap_pairs, GemmJob *job) {
     if (D % GEMM_BK) return mad_fail(ctx, MAD_EINVAL, "correlate: D = %d is not a multiple of %d", D, GEMM_BK);
     if (hi.cap_rows > 65000) return mad_fail(ctx, MAD_EINVAL, "correlate: %lld hi rows exceed the single-launch scan", (long long)hi.cap_rows);
     MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_CMAT), (size_t)cap_c * 4));
@@ -1481,12 +1693,35 @@ static int correlate_device(mad_ctx *ctx, const Side &hi, const Side &lo, int D,
     MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_PAIR_LO), (size_t)cap_pairs * 4));
     MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_PAIR_SCORE), (size_t)cap_pairs * 8));
     MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_CMASK), (size_t)cap_c / 8 + 64));
+    *job = GemmJob{hi.dsc8, lo.dsc8, scratch<int32_t>(ctx, S_CMAT), hi.n_rows, lo.n_rows, cap_c, d_status, hi.norm, lo.norm,
+                   scratch<uint32_t>(ctx, S_CMASK)};
+    return MAD_OK;
+}
+
+static int correlate_gemm(mad_ctx *ctx, int n_jobs, const GemmJob *jobs, int D, double cc) {
+    static const bool old_gemm = getenv("MAD_GEMM_V1") != nullptr;      // diagnostic switch: the 128 x 128 register-staged kernel
+    mad_timer_begin(ctx, MAD_T_CORRELATE);
+    for (int j0 = 0; j0 < n_jobs; j0 += MAD_BATCH_MAX) {
+        if (old_gemm) {
+            for (int j = j0; j < n_jobs && j < j0 + MAD_BATCH_MAX; j++)
+                hipLaunchKernelGGL(k_corr_gemm, dim3(ctx->n_cu * 4), dim3(GEMM_THREADS), 0, ctx->stream, jobs[j].A, jobs[j].B, D, jobs[j].C,
+                                   jobs[j].n_hi, jobs[j].n_lo, jobs[j].cap_c, jobs[j].status, jobs[j].hn, jobs[j].ln, cc, jobs[j].mask);
+            continue;
+        }
+        GemmBatch G;
+        G.n_jobs = std::min(n_jobs - j0, MAD_BATCH_MAX); G.K = D; G.cc = cc;
+        for (int j = 0; j < G.n_jobs; j++) G.job[j] = jobs[j0 + j];
+        MAD_TRY(gemm2_launch(ctx, G));
+    }
+    mad_timer_end(ctx, MAD_T_CORRELATE);
+    MAD_HIP(hipGetLastError());
+    return MAD_OK;
+}
+
+static int correlate_pairs(mad_ctx *ctx, const Side &hi, const Side &lo, double cc, int32_t *d_status, int64_t cap_pairs, uint8_t *d_used_hi,
+                           uint8_t *d_used_lo) {
     int32_t *C = scratch<int32_t>(ctx, S_CMAT);
     uint32_t *mask = scratch<uint32_t>(ctx, S_CMASK);
-    mad_timer_begin(ctx, MAD_T_CORRELATE);
-    hipLaunchKernelGGL(k_corr_gemm, dim3(ctx->n_cu * 4), dim3(GEMM_THREADS), 0, ctx->stream, hi.dsc8, lo.dsc8, D, C, hi.n_rows,
-                       lo.n_rows, cap_c, d_status, hi.norm, lo.norm, cc, mask);
-    mad_timer_end(ctx, MAD_T_CORRELATE);
     mad_timer_begin(ctx, MAD_T_PAIRS);
     hipLaunchKernelGGL(k_pair_count, dim3(ctx->n_cu * 8), dim3(256), 0, ctx->stream, C, mask, hi.n_rows, lo.n_rows, hi.norm, lo.norm, cc,
                        scratch<int32_t>(ctx, S_ROWCNT), d_status);
@@ -1498,6 +1733,14 @@ static int correlate_device(mad_ctx *ctx, const Side &hi, const Side &lo, int D,
     mad_timer_end(ctx, MAD_T_PAIRS);
     MAD_HIP(hipGetLastError());
     return MAD_OK;
+}
+
+static int correlate_device(mad_ctx *ctx, const Side &hi, const Side &lo, int D, double cc, int32_t *d_status, int64_t cap_c,
+                            int64_t cap_pairs, uint8_t *d_used_hi, uint8_t *d_used_lo) {
+    GemmJob job;
+    MAD_TRY(correlate_reserve(ctx, hi, lo, D, cc, d_status, cap_c, cap_pairs, &job));
+    MAD_TRY(correlate_gemm(ctx, 1, &job, D, cc));
+    return correlate_pairs(ctx, hi, lo, cc, d_status, cap_pairs, d_used_hi, d_used_lo);
 }
 
 // Workgroups of the persistent pose search per CU.  Two fill a CU completely (16 waves x 64 registers per SIMD, 130 KB of
@@ -2258,16 +2501,24 @@ static size_t zero_bytes(const mad_set *hi, const mad_set *lo) {
 }
 static size_t tail_bytes(int64_t k) { return (size_t)k * (MAD_RESULT_COLS * 8 + 8) + ST_COUNT * 4; }
 
-static int match_enqueue(mad_ctx *ctx, const mad_set *hi, const mad_set *lo, double cc, double dist, const MatchPlan &P) {
+// A match is enqueued in two halves: what precedes the GEMM (waits, zeroed status, the GEMM's arguments) and what follows it.
+// Between them the caller launches the GEMM -- of this match alone, or of all matches of a bracket in one grid.
+static int match_enqueue_head(mad_ctx *ctx, const mad_set *hi, const mad_set *lo, double cc, const MatchPlan &P, GemmJob *job) {
     int32_t *st = zero_status(ctx);
-    int32_t *hist = zr_hist(st);
-    uint8_t *used_hi = zr_used_hi(st, hi->n_anchors), *used_lo = zr_used_lo(st, hi->n_anchors);
     const Side H = side_of(hi), L = side_of(lo);
     // the sets may have been built on other lanes
     MAD_HIP(hipStreamWaitEvent(ctx->stream, hi->built, 0));
     MAD_HIP(hipStreamWaitEvent(ctx->stream, lo->built, 0));
     mad_zero_words(ctx, st, zero_bytes(hi, lo));      // status, histogram and flags in one launch
-    MAD_TRY(correlate_device(ctx, H, L, hi->D, cc, st, P.cap_c, P.cap_pairs, used_hi, used_lo));
+    return correlate_reserve(ctx, H, L, hi->D, cc, st, P.cap_c, P.cap_pairs, job);
+}
+
+static int match_enqueue_tail(mad_ctx *ctx, const mad_set *hi, const mad_set *lo, double cc, double dist, const MatchPlan &P) {
+    int32_t *st = zero_status(ctx);
+    int32_t *hist = zr_hist(st);
+    uint8_t *used_hi = zr_used_hi(st, hi->n_anchors), *used_lo = zr_used_lo(st, hi->n_anchors);
+    const Side H = side_of(hi), L = side_of(lo);
+    MAD_TRY(correlate_pairs(ctx, H, L, cc, st, P.cap_pairs, used_hi, used_lo));
     // clouds: anchors that take part in at least one pair (MaD.py:427-428)
     const CloudJob job = {(const double *)hi->anc_subv.p, used_hi, hi->n_anchors, scratch<double>(ctx, S_HI_CLOUD), st + ST_LHI,
                           (const int32_t *)hi->dev_n.p, (const int32_t *)lo->dev_n.p, st};      // compacted by the first pose kernel
@@ -2303,6 +2554,13 @@ static int match_enqueue(mad_ctx *ctx, const mad_set *hi, const mad_set *lo, dou
     MAD_HIP(hipMemcpyAsync(ctx->host_res[ctx->res_slot][ctx->lane], mad_sb(ctx, S_RESULTS).p, tail_bytes(P.k), hipMemcpyDeviceToHost, ctx->stream));
     MAD_HIP(hipEventRecord(ctx->lane_done[ctx->res_slot][ctx->lane], ctx->stream));
     return MAD_OK;
+}
+
+static int match_enqueue(mad_ctx *ctx, const mad_set *hi, const mad_set *lo, double cc, double dist, const MatchPlan &P) {
+    GemmJob job;
+    MAD_TRY(match_enqueue_head(ctx, hi, lo, cc, P, &job));
+    MAD_TRY(correlate_gemm(ctx, 1, &job, hi->D, cc));
+    return match_enqueue_tail(ctx, hi, lo, cc, dist, P);
 }
 
 static int match_prepare(mad_ctx *ctx, const mad_set *hi, const mad_set *lo, double dist, int64_t k, MatchPlan *P) {
@@ -2475,12 +2733,53 @@ extern "C" int mad_match_topk_many_begin(mad_ctx *ctx, int n, const mad_set *con
     for (int l = 0; l < MAD_LANES; l++) M.pending[l] = -1;
     ctx->many[M.slot] = Mp;
     int rc_all = MAD_OK;
+    // The first match of every lane goes out in a batch: each lane enqueues what precedes its GEMM, ONE grid then computes the
+    // score tiles of all of them (they share the lo rows, and together their tiles fill the chip's workgroup slots evenly), and
+    // each lane continues behind it with its own pairs, poses and top-k.  Matches that find their lane taken wait their turn below.
+    // Off unless asked for (mad_set_batching): with the lanes overlapped, four separate GEMM launches fill each other's tails and
+    // leave every match free to start as soon as its own sets are ready -- measured on C3: one batched launch 0.106 ms of device
+    // time per step against 0.151 for four, but 1.21 ms per overlapped step against 1.07.
+    const bool no_batch = !ctx->batch_gemm;
+    std::vector<int> batch;
+    std::vector<GemmJob> jobs;
+    bool taken[MAD_LANES] = {};
     for (int i = 0; i < n && rc_all == MAD_OK; i++) {
         n_out[i] = 0;
         if (stats) { stats[4 * i] = stats[4 * i + 1] = stats[4 * i + 2] = stats[4 * i + 3] = 0; }
         if (!hi[i]) { rc_all = mad_fail(ctx, MAD_EINVAL, "mad_match_topk_many: set %d is NULL", i); break; }
-        if (match_trivial(hi[i], lo)) continue;
-        const int lane = hi[i]->lane;      // where its hi set was built: no cross-lane wait for it, and the matches spread like the sets
+        if (match_trivial(hi[i], lo) || no_batch) continue;
+        const int lane = hi[i]->lane;      // where its hi set was built: the matches spread over the lanes like the sets
+        if (taken[lane] || hi[i]->D != hi[0]->D) continue;
+        taken[lane] = true;
+        mad_use_lane(ctx, lane);
+        rc_all = match_prepare(ctx, hi[i], lo, dist, k, &M.plans[lane]);
+        if (rc_all != MAD_OK) break;
+        GemmJob job;
+        rc_all = match_enqueue_head(ctx, hi[i], lo, cc, M.plans[lane], &job);
+        if (rc_all != MAD_OK) break;
+        MAD_HIP(hipEventRecord(ctx->lane_pre[lane], ctx->stream));
+        batch.push_back(i);
+        jobs.push_back(job);
+    }
+    if (rc_all == MAD_OK && !batch.empty()) {
+        const int g = hi[batch[0]]->lane;
+        mad_use_lane(ctx, g);
+        for (int i : batch)
+            if (hi[i]->lane != g) MAD_HIP(hipStreamWaitEvent(ctx->stream, ctx->lane_pre[hi[i]->lane], 0));
+        rc_all = correlate_gemm(ctx, (int)jobs.size(), jobs.data(), hi[batch[0]]->D, cc);
+        if (rc_all == MAD_OK) MAD_HIP(hipEventRecord(ctx->gemm_done[M.slot], ctx->stream));
+        for (size_t b = 0; b < batch.size() && rc_all == MAD_OK; b++) {
+            const int i = batch[b], lane = hi[i]->lane;
+            mad_use_lane(ctx, lane);
+            if (lane != g) MAD_HIP(hipStreamWaitEvent(ctx->stream, ctx->gemm_done[M.slot], 0));
+            rc_all = match_enqueue_tail(ctx, hi[i], lo, cc, dist, M.plans[lane]);
+            M.pending[lane] = i;
+        }
+    }
+    for (int i = 0; i < n && rc_all == MAD_OK; i++) {
+        if (!hi[i] || match_trivial(hi[i], lo)) continue;
+        if (std::find(batch.begin(), batch.end(), i) != batch.end()) continue;
+        const int lane = hi[i]->lane;
         rc_all = many_retire(ctx, M, lane);
         if (rc_all != MAD_OK) break;
         mad_use_lane(ctx, lane);
@@ -2500,6 +2799,12 @@ extern "C" int mad_match_topk_many_begin(mad_ctx *ctx, int n, const mad_set *con
     }
     ctx->res_slot = 0;
     return rc_all;
+}
+
+extern "C" int mad_set_batching(mad_ctx *ctx, int on) {
+    if (!ctx) return MAD_EINVAL;
+    ctx->batch_gemm = on != 0;
+    return MAD_OK;
 }
 
 extern "C" int mad_last_pose_kernel(mad_ctx *ctx) { return ctx ? ctx->last_pose_kernel : -1; }

@@ -77,20 +77,6 @@ struct OrientArgs {
 };
 #define ORI_WFIX_BITS 50
 
-// Several jobs (the anchor lists of several structures) in ONE grid: job j owns the workgroups first[j] .. first[j + 1] - 1.
-// The tables travel in the kernel arguments, so a workgroup finds its job with a few scalar compares and reads that job's
-// arguments with scalar loads.
-#define MAD_BATCH_MAX 16
-template <class Args> struct Batch {
-    int n_jobs;
-    int first[MAD_BATCH_MAX + 1];
-    Args job[MAD_BATCH_MAX];
-};
-template <class Args> __device__ __forceinline__ int batch_job(const Batch<Args> &B, int block) {
-    int j = 0;
-    while (j + 1 < B.n_jobs && block >= B.first[j + 1]) j++;
-    return j;
-}
 
 // Quantise `hist` (Z counts in LDS) to 0..50 of its max (Orientator.py:336-340) into q.
 // Executed by wave 0 only; returns the max (0 = nothing counted, q left = hist).
@@ -777,7 +763,22 @@ __global__ __launch_bounds__(DSC_THREADS, 4) void k_describe(Batch<DescribeArgs>
                     safe &= (q0 > 1e-3f) & (q0 < lim0) & (q1 > 1e-3f) & (q1 < lim1) & (q2 > 1e-3f) & (q2 < lim2);
                     n0 = min(max(n0, 0), F.nx - 1); n1 = min(max(n1, 0), F.ny - 1); n2 = min(max(n2, 0), F.nz - 1);
                 }
+#ifdef MAD_PROBE_TEXB      // diagnostic build: what a texture of MAD_PROBE_TEXB bytes per voxel would cost to sample (the values are garbage)
+                {
+                    const unsigned idx = mad_u24(mad_u24((unsigned)n0, (unsigned)F.ny, (unsigned)n1), (unsigned)F.nz, (unsigned)n2);
+#if MAD_PROBE_TEXB == 4
+                    const unsigned wq = ((const unsigned *)F.tex)[idx];
+                    const unsigned wr = wq >> 5;
+#else
+                    const uint2 w2 = ((const uint2 *)F.tex)[idx];
+                    const unsigned wq = w2.x, wr = w2.y;
+#endif
+                    t[i] = make_float4(__uint_as_float((wq & 0x007fffffu) | 0x3f800000u) - 1.5f, __uint_as_float(((wq >> 9) & 0x007fffffu) | 0x3f800000u) - 1.5f,
+                                       __uint_as_float((wr & 0x007fffffu) | 0x3f800000u) - 1.5f, 1.0f);
+                }
+#else
                 t[i] = F.tex[mad_u24(mad_u24((unsigned)n0, (unsigned)F.ny, (unsigned)n1), (unsigned)F.nz, (unsigned)n2)];      // nx ny < 2^24 (checked at allocation)
+#endif
                 unsure |= safe ? 0u : (1u << i);
             }
         };

@@ -635,6 +635,38 @@ def test_sets_built_in_one_batch_equal_sets_built_one_by_one(lib, fields, n_sets
         s_.close()
 
 
+def test_matches_of_a_bracket_with_one_gemm_grid(lib, fields):
+    """mad_set_batching: the score tiles of all matches of a bracket from ONE grid (jobs of different sizes, a subunit without
+    rows, two subunits on one lane, i.e. one of them outside the batch): top-k rows, pair ranks and statistics are those of the
+    one-GEMM-per-match bracket, bit for bit."""
+    f0, f1 = fields[0], fields[1]
+    a0, a1 = _anchors(f0["shape"], 0, 36, 31), _anchors(f1["shape"], 1, 44, 32)
+    coords = np.concatenate([a0, a1]).astype(np.int32)
+    octave = np.concatenate([np.zeros(len(a0), np.int32), np.ones(len(a1), np.int32)])
+    lo = lib.set_build([f0["slot"], f1["slot"]], coords, octave, coords * np.where(octave[:, None] == 0, 0.75, 1.5), np.arange(len(coords), dtype=np.int32))
+    his = []
+    for i, n in enumerate((30, 12, 0, 41, 25, 18, 33, 27, 22, 16)):      # ten subunits on eight lanes
+        c = _anchors(f1["shape"], 1, n, 60 + i)[:n] if n else np.zeros((0, 3), np.int32)
+        his.append(lib.set_build([-1, f1["slot"]], c, np.ones(len(c), np.int32), c * 1.5 + 0.1 * i, np.arange(len(c), dtype=np.int32)))
+    assert len({h.lane() for h in his}) < len(his)
+    lib.set_batching(False)
+    want = lib.match_topk_many(his, lo, 0.3, 4.0, 25)
+    lib.set_batching(True)
+    try:
+        got = lib.match_topk_many(his, lo, 0.3, 4.0, 25)
+        again = lib.match_topk_many(his[:3], lo, 0.3, 4.0, 25)
+    finally:
+        lib.set_batching(False)
+    assert sum(w[2]["n_pairs"] for w in want) > 200
+    for (ta, ia, sa), (tb, ib, sb) in list(zip(got, want)) + list(zip(again, want[:3])):
+        assert sa == sb
+        np.testing.assert_array_equal(ia, ib)
+        np.testing.assert_array_equal(ta, tb)
+    for h in his:
+        h.close()
+    lo.close()
+
+
 @pytest.mark.parametrize("n_shares", [1, 2, 3, 8])
 def test_set_built_in_shares_equals_unsharded(lib, fields, n_shares):
     """SURVEY.md 8(e) stage A on one GPU: the anchors of a structure (both octaves, border rejects included) dealt round-robin
