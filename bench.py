@@ -225,10 +225,10 @@ def hot_path_step(lib, the_map, subs, cc, dist, k, sets):
 
 
 def run_steps(lib, the_map, subs, cc, dist, k, set_groups, n_steps, after_step=None):
-    """n_steps steps with len(set_groups) of them in flight (2 or 3): while the matches of step i run, the host already
-    enqueues the builds of step i + 1 into the next group of device sets and, with three groups, the matches of step i are
-    only collected after those of step i + 1 have been enqueued (two open match brackets), so the device does not idle over
-    the host's turn-around between steps.  Every step does the same work as hot_path_step; `after_step(tops)` is called once
+    """n_steps steps with len(set_groups) of them in flight (2 to 4): while the matches of step i run, the host already
+    enqueues the builds of step i + 1 into the next group of device sets and, with three (four) groups, the matches of step i are
+    only collected after those of step i + 1 (and i + 2) have been enqueued (up to three open match brackets), so the device does
+    not idle over the host's turn-around between steps.  Every step does the same work as hot_path_step; `after_step(tops)` is called once
     per step, in order."""
     depth = len(set_groups)
     lag = depth - 2      # how many steps behind the enqueue front the results are collected
@@ -406,7 +406,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="auto", choices=sorted(WORKLOADS) + ["auto"], help="auto: c3 on one GPU, c4 (strong scaling) on several")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--in-flight", type=int, default=3, choices=(2, 3), help="steps in flight (groups of device sets)")
+    ap.add_argument("--in-flight", type=int, default=3, choices=(2, 3, 4), help="steps in flight (groups of device sets)")
     ap.add_argument("--serial", action="store_true", help="lanes serialised for the whole run: the mode the rocprofv3 summaries in profiles/ are "
                     "taken in, so that a kernel's average duration there is the one the roofline pass measures")
     ap.add_argument("--batched", action="store_true", help="one launch per stage for all structures of a step (mad_set_build_many) and one GEMM "

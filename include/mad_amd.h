@@ -227,7 +227,7 @@ int mad_match_topk_many(mad_ctx *ctx, int n, const mad_set *const *hi, const mad
  * (the output arrays belong to the bracket until _finish returns: _finish fills them; _begin itself only does so for a
  * match whose lane it has to reuse, n > 8).  Between the two the caller may enqueue other work -- typically
  * mad_set_build of the NEXT batch into other sets: sets read by the open bracket must not be rebuilt or destroyed, and
- * no other match call may be made.  Up to two brackets may be open at once (each has its own pinned result staging);
+ * no other match call may be made.  Up to three brackets may be open at once (each has its own pinned result staging);
  * _finish completes the older one.
  */
 int mad_match_topk_many_begin(mad_ctx *ctx, int n, const mad_set *const *hi, const mad_set *lo, double cc, double dist,

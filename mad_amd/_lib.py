@@ -544,7 +544,7 @@ class Lib(object):
         arr = (C.c_void_p * max(n, 1))(*[x.h.value for x in his])
         self._chk(self.dll.mad_match_topk_many_begin(self.ctx, C.c_int(n), arr, lo.h, C.c_double(cc), C.c_double(dist), C.c_int64(k),
                                                      _p(h["res"]), _p(h["idx"]), _p(h["n_out"]), _p(h["stats"])))
-        self._open_brackets = getattr(self, "_open_brackets", []) + [h]      # at most two; they finish in the order they began
+        self._open_brackets = getattr(self, "_open_brackets", []) + [h]      # at most three (MAD_BRACKETS); they finish in the order they began
         return h
 
     def match_topk_many_finish(self, h):

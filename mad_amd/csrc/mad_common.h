@@ -97,6 +97,7 @@ enum { MAD_T_ORIENT = 0, MAD_T_DESCRIBE, MAD_T_CORRELATE, MAD_T_PAIRS, MAD_T_POS
 
 #define MAD_T_RING 32
 #define MAD_LANES 8
+#define MAD_BRACKETS 3      // mad_match_topk_many_begin brackets that may be open at once (steps in flight - 1)
 
 struct TimerGroup {
     hipEvent_t start[MAD_T_RING];
@@ -158,11 +159,11 @@ struct mad_ctx {
     int lane = 0;                    // the copy the current call works in
     // two result slots per lane: one per open mad_match_topk_many bracket, so that a second batch of matches can be enqueued
     // (and deliver into its own pinned staging) before the first one has been collected
-    hipEvent_t lane_done[2][MAD_LANES]; // recorded behind the last operation a bracket enqueued in each lane
+    hipEvent_t lane_done[MAD_BRACKETS][MAD_LANES]; // recorded behind the last operation a bracket enqueued in each lane
     hipEvent_t lane_pre[MAD_LANES];     // mad_match_topk_many: a lane is ready for the bracket's common GEMM
-    hipEvent_t gemm_done[2];            // ... and that GEMM has been enqueued (per open bracket)
-    void *host_res[2][MAD_LANES] = {};   // pinned staging of a match's results / indices / status
-    size_t host_res_cap[2][MAD_LANES] = {};
+    hipEvent_t gemm_done[MAD_BRACKETS];            // ... and that GEMM has been enqueued (per open bracket)
+    void *host_res[MAD_BRACKETS][MAD_LANES] = {};   // pinned staging of a match's results / indices / status
+    size_t host_res_cap[MAD_BRACKETS][MAD_LANES] = {};
     int res_slot = 0;                    // the slot the match calls below read and write
     // host pinned staging for small read-backs
     int64_t *pinned = nullptr;     // 1024 slots: [16 * lane ..] read-backs of the lane, [64..] two per mad_set
@@ -172,8 +173,8 @@ struct mad_ctx {
     int last_pose_kernel = -1;               // 0 k_pose_lds, 1 k_pose_lds32, 2 k_pose (mad_last_pose_kernel)
     bool lane_pruned[MAD_LANES] = {};        // whether the match last enqueued in a lane pruned its pose search
     int64_t lane_sel_hint[MAD_LANES] = {};   // pairs the last pruned match of a lane sent to the exact search (sizes the next launch)
-    void *many[2] = {nullptr, nullptr};      // open mad_match_topk_many_begin brackets (ManyState, mad_match.hip), by result slot
-    int many_oldest = 0;                     // the slot _finish collects next when both are open
+    void *many[MAD_BRACKETS] = {};           // open mad_match_topk_many_begin brackets (ManyState, mad_match.hip), by result slot: a ring
+    int many_oldest = 0, many_open = 0;      // the slot _finish collects next, and how many are open
     bool timing = false;
     TimerGroup timers[MAD_T_COUNT];
     int n_cu = 256;

@@ -2721,12 +2721,12 @@ static int many_retire(mad_ctx *ctx, ManyState &M, int lane) {
 extern "C" int mad_match_topk_many_begin(mad_ctx *ctx, int n, const mad_set *const *hi, const mad_set *lo, double cc, double dist, int64_t k,
                                          double *results, int64_t *pair_index, int64_t *n_out, int64_t *stats) {
     if (!ctx || !hi || !lo || !n_out || n < 0) return MAD_EINVAL;
-    if (ctx->many[0] && ctx->many[1]) return mad_fail(ctx, MAD_EINVAL, "mad_match_topk_many_begin: two brackets are open already");
+    if (ctx->many_open >= MAD_BRACKETS) return mad_fail(ctx, MAD_EINVAL, "mad_match_topk_many_begin: %d brackets are open already", MAD_BRACKETS);
     if (k < 1) k = 1;
     ManyState *Mp = new ManyState();
     ManyState &M = *Mp;
-    M.slot = ctx->many[0] ? 1 : 0;
-    if (!ctx->many[0] && !ctx->many[1]) ctx->many_oldest = M.slot;
+    M.slot = (ctx->many_oldest + ctx->many_open) % MAD_BRACKETS;      // the slots form a ring: brackets finish in the order they began
+    ctx->many_open++;
     ctx->res_slot = M.slot;
     M.n = n; M.hi.assign(hi, hi + n); M.lo = lo; M.cc = cc; M.dist = dist; M.k = k;
     M.results = results; M.pair_index = pair_index; M.n_out = n_out; M.stats = stats;
@@ -2795,7 +2795,7 @@ extern "C" int mad_match_topk_many_begin(mad_ctx *ctx, int n, const mad_set *con
         const int slot = M.slot;
         delete Mp;
         ctx->many[slot] = nullptr;
-        ctx->many_oldest = slot ^ 1;
+        ctx->many_open--;      // the newest bracket: the ring just shrinks again
     }
     ctx->res_slot = 0;
     return rc_all;
@@ -2813,8 +2813,8 @@ extern "C" int64_t mad_last_pose_selected(mad_ctx *ctx) { return ctx ? ctx->matc
 
 extern "C" int mad_match_topk_many_finish(mad_ctx *ctx) {
     if (!ctx) return MAD_EINVAL;
-    if (!ctx->many[0] && !ctx->many[1]) return mad_fail(ctx, MAD_EINVAL, "mad_match_topk_many_finish: nothing was begun");
-    const int slot = ctx->many[ctx->many_oldest] ? ctx->many_oldest : ctx->many_oldest ^ 1;      // the older of the open brackets
+    if (ctx->many_open <= 0) return mad_fail(ctx, MAD_EINVAL, "mad_match_topk_many_finish: nothing was begun");
+    const int slot = ctx->many_oldest;      // the oldest of the open brackets
     ManyState *Mp = (ManyState *)ctx->many[slot];
     int rc_all = MAD_OK;
     for (int l = 0; l < MAD_LANES; l++) {
@@ -2823,15 +2823,17 @@ extern "C" int mad_match_topk_many_finish(mad_ctx *ctx) {
     }
     delete Mp;
     ctx->many[slot] = nullptr;
-    ctx->many_oldest = slot ^ 1;
+    ctx->many_oldest = (slot + 1) % MAD_BRACKETS;
+    ctx->many_open--;
     ctx->res_slot = 0;
     mad_use_lane(ctx, ctx->match.lane);
     return rc_all;
 }
 
 void mad_many_abandon(mad_ctx *ctx) {      // mad_destroy: a bracket left open
-    for (int r = 0; ctx && r < 2; r++)
+    for (int r = 0; ctx && r < MAD_BRACKETS; r++)
         if (ctx->many[r]) { delete (ManyState *)ctx->many[r]; ctx->many[r] = nullptr; }
+    if (ctx) ctx->many_open = 0;
 }
 
 extern "C" int mad_match_topk_many(mad_ctx *ctx, int n, const mad_set *const *hi, const mad_set *lo, double cc, double dist, int64_t k,

@@ -104,18 +104,25 @@ def test_sets_and_matches_with_nothing_in_them(ctx):
     from mad_amd._lib import MadBackendError
     h = lib.match_topk_many_begin([empty, full, empty], full, 0.5, 4.0, 10)
     other = lib.set_build([-1, slot], coords, np.ones(n, np.int32), subv, np.arange(n))      # building another set in between is allowed
-    h2 = lib.match_topk_many_begin([other, other], full, 0.5, 4.0, 7)      # ... and so is a second bracket
+    h2 = lib.match_topk_many_begin([other, other], full, 0.5, 4.0, 7)      # ... and so are a second bracket
+    h3 = lib.match_topk_many_begin([full, empty], full, 0.5, 4.0, 4)       # and a third (four steps in flight)
     with pytest.raises(MadBackendError):
-        lib.match_topk_many_begin([full], full, 0.5, 4.0, 10)             # a third is not
+        lib.match_topk_many_begin([full], full, 0.5, 4.0, 10)             # a fourth is not
     with pytest.raises(MadBackendError):
         lib.match_topk_many_finish(h2)                                    # they finish in the order they began
     res2 = lib.match_topk_many_finish(h)
     for a, b in zip(res, res2):
         np.testing.assert_array_equal(a[0], b[0])
         np.testing.assert_array_equal(a[1], b[1])
+    h4 = lib.match_topk_many_begin([full], full, 0.5, 4.0, 3)             # the ring of slots wraps around
     res3 = lib.match_topk_many_finish(h2)
     np.testing.assert_array_equal(res3[0][0], res[1][0][:7])
     np.testing.assert_array_equal(res3[1][0], res[1][0][:7])
+    res4 = lib.match_topk_many_finish(h3)
+    np.testing.assert_array_equal(res4[0][0], res[1][0][:4])
+    assert len(res4[1][0]) == 0
+    res5 = lib.match_topk_many_finish(h4)
+    np.testing.assert_array_equal(res5[0][0], res[1][0][:3])
     with pytest.raises(MadBackendError):
         lib.match_topk_many_finish(h)
     np.testing.assert_array_equal(other.download()["dsc"], full.download()["dsc"])
