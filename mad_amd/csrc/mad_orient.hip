@@ -108,8 +108,19 @@ __device__ __forceinline__ void classify_exact64(const EqspFastLds *eq, double r
     eqsp_classify_lds(eq, th, sth, ph, f);
 }
 
+#ifdef MAD_PROBE_STAMPS      // diagnostic build: s_memtime at the phases of every anchor's workgroup (tools/probe_orient.py)
+__device__ long long ori_stamps[4096 * 12];
+#define ORI_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 4096) ori_stamps[blockIdx.x * 12 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+extern "C" int mad_debug_ori_stamps(long long *out, int n) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(ori_stamps), (size_t)n * 8) == hipSuccess ? 0 : -1;
+}
+#else
+#define ORI_STAMP(k) do { } while (0)
+#endif
+
 template <bool GW>
 __global__ __launch_bounds__(ORI_THREADS) void k_orient(Batch<OrientArgs> B) {
+    ORI_STAMP(0);
     const int job = batch_job(B, (int)blockIdx.x);
     const OrientArgs &A = B.job[job];
     extern __shared__ __align__(16) unsigned char smem[];
@@ -163,6 +174,7 @@ __global__ __launch_bounds__(ORI_THREADS) void k_orient(Batch<OrientArgs> B) {
         else atomicAdd(&hist[h][zn], (H)1);
     };
     __syncthreads();
+    ORI_STAMP(1);
 
     // step01: fetch, normalise (float32, Orientator.py:139-147), keep weighted voxels only
     const float cutoff = 1e-5f;
@@ -210,6 +222,7 @@ __global__ __launch_bounds__(ORI_THREADS) void k_orient(Batch<OrientArgs> B) {
         }
     }
     __syncthreads();
+    ORI_STAMP(2);
     const int nvox = s_nvox;
 
     // step02: first binning on the float32 box (Orientator.py:307-334).  Directions well inside a zone
@@ -220,6 +233,7 @@ __global__ __launch_bounds__(ORI_THREADS) void k_orient(Batch<OrientArgs> B) {
         else queue[atomicAdd(&s_nq, 1)] = v;
     }
     __syncthreads();
+    ORI_STAMP(3);
     {
         const float two_pi_f = (float)MAD_TWO_PI;
         const int nq = s_nq;
@@ -236,6 +250,7 @@ __global__ __launch_bounds__(ORI_THREADS) void k_orient(Batch<OrientArgs> B) {
         }
     }
     __syncthreads();
+    ORI_STAMP(4);
     if (tid < MAD_WAVE) {
         const int mx = quantise_wave0(hist[0], qz[0], Z);
         // main bins: quantised count > 0.8 * max (Orientator.py:181)
@@ -249,6 +264,7 @@ __global__ __launch_bounds__(ORI_THREADS) void k_orient(Batch<OrientArgs> B) {
         if (lane == 0) { s_mx = mx; s_nmain = n0 + __popcll(m1); s_nq = 0; }
     }
     __syncthreads();
+    ORI_STAMP(5);
     const int nmain = s_nmain;
     if (s_mx == 0 || nmain == 0 || nmain > A.lim_main) {      // Orientator.py:182-184
         if (tid == 0) A.slot_cnt[a] = 0;
@@ -262,6 +278,7 @@ __global__ __launch_bounds__(ORI_THREADS) void k_orient(Batch<OrientArgs> B) {
         s_domf[i / 9][i % 9] = (float)d;
     }
     __syncthreads();
+    ORI_STAMP(6);
     for (int v = tid; v < nvox; v += ORI_THREADS) {
         const float g0 = vx[v], g1 = vy[v], g2 = vz[v];
         for (int c = 0; c < nmain; c++) {
@@ -282,6 +299,7 @@ __global__ __launch_bounds__(ORI_THREADS) void k_orient(Batch<OrientArgs> B) {
         }
     }
     __syncthreads();
+    ORI_STAMP(7);
     {
         const int nq = min(s_nq, A.nmask);      // ~0.1 % of nvox * nmain in practice; capacity is nmask
         for (int qi = tid; qi < nq; qi += ORI_THREADS) {
@@ -295,6 +313,7 @@ __global__ __launch_bounds__(ORI_THREADS) void k_orient(Batch<OrientArgs> B) {
         }
     }
     __syncthreads();
+    ORI_STAMP(8);
     // quantise + step04 (Orientator.py:228-239) per candidate, one wave each
     for (int c = tid >> 6; c < nmain; c += ORI_THREADS / MAD_WAVE) {
         const int lane = lane_id();
@@ -320,6 +339,7 @@ __global__ __launch_bounds__(ORI_THREADS) void k_orient(Batch<OrientArgs> B) {
         if (lane == 0) sec_cnt[c] = ok ? ns : -1;
     }
     __syncthreads();
+    ORI_STAMP(9);
     // emit rows: candidates in ascending main bin, secondary bins ascending (Orientator.py:90-106)
     int produced = 0, hist_rows = 0;
     for (int c = 0; c < nmain; c++) {
@@ -337,6 +357,7 @@ __global__ __launch_bounds__(ORI_THREADS) void k_orient(Batch<OrientArgs> B) {
         hist_rows++;
     }
     if (tid == 0) A.slot_cnt[a] = produced;
+    ORI_STAMP(10);
 }
 
 // per job: where the per-anchor slots of k_orient lie and where the job's rows go
