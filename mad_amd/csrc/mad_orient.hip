@@ -163,28 +163,16 @@ __global__ __launch_bounds__(ORI_THREADS) void k_orient(Batch<OrientArgs> B) {
             return;
         }
     }
-    if (tid == 0) { s_nvox = 0; s_nq = 0; }
-    for (int i = tid; i < (ORI_MAX_MAIN + 1) * MAD_MAX_Z; i += ORI_THREADS) (&hist[0][0])[i] = 0;
-    if (GW)
-        for (int i = tid; i <= 3 * r * r; i += ORI_THREADS) wl[i] = A.wfix[i];
-    eqsp_fast_stage(A.eq, &fast);
-    // one count (or one weight) of voxel v for zone zn of histogram h
-    auto tally = [&](int h, int zn, int v) {
-        if (GW) atomicAdd(&hist[h][zn], (H)wl[vw[v]]);
-        else atomicAdd(&hist[h][zn], (H)1);
-    };
-    __syncthreads();
-    ORI_STAMP(1);
-
-    // step01: fetch, normalise (float32, Orientator.py:139-147), keep weighted voxels only
-    const float cutoff = 1e-5f;
+    // step01: fetch, normalise (float32, Orientator.py:139-147), keep weighted voxels only.
     // All texels of a thread are requested before the first one is looked at (the box has ceil(nmask / 512) <= ORI_TRIPS of
     // them per thread): a trip that waits for its mask offset, then for its texel, then compacts, costs two memory round trips,
-    // and five such trips in a row were a quarter of the anchor's time.
+    // and five such trips in a row were a quarter of the anchor's time.  The first batch goes out BEFORE the tables are staged
+    // and the histograms zeroed, so that those ~1.5 us run under the texels' flight.
+    const float cutoff = 1e-5f;
     constexpr int ORI_TRIPS = 5;      // r = 8: 2 517 voxels in the sphere; larger boxes take the loop below more than once
-    for (int m00 = 0; m00 < A.nmask; m00 += ORI_TRIPS * ORI_THREADS) {
-        int packed[ORI_TRIPS];
-        float4 tx[ORI_TRIPS];
+    int packed[ORI_TRIPS];
+    float4 tx[ORI_TRIPS];
+    auto request = [&](int m00) {
 #pragma unroll
         for (int k = 0; k < ORI_TRIPS; k++) {
             const int m = m00 + k * ORI_THREADS + tid;
@@ -198,6 +186,22 @@ __global__ __launch_bounds__(ORI_THREADS) void k_orient(Batch<OrientArgs> B) {
                                  (unsigned)(z + __mul24(dz, stride));
             tx[k] = F.tex[src];
         }
+    };
+    request(0);
+    if (tid == 0) { s_nvox = 0; s_nq = 0; }
+    for (int i = tid; i < (ORI_MAX_MAIN + 1) * MAD_MAX_Z; i += ORI_THREADS) (&hist[0][0])[i] = 0;
+    if (GW)
+        for (int i = tid; i <= 3 * r * r; i += ORI_THREADS) wl[i] = A.wfix[i];
+    eqsp_fast_stage(A.eq, &fast);
+    // one count (or one weight) of voxel v for zone zn of histogram h
+    auto tally = [&](int h, int zn, int v) {
+        if (GW) atomicAdd(&hist[h][zn], (H)wl[vw[v]]);
+        else atomicAdd(&hist[h][zn], (H)1);
+    };
+    __syncthreads();
+    ORI_STAMP(1);
+    for (int m00 = 0; m00 < A.nmask; m00 += ORI_TRIPS * ORI_THREADS) {
+        if (m00 > 0) request(m00);
 #pragma unroll
         for (int k = 0; k < ORI_TRIPS; k++) {
             if (m00 + k * ORI_THREADS >= A.nmask) break;      // workgroup-uniform: the ballot below needs whole waves
@@ -234,10 +238,14 @@ __global__ __launch_bounds__(ORI_THREADS) void k_orient(Batch<OrientArgs> B) {
     }
     __syncthreads();
     ORI_STAMP(3);
-    {
+    // One wave closes the first pass while the others wait at ONE barrier: the few directions the fast classifier declined
+    // (the reference's float32 arithmetic), the quantisation, the main bins and their rotations -- four barrier-separated
+    // phases before, a third of the anchor's time for a handful of lanes' work.
+    if (tid < MAD_WAVE) {
         const float two_pi_f = (float)MAD_TWO_PI;
         const int nq = s_nq;
-        for (int qi = tid; qi < nq; qi += ORI_THREADS) {      // the reference's float32 arithmetic
+        const int lane = lane_id();
+        for (int qi = lane; qi < nq; qi += MAD_WAVE) {
             const int v = queue[qi];
             if (eqsp_tier2(&fast, (double)vx[v], (double)vy[v], (double)vz[v], true, [&](int zn) { tally(0, zn, v); })) continue;
             float th = (float)atan2((double)vy[v], (double)vx[v]);
@@ -248,22 +256,28 @@ __global__ __launch_bounds__(ORI_THREADS) void k_orient(Batch<OrientArgs> B) {
             const float ph = (float)acos(cz);
             eqsp_classify_lds(&fast, (double)th, (double)sth, (double)ph, [&](int zn) { tally(0, zn, v); });
         }
-    }
-    __syncthreads();
-    ORI_STAMP(4);
-    if (tid < MAD_WAVE) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // the wave's own LDS atomics above before its reads below
         const int mx = quantise_wave0(hist[0], qz[0], Z);
         // main bins: quantised count > 0.8 * max (Orientator.py:181)
-        const int lane = lane_id();
         const bool p0 = lane < Z && (double)qz[0][lane] > 50 * 0.8;
         const bool p1 = lane + 64 < Z && (double)qz[0][lane + 64] > 50 * 0.8;
         const unsigned long long m0 = __ballot(p0), m1 = __ballot(p1);
-        const int n0 = __popcll(m0);
+        const int n0 = __popcll(m0), nm = n0 + __popcll(m1);
         if (p0) main_list[__popcll(m0 & lanemask_lt())] = lane;
         if (p1) main_list[n0 + __popcll(m1 & lanemask_lt())] = lane + 64;
-        if (lane == 0) { s_mx = mx; s_nmain = n0 + __popcll(m1); s_nq = 0; }
+        if (lane == 0) { s_mx = mx; s_nmain = nm; s_nq = 0; }
+        // step03's rotations (Orientator.py:204-206) for the accepted candidates
+        if (mx != 0 && nm > 0 && nm <= A.lim_main) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            for (int i = lane; i < nm * 9; i += MAD_WAVE) {
+                const double d = A.eq->to_dom[main_list[i / 9]][i % 9];
+                s_dom[i / 9][i % 9] = d;
+                s_domf[i / 9][i % 9] = (float)d;
+            }
+        }
     }
     __syncthreads();
+    ORI_STAMP(4);
     ORI_STAMP(5);
     const int nmain = s_nmain;
     if (s_mx == 0 || nmain == 0 || nmain > A.lim_main) {      // Orientator.py:182-184
@@ -271,13 +285,7 @@ __global__ __launch_bounds__(ORI_THREADS) void k_orient(Batch<OrientArgs> B) {
         return;
     }
 
-    // step03 for every main-bin candidate at once: rotate by to_dom (Orientator.py:204-206, 303) and re-bin
-    for (int i = tid; i < nmain * 9; i += ORI_THREADS) {
-        const double d = A.eq->to_dom[main_list[i / 9]][i % 9];
-        s_dom[i / 9][i % 9] = d;
-        s_domf[i / 9][i % 9] = (float)d;
-    }
-    __syncthreads();
+    // step03 for every main-bin candidate at once: rotate by to_dom (Orientator.py:303) and re-bin
     ORI_STAMP(6);
     for (int v = tid; v < nvox; v += ORI_THREADS) {
         const float g0 = vx[v], g1 = vy[v], g2 = vz[v];
