@@ -1111,6 +1111,7 @@ __global__ __launch_bounds__(256) void k_count_hist(const int32_t *__restrict__ 
                                                     int32_t *__restrict__ hist, int nbins);
 
 #define PB_THREADS 1024
+#define PB_MAX_SETS 16      // hi clouds of up to 16 x 64 points are bracketed (the per-set lookup state lives in registers: ~7 per set)
 struct PoseCoarse {
     PoseBits B;
     int n_words;
@@ -1859,7 +1860,11 @@ static int pose_device(mad_ctx *ctx, const Side &hi, const Side &lo, int32_t *d_
                            scratch<int32_t>(ctx, S_PG_START), d_start16, scratch<double>(ctx, S_PG_PTS),
                            fits64 ? (float4 *)nullptr : scratch<float4>(ctx, S_PG_PTSF), d_status + ST_LLO, job ? *job : no_job);
         static const bool no_prune = getenv("MAD_NO_PRUNE") != nullptr;      // diagnostic switch
-        const bool prune = prune_k > 0 && hist2 && bits_rad_in > 0.5 && PC.B.h <= 16.0 && l_hi_max <= 8 * MAD_WAVE && !no_prune;
+        const bool prune = prune_k > 0 && hist2 && bits_rad_in > 0.5 && PC.B.h <= 16.0 && l_hi_max <= PB_MAX_SETS * MAD_WAVE && !no_prune;
+        static const bool dbg_prune = getenv("MAD_DEBUG_PRUNE") != nullptr;
+        if (dbg_prune)
+            fprintf(stderr, "pose_device: prune=%d prune_k=%lld hist2=%p rad_in=%g coarse h=%g l_hi_max=%d fits64=%d fits32=%d fine h=%g n_cloud=%d\n", (int)prune,
+                    (long long)prune_k, (void *)hist2, bits_rad_in, PC.B.h, l_hi_max, (int)fits64, (int)fits32, B.h, n_cloud);
         // fine bitmap, then (when pruning) the coarse one, in one buffer: one zero fill, one launch marks all planes
         const size_t fine_bytes = pad16(n_words * 4);
         const size_t coarse_bytes = prune ? pad16((size_t)PC.n_words * 4) : 0;
@@ -1895,11 +1900,14 @@ static int pose_device(mad_ctx *ctx, const Side &hi, const Side &lo, int32_t *d_
                 MAD_HIP(hipFuncSetAttribute((const void *)k_pose_bounds<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                 MAD_HIP(hipFuncSetAttribute((const void *)k_pose_bounds<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                 MAD_HIP(hipFuncSetAttribute((const void *)k_pose_bounds<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                MAD_HIP(hipFuncSetAttribute((const void *)k_pose_bounds<10>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                MAD_HIP(hipFuncSetAttribute((const void *)k_pose_bounds<12>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                MAD_HIP(hipFuncSetAttribute((const void *)k_pose_bounds<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                 attr_b = true;
             }
             static const int probe_mode = getenv("MAD_PB_PROBE") ? atoi(getenv("MAD_PB_PROBE")) : 0;
             const int nb = (l_hi_max + MAD_WAVE - 1) / MAD_WAVE;      // point sets of 64 an entire hi cloud needs
-            const int nbv = nb <= 2 ? 2 : (nb <= 4 ? 4 : (nb <= 6 ? 6 : 8));
+            const int nbv = nb <= 2 ? 2 : (nb <= 4 ? 4 : (nb <= 6 ? 6 : (nb <= 8 ? 8 : (nb <= 10 ? 10 : (nb <= 12 ? 12 : 16)))));
             const size_t lds_b = pad16((size_t)PC.n_words * 4) + pad16((size_t)(l_hi_max + 4) * 16) + (size_t)(PB_THREADS / MAD_WAVE) * nbv * MAD_WAVE * 2 +
                                  pad16((size_t)nbins * 4) + 16;
 #define MAD_PB_LAUNCH(NBV)                                                                                                              \
@@ -1908,7 +1916,10 @@ static int pose_device(mad_ctx *ctx, const Side &hi, const Side &lo, int32_t *d_
             if (nbv == 2) MAD_PB_LAUNCH(2);
             else if (nbv == 4) MAD_PB_LAUNCH(4);
             else if (nbv == 6) MAD_PB_LAUNCH(6);
-            else MAD_PB_LAUNCH(8);
+            else if (nbv == 8) MAD_PB_LAUNCH(8);
+            else if (nbv == 10) MAD_PB_LAUNCH(10);
+            else if (nbv == 12) MAD_PB_LAUNCH(12);
+            else MAD_PB_LAUNCH(16);
 #undef MAD_PB_LAUNCH
             hipLaunchKernelGGL(k_prune_select, dim3(ctx->n_cu / 2), dim3(256), 0, ctx->stream, d_status, cap_pairs, hist2, nbins, prune_k,
                                scratch<unsigned short>(ctx, S_TMP_C), scratch<int32_t>(ctx, S_TMP_D), d_status + ST_NSEL, hist2 + nbins,
