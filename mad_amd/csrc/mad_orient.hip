@@ -693,8 +693,14 @@ template <int S, int NSUB> __device__ __forceinline__ int sub_of_i(int i) {
 }
 
 #define DSC_CHUNK 8
+#ifndef DSC_PASSES
+#define DSC_PASSES 1      // texel passes per thread at S = 16 (probe builds: -DDSC_PASSES=2 -DDSC_OCC=5)
+#endif
+#ifndef DSC_OCC
+#define DSC_OCC 4         // workgroups per CU the register budget is set for
+#endif
 template <int S, int NSUB = 64>
-__global__ __launch_bounds__(DSC_THREADS, 4) void k_describe(Batch<DescribeArgs> B) {
+__global__ __launch_bounds__(DSC_THREADS, DSC_OCC) void k_describe(Batch<DescribeArgs> B) {
     const int job = batch_job(B, (int)blockIdx.x);
     const DescribeArgs &A = B.job[job];
     const int bid = (int)blockIdx.x - B.first[job], gdim = B.first[job + 1] - B.first[job];      // this job's part of the grid (multiples of 8)
@@ -764,8 +770,10 @@ __global__ __launch_bounds__(DSC_THREADS, 4) void k_describe(Batch<DescribeArgs>
     const int reach = (int)(1.7320508 * fabs(lbase)) + 2;
     const bool interior = ic0 - reach >= 1 && ic0 + reach <= F.nx - 2 && ic1 - reach >= 1 && ic1 + reach <= F.ny - 2 &&
                           ic2 - reach >= 1 && ic2 + reach <= F.nz - 2;      // uniform over the workgroup
-    float4 t[S];
-    unsigned unsure = 0;      // bit i: the float32 guess of sample i is too close to a tie to be trusted
+    // The S samples of a thread go through in DSC_PASSES passes: the texel requests of a pass all go out before its first texel is
+    // looked at, then the pass is classified.  DSC_PASSES = 1 keeps all S texels (64 registers at S = 16) in flight at once.
+    constexpr int NP = (S % (DSC_CHUNK * DSC_PASSES) == 0) ? DSC_PASSES : 1;
+    constexpr int PS = S / NP;
     bool oob = false;
     if (active) {
         // float32 guess of the offset from the anchor voxel, |error| < 1e-5 voxel: the nearest voxel is known unless the
@@ -776,46 +784,76 @@ __global__ __launch_bounds__(DSC_THREADS, 4) void k_describe(Batch<DescribeArgs>
         const float m1 = (float)l1, m2 = (float)l2;
         const float b0 = fmaf(m1, h1, m2 * h2), b1 = fmaf(m1, h4, m2 * h5), b2 = fmaf(m1, h7, m2 * h8);
         const float lbf = (float)lbase, lsf = (float)lstep;
-        auto guess = [&](auto border) {
-            const float fc0 = (float)ic0, fc1 = (float)ic1, fc2 = (float)ic2;
-            const float lim0 = (float)(F.nx - 1) - 1e-3f, lim1 = (float)(F.ny - 1) - 1e-3f, lim2 = (float)(F.nz - 1) - 1e-3f;
+        const int sub_jk = sub_of_jk<S, NSUB>(j, k);      // Descriptor.py:44-93
 #pragma unroll
-            for (int i = 0; i < S; i++) {
-                const float m0 = lbf + lsf * (float)i;      // exact: half-integers below 32
-                const float a0 = fmaf(m0, h0, b0), a1 = fmaf(m0, h3, b1), a2 = fmaf(m0, h6, b2);
-                // nearest voxel = floor(a + 0.5) unless the fraction is within 2e-4 of the tie (then the float64 expression decides)
-                const float fr0 = __builtin_amdgcn_fractf(a0), fr1 = __builtin_amdgcn_fractf(a1), fr2 = __builtin_amdgcn_fractf(a2);
-                bool safe = (fabsf(fr0 - 0.5f) > 2e-4f) & (fabsf(fr1 - 0.5f) > 2e-4f) & (fabsf(fr2 - 0.5f) > 2e-4f);
-                int n0 = ic0 + cvt_round(a0), n1 = ic1 + cvt_round(a1), n2 = ic2 + cvt_round(a2);
-                if (decltype(border)::value) {
-                    const float q0 = a0 + fc0, q1 = a1 + fc1, q2 = a2 + fc2;
-                    safe &= (q0 > 1e-3f) & (q0 < lim0) & (q1 > 1e-3f) & (q1 < lim1) & (q2 > 1e-3f) & (q2 < lim2);
-                    n0 = min(max(n0, 0), F.nx - 1); n1 = min(max(n1, 0), F.ny - 1); n2 = min(max(n2, 0), F.nz - 1);
+        for (int pass = 0; pass < NP; pass++) {
+            float4 t[PS];
+            unsigned unsure = 0;      // bit i: the float32 guess of sample i of this pass is too close to a tie to be trusted
+            auto guess = [&](auto border) {
+                const float fc0 = (float)ic0, fc1 = (float)ic1, fc2 = (float)ic2;
+                const float lim0 = (float)(F.nx - 1) - 1e-3f, lim1 = (float)(F.ny - 1) - 1e-3f, lim2 = (float)(F.nz - 1) - 1e-3f;
+#pragma unroll
+                for (int i = 0; i < PS; i++) {
+                    const float m0 = lbf + lsf * (float)(pass * PS + i);      // exact: half-integers below 32
+                    const float a0 = fmaf(m0, h0, b0), a1 = fmaf(m0, h3, b1), a2 = fmaf(m0, h6, b2);
+                    // nearest voxel = floor(a + 0.5) unless the fraction is within 2e-4 of the tie (then the float64 expression decides)
+                    const float fr0 = __builtin_amdgcn_fractf(a0), fr1 = __builtin_amdgcn_fractf(a1), fr2 = __builtin_amdgcn_fractf(a2);
+                    bool safe = (fabsf(fr0 - 0.5f) > 2e-4f) & (fabsf(fr1 - 0.5f) > 2e-4f) & (fabsf(fr2 - 0.5f) > 2e-4f);
+                    int n0 = ic0 + cvt_round(a0), n1 = ic1 + cvt_round(a1), n2 = ic2 + cvt_round(a2);
+                    if (decltype(border)::value) {
+                        const float q0 = a0 + fc0, q1 = a1 + fc1, q2 = a2 + fc2;
+                        safe &= (q0 > 1e-3f) & (q0 < lim0) & (q1 > 1e-3f) & (q1 < lim1) & (q2 > 1e-3f) & (q2 < lim2);
+                        n0 = min(max(n0, 0), F.nx - 1); n1 = min(max(n1, 0), F.ny - 1); n2 = min(max(n2, 0), F.nz - 1);
+                    }
+                    t[i] = F.tex[mad_u24(mad_u24((unsigned)n0, (unsigned)F.ny, (unsigned)n1), (unsigned)F.nz, (unsigned)n2)];      // nx ny < 2^24 (checked at allocation)
+                    unsure |= safe ? 0u : (1u << i);
                 }
-#ifdef MAD_PROBE_TEXB      // diagnostic build: what a texture of MAD_PROBE_TEXB bytes per voxel would cost to sample (the values are garbage)
-                {
-                    const unsigned idx = mad_u24(mad_u24((unsigned)n0, (unsigned)F.ny, (unsigned)n1), (unsigned)F.nz, (unsigned)n2);
-#if MAD_PROBE_TEXB == 4
-                    const unsigned wq = ((const unsigned *)F.tex)[idx];
-                    const unsigned wr = wq >> 5;
-#else
-                    const uint2 w2 = ((const uint2 *)F.tex)[idx];
-                    const unsigned wq = w2.x, wr = w2.y;
-#endif
-                    t[i] = make_float4(__uint_as_float((wq & 0x007fffffu) | 0x3f800000u) - 1.5f, __uint_as_float(((wq >> 9) & 0x007fffffu) | 0x3f800000u) - 1.5f,
-                                       __uint_as_float((wr & 0x007fffffu) | 0x3f800000u) - 1.5f, 1.0f);
-                }
-#else
-                t[i] = F.tex[mad_u24(mad_u24((unsigned)n0, (unsigned)F.ny, (unsigned)n1), (unsigned)F.nz, (unsigned)n2)];      // nx ny < 2^24 (checked at allocation)
-#endif
-                unsure |= safe ? 0u : (1u << i);
+            };
+            if (interior) guess(std::false_type()); else guess(std::true_type());
+            if (unsure) {      // rare: the reference's float64 expression for those samples, and their texels again
+#pragma unroll
+                for (int i = 0; i < PS; i++)
+                    if (unsure & (1u << i)) t[i] = F.tex[lattice_index_exact(lbase + lstep * (pass * PS + i), l1, l2, sInv, c0, c1, c2, F, &oob)];
             }
-        };
-        if (interior) guess(std::false_type()); else guess(std::true_type());
-        if (unsure) {      // rare: the reference's float64 expression for those samples, and their texels again
+            // DSC_CHUNK points at a time: first their zones, in straight-line code (approximate unit direction, rotated in
+            // float32: a guess, verified with guard bands inside eqsp_fast32), so that the table reads of different points
+            // overlap; then the histogram updates.  The few points the fast classifier declines (~2 per row) are collected in
+            // a bit mask and handed to the exact path afterwards.  (A sample that left the grid zeroes the whole row below:
+            // what its pass counted in the meantime is never written.)
+            unsigned undecided = 0;
+            // (the rotation is converted here, behind the requests: nine registers fewer while the texels are in flight)
+            const float f0 = (float)Rrow[0], f1 = (float)Rrow[1], f2 = (float)Rrow[2], f3 = (float)Rrow[3], f4 = (float)Rrow[4], f5 = (float)Rrow[5],
+                        f6 = (float)Rrow[6], f7 = (float)Rrow[7], f8 = (float)Rrow[8];
 #pragma unroll
-            for (int i = 0; i < S; i++)
-                if (unsure & (1u << i)) t[i] = F.tex[lattice_index_exact(lbase + lstep * i, l1, l2, sInv, c0, c1, c2, F, &oob)];
+            for (int i0 = 0; i0 < PS; i0 += DSC_CHUNK) {
+                int zone[DSC_CHUNK];
+#pragma unroll
+                for (int u = 0; u < DSC_CHUNK; u++) {
+                    if (i0 + u >= PS) { zone[u] = -2; continue; }      // S = 4, 12: the last chunk is short
+                    const float4 tx = t[i0 + u];
+                    const float inv = __builtin_amdgcn_rcpf(fmaxf(tx.w, 1e-30f));
+                    const float gx = tx.x * inv, gy = tx.y * inv, gz = tx.z * inv;
+                    const float rx = fmaf(gz, f2, fmaf(gy, f1, gx * f0));
+                    const float ry = fmaf(gz, f5, fmaf(gy, f4, gx * f3));
+                    const float rz = fmaf(gz, f8, fmaf(gy, f7, gx * f6));
+                    const int zn = eqsp_fast32(&fast, rx, ry, rz);
+                    zone[u] = tx.w < 1e-5f ? -2 : zn;                         // -2: Descriptor.py:190 (zone -1, not counted)
+                }
+#pragma unroll
+                for (int u = 0; u < DSC_CHUNK; u++) {
+                    if (i0 + u >= PS) continue;
+                    if (zone[u] >= 0) atomicAdd(&hist[(sub_jk + sub_of_i<S, NSUB>(pass * PS + i0 + u)) * Z + zone[u]], 1);
+                    undecided |= zone[u] == -1 ? (1u << (i0 + u)) : 0u;
+                }
+            }
+            if (undecided) {      // decide later with the exact arithmetic, with full lanes
+#pragma unroll
+                for (int i = 0; i < PS; i++)
+                    if (undecided & (1u << i)) {
+                        const int slot = atomicAdd(&s_nq, 1);
+                        if (slot < DSC_QUEUE) { qv[slot] = t[i]; qsub[slot] = sub_jk + sub_of_i<S, NSUB>(pass * PS + i); }
+                    }
+            }
         }
     }
     if (oob) s_oob = 1;
@@ -827,44 +865,6 @@ __global__ __launch_bounds__(DSC_THREADS, 4) void k_describe(Batch<DescribeArgs>
             if (tid == 0) A.norm[row] = 0.0;
         }
         return;
-    }
-    if (active) {
-        const float f0 = (float)Rrow[0], f1 = (float)Rrow[1], f2 = (float)Rrow[2], f3 = (float)Rrow[3], f4 = (float)Rrow[4], f5 = (float)Rrow[5],
-                    f6 = (float)Rrow[6], f7 = (float)Rrow[7], f8 = (float)Rrow[8];
-        // DSC_CHUNK points at a time: first their zones, in straight-line code (approximate unit direction, rotated in
-        // float32: a guess, verified with guard bands inside eqsp_fast32), so that the table reads of different points
-        // overlap; then the histogram updates.  The few points the fast classifier declines (~2 per row) are collected in
-        // a bit mask and handed to the exact path afterwards.
-        unsigned undecided = 0;
-        const int sub_jk = sub_of_jk<S, NSUB>(j, k);      // Descriptor.py:44-93
-#pragma unroll
-        for (int i0 = 0; i0 < S; i0 += DSC_CHUNK) {
-            int zone[DSC_CHUNK];
-#pragma unroll
-            for (int u = 0; u < DSC_CHUNK; u++) {
-                const float4 tx = t[i0 + u];
-                const float inv = __builtin_amdgcn_rcpf(fmaxf(tx.w, 1e-30f));
-                const float gx = tx.x * inv, gy = tx.y * inv, gz = tx.z * inv;
-                const float rx = fmaf(gz, f2, fmaf(gy, f1, gx * f0));
-                const float ry = fmaf(gz, f5, fmaf(gy, f4, gx * f3));
-                const float rz = fmaf(gz, f8, fmaf(gy, f7, gx * f6));
-                const int zn = eqsp_fast32(&fast, rx, ry, rz);
-                zone[u] = tx.w < 1e-5f ? -2 : zn;                         // -2: Descriptor.py:190 (zone -1, not counted)
-            }
-#pragma unroll
-            for (int u = 0; u < DSC_CHUNK; u++) {
-                if (zone[u] >= 0) atomicAdd(&hist[(sub_jk + sub_of_i<S, NSUB>(i0 + u)) * Z + zone[u]], 1);
-                undecided |= zone[u] == -1 ? (1u << (i0 + u)) : 0u;
-            }
-        }
-        if (undecided) {      // decide later with the exact arithmetic, with full lanes
-#pragma unroll
-            for (int i = 0; i < S; i++)
-                if (undecided & (1u << i)) {
-                    const int slot = atomicAdd(&s_nq, 1);
-                    if (slot < DSC_QUEUE) { qv[slot] = t[i]; qsub[slot] = sub_jk + sub_of_i<S, NSUB>(i); }
-                }
-        }
     }
     __syncthreads();
     if (s_nq > DSC_QUEUE) {

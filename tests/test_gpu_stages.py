@@ -635,6 +635,22 @@ def test_sets_built_in_one_batch_equal_sets_built_one_by_one(lib, fields, n_sets
         s_.close()
 
 
+@pytest.mark.parametrize("r", [2, 4, 6])
+def test_describe_other_lattice_sizes_match_oracle(lib, fields, r):
+    """`Descriptor(dsc_radius = 4 | 8 | 12)` (Descriptor.py:34-35: 2 r samples per axis): k_describe<4>, <8>, <12>.  Their last
+    classification chunk is short (4 of 8 samples) -- a round-2 review found it reading four texels past the thread's array."""
+    for octave in (1, 0):
+        f = fields[octave]
+        coords = synth.interior_anchors(f["shape"], 40, (8 if octave == 1 else 16) + 2, 70 + r)
+        rows = O.orient(f["gx"], f["gy"], f["gz"], octave, coords, E112.sphere_eqsp, E112.p_centers_eqsp)
+        rc, R = coords[rows["anchor"]], rows["R"]
+        assert len(rc) > 40
+        ref = O.describe(f["gx"], f["gy"], f["gz"], octave, rc, R, E16.sphere_eqsp, r=r)
+        got = lib.describe(f["slot"], octave, rc, R, r=r)
+        assert ref.sum() > 0 and ref.sum() == got.sum()
+        np.testing.assert_array_equal(got, ref)
+
+
 def test_matches_of_a_bracket_with_one_gemm_grid(lib, fields):
     """mad_set_batching: the score tiles of all matches of a bracket from ONE grid (jobs of different sizes, a subunit without
     rows, two subunits on one lane, i.e. one of them outside the batch): top-k rows, pair ranks and statistics are those of the
