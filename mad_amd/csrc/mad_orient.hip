@@ -509,6 +509,15 @@ static int orient_batch(mad_ctx *ctx, int n_jobs, const OrientJob *jobs, int r, 
     // unit gradients (SoA) + the undecided-voxel queue; with a window also the voxels' squared offsets and the weight table
     const bool gw = ctx->gw_sig != 0.0;
     const size_t lds = gw ? ((((size_t)ctx->mask_n * 18 + 15) & ~(size_t)15) + (size_t)(3 * r * r + 1) * 8) : (size_t)ctx->mask_n * 4 * sizeof(float);
+    if (lds > 48 * 1024) {      // boxes beyond r = 8 (Orientator(ori_radius > 16)): more dynamic LDS than a kernel gets by default
+        static bool attr = false;
+        if (!attr) {
+            MAD_HIP(hipFuncSetAttribute((const void *)k_orient<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+            MAD_HIP(hipFuncSetAttribute((const void *)k_orient<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+            attr = true;
+        }
+        if (lds > 128 * 1024) return mad_fail(ctx, MAD_EINVAL, "mad_orient: a box of side %d needs %zu bytes of LDS", r, lds);
+    }
     if (gw) hipLaunchKernelGGL(k_orient<true>, dim3((unsigned)a0), dim3(ORI_THREADS), lds, ctx->stream, B);
     else hipLaunchKernelGGL(k_orient<false>, dim3((unsigned)a0), dim3(ORI_THREADS), lds, ctx->stream, B);
     mad_timer_end(ctx, MAD_T_ORIENT);

@@ -635,6 +635,25 @@ def test_sets_built_in_one_batch_equal_sets_built_one_by_one(lib, fields, n_sets
         s_.close()
 
 
+@pytest.mark.parametrize("r,lim_main,lim_sec", [(4, 6, 6), (10, 6, 6), (8, 3, 4), (8, 1, 1)])
+def test_orient_other_box_sizes_and_limits_match_oracle(lib, fields, r, lim_main, lim_sec):
+    """`Orientator(ori_radius = 8 | 20)` (box side r = 4 / 10: the 10-voxel sphere holds 4 945 voxels, two request batches per
+    thread and 77 KB of LDS) and other `main_ori` / `sec_ori` limits than 6 / 6 (Orientator.py:13, 181-184, 232-235)."""
+    for octave in (1, 0):
+        f = fields[octave]
+        margin = r * (1 if octave == 1 else 2) + 1
+        coords = np.concatenate([synth.interior_anchors(f["shape"], 30, margin + 1, 90 + r + octave),
+                                 np.array([[margin - 2, f["shape"][1] // 2, f["shape"][2] // 2]], np.int32)]).astype(np.int32)      # one border reject
+        ref = O.orient(f["gx"], f["gy"], f["gz"], octave, coords, E112.sphere_eqsp, E112.p_centers_eqsp, r=r, lim_main=lim_main, lim_sec=lim_sec)
+        got = lib.orient(f["slot"], octave, coords, r=r, lim_main=lim_main, lim_sec=lim_sec)
+        assert got["n_reject"] == ref["n_reject"] >= 1
+        if (lim_main, lim_sec) == (6, 6):
+            assert len(ref["anchor"]) > 10
+        for key in ("anchor", "main", "sec", "counts"):
+            np.testing.assert_array_equal(got[key], ref[key], err_msg=key)
+        np.testing.assert_allclose(got["R"], ref["R"], rtol=0, atol=1e-14)
+
+
 @pytest.mark.parametrize("r", [2, 4, 6])
 def test_describe_other_lattice_sizes_match_oracle(lib, fields, r):
     """`Descriptor(dsc_radius = 4 | 8 | 12)` (Descriptor.py:34-35: 2 r samples per axis): k_describe<4>, <8>, <12>.  Their last
