@@ -1124,6 +1124,19 @@ struct PoseCoarse {
 //   fine phase   : the queued points, now in full lanes, are mapped into the FINE two-plane bitmap in global memory (one
 //                  scattered L2 request per lane: what bounded the search when every point made one) and tallied:
 //                  inner bit = certainly within dist (lower bound), outer bit = possibly (upper bound).
+// median of (x, 0, hi) = x clamped into [0, hi], hi >= 0 and wave-uniform: one instruction
+__device__ __forceinline__ int clamp0(int x, int hi) {
+    int r;
+    asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(x), "s"(hi));
+    return r;
+}
+// a * b + c in 24-bit arithmetic with a wave-uniform b straight from its scalar register
+__device__ __forceinline__ unsigned mad_u24s(unsigned a, unsigned b, unsigned c) {
+    unsigned r;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b), "v"(c));
+    return r;
+}
+
 // Software-pipelined over pairs: the fine lookups of pair i are in flight while the coarse phase of pair i + 1 runs.
 template <int NB>
 __global__ __launch_bounds__(PB_THREADS) void k_pose_bounds(const int32_t *__restrict__ status, int64_t cap_pairs,
@@ -1138,11 +1151,11 @@ __global__ __launch_bounds__(PB_THREADS) void k_pose_bounds(const int32_t *__res
     const int64_t n_pairs = min((int64_t)status[ST_NPAIRS], cap_pairs);
     const int l_hi = status[ST_LHI];
     // histogram of the lower bounds (k_prune_select takes its threshold from it): per workgroup in LDS, flushed once at the end
-    int *lh = (int *)(smem + pad16((size_t)C.n_words * 4) + pad16((size_t)(l_hi + 4) * 16) + (size_t)(PB_THREADS / MAD_WAVE) * (NB * MAD_WAVE) * 2);
+    int *lh = (int *)(smem + pad16((size_t)C.n_words * 4) + pad16((size_t)(l_hi + 4) * 16) + (size_t)(PB_THREADS / MAD_WAVE) * ((NB + 1) * MAD_WAVE) * 2);
     for (int i = threadIdx.x; i < nbins; i += PB_THREADS) lh[i] = 0;
-    // one queue of NB x 64 point ids per wave (LDS operations of a wave execute in order: the lookups of a pair have read it
+    // one queue of NB x 64 point ids (+ 64 dump slots) per wave (LDS operations of a wave execute in order: the lookups of a pair have read it
     // before the next pair's filter writes it)
-    unsigned short *queue = (unsigned short *)(smem + pad16((size_t)C.n_words * 4) + pad16((size_t)(l_hi + 4) * 16)) + (threadIdx.x >> 6) * (NB * MAD_WAVE);
+    unsigned short *queue = (unsigned short *)(smem + pad16((size_t)C.n_words * 4) + pad16((size_t)(l_hi + 4) * 16)) + (threadIdx.x >> 6) * ((NB + 1) * MAD_WAVE);
     stage_lds(lb, bits_c, (size_t)C.n_words * 4);
     for (int i = threadIdx.x; i < l_hi; i += PB_THREADS)
         clf[i] = make_float4((float)hi_cloud[3 * i], (float)hi_cloud[3 * i + 1], (float)hi_cloud[3 * i + 2], 0.f);
@@ -1151,25 +1164,52 @@ __global__ __launch_bounds__(PB_THREADS) void k_pose_bounds(const int32_t *__res
     const int64_t wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (PB_THREADS / MAD_WAVE) + (threadIdx.x >> 6)));
     const int64_t nwaves = (int64_t)gridDim.x * (PB_THREADS / MAD_WAVE);
 
-    // coarse phase of one pair -> number of queued points (wave-uniform)
+    // coarse phase of one pair -> number of queued points (wave-uniform).  Straight-line per set of 64 points, ~26 vector
+    // instructions and no branch: the lane's points stay in registers from pair to pair (up to 8 sets; a lane beyond the cloud
+    // holds NaNs, which convert to voxel 0), a coordinate outside the bitmap is clamped onto its outermost layer -- never
+    // marked, the box is a whole voxel wider than any marked one on every side (pose_device) -- instead of being tested, the
+    // bit comes out with one v_bfe, and a lane that does not pass writes its id to a dump slot instead of being masked off.
+    constexpr bool CACHE = NB <= 8;
+    float pcx[CACHE ? NB : 1], pcy[CACHE ? NB : 1], pcz[CACHE ? NB : 1];
+    if (CACHE) {
+#pragma unroll
+        for (int u = 0; u < NB; u++) {
+            const int a = u * MAD_WAVE + lane;
+            const float4 c = clf[min(a, max(l_hi - 1, 0))];
+            const float bad = __int_as_float(0x7fc00000);
+            pcx[u] = a < l_hi ? c.x : bad; pcy[u] = a < l_hi ? c.y : bad; pcz[u] = a < l_hi ? c.z : bad;
+        }
+    }
+    unsigned short *dump = queue + NB * MAD_WAVE;      // 64 entries behind the wave's queue, never read
+    const int dx1 = C.B.dim[0] - 1, dy1 = C.B.dim[1] - 1, dz1 = C.B.dim[2] - 1;
     auto filter = [&](const PoseVox &V, unsigned short *q) -> int {
         int nq = 0;
+        // the translation in vector registers, once per pair (a v_fma takes one scalar operand: as an addend beside a scalar
+        // matrix entry it would be copied for every set)
+        float t0, t1, t2;
+        asm volatile("v_mov_b32 %0, %3\n\tv_mov_b32 %1, %4\n\tv_mov_b32 %2, %5" : "=&v"(t0), "=&v"(t1), "=&v"(t2) : "s"(V.t[0]), "s"(V.t[1]), "s"(V.t[2]));
 #pragma unroll
         for (int u = 0; u < NB; u++) {
             if (u * MAD_WAVE >= l_hi) break;      // wave-uniform
             const int a = u * MAD_WAVE + lane;
-            const float4 c = clf[min(a, l_hi - 1)];
-            const float vx = fmaf(c.z, V.m[2], fmaf(c.y, V.m[1], fmaf(c.x, V.m[0], V.t[0])));
-            const float vy = fmaf(c.z, V.m[5], fmaf(c.y, V.m[4], fmaf(c.x, V.m[3], V.t[1])));
-            const float vz = fmaf(c.z, V.m[8], fmaf(c.y, V.m[7], fmaf(c.x, V.m[6], V.t[2])));
-            const int jx = cvt_floor(vx), jy = cvt_floor(vy), jz = cvt_floor(vz);
-            const bool in = (a < l_hi) & ((unsigned)jx < (unsigned)C.B.dim[0]) & ((unsigned)jy < (unsigned)C.B.dim[1]) & ((unsigned)jz < (unsigned)C.B.dim[2]);
-            const unsigned cw = lb[in ? mad_u24(mad_u24((unsigned)jx, (unsigned)C.B.dim[1], (unsigned)jy), (unsigned)C.B.wz, (unsigned)(jz >> 5)) : 0u];
-            const bool pass = in & (((cw >> (jz & 31)) & 1u) != 0u);
+            float cx, cy, cz;
+            if (CACHE) { cx = pcx[u]; cy = pcy[u]; cz = pcz[u]; }
+            else {
+                const float4 c = clf[min(a, l_hi - 1)];
+                const float bad = __int_as_float(0x7fc00000);
+                cx = a < l_hi ? c.x : bad; cy = a < l_hi ? c.y : bad; cz = a < l_hi ? c.z : bad;
+            }
+            const float vx = fmaf(cz, V.m[2], fmaf(cy, V.m[1], fmaf(cx, V.m[0], t0)));
+            const float vy = fmaf(cz, V.m[5], fmaf(cy, V.m[4], fmaf(cx, V.m[3], t1)));
+            const float vz = fmaf(cz, V.m[8], fmaf(cy, V.m[7], fmaf(cx, V.m[6], t2)));
+            const int jx = clamp0(cvt_floor(vx), dx1), jy = clamp0(cvt_floor(vy), dy1), jz = clamp0(cvt_floor(vz), dz1);
+            const unsigned cw = lb[mad_u24s(mad_u24s((unsigned)jx, (unsigned)C.B.dim[1], (unsigned)jy), (unsigned)C.B.wz, (unsigned)(jz >> 5))];
+            const bool pass = __builtin_amdgcn_ubfe(cw, (unsigned)jz, 1u) != 0u;      // v_bfe_u32 takes the offset from the low five bits
             const unsigned long long bal = __ballot(pass);
             // set bits below this lane: two instructions (v_mbcnt_lo / _hi) where a lane mask costs a 64-bit shift and two population counts
             const int below = __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
-            if (pass) q[nq + below] = (unsigned short)a;
+            unsigned short *dst = pass ? q + nq + below : dump + lane;
+            *dst = (unsigned short)a;
             nq += __popcll(bal);
         }
         return nq;
@@ -1818,7 +1858,7 @@ static int pose_device(mad_ctx *ctx, const Side &hi, const Side &lo, int32_t *d_
         PoseBits &Bc = PC.B;
         // beside the bitmap: the float32 hi cloud and one queue of 2-byte point ids per wave
         const int nb_sets = (l_hi_max + MAD_WAVE - 1) / MAD_WAVE;
-        const size_t budget = (size_t)150 * 1024 - pad16((size_t)(l_hi_max + 4) * 16) - (size_t)(PB_THREADS / MAD_WAVE) * ((nb_sets + 1) & ~1) * MAD_WAVE * 2 - pad16((size_t)(l_hi_max + 1) * 4) - 64;
+        const size_t budget = (size_t)150 * 1024 - pad16((size_t)(l_hi_max + 4) * 16) - (size_t)(PB_THREADS / MAD_WAVE) * (((nb_sets + 1) & ~1) + 5) * MAD_WAVE * 2 - pad16((size_t)(l_hi_max + 1) * 4) - 64;      // queue: up to 4 sets of rounding (nbv) + the dump slots
         size_t n_words_c = 0;
         for (Bc.h = std::max(1.2, B.h);; Bc.h *= 1.05) {
             const double guard = dist + Bc.h * 0.8660254037844387 + slack + Bc.h;
@@ -1908,7 +1948,7 @@ static int pose_device(mad_ctx *ctx, const Side &hi, const Side &lo, int32_t *d_
             static const int probe_mode = getenv("MAD_PB_PROBE") ? atoi(getenv("MAD_PB_PROBE")) : 0;
             const int nb = (l_hi_max + MAD_WAVE - 1) / MAD_WAVE;      // point sets of 64 an entire hi cloud needs
             const int nbv = nb <= 2 ? 2 : (nb <= 4 ? 4 : (nb <= 6 ? 6 : (nb <= 8 ? 8 : (nb <= 10 ? 10 : (nb <= 12 ? 12 : 16)))));
-            const size_t lds_b = pad16((size_t)PC.n_words * 4) + pad16((size_t)(l_hi_max + 4) * 16) + (size_t)(PB_THREADS / MAD_WAVE) * nbv * MAD_WAVE * 2 +
+            const size_t lds_b = pad16((size_t)PC.n_words * 4) + pad16((size_t)(l_hi_max + 4) * 16) + (size_t)(PB_THREADS / MAD_WAVE) * (nbv + 1) * MAD_WAVE * 2 +
                                  pad16((size_t)nbins * 4) + 16;
 #define MAD_PB_LAUNCH(NBV)                                                                                                              \
     hipLaunchKernelGGL(k_pose_bounds<NBV>, dim3(ctx->n_cu), dim3(PB_THREADS), lds_b, ctx->stream, d_status, cap_pairs, d_rec, d_hi_cloud, B, \
