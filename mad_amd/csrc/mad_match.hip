@@ -1172,7 +1172,7 @@ __global__ __launch_bounds__(PB_THREADS) void k_pose_bounds(const int32_t *__res
     constexpr bool CACHE = NB <= 8;
     float pcx[CACHE ? NB : 1], pcy[CACHE ? NB : 1], pcz[CACHE ? NB : 1];
     if (CACHE) {
-#pragma unroll
+#pragma unroll NB
         for (int u = 0; u < NB; u++) {
             const int a = u * MAD_WAVE + lane;
             const float4 c = clf[min(a, max(l_hi - 1, 0))];
@@ -1188,7 +1188,7 @@ __global__ __launch_bounds__(PB_THREADS) void k_pose_bounds(const int32_t *__res
         // matrix entry it would be copied for every set)
         float t0, t1, t2;
         asm volatile("v_mov_b32 %0, %3\n\tv_mov_b32 %1, %4\n\tv_mov_b32 %2, %5" : "=&v"(t0), "=&v"(t1), "=&v"(t2) : "s"(V.t[0]), "s"(V.t[1]), "s"(V.t[2]));
-#pragma unroll
+#pragma unroll NB
         for (int u = 0; u < NB; u++) {
             if (u * MAD_WAVE >= l_hi) break;      // wave-uniform
             const int a = u * MAD_WAVE + lane;
@@ -1214,33 +1214,36 @@ __global__ __launch_bounds__(PB_THREADS) void k_pose_bounds(const int32_t *__res
         }
         return nq;
     };
-    // fine phase, first half: the lookups of the queued points go out
+    // fine phase, first half: the lookups of the queued points go out.  Coordinates are clamped onto the fine bitmap's outermost
+    // layer (never marked either: same construction), so the only predicate left is "this lane holds a queued point".
+    const int fx1 = B.dim[0] - 1, fy1 = B.dim[1] - 1, fz1 = B.dim[2] - 1;
     auto lookup = [&](const PoseVox &V, const unsigned short *q, int nq, uint2 (&w)[NB], int (&bit)[NB]) {
         __builtin_amdgcn_wave_barrier();      // the queue was written by this wave's own lanes
-#pragma unroll
+        float t0, t1, t2;
+        asm volatile("v_mov_b32 %0, %3\n\tv_mov_b32 %1, %4\n\tv_mov_b32 %2, %5" : "=&v"(t0), "=&v"(t1), "=&v"(t2) : "s"(V.t[0]), "s"(V.t[1]), "s"(V.t[2]));
+        const float m0 = V.m[0], m1 = V.m[1], m2 = V.m[2], m3 = V.m[3], m4 = V.m[4], m5 = V.m[5], m6 = V.m[6], m7 = V.m[7], m8 = V.m[8];
+#pragma unroll NB
         for (int u = 0; u < NB; u++) {
             w[u] = make_uint2(0u, 0u); bit[u] = 0;
             if (u * MAD_WAVE >= nq) continue;      // wave-uniform
             const int e = u * MAD_WAVE + lane;
             const float4 c = clf[q[min(e, nq - 1)]];
-            const float vx = fmaf(c.z, V.m[2], fmaf(c.y, V.m[1], fmaf(c.x, V.m[0], V.t[0])));
-            const float vy = fmaf(c.z, V.m[5], fmaf(c.y, V.m[4], fmaf(c.x, V.m[3], V.t[1])));
-            const float vz = fmaf(c.z, V.m[8], fmaf(c.y, V.m[7], fmaf(c.x, V.m[6], V.t[2])));
-            const int ix = cvt_floor(vx), iy = cvt_floor(vy), iz = cvt_floor(vz);
-            bit[u] = iz & 31;
-            const bool in = (e < nq) & ((unsigned)ix < (unsigned)B.dim[0]) & ((unsigned)iy < (unsigned)B.dim[1]) & ((unsigned)iz < (unsigned)B.dim[2]);
-            unsigned fi = mad_u24(mad_u24((unsigned)ix, (unsigned)B.dim[1], (unsigned)iy), (unsigned)B.wz, (unsigned)(iz >> 5));
-            if (probe == 3) fi &= 1023u;      // timing probe (MAD_PB_PROBE=3): every lookup an L1 hit; the results are wrong
-            if (in) w[u] = ((const uint2 *)bits)[fi];
+            const float vx = fmaf(c.z, m2, fmaf(c.y, m1, fmaf(c.x, m0, t0)));
+            const float vy = fmaf(c.z, m5, fmaf(c.y, m4, fmaf(c.x, m3, t1)));
+            const float vz = fmaf(c.z, m8, fmaf(c.y, m7, fmaf(c.x, m6, t2)));
+            const int ix = clamp0(cvt_floor(vx), fx1), iy = clamp0(cvt_floor(vy), fy1), iz = clamp0(cvt_floor(vz), fz1);
+            bit[u] = iz;      // the bit tests use its low five bits
+            const unsigned fi = mad_u24s(mad_u24s((unsigned)ix, (unsigned)B.dim[1], (unsigned)iy), (unsigned)B.wz, (unsigned)(iz >> 5));
+            if (e < nq) w[u] = ((const uint2 *)bits)[fi];
         }
     };
     // second half: the inner ball lies inside the outer one, so L = the inner count (low half), U = the outer count (high half)
     auto tally = [&](const uint2 (&w)[NB], const int (&bit)[NB], int nq) -> int {
         int acc = 0;
-#pragma unroll
+#pragma unroll NB
         for (int u = 0; u < NB; u++) {
             if (u * MAD_WAVE >= nq) break;      // wave-uniform
-            const unsigned in = (w[u].y >> bit[u]) & 1u, out = ((w[u].x | w[u].y) >> bit[u]) & 1u;
+            const unsigned in = __builtin_amdgcn_ubfe(w[u].y, (unsigned)bit[u], 1u), out = __builtin_amdgcn_ubfe(w[u].x | w[u].y, (unsigned)bit[u], 1u);
             acc += (int)(in + (out << 16));
         }
         return wave_sum_i32(acc);
