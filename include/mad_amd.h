@@ -238,6 +238,11 @@ int mad_match_topk_many_finish(mad_ctx *ctx);
  * the slowest set; off (default): one GEMM per match, each on its own lane, which overlaps better when several lanes are busy
  * (1.07 against 1.21 ms per overlapped C3 step).  Results are identical either way. */
 int mad_set_batching(mad_ctx *ctx, int on);
+/* Tuning values that change speed, never results.  "pose_split" (-1 auto: subunits of more than 512 anchors; 0 off; 1 on): the
+ * pose search of mad_match_topk* brackets the best-scoring pairs first and, in a second launch, abandons every other pair as
+ * soon as its running upper bound falls below the k-th lower bound of the first batch.  "pose_split_min": that first batch
+ * holds at least this many pairs (default 4096) and at least 64 k. */
+int mad_set_option(mad_ctx *ctx, const char *name, double value);
 
 /*
  * Which pose-scoring kernel the most recently enqueued match used: 0 = k_pose_lds (both clouds in LDS as float64),

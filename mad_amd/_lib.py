@@ -23,7 +23,7 @@ SYMBOLS = [
     "mad_set_eqsp", "mad_upload_field", "mad_upload_field_device", "mad_free_field",
     "mad_set_orient_window", "mad_orient", "mad_describe", "mad_describe_sized", "mad_correlate", "mad_pose_score", "mad_topk",
     "mad_set_create", "mad_set_destroy", "mad_set_build", "mad_set_build_many", "mad_set_load", "mad_set_size", "mad_set_download",
-    "mad_match_topk", "mad_match_topk_many", "mad_match_topk_many_begin", "mad_match_topk_many_finish", "mad_set_batching", "mad_last_pose_kernel", "mad_last_pose_selected", "mad_match_fetch", "mad_match_results", "mad_match_used",
+    "mad_match_topk", "mad_match_topk_many", "mad_match_topk_many_begin", "mad_match_topk_many_finish", "mad_set_batching", "mad_set_option", "mad_last_pose_kernel", "mad_last_pose_selected", "mad_match_fetch", "mad_match_results", "mad_match_used",
     "mad_match_shard_pairs", "mad_match_shard_topk",
     "mad_set_wire_bytes", "mad_set_export", "mad_set_import", "mad_set_lane", "mad_set_stream", "mad_set_bind_lane",
     "mad_upload_density", "mad_refine", "mad_structure_to_density", "mad_ccc", "mad_density_ccc", "mad_grid_overlap", "mad_overlap_matrix",
@@ -337,6 +337,10 @@ class Lib(object):
     def set_batching(self, on):
         """One GEMM launch for all matches of a `match_topk_many` bracket (True) or one per match (False, default)."""
         self._chk(self.dll.mad_set_batching(self.ctx, C.c_int(1 if on else 0)))
+
+    def set_option(self, name, value):
+        """Tuning values that change speed, never results (`mad_set_option`)."""
+        self._chk(self.dll.mad_set_option(self.ctx, name.encode(), C.c_double(float(value))))
 
     def timing_get(self, what):
         t = C.c_double(0)

@@ -61,6 +61,8 @@ extern "C" int mad_init(int device, mad_ctx **out) {
     mad_ctx *ctx = new mad_ctx();
     ctx->spatial_order = getenv("MAD_NO_SPATIAL_ORDER") == nullptr;      // diagnostic switch: build in list order
     ctx->batch_gemm = getenv("MAD_GEMM_BATCH") != nullptr;
+    if (getenv("MAD_POSE_SPLIT_MIN")) ctx->pose_split_min = atoll(getenv("MAD_POSE_SPLIT_MIN"));
+    if (getenv("MAD_POSE_SPLIT")) ctx->pose_split = atoi(getenv("MAD_POSE_SPLIT"));
     ctx->device = device;
     ctx->n_cu = prop.multiProcessorCount;
     for (int i = 0; i < MAD_MAX_FIELDS; i++) {

@@ -1112,6 +1112,8 @@ __global__ __launch_bounds__(256) void k_count_hist(const int32_t *__restrict__ 
 
 #define PB_THREADS 1024
 #define PB_MAX_SETS 16      // hi clouds of up to 16 x 64 points are bracketed (the per-set lookup state lives in registers: ~7 per set)
+#define PB_SAMPLE 2048          // scores sampled for the threshold between the two phases of the bounds pass
+#define PB_SCORE_BINS 1024      // ... and the bins of [0, 1] they are counted in
 struct PoseCoarse {
     PoseBits B;
     int n_words;
@@ -1138,18 +1140,52 @@ __device__ __forceinline__ unsigned mad_u24s(unsigned a, unsigned b, unsigned c)
 }
 
 // Software-pipelined over pairs: the fine lookups of pair i are in flight while the coarse phase of pair i + 1 runs.
-template <int NB>
+template <int NB, bool SPLIT>
 __global__ __launch_bounds__(PB_THREADS) void k_pose_bounds(const int32_t *__restrict__ status, int64_t cap_pairs,
                                                             const PosePair *__restrict__ rec, const double *__restrict__ hi_cloud,
                                                             PoseBits B, const unsigned *__restrict__ bits, PoseCoarse C,
                                                             const unsigned *__restrict__ bits_c, int32_t *__restrict__ lower,
-                                                            unsigned short *__restrict__ upper, int32_t *__restrict__ hist, int nbins, int probe) {
+                                                            unsigned short *__restrict__ upper, int32_t *__restrict__ hist, int nbins,
+                                                            const double *__restrict__ score, int phase, int64_t target_a, int64_t k_stop) {
     extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ int t_wt[PB_THREADS / MAD_WAVE + 1];
+    __shared__ int t_sh[3];
+    __shared__ int s_hist[PB_SCORE_BINS];
     if (status[ST_FLAG_C] || status[ST_FLAG_PAIRS]) return;
     unsigned *lb = (unsigned *)smem;                                           // coarse bitmap
     float4 *clf = (float4 *)(smem + pad16((size_t)C.n_words * 4));             // hi cloud, float32
     const int64_t n_pairs = min((int64_t)status[ST_NPAIRS], cap_pairs);
     const int l_hi = status[ST_LHI];
+    // Two launches per match, best-scoring pairs first.  A pair's correlation score predicts its match count well (on the C3
+    // workload the 60 largest counts all lie within the best-scoring 15 % of the pairs, all but a few within the best 1 %), so
+    // phase 1 brackets the pairs whose score lies in the top ~target_a (a threshold taken from PB_SAMPLE scores at a fixed
+    // stride, which every workgroup derives for itself) and phase 2 the others, with k_stop > 0: a pair is ABANDONED as soon
+    // as (coarse hits so far) + (points not yet looked at) -- an upper bound of its upper bound -- falls below T_stop = the
+    // k_stop-th largest lower bound already in the histogram (phase 1's): at least k_stop pairs have a count >= T_stop, so such a
+    // pair cannot be among the k_stop best, and the final threshold of k_prune_select (over all pairs) can only be higher.  It
+    // gets lower bound 0 and that upper bound.  Nothing depends on the prediction being right: a poor one only prunes less.
+    // phase 0: all pairs in one launch, nothing abandoned.
+    auto bin_of = [](double v) { return min(max((int)(v * PB_SCORE_BINS), 0), PB_SCORE_BINS - 1); };
+    int b_star = 0;      // phase 1 takes the pairs whose score bin is >= b_star, phase 2 the others
+    int t_stop = 0;
+    if (SPLIT && phase != 0) {
+        if (target_a < n_pairs) {
+            for (int i = threadIdx.x; i < PB_SCORE_BINS; i += PB_THREADS) s_hist[i] = 0;
+            __syncthreads();
+            const int64_t n_s = min((int64_t)PB_SAMPLE, n_pairs), stride = n_pairs / n_s;
+            for (int64_t i = threadIdx.x; i < n_s; i += PB_THREADS) atomicAdd(&s_hist[bin_of(score[i * stride])], 1);
+            __syncthreads();
+            int need;
+            b_star = max(topk_threshold(s_hist, PB_SCORE_BINS, max((target_a * n_s + n_pairs - 1) / n_pairs, (int64_t)1), t_wt, t_sh, &need), 0);
+            __syncthreads();
+        }
+        if (phase == 2 && b_star == 0) return;      // everything went through in phase 1
+        if (phase == 2 && k_stop > 0) {
+            int need;
+            t_stop = max(topk_threshold(hist, nbins, k_stop, t_wt, t_sh, &need), 0);
+            __syncthreads();
+        }
+    }
     // histogram of the lower bounds (k_prune_select takes its threshold from it): per workgroup in LDS, flushed once at the end
     int *lh = (int *)(smem + pad16((size_t)C.n_words * 4) + pad16((size_t)(l_hi + 4) * 16) + (size_t)(PB_THREADS / MAD_WAVE) * ((NB + 1) * MAD_WAVE) * 2);
     for (int i = threadIdx.x; i < nbins; i += PB_THREADS) lh[i] = 0;
@@ -1211,6 +1247,10 @@ __global__ __launch_bounds__(PB_THREADS) void k_pose_bounds(const int32_t *__res
             unsigned short *dst = pass ? q + nq + below : dump + lane;
             *dst = (unsigned short)a;
             nq += __popcll(bal);
+            if (SPLIT) {
+                const int bound = nq + max(l_hi - (u + 1) * MAD_WAVE, 0);      // wave-uniform
+                if (bound < t_stop) return -bound - 1;
+            }
         }
         return nq;
     };
@@ -1251,25 +1291,53 @@ __global__ __launch_bounds__(PB_THREADS) void k_pose_bounds(const int32_t *__res
 
     uint2 wA[NB], wB[NB];
     int bitA[NB], bitB[NB];
-    int nqA = 0, nqB = 0;
-    auto put = [&](int64_t p, int acc) {
+    int nqA = 0, nqB = 0;      // < 0: abandoned, -(upper bound) - 1
+    auto put = [&](int64_t p, int acc, int nq) {
+        if (nq < 0) acc = (-nq - 1) << 16;      // lower bound 0
         if (lane == 0) { lower[p] = acc & 0xffff; upper[p] = (unsigned short)(acc >> 16); atomicAdd(&lh[min(acc & 0xffff, nbins - 1)], 1); }
     };
-    int64_t p = wave;
-    if (p < n_pairs) {
+    // The wave's pairs are wave, wave + nwaves, ...; which of them belong to this launch's phase is found 64 at a time (one
+    // strided load of their scores, one ballot), then the set bits are walked.
+    int64_t chunk = 0;                 // the next 64 candidates start at index wave + chunk * nwaves
+    unsigned long long todo = 0ull;    // members of the current chunk not yet handed out
+    int64_t todo_base = 0;
+    int64_t plain = wave;      // SPLIT = false: the pairs wave, wave + nwaves, ... in turn
+    auto next_pair = [&]() -> int64_t {
+        if (!SPLIT) {
+            const int64_t r = plain < n_pairs ? plain : -1;
+            plain += nwaves;
+            return r;
+        }
+        while (todo == 0ull) {
+            const int64_t first = wave + chunk * nwaves;
+            if (first >= n_pairs) return -1;
+            const int64_t mine = first + (int64_t)lane * nwaves;
+            bool take = mine < n_pairs;
+            if (take && phase != 0) take = (bin_of(score[mine]) >= b_star) == (phase == 1);
+            todo = __ballot(take);
+            todo_base = first;
+            chunk += MAD_WAVE;
+        }
+        const int j = __builtin_ctzll(todo);
+        todo &= todo - 1ull;
+        return todo_base + (int64_t)j * nwaves;
+    };
+    int64_t p = next_pair(), pb = -1, pa = -1;
+    if (p >= 0) {
         nqA = filter(rec[p].vc, queue);
-        lookup(rec[p].vf, queue, nqA, wA, bitA);
+        lookup(rec[p].vf, queue, max(nqA, 0), wA, bitA);
     }
-    while (p < n_pairs) {      // two pairs per trip (A, then B): the buffers swap roles without register copies
-        const int64_t pb = p + nwaves, pa = pb + nwaves;
-        if (pb < n_pairs) nqB = filter(rec[pb].vc, queue);      // while the lookups of pair p are in flight
-        put(p, tally(wA, bitA, nqA));
-        if (pb >= n_pairs) break;
-        lookup(rec[pb].vf, queue, nqB, wB, bitB);
-        if (pa < n_pairs) nqA = filter(rec[pa].vc, queue);
-        put(pb, tally(wB, bitB, nqB));
-        if (pa >= n_pairs) break;
-        lookup(rec[pa].vf, queue, nqA, wA, bitA);
+    while (p >= 0) {      // two pairs per trip (A, then B): the buffers swap roles without register copies
+        pb = next_pair();
+        if (pb >= 0) nqB = filter(rec[pb].vc, queue);      // while the lookups of pair p are in flight
+        put(p, tally(wA, bitA, max(nqA, 0)), nqA);
+        if (pb < 0) break;
+        lookup(rec[pb].vf, queue, max(nqB, 0), wB, bitB);
+        pa = next_pair();
+        if (pa >= 0) nqA = filter(rec[pa].vc, queue);
+        put(pb, tally(wB, bitB, max(nqB, 0)), nqB);
+        if (pa < 0) break;
+        lookup(rec[pa].vf, queue, max(nqA, 0), wA, bitA);
         p = pa;
     }
     __syncthreads();
@@ -1938,31 +2006,61 @@ static int pose_device(mad_ctx *ctx, const Side &hi, const Side &lo, int32_t *d_
             MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_TMP_D), (size_t)cap_pairs * 4 + 64));
             const int nbins = l_hi_max + 1;
             static bool attr_b = false;
-            if (!attr_b) {
-                MAD_HIP(hipFuncSetAttribute((const void *)k_pose_bounds<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                MAD_HIP(hipFuncSetAttribute((const void *)k_pose_bounds<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                MAD_HIP(hipFuncSetAttribute((const void *)k_pose_bounds<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                MAD_HIP(hipFuncSetAttribute((const void *)k_pose_bounds<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                MAD_HIP(hipFuncSetAttribute((const void *)k_pose_bounds<10>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                MAD_HIP(hipFuncSetAttribute((const void *)k_pose_bounds<12>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                MAD_HIP(hipFuncSetAttribute((const void *)k_pose_bounds<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            if (!attr_b) {      // (155 KB: the kernel has 4.2 KB of static LDS beside the dynamic part)
+                MAD_HIP(hipFuncSetAttribute((const void *)k_pose_bounds<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+                MAD_HIP(hipFuncSetAttribute((const void *)k_pose_bounds<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+                MAD_HIP(hipFuncSetAttribute((const void *)k_pose_bounds<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+                MAD_HIP(hipFuncSetAttribute((const void *)k_pose_bounds<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+                MAD_HIP(hipFuncSetAttribute((const void *)k_pose_bounds<6, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+                MAD_HIP(hipFuncSetAttribute((const void *)k_pose_bounds<6, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+                MAD_HIP(hipFuncSetAttribute((const void *)k_pose_bounds<8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+                MAD_HIP(hipFuncSetAttribute((const void *)k_pose_bounds<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+                MAD_HIP(hipFuncSetAttribute((const void *)k_pose_bounds<10, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+                MAD_HIP(hipFuncSetAttribute((const void *)k_pose_bounds<10, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+                MAD_HIP(hipFuncSetAttribute((const void *)k_pose_bounds<12, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+                MAD_HIP(hipFuncSetAttribute((const void *)k_pose_bounds<12, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+                MAD_HIP(hipFuncSetAttribute((const void *)k_pose_bounds<16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+                MAD_HIP(hipFuncSetAttribute((const void *)k_pose_bounds<16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
                 attr_b = true;
             }
-            static const int probe_mode = getenv("MAD_PB_PROBE") ? atoi(getenv("MAD_PB_PROBE")) : 0;
+            // two launches of the bounds kernel, best-scoring pairs first: the second abandons pairs early (k_pose_bounds)
+            // ... when a pair has more than eight sets of 64 points to lose: with fewer (C3, C4: ~430 points) the second launch's
+            // fixed cost (staging the bitmap again, the score sample) eats what abandoning saves -- measured: C5 (700 points) 8.1 ->
+            // 6.8 ms per step, C4 2.28 -> 2.20, C3 1.05 -> 1.05 with its pose stage 0.307 -> 0.342 ms when serialised.
+            // mad_set_option "pose_split" (MAD_POSE_SPLIT in the environment) = 1 / 0 forces it on / off.
+            const bool split = ctx->pose_split >= 0 ? ctx->pose_split != 0 : l_hi_max > 8 * MAD_WAVE;
+            // phase 1: ~5 % of the pairs at the default, at least 64 k of them (fewer pairs than that: everything in one phase)
+            static const int split_factor = getenv("MAD_POSE_SPLIT_FACTOR") ? atoi(getenv("MAD_POSE_SPLIT_FACTOR")) : 64;      // diagnostic switch
+            const int64_t target_a = std::max<int64_t>(ctx->pose_split_min, (int64_t)split_factor * prune_k);
             const int nb = (l_hi_max + MAD_WAVE - 1) / MAD_WAVE;      // point sets of 64 an entire hi cloud needs
             const int nbv = nb <= 2 ? 2 : (nb <= 4 ? 4 : (nb <= 6 ? 6 : (nb <= 8 ? 8 : (nb <= 10 ? 10 : (nb <= 12 ? 12 : 16)))));
             const size_t lds_b = pad16((size_t)PC.n_words * 4) + pad16((size_t)(l_hi_max + 4) * 16) + (size_t)(PB_THREADS / MAD_WAVE) * (nbv + 1) * MAD_WAVE * 2 +
                                  pad16((size_t)nbins * 4) + 16;
-#define MAD_PB_LAUNCH(NBV)                                                                                                              \
-    hipLaunchKernelGGL(k_pose_bounds<NBV>, dim3(ctx->n_cu), dim3(PB_THREADS), lds_b, ctx->stream, d_status, cap_pairs, d_rec, d_hi_cloud, B, \
-                       d_bits, PC, d_bits_c, scratch<int32_t>(ctx, S_COUNTS), scratch<unsigned short>(ctx, S_TMP_C), hist2, nbins, probe_mode)
-            if (nbv == 2) MAD_PB_LAUNCH(2);
-            else if (nbv == 4) MAD_PB_LAUNCH(4);
-            else if (nbv == 6) MAD_PB_LAUNCH(6);
-            else if (nbv == 8) MAD_PB_LAUNCH(8);
-            else if (nbv == 10) MAD_PB_LAUNCH(10);
-            else if (nbv == 12) MAD_PB_LAUNCH(12);
-            else MAD_PB_LAUNCH(16);
+#define MAD_PB_LAUNCH(NBV, SPL)                                                                                                              \
+    hipLaunchKernelGGL((k_pose_bounds<NBV, SPL>), dim3(ctx->n_cu), dim3(PB_THREADS), lds_b, ctx->stream, d_status, cap_pairs, d_rec, d_hi_cloud, B, \
+                       d_bits, PC, d_bits_c, scratch<int32_t>(ctx, S_COUNTS), scratch<unsigned short>(ctx, S_TMP_C), hist2, nbins,              \
+                       (const double *)scratch<double>(ctx, S_PAIR_SCORE), pb_phase, target_a, pb_stop)
+            for (int pass = 0; pass < (split ? 2 : 1); pass++) {
+                const int pb_phase = split ? pass + 1 : 0;
+                const int64_t pb_stop = pass == 1 ? prune_k : 0;
+                if (split) {
+                    if (nbv == 2) MAD_PB_LAUNCH(2, true);
+                    else if (nbv == 4) MAD_PB_LAUNCH(4, true);
+                    else if (nbv == 6) MAD_PB_LAUNCH(6, true);
+                    else if (nbv == 8) MAD_PB_LAUNCH(8, true);
+                    else if (nbv == 10) MAD_PB_LAUNCH(10, true);
+                    else if (nbv == 12) MAD_PB_LAUNCH(12, true);
+                    else MAD_PB_LAUNCH(16, true);
+                } else {
+                    if (nbv == 2) MAD_PB_LAUNCH(2, false);
+                    else if (nbv == 4) MAD_PB_LAUNCH(4, false);
+                    else if (nbv == 6) MAD_PB_LAUNCH(6, false);
+                    else if (nbv == 8) MAD_PB_LAUNCH(8, false);
+                    else if (nbv == 10) MAD_PB_LAUNCH(10, false);
+                    else if (nbv == 12) MAD_PB_LAUNCH(12, false);
+                    else MAD_PB_LAUNCH(16, false);
+                }
+            }
 #undef MAD_PB_LAUNCH
             hipLaunchKernelGGL(k_prune_select, dim3(ctx->n_cu / 2), dim3(256), 0, ctx->stream, d_status, cap_pairs, hist2, nbins, prune_k,
                                scratch<unsigned short>(ctx, S_TMP_C), scratch<int32_t>(ctx, S_TMP_D), d_status + ST_NSEL, hist2 + nbins,
@@ -2853,6 +2951,20 @@ extern "C" int mad_match_topk_many_begin(mad_ctx *ctx, int n, const mad_set *con
     }
     ctx->res_slot = 0;
     return rc_all;
+}
+
+extern "C" int mad_set_option(mad_ctx *ctx, const char *name, double value) {
+    if (!ctx || !name) return MAD_EINVAL;
+    if (!strcmp(name, "pose_split_min")) {      // (MAD_POSE_SPLIT_MIN in the environment sets the initial value)
+        if (!(value >= 0) || !(value < 1e12)) return mad_fail(ctx, MAD_EINVAL, "mad_set_option: pose_split_min = %g", value);
+        ctx->pose_split_min = (int64_t)value;
+        return MAD_OK;
+    }
+    if (!strcmp(name, "pose_split")) {      // -1: on for hi clouds of more than 512 points (default), 0: off, 1: on
+        ctx->pose_split = value < 0 ? -1 : (value != 0 ? 1 : 0);
+        return MAD_OK;
+    }
+    return mad_fail(ctx, MAD_EINVAL, "mad_set_option: unknown option '%s'", name);
 }
 
 extern "C" int mad_set_batching(mad_ctx *ctx, int on) {

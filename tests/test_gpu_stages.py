@@ -850,5 +850,18 @@ def test_pruned_pose_search_returns_the_rows_of_the_full_search(lib, k):
     res = lib.match_results(hi, lo, st["n_pairs"])
     np.testing.assert_array_equal(res[:, 1], 100.0 * cnt / st["l_hi"])
     np.testing.assert_array_equal(res[order], top)
+    # the bounds pass looks at the best-scoring pairs first and abandons the others early: with other sizes of that first list
+    # (64 k pairs at least; everything in it, i.e. no abandoning at all) the k rows must not change
+    for split_min in (0, 4096, 10 ** 9):
+        lib.set_option("pose_split", 1)
+        lib.set_option("pose_split_min", split_min)
+        try:
+            top3, idx3, st3 = lib.match_topk(hi, lo, 0.9, 4.0, k)
+        finally:
+            lib.set_option("pose_split_min", 4096)
+            lib.set_option("pose_split", -1)
+        assert st3 == st
+        np.testing.assert_array_equal(idx3, idx)
+        np.testing.assert_array_equal(top3, top)
     hi.close()
     lo.close()
