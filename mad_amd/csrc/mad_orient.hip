@@ -740,11 +740,19 @@ __global__ __launch_bounds__(DSC_THREADS, DSC_OCC) void k_describe(Batch<Describ
     }
     const int64_t work = (int64_t)(bid & 7) * chunk + (bid >> 3);
     if ((int64_t)(bid >> 3) >= chunk || work >= n_rows) return;
-    const int64_t row = A.row_perm ? (int64_t)A.row_perm[work] : work;
+    // row -> anchor -> octave, coordinates: a chain of dependent loads before the first texel can be asked for.  Written so that
+    // every link is a SCALAR load (the conditional-pointer forms compiled into flat vector loads, and the field into a
+    // dependent fetch from the kernel arguments): both fields' descriptors are read up front and one is selected.
+    int64_t row = work;
+    if (A.row_perm) row = (int64_t)__builtin_amdgcn_readfirstlane(A.row_perm[work]);
     eqsp_fast_stage(A.eq, &fast);
-    const int a = A.row_anchor ? A.row_anchor[row] : (int)row;
-    const int oct = A.anc_octave ? A.anc_octave[a] : A.uniform_octave;
-    const FieldDev F = A.f[oct == 1 ? 1 : 0];
+    int a = (int)row;
+    if (A.row_anchor) a = __builtin_amdgcn_readfirstlane(A.row_anchor[row]);
+    int oct = A.uniform_octave;
+    if (A.anc_octave) oct = __builtin_amdgcn_readfirstlane(A.anc_octave[a]);
+    const FieldDev F0 = A.f[0], F1 = A.f[1];
+    FieldDev F;
+    F.tex = oct == 1 ? F1.tex : F0.tex; F.nx = oct == 1 ? F1.nx : F0.nx; F.ny = oct == 1 ? F1.ny : F0.ny; F.nz = oct == 1 ? F1.nz : F0.nz;
     const int Z = A.eq->Z;
     const int D = NSUB * Z;            // S = 2 r samples per axis (16), NSUB sub-regions of Z zones each
 
@@ -764,7 +772,8 @@ __global__ __launch_bounds__(DSC_THREADS, DSC_OCC) void k_describe(Batch<Describ
     for (int i = tid; i < D; i += DSC_THREADS) hist[i] = 0;
     __syncthreads();
 
-    const int ic0 = A.anc_coords[3 * a], ic1 = A.anc_coords[3 * a + 1], ic2 = A.anc_coords[3 * a + 2];
+    const int ic0 = __builtin_amdgcn_readfirstlane(A.anc_coords[3 * a]), ic1 = __builtin_amdgcn_readfirstlane(A.anc_coords[3 * a + 1]),
+              ic2 = __builtin_amdgcn_readfirstlane(A.anc_coords[3 * a + 2]);
     const double c0 = (double)ic0, c1 = (double)ic1, c2 = (double)ic2;
     const float h0 = (float)inv9[0], h1 = (float)inv9[1], h2 = (float)inv9[2], h3 = (float)inv9[3], h4 = (float)inv9[4], h5 = (float)inv9[5],
                 h6 = (float)inv9[6], h7 = (float)inv9[7], h8 = (float)inv9[8];
