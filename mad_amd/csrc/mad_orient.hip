@@ -142,14 +142,21 @@ __global__ __launch_bounds__(ORI_THREADS) void k_orient(Batch<OrientArgs> B) {
     __shared__ float s_domf[ORI_MAX_MAIN][9];
     __shared__ EqspFastLds fast;
 
-    const int a = A.order ? A.order[(int)blockIdx.x - B.first[job]] : (int)blockIdx.x - B.first[job];
+    // anchor -> octave, coordinates -> texel addresses: every link a scalar load, the field selected from both descriptors
+    // (as in k_describe: the conditional-pointer forms compile into flat vector loads and a dependent fetch)
+    int a = (int)blockIdx.x - B.first[job];
+    if (A.order) a = __builtin_amdgcn_readfirstlane(A.order[a]);
     const int tid = threadIdx.x;
-    const int oct = A.octave ? A.octave[a] : A.uniform_octave;
-    const FieldDev F = A.f[oct == 1 ? 1 : 0];
+    int oct = A.uniform_octave;
+    if (A.octave) oct = __builtin_amdgcn_readfirstlane(A.octave[a]);
+    const FieldDev F0 = A.f[0], F1 = A.f[1];
+    FieldDev F;
+    F.tex = oct == 1 ? F1.tex : F0.tex; F.nx = oct == 1 ? F1.nx : F0.nx; F.ny = oct == 1 ? F1.ny : F0.ny; F.nz = oct == 1 ? F1.nz : F0.nz;
     const int stride = (oct == 1) ? 1 : 2;
     const int r = A.r;
     const int Z = A.eq->Z;
-    const int x = A.coords[3 * a], y = A.coords[3 * a + 1], z = A.coords[3 * a + 2];
+    const int x = __builtin_amdgcn_readfirstlane(A.coords[3 * a]), y = __builtin_amdgcn_readfirstlane(A.coords[3 * a + 1]),
+              z = __builtin_amdgcn_readfirstlane(A.coords[3 * a + 2]);
 
     // step01 border test (Orientator.py:128-135 / 149-155)
     {

@@ -789,6 +789,19 @@ def test_sharded_set_build_object_on_one_rank(lib, fields):
             for key in ("anchor", "main", "sec", "R", "dsc"):
                 np.testing.assert_array_equal(got[key], want[key])
     assert b.share.size()[0] < ref.size()[0]
+    # the share built in one batch with another structure (bench.py --batched: build_job() + set_build_many + finish())
+    other = _anchors(f1["shape"], 1, 25, 32)
+    jobs = [b.build_job(), ([-1, f1["slot"]], other, np.ones(len(other), np.int32), other * 1.5, np.arange(len(other), dtype=np.int32))]
+    batch = lib.prepare_build_many(jobs)
+    for _ in range(2):
+        built = batch.run()
+        got = b.finish().download()
+        for key in ("anchor", "main", "sec", "R", "dsc"):
+            np.testing.assert_array_equal(got[key], want[key])
+    alone = lib.set_build(*jobs[1])
+    np.testing.assert_array_equal(built[1].download()["dsc"], alone.download()["dsc"])
+    alone.close()
+    built[1].close()
     b.close()
     ref.close()
 
