@@ -806,15 +806,15 @@ def test_sharded_set_build_object_on_one_rank(lib, fields):
     ref.close()
 
 
-@pytest.mark.parametrize("k", [1, 7, 60, 400, 5000])
-def test_pruned_pose_search_returns_the_rows_of_the_full_search(lib, k):
+@pytest.mark.parametrize("k,n_hi_a", [(1, 90), (7, 90), (60, 90), (400, 90), (5000, 90), (60, 600), (60, 900)])
+def test_pruned_pose_search_returns_the_rows_of_the_full_search(lib, k, n_hi_a):
     """mad_match_topk only reports k pairs, so the pose search brackets every pair's count with the occupancy bitmaps and
     searches exactly only the pairs whose upper bound reaches the k-th largest lower bound.  On clouds made to produce ties
     en masse at the k-th place (a planted pose that a third of the rows share, rows duplicated, lo points exactly at the
     distance threshold) the k rows and their order must be those of python's stable sort over the EXACT counts of all pairs
     (MaD.py:480), which mad_match_fetch delivers afterwards."""
     rng = np.random.default_rng(11)
-    n_lo_a, n_hi_a = 260, 90
+    n_lo_a = 260      # (n_hi_a = 600 / 900: hi clouds of 10 / 15 sets of 64 points -- k_pose_bounds<10>, <16> -- and the two-launch form by itself)
     lo_p = rng.uniform(0, 110, size=(n_lo_a, 3))
     Q = synth.random_rotation(rng)
     shift = np.array([7.0, -3.0, 5.0])
