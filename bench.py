@@ -163,7 +163,7 @@ HOST_T = {}
 
 
 _BATCHES = {}
-BATCHED = {"on": os.environ.get("MAD_BUILD_BATCH", "0") == "1"}
+BATCHED = {"on": os.environ.get("MAD_BUILD_BATCH", "0") == "1", "asked": "MAD_BUILD_BATCH" in os.environ}
 
 
 def enqueue_builds(lib, the_map, subs, sets):
@@ -406,7 +406,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="auto", choices=sorted(WORKLOADS) + ["auto"], help="auto: c3 on one GPU, c4 (strong scaling) on several")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--in-flight", type=int, default=3, choices=(2, 3, 4), help="steps in flight (groups of device sets)")
+    ap.add_argument("--in-flight", type=int, default=0, choices=(0, 2, 3, 4), help="steps in flight (groups of device sets); 0 = 3, or 4 when this "
+                    "rank holds a single subunit (its step is then a string of short launches, and the host's turn-around shows)")
     ap.add_argument("--serial", action="store_true", help="lanes serialised for the whole run: the mode the rocprofv3 summaries in profiles/ are "
                     "taken in, so that a kernel's average duration there is the one the roofline pass measures")
     ap.add_argument("--batched", action="store_true", help="one launch per stage for all structures of a step (mad_set_build_many) and one GEMM "
@@ -493,12 +494,18 @@ def main():
                                          emulate=(emu, 0) if emu else None, force=True)
         return _lib.DeviceSet(lib)
 
+    # A rank with a single subunit (C4 on 8 GPUs) runs ~35 short launches per step: there the batched launches (one per stage for
+    # its share of the map + its subunit) and a fourth step in flight pay -- rehearsed: 0.345 -> 0.317 ms per step -- while a rank
+    # with several subunits is better off with one launch per structure and three steps.
+    light = (world > 1 or emu) and len(subs) <= 1
+    if args.in_flight == 0:
+        args.in_flight = 4 if light else 3
+    if args.batched or (light and not BATCHED["asked"]):
+        BATCHED["on"] = True
     set_groups = [[map_set()] + [_lib.DeviceSet(lib) for _ in subs] for _ in range(args.in_flight)]
     sets = set_groups[0]
     if args.serial:
         lib.set_overlap(False)
-    if args.batched:
-        BATCHED["on"] = True
     if BATCHED["on"]:
         lib.set_batching(True)
     # Setup, not a step: all groups of device sets are created, sized and given their launch-size hints here (a set sizes
@@ -581,7 +588,10 @@ def main():
         shard_check = bool(all(np.array_equal(a[f], b[f]) for f in ("anchor", "main", "sec", "R", "dsc")))
         ref_set.close()
         _, all_subs, _ = build_inputs(lib, W, 0, 1)
-        groups1 = [[_lib.DeviceSet(lib) for _ in range(1 + len(all_subs))] for _ in range(args.in_flight)]
+        was_batched = BATCHED["on"]      # the whole workload on one GPU in ITS best form: one launch per structure, three steps in flight
+        BATCHED["on"] = False
+        lib.set_batching(False)
+        groups1 = [[_lib.DeviceSet(lib) for _ in range(1 + len(all_subs))] for _ in range(3)]
         for grp in groups1:
             for _ in range(2):
                 hot_path_step(lib, the_map, all_subs, cc, dist_thr, k, grp)
@@ -602,6 +612,8 @@ def main():
         for grp in groups1:
             for s_ in grp:
                 s_.close()
+        BATCHED["on"] = was_batched
+        lib.set_batching(was_batched)
     if world > 1:
         dist.barrier()
 
