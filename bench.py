@@ -497,7 +497,10 @@ def main():
     # A rank with a single subunit (C4 on 8 GPUs) runs ~35 short launches per step: there the batched launches (one per stage for
     # its share of the map + its subunit) and a fourth step in flight pay -- rehearsed: 0.345 -> 0.317 ms per step -- while a rank
     # with several subunits is better off with one launch per structure and three steps.
-    light = (world > 1 or emu) and len(subs) <= 1
+    # (decided from the job's shape, not from this rank's share: every rank must issue the same sequence of collectives, and the
+    # depth of the pipeline is part of that sequence)
+    n_ranks_job = emu if emu else world
+    light = n_ranks_job > 1 and -(-W["n_sub"] // n_ranks_job) <= 1
     if args.in_flight == 0:
         args.in_flight = 4 if light else 3
     if args.batched or (light and not BATCHED["asked"]):
