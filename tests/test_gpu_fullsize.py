@@ -101,11 +101,12 @@ def test_full_size_properties(lib, workload):
             st_.ms.release_device()
 
 
-@pytest.mark.parametrize("workload", ["c2", "c3", "c5"])
+@pytest.mark.parametrize("workload", ["c2", "c3", "c4", "c5"])
 def test_whole_workload_equals_the_oracle(lib, workload):
     """The benchmark's own workload (c3: 256^3 map, 4 subunits, every anchor of both octaves) through the CPU oracle on
     the host threads and through the device path: rows, descriptors, pair lists, match counts and top-k must be
-    identical (~10 s on 16 threads).  c5 is the same comparison at the largest size: the whole 512^3 map (~30 000 rows,
+    identical (~10 s on 16 threads).  c4 is the multi-GPU workload (256^3 map of 8 subunits, seeds 30-37): its whole map against
+    its first 4 subunits.  c5 is the same comparison at the largest size: the whole 512^3 map (~30 000 rows,
     5 400 anchors: the pose search runs in k_pose_lds32) against its first 2 subunits (70 s, most of it the oracle);
     MAD_TEST_C5_ORACLE=n takes the first n of the 12."""
     import bench
