@@ -120,6 +120,7 @@ def test_whole_workload_equals_the_oracle(lib, workload):
     cc, dist, k = 0.6, 4.0, 60
     threads = min(16, os.cpu_count() or 1)
     the_map, subs, _ = bench.build_inputs(lib, bench.WORKLOADS[workload], 0)
+    all_subs = list(subs)
     n_subs = int(os.environ.get("MAD_TEST_C5_ORACLE", "0"))
     subs = subs[:4] if workload != "c5" else subs[:max(n_subs, 2)]
 
@@ -174,3 +175,5 @@ def test_whole_workload_equals_the_oracle(lib, workload):
         hi_d.close()
     lo_d.close()
     lib.set_option("pose_split", -1)
+    for st_ in [the_map] + all_subs:      # the field slots of the workload's structures (64 per context)
+        st_.ms.release_device()
