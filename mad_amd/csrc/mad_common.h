@@ -125,7 +125,8 @@ struct MatchState {            // the most recent mad_match_topk call
     // the pose search of that match was pruned by bounds: S_COUNTS holds exact counts only for the pairs that could reach the
     // top k.  mad_match_fetch / mad_match_results complete it on demand (they need the two sets alive and the distance).
     bool pruned = false, fits = true;
-    const void *hi = nullptr, *lo = nullptr;
+    const void *hi = nullptr, *lo = nullptr;      // cleared by mad_set_destroy; hi_gen / lo_gen: the builds those counts belong to
+    uint64_t hi_gen = 0, lo_gen = 0;
     double dist = 0;
     int64_t cap_pairs_used = 0;
     int64_t n_sel = 0;         // pairs that went through the exact search (= n_pairs when nothing was pruned)
@@ -173,7 +174,6 @@ struct mad_ctx {
     DensityDev dens;
     MatchState match;
     int last_pose_kernel = -1;               // 0 k_pose_lds, 1 k_pose_lds32, 2 k_pose (mad_last_pose_kernel)
-    bool lane_pruned[MAD_LANES] = {};        // whether the match last enqueued in a lane pruned its pose search
     int64_t lane_sel_hint[MAD_LANES] = {};   // pairs the last pruned match of a lane sent to the exact search (sizes the next launch)
     void *many[MAD_BRACKETS] = {};           // open mad_match_topk_many_begin brackets (ManyState, mad_match.hip), by result slot: a ring
     int many_oldest = 0, many_open = 0;      // the slot _finish collects next, and how many are open
@@ -184,6 +184,7 @@ struct mad_ctx {
 
 struct mad_set {
     int32_t n_anchors = 0;
+    uint64_t gen = 0;            // counts the builds / loads / imports of this set: results that refer to an earlier one are stale
     int64_t cap_rows = 0;        // capacity of the row buffers (rows are produced on the device; see dev_n)
     int D = 0;
     // per anchor: views into anc_blob = [dev_n 64 B][subv n x 3 f64][coords n x 3 i32][octave n i32][index n i32], which one
@@ -316,6 +317,7 @@ int mad_describe_device(mad_ctx *ctx, FieldDev f0, FieldDev f1, const int32_t *d
                         double *d_norm = nullptr, int dsc_size = 64);
 void mad_many_abandon(mad_ctx *ctx);
 void mad_zero_words(mad_ctx *ctx, void *p, size_t bytes);              // one-launch zero fill (bytes rounded up to 16)
+void mad_zero_words3(mad_ctx *ctx, void *p, size_t bytes_p, void *q, size_t bytes_q, void *r, size_t bytes_r);      // the same for up to three regions, still one launch
 void mad_copy_words(mad_ctx *ctx, void *dst, const void *src, size_t bytes);      // kernel copy, e.g. out of pinned host memory
 int mad_build_cells(mad_ctx *ctx, mad_set *set, double cell);
 

@@ -402,6 +402,22 @@ void mad_zero_words(mad_ctx *ctx, void *p, size_t bytes) {
     hipLaunchKernelGGL(k_zero_words, dim3((unsigned)std::min<size_t>((n16 + 255) / 256, 1024)), dim3(256), 0, ctx->stream, (uint4 *)p, n16);
 }
 
+// up to three regions in one launch (a match's status words, its bitmaps and the row descriptors of its pair compaction)
+__global__ __launch_bounds__(256) void k_zero_words3(uint4 *__restrict__ p, size_t n16, uint4 *__restrict__ q, size_t m16, uint4 *__restrict__ r,
+                                                     size_t l16) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16 + m16 + l16; i += (size_t)gridDim.x * blockDim.x) {
+        if (i < n16) p[i] = make_uint4(0, 0, 0, 0);
+        else if (i < n16 + m16) q[i - n16] = make_uint4(0, 0, 0, 0);
+        else r[i - n16 - m16] = make_uint4(0, 0, 0, 0);
+    }
+}
+
+void mad_zero_words3(mad_ctx *ctx, void *p, size_t bytes_p, void *q, size_t bytes_q, void *r, size_t bytes_r) {
+    const size_t n16 = (bytes_p + 15) / 16, m16 = (bytes_q + 15) / 16, l16 = (bytes_r + 15) / 16;
+    hipLaunchKernelGGL(k_zero_words3, dim3((unsigned)std::min<size_t>((n16 + m16 + l16 + 255) / 256, 1024)), dim3(256), 0, ctx->stream, (uint4 *)p,
+                       n16, (uint4 *)q, m16, (uint4 *)r, l16);
+}
+
 void mad_copy_words(mad_ctx *ctx, void *dst, const void *src, size_t bytes) {
     const size_t n16 = (bytes + 15) / 16;
     hipLaunchKernelGGL(k_copy_words, dim3((unsigned)std::min<size_t>((n16 + 255) / 256, 1024)), dim3(256), 0, ctx->stream, (uint4 *)dst,

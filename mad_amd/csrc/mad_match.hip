@@ -510,6 +510,75 @@ __global__ __launch_bounds__(256) void k_pair_emit(const int32_t *__restrict__ C
     }
 }
 
+// k_pair_emit with the scan inside (round 3: one launch fewer per match).  A workgroup takes the rows b, b + G, b + 2 G, ...; the
+// number of pairs before row b is a block reduction over row_cnt[0 .. b), and from one of its rows to the next it adds the G counts
+// in between -- a handful of cached loads per thread instead of a one-workgroup scan launch between count and emit.  Workgroup 0
+// also forms the total (status[ST_NPAIRS], the overflow flag).  Rows, order and scores are those of k_pair_emit.
+// (Also tried: count + scan + emit as ONE launch, rows ticketed in order and the offsets by a decoupled look-back over 8-byte row
+// descriptors -- correct, and 75-85 us per match against 28 for the three launches: 2 200 workgroups that reach the look-back together
+// find no inclusive prefix nearby and poll each other's descriptors through the fabric.)
+__global__ __launch_bounds__(256) void k_pair_emit2(const int32_t *__restrict__ C, const uint32_t *__restrict__ mask,
+                                                    const int32_t *__restrict__ n_hi_ptr, const int32_t *__restrict__ n_lo_ptr,
+                                                    const double *__restrict__ hn, const double *__restrict__ ln,
+                                                    const int32_t *__restrict__ row_cnt, int64_t cap_pairs,
+                                                    int32_t *__restrict__ pair_hi, int32_t *__restrict__ pair_lo,
+                                                    double *__restrict__ pair_score, const int32_t *__restrict__ hi_row_anchor,
+                                                    const int32_t *__restrict__ lo_row_anchor, const int32_t *__restrict__ hi_canon,
+                                                    const int32_t *__restrict__ lo_canon, uint8_t *__restrict__ used_hi,
+                                                    uint8_t *__restrict__ used_lo, int32_t *__restrict__ status) {
+    __shared__ int wt[5];
+    __shared__ long long s_sum[4];
+    if (status[ST_FLAG_C]) return;
+    const int64_t n_hi = *n_hi_ptr, n_lo = *n_lo_ptr;
+    const int64_t ldc = (n_lo + GEMM_BN - 1) / GEMM_BN * GEMM_BN, ldm = ldc / 32;
+    // sum of row_cnt[a .. b) over the workgroup
+    auto block_sum = [&](int64_t a, int64_t b) -> long long {
+        long long v = 0;
+        for (int64_t q = a + threadIdx.x; q < b; q += 256) v += row_cnt[q];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, MAD_WAVE);
+        __syncthreads();
+        if (lane_id() == 0) s_sum[threadIdx.x >> 6] = v;
+        __syncthreads();
+        return s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
+    };
+    if (blockIdx.x == 0) {
+        const long long total = block_sum(0, n_hi);
+        if (threadIdx.x == 0) {
+            status[ST_NPAIRS] = (int32_t)min(total, (long long)INT32_MAX);
+            if (total > cap_pairs) status[ST_FLAG_PAIRS] = 1;
+        }
+    }
+    int64_t done = 0;      // rows whose counts are in `before`
+    long long before = 0;
+    for (int64_t i = blockIdx.x; i < n_hi; i += gridDim.x) {
+        before += block_sum(done, i);
+        done = i;
+        const int count = row_cnt[i];
+        if (count == 0 || before + count > cap_pairs) continue;      // (a list that overflows is never read: the match is repeated)
+        const double nh = hn[i];
+        int64_t base = before;
+        for (int64_t w0 = 0; w0 < ldm; w0 += 256) {
+            const int64_t w = w0 + threadIdx.x;
+            unsigned m = w < ldm ? mask[i * ldm + w] : 0;
+            int tot;
+            int64_t o = base + block_excl_scan(__popc(m), wt, &tot);
+            while (m) {      // ascending columns: the row-major order of np.where (MaD.py:423)
+                const int b = __ffs(m) - 1;
+                m &= m - 1;
+                const int64_t j = w * 32 + b;
+                pair_hi[o] = (int32_t)i;
+                pair_lo[o] = (int32_t)j;
+                pair_score[o] = corr_score(C[i * ldc + j], nh, ln[j]);
+                if (used_lo) { const int a = lo_row_anchor ? lo_row_anchor[j] : (int)j; used_lo[lo_canon ? lo_canon[a] : a] = 1; }
+                o++;
+            }
+            base += tot;
+        }
+        if (threadIdx.x == 0 && used_hi) { const int a = hi_row_anchor ? hi_row_anchor[i] : (int)i; used_hi[hi_canon ? hi_canon[a] : a] = 1; }
+    }
+}
+
 // ---------------------------------------------------------------------------
 // pose scoring
 // ---------------------------------------------------------------------------
@@ -576,18 +645,12 @@ __device__ __forceinline__ int pg_cell(double v, double mn, double inv, int dim)
 }
 
 // one workgroup: counting sort of the used points into cells; sorted points and offsets to global
-__global__ __launch_bounds__(1024) void k_pose_grid_build(const double *__restrict__ pts, const uint8_t *__restrict__ used, int n,
-                                                          PoseGrid G, int32_t *__restrict__ cell_start,
-                                                          unsigned short *__restrict__ cell_start16, double *__restrict__ sorted,
-                                                          float4 *__restrict__ sorted_f, int32_t *__restrict__ n_used, CloudJob J) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    int *cnt = (int *)smem;
-    __shared__ int wt[17];
-    __shared__ int carry;
-    if (J.subv) {      // the hi cloud of the same match, compacted by this workgroup too: one launch fewer on the match's critical path
-        compact_cloud_block(J, wt, &carry);
-        __syncthreads();
-    }
+// (1024 threads; cnt = G.ncell ints of LDS, wt = 17 ints, carry = 1 int)
+__device__ __forceinline__ void pose_grid_block(const double *__restrict__ pts, const uint8_t *__restrict__ used, int n, const PoseGrid &G,
+                                                int32_t *__restrict__ cell_start, unsigned short *__restrict__ cell_start16,
+                                                double *__restrict__ sorted, float4 *__restrict__ sorted_f, int32_t *__restrict__ n_used,
+                                                int *cnt, int *wt, int *carry_p) {
+    int &carry = *carry_p;
     for (int c = threadIdx.x; c < G.ncell; c += 1024) cnt[c] = 0;
     if (threadIdx.x == 0) carry = 0;
     __syncthreads();
@@ -599,14 +662,20 @@ __global__ __launch_bounds__(1024) void k_pose_grid_build(const double *__restri
             atomicAdd(&cnt[c], 1);
         }
     __syncthreads();
-    for (int base = 0; base < G.ncell; base += 1024) {
-        const int c = base + threadIdx.x;
-        const int v = c < G.ncell ? cnt[c] : 0;
+    {   // exclusive scan of the cell counts: a thread sums a run of consecutive cells, ONE block scan over the runs (round 3; a block
+        // scan per 1 024 cells before: sixteen of them, ~8 us of barriers, for the 25^3 cells of a 256^3 map)
+        const int per = (G.ncell + 1023) / 1024;
+        const int c0 = min((int)threadIdx.x * per, G.ncell), c1 = min(c0 + per, G.ncell);
+        int sum = 0;
+        for (int c = c0; c < c1; c++) sum += cnt[c];
         int tot;
-        const int ex = block_excl_scan(v, wt, &tot);
-        if (c < G.ncell) { cnt[c] = carry + ex; cell_start[c] = carry + ex; cell_start16[c] = (unsigned short)(carry + ex); }
-        __syncthreads();
-        if (threadIdx.x == 0) carry += tot;
+        int run = block_excl_scan(sum, wt, &tot);
+        for (int c = c0; c < c1; c++) {
+            const int v = cnt[c];
+            cnt[c] = run; cell_start[c] = run; cell_start16[c] = (unsigned short)run;
+            run += v;
+        }
+        if (threadIdx.x == 0) carry = tot;
         __syncthreads();
     }
     if (threadIdx.x == 0) {
@@ -625,6 +694,20 @@ __global__ __launch_bounds__(1024) void k_pose_grid_build(const double *__restri
             if (sorted_f)
                 sorted_f[o] = make_float4((float)(pts[3 * i] - G.mn[0]), (float)(pts[3 * i + 1] - G.mn[1]), (float)(pts[3 * i + 2] - G.mn[2]), 0.f);
         }
+}
+
+__global__ __launch_bounds__(1024) void k_pose_grid_build(const double *__restrict__ pts, const uint8_t *__restrict__ used, int n,
+                                                          PoseGrid G, int32_t *__restrict__ cell_start,
+                                                          unsigned short *__restrict__ cell_start16, double *__restrict__ sorted,
+                                                          float4 *__restrict__ sorted_f, int32_t *__restrict__ n_used, CloudJob J) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ int wt[17];
+    __shared__ int carry;
+    if (J.subv) {      // the hi cloud of the same match, compacted by this workgroup too: one launch fewer on the match's critical path
+        compact_cloud_block(J, wt, &carry);
+        __syncthreads();
+    }
+    pose_grid_block(pts, used, n, G, cell_start, cell_start16, sorted, sorted_f, n_used, (int *)smem, wt, &carry);
 }
 
 __host__ __device__ __forceinline__ size_t pad16(size_t b) { return (b + 15) & ~(size_t)15; }
@@ -653,38 +736,42 @@ struct PoseBitsJobs {
     unsigned *bits[4];
 };
 
+// The marking of ONE point p into one bitmap job, by a group of `nthr` threads (thread t of the group): shared by k_pose_bits
+// (one 256-thread workgroup per point) and k_pose_setup (four 256-thread groups per workgroup).
+__device__ __forceinline__ void pose_bits_point(const PoseBits &B, double rad, int plane, int planes, unsigned *__restrict__ bits, double qx,
+                                                double qy, double qz, int t0, int nthr) {
+    const double inv_h = 1.0 / B.h, rad2 = rad * rad;
+    const double px = qx - B.mn[0], py = qy - B.mn[1], pz = qz - B.mn[2];
+    // voxel k has its centre at (k + 0.5) h; the index ranges below are supersets, the row test is exact
+    const int x0 = max((int)floor((px - rad) * inv_h - 0.5), 0), x1 = min((int)ceil((px + rad) * inv_h - 0.5), B.dim[0] - 1);
+    const int y0 = max((int)floor((py - rad) * inv_h - 0.5), 0), y1 = min((int)ceil((py + rad) * inv_h - 0.5), B.dim[1] - 1);
+    const int ny = y1 - y0 + 1, nrow = (x1 - x0 + 1) * ny;
+    for (int t = t0; t < nrow; t += nthr) {
+        const int kx = x0 + t / ny, ky = y0 + t % ny;
+        const double dx = (kx + 0.5) * B.h - px, dy = (ky + 0.5) * B.h - py;
+        const double rem = rad2 - dx * dx - dy * dy;
+        if (rem < 0.0) continue;
+        const double sq = sqrt(rem);
+        // outer plane: a superset of the voxels within rad is harmless; inner plane: it must be a subset
+        const int z0 = max(plane == 0 ? (int)floor((pz - sq) * inv_h - 0.5) : (int)ceil((pz - sq) * inv_h - 0.5 + 1e-9), 0);
+        const int z1 = min(plane == 0 ? (int)ceil((pz + sq) * inv_h - 0.5) : (int)floor((pz + sq) * inv_h - 0.5 - 1e-9), B.dim[2] - 1);
+        if (z1 < z0) continue;
+        unsigned *row = bits + planes * ((size_t)kx * B.dim[1] + ky) * B.wz + plane;      // planes interleaved: [outer][inner] per word
+        for (int w = z0 >> 5; w <= (z1 >> 5); w++) {
+            const int lo = max(z0 - 32 * w, 0), hi = min(z1 - 32 * w, 31);
+            const unsigned m = (hi == 31 ? 0xffffffffu : ((1u << (hi + 1)) - 1u)) & ~((1u << lo) - 1u);
+            atomicOr(&row[planes * w], m);
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_pose_bits(const double *__restrict__ sorted, const int32_t *__restrict__ cell_start, int ncell,
                                                    PoseBitsJobs J) {
     const PoseBits B = J.B[blockIdx.y];
-    const double rad = J.rad[blockIdx.y];
-    const int plane = J.plane[blockIdx.y], planes = J.planes[blockIdx.y];
-    unsigned *__restrict__ bits = J.bits[blockIdx.y];
     const int l_lo = cell_start[ncell];
-    const double inv_h = 1.0 / B.h, rad2 = rad * rad;
-    for (int p = blockIdx.x; p < l_lo; p += gridDim.x) {
-        const double px = sorted[3 * p] - B.mn[0], py = sorted[3 * p + 1] - B.mn[1], pz = sorted[3 * p + 2] - B.mn[2];
-        // voxel k has its centre at (k + 0.5) h; the index ranges below are supersets, the row test is exact
-        const int x0 = max((int)floor((px - rad) * inv_h - 0.5), 0), x1 = min((int)ceil((px + rad) * inv_h - 0.5), B.dim[0] - 1);
-        const int y0 = max((int)floor((py - rad) * inv_h - 0.5), 0), y1 = min((int)ceil((py + rad) * inv_h - 0.5), B.dim[1] - 1);
-        const int ny = y1 - y0 + 1, nrow = (x1 - x0 + 1) * ny;
-        for (int t = threadIdx.x; t < nrow; t += 256) {
-            const int kx = x0 + t / ny, ky = y0 + t % ny;
-            const double dx = (kx + 0.5) * B.h - px, dy = (ky + 0.5) * B.h - py;
-            const double rem = rad2 - dx * dx - dy * dy;
-            if (rem < 0.0) continue;
-            const double sq = sqrt(rem);
-            // outer plane: a superset of the voxels within rad is harmless; inner plane: it must be a subset
-            const int z0 = max(plane == 0 ? (int)floor((pz - sq) * inv_h - 0.5) : (int)ceil((pz - sq) * inv_h - 0.5 + 1e-9), 0);
-            const int z1 = min(plane == 0 ? (int)ceil((pz + sq) * inv_h - 0.5) : (int)floor((pz + sq) * inv_h - 0.5 - 1e-9), B.dim[2] - 1);
-            if (z1 < z0) continue;
-            unsigned *row = bits + planes * ((size_t)kx * B.dim[1] + ky) * B.wz + plane;      // planes interleaved: [outer][inner] per word
-            for (int w = z0 >> 5; w <= (z1 >> 5); w++) {
-                const int lo = max(z0 - 32 * w, 0), hi = min(z1 - 32 * w, 31);
-                const unsigned m = (hi == 31 ? 0xffffffffu : ((1u << (hi + 1)) - 1u)) & ~((1u << lo) - 1u);
-                atomicOr(&row[planes * w], m);
-            }
-        }
-    }
+    for (int p = blockIdx.x; p < l_lo; p += gridDim.x)
+        pose_bits_point(B, J.rad[blockIdx.y], J.plane[blockIdx.y], J.planes[blockIdx.y], J.bits[blockIdx.y], sorted[3 * p], sorted[3 * p + 1],
+                        sorted[3 * p + 2], (int)threadIdx.x, 256);
 }
 
 // float32 map from a hi-cloud point to bitmap voxel coordinates for one pair: v = M c + t
@@ -776,15 +863,12 @@ struct PosePair {
     PoseVox vf, vc;   // hi-cloud point -> voxel coordinates of the fine / of the coarse bitmap (float32; pose_vox_setup)
 };
 
-__global__ __launch_bounds__(256) void k_pose_prep(const int32_t *__restrict__ pair_hi, const int32_t *__restrict__ pair_lo,
-                                                   const int32_t *__restrict__ status, int64_t cap_pairs,
-                                                   const double *__restrict__ hi_p, const double *__restrict__ hi_R,
-                                                   const double *__restrict__ lo_p, const double *__restrict__ lo_Rinv,
-                                                   const int32_t *__restrict__ hi_row_anchor, const int32_t *__restrict__ lo_row_anchor,
-                                                   PoseBits Bf, PoseBits Bc, PosePair *__restrict__ rec) {
-    if (status[ST_FLAG_C] || status[ST_FLAG_PAIRS]) return;
-    const int64_t n_pairs = min((int64_t)status[ST_NPAIRS], cap_pairs);
-    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < n_pairs; p += (int64_t)gridDim.x * 256) {
+__device__ __forceinline__ void pose_prep_range(const int32_t *__restrict__ pair_hi, const int32_t *__restrict__ pair_lo, int64_t n_pairs,
+                                                int64_t first, int64_t stride, const double *__restrict__ hi_p, const double *__restrict__ hi_R,
+                                                const double *__restrict__ lo_p, const double *__restrict__ lo_Rinv,
+                                                const int32_t *__restrict__ hi_row_anchor, const int32_t *__restrict__ lo_row_anchor,
+                                                const PoseBits &Bf, const PoseBits &Bc, PosePair *__restrict__ rec) {
+    for (int64_t p = first; p < n_pairs; p += stride) {
         const int ih = pair_hi[p], il = pair_lo[p];
         PosePair P;
         mat3_mul(lo_Rinv + 9 * il, hi_R + 9 * ih, P.R);
@@ -797,10 +881,89 @@ __global__ __launch_bounds__(256) void k_pose_prep(const int32_t *__restrict__ p
     }
 }
 
+__global__ __launch_bounds__(256) void k_pose_prep(const int32_t *__restrict__ pair_hi, const int32_t *__restrict__ pair_lo,
+                                                   const int32_t *__restrict__ status, int64_t cap_pairs,
+                                                   const double *__restrict__ hi_p, const double *__restrict__ hi_R,
+                                                   const double *__restrict__ lo_p, const double *__restrict__ lo_Rinv,
+                                                   const int32_t *__restrict__ hi_row_anchor, const int32_t *__restrict__ lo_row_anchor,
+                                                   PoseBits Bf, PoseBits Bc, PosePair *__restrict__ rec) {
+    if (status[ST_FLAG_C] || status[ST_FLAG_PAIRS]) return;
+    const int64_t n_pairs = min((int64_t)status[ST_NPAIRS], cap_pairs);
+    pose_prep_range(pair_hi, pair_lo, n_pairs, (int64_t)blockIdx.x * 256 + threadIdx.x, (int64_t)gridDim.x * 256, hi_p, hi_R, lo_p, lo_Rinv,
+                    hi_row_anchor, lo_row_anchor, Bf, Bc, rec);
+}
+
+// What a match needs between its pair list and its pose search, in ONE launch of 1024-thread workgroups with different roles
+// (they depend on the pair list and on the "takes part in a pair" flags only, not on each other):
+//   workgroup 0                : the used lo anchors binned into the search grid (k_pose_grid_build)
+//   workgroup 1                : the used hi anchors compacted into the hi cloud; the sets' row counts mirrored into the status words
+//   workgroups 2 .. 2 + n_bits : the occupancy bitmaps of the lo cloud (k_pose_bits), a 256-thread group per point, straight from the
+//                                anchor list and its flags (the marks do not depend on the order of the points)
+//   the rest                   : the per-pair records (k_pose_prep)
+// -- four launches before (grid, zero fill of the bitmaps, bits, prep; the zero fill now travels with the match's status words).
+struct PoseSetup {
+    const double *pts; const uint8_t *used; int n;      // the lo anchors and their flags (nullptr: all)
+    PoseGrid G;
+    int32_t *cell_start; unsigned short *cell_start16; double *sorted; float4 *sorted_f; int32_t *n_used;
+    CloudJob J;
+    PoseBitsJobs bits; int n_bit_jobs; int n_bits_wgs;
+    const int32_t *pair_hi, *pair_lo; const int32_t *status; int64_t cap_pairs;
+    const double *hi_p, *hi_R, *lo_p, *lo_Rinv; const int32_t *hi_row_anchor, *lo_row_anchor;
+    PoseBits Bf, Bc; PosePair *rec;
+    int roles;      // bit mask, 15 = all (diagnostic: MAD_PROBE_SETUP repeats the launch role by role for a kernel trace)
+};
+
+__global__ __launch_bounds__(1024, 8) void k_pose_setup(PoseSetup S) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ int wt[17];
+    __shared__ int carry;
+    const int b = (int)blockIdx.x;
+    if (b == 0) {
+        if (S.roles & 1) pose_grid_block(S.pts, S.used, S.n, S.G, S.cell_start, S.cell_start16, S.sorted, S.sorted_f, S.n_used, (int *)smem, wt, &carry);
+        return;
+    }
+    if (b == 1) {
+        if (S.J.subv && (S.roles & 2)) compact_cloud_block(S.J, wt, &carry);
+        return;
+    }
+    if (b < 2 + S.n_bits_wgs) {
+        if (!(S.roles & 4)) return;
+        const int groups = S.n_bits_wgs * 4 / S.n_bit_jobs;              // 256-thread groups per bitmap job
+        const int g = (b - 2) * 4 + ((int)threadIdx.x >> 8);
+        const int job = g / groups, first = g % groups;
+        if (job >= S.n_bit_jobs) return;
+        const PoseBits B = S.bits.B[job];
+        for (int p = first; p < S.n; p += groups) {
+            if (S.used && !S.used[p]) continue;
+            pose_bits_point(B, S.bits.rad[job], S.bits.plane[job], S.bits.planes[job], S.bits.bits[job], S.pts[3 * p], S.pts[3 * p + 1],
+                            S.pts[3 * p + 2], (int)threadIdx.x & 255, 256);
+        }
+        return;
+    }
+    if (S.status[ST_FLAG_C] || S.status[ST_FLAG_PAIRS] || !(S.roles & 8)) return;
+    const int64_t n_pairs = min((int64_t)S.status[ST_NPAIRS], S.cap_pairs);
+    const int64_t wg = b - 2 - S.n_bits_wgs, n_wg = (int64_t)gridDim.x - 2 - S.n_bits_wgs;
+    pose_prep_range(S.pair_hi, S.pair_lo, n_pairs, wg * 1024 + threadIdx.x, n_wg * 1024, S.hi_p, S.hi_R, S.lo_p, S.lo_Rinv, S.hi_row_anchor,
+                    S.lo_row_anchor, S.Bf, S.Bc, S.rec);
+}
+
 #define POSE_LDS_THREADS 1024
+__device__ __forceinline__ int topk_threshold(const int32_t *__restrict__ hist, int nbins, int64_t k, int *wt, int *sh, int *need);
 #define POSE_PARTS 4                        // waves that share one listed pair of a pruned search
 #define POSE_RING 256                       // survivor queue of a wave (entries), a power of two >= 2 x 64
 #define POSE_WAVE_LDS (POSE_RING * 2 + 256) // bytes per wave: the queue + two pair records of 128 bytes
+#define POSE_OWN_CAP 2048                   // pairs a workgroup of k_pose_lds may list for itself (PoseOwnSel)
+
+// k_pose_lds selecting its own pairs (see there); upper == nullptr: the pairs are all, or listed in `sel`
+struct PoseOwnSel {
+    const unsigned short *upper;      // per pair: upper bound of its count (k_pose_bounds)
+    const int32_t *hist;              // histogram of the lower bounds, nbins bins
+    int nbins;
+    int64_t k;
+    int32_t *sel_out;                 // the listed pairs of all workgroups, in no particular order; status_w[ST_NSEL] counts them
+    int64_t sel_cap;
+    int32_t *status_w;
+};
 
 // MaD.py:433-448.  One wave per pair, lanes over the hi cloud.  `dd_lim` is the smallest double whose square root is >=
 // dist, so dd < dd_lim is exactly the reference's sqrt(dd) < dist without the root.
@@ -816,8 +979,11 @@ __global__ __launch_bounds__(POSE_LDS_THREADS) void k_pose_lds(const int32_t *__
                                                                const unsigned short *__restrict__ cell_start16, PoseGrid G, int l_hi_cap,
                                                                int l_lo_cap, float reach, double dd_lim, PoseBits B,
                                                                const unsigned *__restrict__ bits, int32_t *__restrict__ counts,
-                                                               const int32_t *__restrict__ sel) {
+                                                               const int32_t *__restrict__ sel, PoseOwnSel own) {
     extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ int t_wt[POSE_LDS_THREADS / MAD_WAVE + 1];
+    __shared__ int t_sh[3];
+    __shared__ int s_nloc, s_gbase;
     if (status[ST_FLAG_C] || status[ST_FLAG_PAIRS]) return;
     // LDS regions, each a multiple of 16 bytes (pose_device on the host mirrors this)
     double *cl = (double *)smem;                                                     // hi cloud
@@ -830,26 +996,73 @@ __global__ __launch_bounds__(POSE_LDS_THREADS) void k_pose_lds(const int32_t *__
     // sel != nullptr: only the pairs listed there (status[ST_NSEL] of them; the others keep the lower bound k_pose_bounds left in
     // counts).  The listed pairs are few (hundreds) and heavy (good poses: most hi points reach the exact search), so each is cut
     // into POSE_PARTS runs of hi points, one wave each, whose counts add up atomically in counts[pair] (zeroed by k_prune_select).
-    const int parts = sel ? POSE_PARTS : 1;
-    const int64_t n_pairs = sel ? (int64_t)status[ST_NSEL] * parts : min((int64_t)status[ST_NPAIRS], cap_pairs);      // work items
+    // own.upper != nullptr: the selection itself happens here as well (k_prune_select's work, one launch fewer).  Every workgroup
+    // derives T, the k-th largest lower bound, from the histogram of k_pose_bounds, takes every gridDim.x-th pair, lists
+    // those whose upper bound reaches T in LDS (and, for the top-k kernel behind it, in own.sel_out), and searches ITS list with its
+    // 16 waves.  A workgroup whose list outgrows
+    // POSE_OWN_CAP raises ST_FLAG_SEL -- the host repeats the match with the separate selection kernel.
+    const bool own_sel = own.upper != nullptr;
+    const bool listed = own_sel || sel != nullptr;
+    const int parts = listed ? POSE_PARTS : 1;
     const int l_hi = status[ST_LHI];
     const int l_lo = cell_start[G.ncell];
     stage_lds(lp, lo_sorted, (size_t)l_lo * 24);
     stage_lds(cs, cell_start16, (size_t)((G.ncell + 2) & ~1) * 2);
     stage_lds(cl, hi_cloud, (size_t)l_hi * 24);
+    const int lane = lane_id();
+    int *own_list = (int *)((unsigned char *)cs + pad16((size_t)(G.ncell + 1) * 2) + (POSE_LDS_THREADS / MAD_WAVE) * POSE_WAVE_LDS);
+    if (own_sel) {
+        const int64_t n_all = min((int64_t)status[ST_NPAIRS], cap_pairs);
+        int need;
+        const int T = max(topk_threshold(own.hist, own.nbins, min(own.k, n_all), t_wt, t_sh, &need), 0);
+        if (threadIdx.x == 0) s_nloc = 0;
+        __syncthreads();
+        // pair i belongs to workgroup i % gridDim.x: good pairs cluster by hi row (runs of consecutive pairs), and a run that
+        // stayed in one workgroup made it the launch's tail (runs of 64: 28 us against 11 for the same pairs dealt evenly)
+        const int64_t per_wg = (n_all + gridDim.x - 1) / gridDim.x;
+        for (int64_t j0 = 0; j0 < per_wg; j0 += POSE_LDS_THREADS) {      // (workgroup-uniform trip count: the ballots need whole waves)
+            const int64_t i = (int64_t)blockIdx.x + (int64_t)gridDim.x * (j0 + threadIdx.x);
+            const bool take = i < n_all && (int)own.upper[i] >= T;
+            const unsigned long long bal = __ballot(take);
+            if (bal == 0ull) continue;
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&s_nloc, __popcll(bal));
+            base = __shfl(base, 0, MAD_WAVE);
+            const int o = base + __popcll(bal & lanemask_lt());
+            if (take) {
+                if (o < POSE_OWN_CAP) own_list[o] = (int)i;
+                counts[i] = 0;      // the parts of a listed pair add up atomically
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int n_loc = s_nloc;
+            if (n_loc > POSE_OWN_CAP) { own.status_w[ST_FLAG_SEL] = 1; s_gbase = -1; }
+            else s_gbase = n_loc ? atomicAdd(own.status_w + ST_NSEL, n_loc) : 0;
+        }
+    }
     __syncthreads();
+    if (own_sel) {
+        if (s_gbase < 0) return;      // (workgroup-uniform)
+        for (int i = threadIdx.x; i < s_nloc; i += POSE_LDS_THREADS)
+            if (s_gbase + i < own.sel_cap) own.sel_out[s_gbase + i] = own_list[i];
+            else own.status_w[ST_FLAG_SEL] = 1;
+    }
+    const int *lst = own_sel ? own_list : sel;      // (LDS or global: generic loads)
+    const int64_t n_pairs = own_sel ? (int64_t)s_nloc * parts
+                                    : (sel ? (int64_t)status[ST_NSEL] * parts : min((int64_t)status[ST_NPAIRS], cap_pairs));      // work items
     for (int i = threadIdx.x; i < l_hi; i += POSE_LDS_THREADS)
         clf[i] = make_float4((float)cl[3 * i], (float)cl[3 * i + 1], (float)cl[3 * i + 2], 0.f);
     __syncthreads();
-    const int lane = lane_id();
-    const int64_t wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (POSE_LDS_THREADS / MAD_WAVE) + (threadIdx.x >> 6)));
-    const int64_t nwaves = (int64_t)gridDim.x * (POSE_LDS_THREADS / MAD_WAVE);
+    const int64_t wave = own_sel ? (int64_t)(threadIdx.x >> 6)
+                                 : (int64_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (POSE_LDS_THREADS / MAD_WAVE) + (threadIdx.x >> 6)));
+    const int64_t nwaves = own_sel ? (int64_t)(POSE_LDS_THREADS / MAD_WAVE) : (int64_t)gridDim.x * (POSE_LDS_THREADS / MAD_WAVE);
     PosePair cur;
-    if (wave < n_pairs) cur = rec[sel ? sel[wave / parts] : wave];
+    if (wave < n_pairs) cur = rec[listed ? lst[wave / parts] : wave];
     const float mnx = (float)G.mn[0], mny = (float)G.mn[1], mnz = (float)G.mn[2];
     const int part_len = (l_hi + parts - 1) / parts;
     auto emit = [&](int64_t p, int c) {      // a pair's (partial) count
-        if (sel) atomicAdd(&counts[p], c);
+        if (listed) atomicAdd(&counts[p], c);
         else counts[p] = c;
     };
 
@@ -914,10 +1127,10 @@ __global__ __launch_bounds__(POSE_LDS_THREADS) void k_pose_lds(const int32_t *__
         }
     };
     for (int64_t it = wave; it < n_pairs; it += nwaves) {
-        const int64_t p = sel ? sel[it / parts] : it;
-        const int a_begin = sel ? (int)(it % parts) * part_len : 0, a_end = sel ? min(a_begin + part_len, l_hi) : l_hi;      // this item's hi points
+        const int64_t p = listed ? lst[it / parts] : it;
+        const int a_begin = listed ? (int)(it % parts) * part_len : 0, a_end = listed ? min(a_begin + part_len, l_hi) : l_hi;      // this item's hi points
         PosePair nxt;      // requested now, needed one iteration later
-        if (it + nwaves < n_pairs) nxt = rec[sel ? sel[(it + nwaves) / parts] : it + nwaves];
+        if (it + nwaves < n_pairs) nxt = rec[listed ? lst[(it + nwaves) / parts] : it + nwaves];
         const PoseVox V = cur.vf;
         if (lane == 0) {      // this pair's transform for the exact search (the slot's previous user is complete by now)
             double *P = recs + 16 * slot;
@@ -1442,6 +1655,31 @@ __global__ __launch_bounds__(POSE_THREADS) void k_pose(const int32_t *__restrict
     }
 }
 
+// What a result row (MaD.py:451) is made from; out = [n_cap x 23 rows][n_cap int64 pair ranks][ST_COUNT int32 status] when a kernel
+// writes the tail as well (out may be pinned HOST memory: the k rows of a match go straight to where the host reads them).
+struct ResultArgs {
+    const int32_t *pair_hi, *pair_lo;
+    const double *pair_score;
+    const int32_t *counts;
+    const double *hi_p, *hi_R;
+    const int32_t *hi_meta;
+    const double *lo_p, *lo_Rinv;
+    const int32_t *lo_meta, *hi_row_anchor, *lo_row_anchor;
+    double *out;
+    int64_t n_cap;
+};
+__device__ __forceinline__ void result_row(const ResultArgs &R, int64_t p, int l_hi, double *__restrict__ o) {
+    const int ih = R.pair_hi[p], il = R.pair_lo[p];
+    const int ah = R.hi_row_anchor ? R.hi_row_anchor[ih] : ih, al = R.lo_row_anchor ? R.lo_row_anchor[il] : il;
+    o[0] = R.pair_score[p];
+    o[1] = 100.0 * (double)R.counts[p] / (double)l_hi;      // MaD.py:448
+    o[2] = R.lo_meta[3 * il]; o[3] = R.lo_meta[3 * il + 1]; o[4] = R.lo_meta[3 * il + 2];
+    o[5] = R.hi_meta[3 * ih]; o[6] = R.hi_meta[3 * ih + 1]; o[7] = R.hi_meta[3 * ih + 2];
+    o[8] = R.hi_p[3 * ah]; o[9] = R.hi_p[3 * ah + 1]; o[10] = R.hi_p[3 * ah + 2];
+    o[11] = R.lo_p[3 * al]; o[12] = R.lo_p[3 * al + 1]; o[13] = R.lo_p[3 * al + 2];
+    mat3_mul(R.lo_Rinv + 9 * il, R.hi_R + 9 * ih, o + 14);
+}
+
 // rows of MaD.py:451 for the pairs listed in sel (or all pairs when sel == nullptr)
 __global__ void k_results(const int64_t *__restrict__ sel, const int32_t *__restrict__ n_sel_ptr, int64_t n_sel_cap,
                           const int32_t *__restrict__ pair_hi, const int32_t *__restrict__ pair_lo,
@@ -1605,14 +1843,29 @@ __global__ __launch_bounds__(1024) void k_topk_sort(const unsigned long long *__
 // MaD.py:480) over the list are those over all pairs.  One workgroup: keys (maxc - count) << 40 | pair, bitonic sort in LDS over
 // the next power of two >= the list length, the first k out.  A list longer than TKS_CAP raises ST_FLAG_SEL instead.
 #define TKS_CAP 8192
+// R.out != nullptr: the k result rows, their pair ranks and the status words are written here as well (k_results' work for a
+// match, one launch fewer).
 __global__ __launch_bounds__(1024) void k_topk_selected(const int32_t *__restrict__ counts, const int32_t *__restrict__ sel,
-                                                        int32_t *__restrict__ status, int64_t k, int maxc, int64_t *__restrict__ order) {
+                                                        int32_t *__restrict__ status, int64_t k, int maxc, int64_t *__restrict__ order,
+                                                        ResultArgs R) {
     extern __shared__ __align__(16) unsigned char smem[];
     unsigned long long *s = (unsigned long long *)smem;
     const bool failed = status[ST_FLAG_C] || status[ST_FLAG_PAIRS];
     const int n = failed ? 0 : status[ST_NSEL];
+    const int l_hi = status[ST_LHI];
+    int64_t *ti = R.out ? (int64_t *)(R.out + MAD_RESULT_COLS * R.n_cap) : nullptr;
+    // the status words as the host will read them: the two this kernel sets itself are substituted, not re-read
+    auto tail_status = [&](int n_keys, int flag_sel) {
+        if (R.out && threadIdx.x < ST_COUNT) {
+            int v = status[threadIdx.x];
+            if (threadIdx.x == ST_NKEYS) v = n_keys;
+            if (threadIdx.x == ST_FLAG_SEL) v = v | flag_sel;
+            ((int32_t *)(ti + R.n_cap))[threadIdx.x] = v;
+        }
+    };
     if (n > TKS_CAP) {
         if (threadIdx.x == 0) { status[ST_FLAG_SEL] = 1; status[ST_NKEYS] = 0; }
+        tail_status(0, 1);
         return;
     }
     int cap = 64;
@@ -1631,9 +1884,14 @@ __global__ __launch_bounds__(1024) void k_topk_selected(const int32_t *__restric
             const unsigned long long mine = s[threadIdx.x];
             int rank = 0;
             for (int j = 0; j < n; j++) rank += s[j] < mine ? 1 : 0;
-            if (rank < n_out) order[rank] = (int64_t)(mine & ((1ull << 40) - 1));
+            if (rank < n_out) {
+                const int64_t p = (int64_t)(mine & ((1ull << 40) - 1));
+                order[rank] = p;
+                if (R.out) { result_row(R, p, l_hi, R.out + MAD_RESULT_COLS * rank); ti[rank] = p; }
+            }
         }
         if (threadIdx.x == 0) status[ST_NKEYS] = n_out;
+        tail_status(n_out, 0);
         return;
     }
     for (int kk = 2; kk <= cap; kk <<= 1)
@@ -1649,8 +1907,13 @@ __global__ __launch_bounds__(1024) void k_topk_selected(const int32_t *__restric
             __syncthreads();
         }
     const int n_out = (int)min((int64_t)n, k);
-    for (int i = threadIdx.x; i < n_out; i += 1024) order[i] = (int64_t)(s[i] & ((1ull << 40) - 1));
+    for (int i = threadIdx.x; i < n_out; i += 1024) {
+        const int64_t p = (int64_t)(s[i] & ((1ull << 40) - 1));
+        order[i] = p;
+        if (R.out) { result_row(R, p, l_hi, R.out + MAD_RESULT_COLS * i); ti[i] = p; }
+    }
     if (threadIdx.x == 0) status[ST_NKEYS] = n_out;
+    tail_status(n_out, 0);
 }
 
 // Selects the first k pairs of the (count desc, index asc) order into d_order (sorted); their number goes to
@@ -1834,6 +2097,19 @@ static int correlate_pairs(mad_ctx *ctx, const Side &hi, const Side &lo, double 
                            uint8_t *d_used_lo) {
     int32_t *C = scratch<int32_t>(ctx, S_CMAT);
     uint32_t *mask = scratch<uint32_t>(ctx, S_CMASK);
+    static const bool no_fuse = getenv("MAD_NO_FUSE") != nullptr;      // diagnostic switch: the launch-per-step form of round 2
+    if (!no_fuse) {
+        mad_timer_begin(ctx, MAD_T_PAIRS);
+        hipLaunchKernelGGL(k_pair_count, dim3(ctx->n_cu * 8), dim3(256), 0, ctx->stream, C, mask, hi.n_rows, lo.n_rows, hi.norm, lo.norm, cc,
+                           scratch<int32_t>(ctx, S_ROWCNT), d_status);
+        hipLaunchKernelGGL(k_pair_emit2, dim3(ctx->n_cu * 8), dim3(256), 0, ctx->stream, C, mask, hi.n_rows, lo.n_rows, hi.norm, lo.norm,
+                           scratch<int32_t>(ctx, S_ROWCNT), cap_pairs, scratch<int32_t>(ctx, S_PAIR_HI), scratch<int32_t>(ctx, S_PAIR_LO),
+                           scratch<double>(ctx, S_PAIR_SCORE), hi.row_anchor, lo.row_anchor, hi.anc_canon, lo.anc_canon, d_used_hi, d_used_lo,
+                           d_status);
+        mad_timer_end(ctx, MAD_T_PAIRS);
+        MAD_HIP(hipGetLastError());
+        return MAD_OK;
+    }
     mad_timer_begin(ctx, MAD_T_PAIRS);
     hipLaunchKernelGGL(k_pair_count, dim3(ctx->n_cu * 8), dim3(256), 0, ctx->stream, C, mask, hi.n_rows, lo.n_rows, hi.norm, lo.norm, cc,
                        scratch<int32_t>(ctx, S_ROWCNT), d_status);
@@ -1864,22 +2140,28 @@ static int pose_wgs_per_cu() {
     return v == 2 ? 2 : 1;
 }
 
-// Scores the pairs in S_PAIR_* into S_COUNTS.  The lo cloud is the set of points `d_cloud[0..n_cloud)` whose flag in
-// `d_cloud_used` is set (all when nullptr); `fallback` (cell = dist, built over the same points) is used when the clouds
-// do not fit LDS.
-// prune_k > 0 (with hist2 = l_hi_max + 1 zeroed ints, and status[ST_NSEL] zero): only the k best pairs will be asked for, so the
-// exact search runs on the pairs the bounds cannot exclude (k_pose_bounds, k_prune_select) and S_COUNTS holds lower bounds for
-// the rest.  *pruned (nullable) tells whether that happened (it needs the LDS path and both bitmap planes).
-static int pose_device(mad_ctx *ctx, const Side &hi, const Side &lo, int32_t *d_status, int64_t cap_pairs,
-                       const double *d_hi_cloud, int l_hi_max, const double *d_cloud, int n_cloud, const uint8_t *d_cloud_used,
-                       const double bb_min[3], const double bb_max[3], const CellGrid *fallback, double dist, int64_t prune_k = 0,
-                       int32_t *hist2 = nullptr, bool *pruned = nullptr, const CloudJob *job = nullptr) {
-    if (pruned) *pruned = false;
-    const CloudJob no_job = {nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr};
-    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_COUNTS), (size_t)cap_pairs * 4));
-    const double dd_lim = sqrt_limit(dist);
-    const double reach = dist + 0.01;
+// Everything about the pose stage of one match that follows from the host's knowledge alone (cloud capacities, the lo cloud's
+// bounding box, dist): the search grid, the bitmaps, the LDS budgets, which kernels run.  Computed before the match's first launch,
+// so that the zero fill of the bitmaps can travel with the zero fill of the match's status words.
+struct PosePlan {
     PoseGrid G;
+    PoseBits B;                      // fine bitmap, two planes
+    PoseCoarse PC;                   // coarse outer plane of the pruning pass
+    double bits_rad, bits_rad_in, rad_c_out, dd_lim, reach;
+    size_t n_words, fine_bytes, coarse_bytes, lds, lds32, lds32_hi;
+    float lim_in, lim_out;
+    bool fits64, fits32, hi_in_lds, lds_path, prune;
+    int l_hi_max, n_cloud;
+};
+
+static void pose_plan(const mad_ctx *ctx, int l_hi_max, int n_cloud, const double bb_min[3], const double bb_max[3], bool have_fallback,
+                      double dist, int64_t prune_k, bool have_hist2, PosePlan *Q) {
+    PosePlan &P = *Q;
+    P.l_hi_max = l_hi_max; P.n_cloud = n_cloud;
+    P.dd_lim = sqrt_limit(dist);
+    P.reach = dist + 0.01;
+    const double reach = P.reach;
+    PoseGrid &G = P.G;
     G.ncell = 1;
     for (int d = 0; d < 3; d++) {
         const double ext = bb_max[d] - bb_min[d];
@@ -1894,21 +2176,20 @@ static int pose_device(mad_ctx *ctx, const Side &hi, const Side &lo, int32_t *d_
     }
     const size_t stacks = (size_t)(POSE_LDS_THREADS / MAD_WAVE) * POSE_WAVE_LDS;      // k_pose_lds: per-wave queue + two pair records
     const size_t stacks32 = (size_t)(POSE_LDS_THREADS / MAD_WAVE) * POSE_STACK * 2;   // k_pose_lds32: per-wave survivor stack only
-    const size_t lds32 = (size_t)(n_cloud + 1) * 16 + pad16((size_t)(G.ncell + 1) * 2) + stacks32 + 16;
-    const size_t lds32_hi = lds32 + pad16((size_t)l_hi_max * 24) + (size_t)l_hi_max * 16;      // with the hi cloud in LDS as well
-    const bool hi_in_lds = lds32_hi <= 150 * 1024;
+    P.lds32 = (size_t)(n_cloud + 1) * 16 + pad16((size_t)(G.ncell + 1) * 2) + stacks32 + 16;
+    P.lds32_hi = P.lds32 + pad16((size_t)l_hi_max * 24) + (size_t)l_hi_max * 16;      // with the hi cloud in LDS as well
+    P.hi_in_lds = P.lds32_hi <= 150 * 1024;
     // occupancy bitmap of the lo cloud (k_pose_bits), in global memory: voxel edge MAD_POSE_VOXEL (default 0.8 A: 0.6-0.8 measure the same, 1.0 is 3 % slower) unless that
     // needs more than 16 MB.  It was tried in LDS too: there it has to be coarser (1.7 A beside the C3 clouds), lets 74
     // instead of 57 points per pair through, and the second round of the exact search that this costs outweighs the
     // cheaper lookup (0.77 against 0.66 ms per C3 step).
     const size_t lds_base = pad16((size_t)l_hi_max * 24) + pad16((size_t)n_cloud * 24) + (size_t)l_hi_max * 16 + pad16((size_t)(G.ncell + 1) * 2) +
-                            stacks + 16;      // the regions of k_pose_lds
+                            stacks + (size_t)POSE_OWN_CAP * 4 + 16;      // the regions of k_pose_lds (the last: its own selection list)
     const bool base64 = lds_base <= 150 * 1024;
     const size_t bits_budget = (size_t)16 << 20;
     static const double h0 = getenv("MAD_POSE_VOXEL") ? atof(getenv("MAD_POSE_VOXEL")) : 0.8;
-    PoseBits B;
+    PoseBits &B = P.B;
     const double slack = 0.02;
-    size_t n_words;
     for (B.h = (h0 >= 0.25 && h0 <= 8.0) ? h0 : 0.8;; B.h *= 1.08) {
         const double guard = dist + B.h * 0.8660254037844387 + slack + B.h;
         for (int d = 0; d < 3; d++) {
@@ -1916,17 +2197,16 @@ static int pose_device(mad_ctx *ctx, const Side &hi, const Side &lo, int32_t *d_
             B.dim[d] = (int)ceil((bb_max[d] - bb_min[d] + 2.0 * guard) / B.h) + 1;
         }
         B.wz = (B.dim[2] + 31) / 32;
-        n_words = 2 * (size_t)B.dim[0] * B.dim[1] * B.wz;      // two planes
-        if (n_words * 4 <= bits_budget) break;
+        P.n_words = 2 * (size_t)B.dim[0] * B.dim[1] * B.wz;      // two planes
+        if (P.n_words * 4 <= bits_budget) break;
     }
-    const size_t lds = lds_base;
-    const double bits_rad = dist + B.h * 0.8660254037844387 + slack, bits_rad_in = dist - B.h * 0.8660254037844387 - slack;
+    P.lds = lds_base;
+    P.bits_rad = dist + B.h * 0.8660254037844387 + slack;
+    P.bits_rad_in = dist - B.h * 0.8660254037844387 - slack;
     // The coarse outer-plane bitmap of the pruning pass (k_pose_bounds keeps it in LDS beside the float32 hi cloud): the finest voxel
     // with which it fits.  A coarser voxel lets more points through to the global lookup, it never changes a count.
-    PoseCoarse PC;
-    double rad_c_out = 0;
     {
-        PoseBits &Bc = PC.B;
+        PoseBits &Bc = P.PC.B;
         // beside the bitmap: the float32 hi cloud and one queue of 2-byte point ids per wave
         const int nb_sets = (l_hi_max + MAD_WAVE - 1) / MAD_WAVE;
         const size_t budget = (size_t)150 * 1024 - pad16((size_t)(l_hi_max + 4) * 16) - (size_t)(PB_THREADS / MAD_WAVE) * (((nb_sets + 1) & ~1) + 5) * MAD_WAVE * 2 - pad16((size_t)(l_hi_max + 1) * 4) - 64;      // queue: up to 4 sets of rounding (nbv) + the dump slots
@@ -1941,8 +2221,8 @@ static int pose_device(mad_ctx *ctx, const Side &hi, const Side &lo, int32_t *d_
             n_words_c = (size_t)Bc.dim[0] * Bc.dim[1] * Bc.wz;
             if (n_words_c * 4 <= budget || Bc.h > 16.0) break;
         }
-        PC.n_words = (int)n_words_c;
-        rad_c_out = dist + Bc.h * 0.8660254037844387 + slack;      // float32 voxel coordinates, as for the fine bitmap: same slack
+        P.PC.n_words = (int)n_words_c;
+        P.rad_c_out = dist + Bc.h * 0.8660254037844387 + slack;      // float32 voxel coordinates, as for the fine bitmap: same slack
     }
     // float32 tier of k_pose_lds32: offsets from the grid origin are below M = extent + reach, each rounded once (error
     // <= ulp(M) / 2); a squared distance near dist^2 is then off by < 2 sqrt(3) (dist + 1) ulp(M) plus ~1e-5 of float32
@@ -1951,10 +2231,46 @@ static int pose_device(mad_ctx *ctx, const Side &hi, const Side &lo, int32_t *d_
     for (int d = 0; d < 3; d++) M = std::max(M, bb_max[d] - bb_min[d] + 2.0 * reach);
     const double ulpM = ldexp(1.0, (int)ceil(log2(M)) - 23);
     const double band = 4.0 * (2.0 * sqrt(3.0) * (dist + 1.0) * ulpM + 1e-5 * dist * dist);
-    const float lim_in = nextafterf((float)(dist * dist - band), 0.f), lim_out = nextafterf((float)(dist * dist + band), 1e30f);
+    P.lim_in = nextafterf((float)(dist * dist - band), 0.f);
+    P.lim_out = nextafterf((float)(dist * dist + band), 1e30f);
     // queue entries are 15 (k_pose_lds) / 16 (k_pose_lds32) bits of hi-cloud index
-    const bool fits64 = base64 && l_hi_max < 32768, fits32 = lds32 <= 150 * 1024 && lim_in > 0.f && l_hi_max < 65536;
-    if (!fallback && (fits64 || fits32) && n_cloud < 65535 && G.ncell <= 30000) {
+    P.fits64 = base64 && l_hi_max < 32768;
+    P.fits32 = P.lds32 <= 150 * 1024 && P.lim_in > 0.f && l_hi_max < 65536;
+    P.lds_path = !have_fallback && (P.fits64 || P.fits32) && n_cloud < 65535 && G.ncell <= 30000;
+    static const bool no_prune = getenv("MAD_NO_PRUNE") != nullptr;      // diagnostic switch
+    P.prune = P.lds_path && prune_k > 0 && have_hist2 && P.bits_rad_in > 0.5 && P.PC.B.h <= 16.0 && l_hi_max <= PB_MAX_SETS * MAD_WAVE && !no_prune;
+    P.fine_bytes = P.lds_path ? pad16(P.n_words * 4) : 0;
+    P.coarse_bytes = P.prune ? pad16((size_t)P.PC.n_words * 4) : 0;
+    (void)ctx;
+}
+
+// Scores the pairs in S_PAIR_* into S_COUNTS.  The lo cloud is the set of points `d_cloud[0..n_cloud)` whose flag in
+// `d_cloud_used` is set (all when nullptr); `fallback` (cell = dist, built over the same points) is used when the clouds
+// do not fit LDS.
+// prune_k > 0 (with hist2 = l_hi_max + 1 zeroed ints, and status[ST_NSEL] zero): only the k best pairs will be asked for, so the
+// exact search runs on the pairs the bounds cannot exclude (k_pose_bounds, k_prune_select) and S_COUNTS holds lower bounds for
+// the rest.  *pruned (nullable) tells whether that happened (it needs the LDS path and both bitmap planes).
+// pre (nullable): the plan of this very call, made by the caller, who has also reserved S_PG_BITS and enqueued its zero fill
+// (match_enqueue_head: one fill for status words and bitmaps).  fused: the fewest launches -- k_pose_setup, and the exact search
+// selecting its own pairs when a previous match of this lane has told how many to expect (*own_sel reports that).
+static int pose_device(mad_ctx *ctx, const Side &hi, const Side &lo, int32_t *d_status, int64_t cap_pairs,
+                       const double *d_hi_cloud, int l_hi_max, const double *d_cloud, int n_cloud, const uint8_t *d_cloud_used,
+                       const double bb_min[3], const double bb_max[3], const CellGrid *fallback, double dist, int64_t prune_k = 0,
+                       int32_t *hist2 = nullptr, bool *pruned = nullptr, const CloudJob *job = nullptr, const PosePlan *pre = nullptr,
+                       bool fused = false, bool *own_sel = nullptr) {
+    if (pruned) *pruned = false;
+    if (own_sel) *own_sel = false;
+    const CloudJob no_job = {nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr};
+    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_COUNTS), (size_t)cap_pairs * 4));
+    PosePlan local;
+    if (!pre) pose_plan(ctx, l_hi_max, n_cloud, bb_min, bb_max, fallback != nullptr, dist, prune_k, hist2 != nullptr, &local);
+    const PosePlan &P = pre ? *pre : local;
+    const PoseGrid &G = P.G;
+    const PoseBits &B = P.B;
+    const PoseCoarse &PC = P.PC;
+    const double dd_lim = P.dd_lim, reach = P.reach;
+    const bool fits64 = P.fits64;
+    if (P.lds_path) {
         MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_PG_START), (size_t)(G.ncell + 2) * 4 + pad16((size_t)(G.ncell + 2) * 2) + 16));
         unsigned short *d_start16 = (unsigned short *)(scratch<char>(ctx, S_PG_START) + pad16((size_t)(G.ncell + 2) * 4));
         MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_PG_PTS), (size_t)(n_cloud + 2) * 24));
@@ -1963,44 +2279,68 @@ static int pose_device(mad_ctx *ctx, const Side &hi, const Side &lo, int32_t *d_
         if (!attr_set) {
             MAD_HIP(hipFuncSetAttribute((const void *)k_pose_lds32<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             MAD_HIP(hipFuncSetAttribute((const void *)k_pose_lds32<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            MAD_HIP(hipFuncSetAttribute((const void *)k_pose_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            MAD_HIP(hipFuncSetAttribute((const void *)k_pose_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));      // (+ its static LDS)
             MAD_HIP(hipFuncSetAttribute((const void *)k_pose_grid_build, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+            MAD_HIP(hipFuncSetAttribute((const void *)k_pose_setup, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
             attr_set = true;
         }
-        hipLaunchKernelGGL(k_pose_grid_build, dim3(1), dim3(1024), (size_t)G.ncell * 4, ctx->stream, d_cloud, d_cloud_used, n_cloud, G,
-                           scratch<int32_t>(ctx, S_PG_START), d_start16, scratch<double>(ctx, S_PG_PTS),
-                           fits64 ? (float4 *)nullptr : scratch<float4>(ctx, S_PG_PTSF), d_status + ST_LLO, job ? *job : no_job);
-        static const bool no_prune = getenv("MAD_NO_PRUNE") != nullptr;      // diagnostic switch
-        const bool prune = prune_k > 0 && hist2 && bits_rad_in > 0.5 && PC.B.h <= 16.0 && l_hi_max <= PB_MAX_SETS * MAD_WAVE && !no_prune;
+        const bool prune = P.prune;
         static const bool dbg_prune = getenv("MAD_DEBUG_PRUNE") != nullptr;
         if (dbg_prune)
             fprintf(stderr, "pose_device: prune=%d prune_k=%lld hist2=%p rad_in=%g coarse h=%g l_hi_max=%d fits64=%d fits32=%d fine h=%g n_cloud=%d\n", (int)prune,
-                    (long long)prune_k, (void *)hist2, bits_rad_in, PC.B.h, l_hi_max, (int)fits64, (int)fits32, B.h, n_cloud);
+                    (long long)prune_k, (void *)hist2, P.bits_rad_in, PC.B.h, l_hi_max, (int)fits64, (int)P.fits32, B.h, n_cloud);
         // fine bitmap, then (when pruning) the coarse one, in one buffer: one zero fill, one launch marks all planes
-        const size_t fine_bytes = pad16(n_words * 4);
-        const size_t coarse_bytes = prune ? pad16((size_t)PC.n_words * 4) : 0;
-        MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_PG_BITS), fine_bytes + coarse_bytes + 16));
+        const size_t fine_bytes = P.fine_bytes, coarse_bytes = P.coarse_bytes;
+        if (!pre) {
+            MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_PG_BITS), fine_bytes + coarse_bytes + 16));
+            mad_zero_words(ctx, scratch<unsigned>(ctx, S_PG_BITS), fine_bytes + coarse_bytes);
+        }
         unsigned *d_bits = scratch<unsigned>(ctx, S_PG_BITS);
         unsigned *d_bits_c = (unsigned *)(scratch<char>(ctx, S_PG_BITS) + fine_bytes);
-        mad_zero_words(ctx, d_bits, fine_bytes + coarse_bytes);
         PoseBitsJobs J;
         int n_jobs = 0;
-        auto job = [&](const PoseBits &b, double rad, int plane, int planes, unsigned *bits) {
+        auto bjob = [&](const PoseBits &b, double rad, int plane, int planes, unsigned *bits) {
             J.B[n_jobs] = b; J.rad[n_jobs] = rad; J.plane[n_jobs] = plane; J.planes[n_jobs] = planes; J.bits[n_jobs] = bits; n_jobs++;
         };
-        job(B, bits_rad, 0, 2, d_bits);
-        if (bits_rad_in > 0.5) job(B, bits_rad_in, 1, 2, d_bits);
-        if (prune) job(PC.B, rad_c_out, 0, 1, d_bits_c);
+        bjob(B, P.bits_rad, 0, 2, d_bits);
+        if (P.bits_rad_in > 0.5) bjob(B, P.bits_rad_in, 1, 2, d_bits);
+        if (prune) bjob(PC.B, P.rad_c_out, 0, 1, d_bits_c);
         for (int j = n_jobs; j < 4; j++) { J.B[j] = B; J.rad[j] = 0; J.plane[j] = 0; J.planes[j] = 2; J.bits[j] = nullptr; }
-        hipLaunchKernelGGL(k_pose_bits, dim3((unsigned)std::min(std::max(n_cloud, 1), ctx->n_cu * 4), n_jobs), dim3(256), 0, ctx->stream,
-                           (const double *)scratch<double>(ctx, S_PG_PTS), (const int32_t *)scratch<int32_t>(ctx, S_PG_START), G.ncell, J);
         MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_PG_PAIRS), (size_t)cap_pairs * sizeof(PosePair)));
         PosePair *d_rec = scratch<PosePair>(ctx, S_PG_PAIRS);
-        hipLaunchKernelGGL(k_pose_prep, dim3(ctx->n_cu * 8), dim3(256), 0, ctx->stream, scratch<int32_t>(ctx, S_PAIR_HI),
-                           scratch<int32_t>(ctx, S_PAIR_LO), d_status, cap_pairs, hi.p, hi.R, lo.p, lo.Rinv, hi.row_anchor, lo.row_anchor, B, PC.B, d_rec);
+        static const bool no_fuse = getenv("MAD_NO_FUSE") != nullptr;      // diagnostic switch: the launch-per-step form of round 2
+        if (fused && !no_fuse) {
+            PoseSetup S;
+            S.pts = d_cloud; S.used = d_cloud_used; S.n = n_cloud; S.G = G;
+            S.cell_start = scratch<int32_t>(ctx, S_PG_START); S.cell_start16 = d_start16; S.sorted = scratch<double>(ctx, S_PG_PTS);
+            S.sorted_f = fits64 ? (float4 *)nullptr : scratch<float4>(ctx, S_PG_PTSF); S.n_used = d_status + ST_LLO;
+            S.J = job ? *job : no_job;
+            S.bits = J; S.n_bit_jobs = n_jobs; S.n_bits_wgs = n_jobs * 64;
+            S.pair_hi = scratch<int32_t>(ctx, S_PAIR_HI); S.pair_lo = scratch<int32_t>(ctx, S_PAIR_LO); S.status = d_status; S.cap_pairs = cap_pairs;
+            S.hi_p = hi.p; S.hi_R = hi.R; S.lo_p = lo.p; S.lo_Rinv = lo.Rinv; S.hi_row_anchor = hi.row_anchor; S.lo_row_anchor = lo.row_anchor;
+            S.Bf = B; S.Bc = PC.B; S.rec = d_rec;
+            const int prep_wgs = std::max(ctx->n_cu * 2 - 2 - S.n_bits_wgs, ctx->n_cu / 2);
+            S.roles = 15;
+            hipLaunchKernelGGL(k_pose_setup, dim3((unsigned)(2 + S.n_bits_wgs + prep_wgs)), dim3(1024), (size_t)G.ncell * 4, ctx->stream, S);
+            static const bool probe_setup = getenv("MAD_PROBE_SETUP") != nullptr;      // every role once more on its own (idempotent)
+            if (probe_setup)
+                for (int r = 1; r < 16; r <<= 1) {
+                    S.roles = r;
+                    hipLaunchKernelGGL(k_pose_setup, dim3((unsigned)(2 + S.n_bits_wgs + prep_wgs)), dim3(1024), (size_t)G.ncell * 4, ctx->stream, S);
+                }
+        } else {
+            hipLaunchKernelGGL(k_pose_grid_build, dim3(1), dim3(1024), (size_t)G.ncell * 4, ctx->stream, d_cloud, d_cloud_used, n_cloud, G,
+                               scratch<int32_t>(ctx, S_PG_START), d_start16, scratch<double>(ctx, S_PG_PTS),
+                               fits64 ? (float4 *)nullptr : scratch<float4>(ctx, S_PG_PTSF), d_status + ST_LLO, job ? *job : no_job);
+            hipLaunchKernelGGL(k_pose_bits, dim3((unsigned)std::min(std::max(n_cloud, 1), ctx->n_cu * 4), n_jobs), dim3(256), 0, ctx->stream,
+                               (const double *)scratch<double>(ctx, S_PG_PTS), (const int32_t *)scratch<int32_t>(ctx, S_PG_START), G.ncell, J);
+            hipLaunchKernelGGL(k_pose_prep, dim3(ctx->n_cu * 8), dim3(256), 0, ctx->stream, scratch<int32_t>(ctx, S_PAIR_HI),
+                               scratch<int32_t>(ctx, S_PAIR_LO), d_status, cap_pairs, hi.p, hi.R, lo.p, lo.Rinv, hi.row_anchor, lo.row_anchor, B, PC.B, d_rec);
+        }
         ctx->last_pose_kernel = fits64 ? 0 : 1;
         mad_timer_begin(ctx, MAD_T_POSE);      // the pose stage: bounds + selection (when pruning) + the exact search
         const int32_t *d_sel = nullptr;
+        PoseOwnSel own = {nullptr, nullptr, 0, 0, nullptr, 0, nullptr};
         if (prune) {
             MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_TMP_C), (size_t)cap_pairs * 2 + 64));
             MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_TMP_D), (size_t)cap_pairs * 4 + 64));
@@ -2062,31 +2402,40 @@ static int pose_device(mad_ctx *ctx, const Side &hi, const Side &lo, int32_t *d_
                 }
             }
 #undef MAD_PB_LAUNCH
-            hipLaunchKernelGGL(k_prune_select, dim3(ctx->n_cu / 2), dim3(256), 0, ctx->stream, d_status, cap_pairs, hist2, nbins, prune_k,
-                               scratch<unsigned short>(ctx, S_TMP_C), scratch<int32_t>(ctx, S_TMP_D), d_status + ST_NSEL, hist2 + nbins,
-                               fits64 ? scratch<int32_t>(ctx, S_COUNTS) : (int32_t *)nullptr);      // k_pose_lds adds up partial counts
-            d_sel = scratch<int32_t>(ctx, S_TMP_D);
+            // the selection: inside the exact search itself (k_pose_lds, own) when this lane's previous match has told how many pairs
+            // to expect, else a launch of its own
+            if (fused && !no_fuse && fits64 && ctx->lane_sel_hint[ctx->lane] > 0) {
+                own.upper = scratch<unsigned short>(ctx, S_TMP_C); own.hist = hist2; own.nbins = nbins; own.k = prune_k;
+                own.sel_out = scratch<int32_t>(ctx, S_TMP_D); own.sel_cap = cap_pairs; own.status_w = d_status;
+                if (own_sel) *own_sel = true;
+            } else {
+                hipLaunchKernelGGL(k_prune_select, dim3(ctx->n_cu / 2), dim3(256), 0, ctx->stream, d_status, cap_pairs, hist2, nbins, prune_k,
+                                   scratch<unsigned short>(ctx, S_TMP_C), scratch<int32_t>(ctx, S_TMP_D), d_status + ST_NSEL, hist2 + nbins,
+                                   fits64 ? scratch<int32_t>(ctx, S_COUNTS) : (int32_t *)nullptr);      // k_pose_lds adds up partial counts
+                d_sel = scratch<int32_t>(ctx, S_TMP_D);
+            }
             if (pruned) *pruned = true;
         }
         // the exact search of a pruned match sees a few hundred pairs: a grid sized from what the previous match in this lane
         // selected (one pair per wave, 25 % spare) instead of one workgroup per CU staging both clouds for nothing.  A larger
         // selection than expected is still searched completely, the kernels are persistent.
         unsigned wgs_sel = (unsigned)ctx->n_cu;
-        if (d_sel && ctx->lane_sel_hint[ctx->lane] > 0)
+        if ((d_sel || own.upper) && ctx->lane_sel_hint[ctx->lane] > 0)
             wgs_sel = (unsigned)std::min<int64_t>(ctx->n_cu, std::max<int64_t>(16, (ctx->lane_sel_hint[ctx->lane] * (fits64 ? POSE_PARTS : 1) * 5 / 4) / (POSE_LDS_THREADS / MAD_WAVE) + 4));
+        const bool listed = d_sel || own.upper;
         if (fits64)
-            hipLaunchKernelGGL(k_pose_lds, dim3(d_sel ? wgs_sel : ctx->n_cu * (lds > 80 * 1024 ? 1 : pose_wgs_per_cu())), dim3(POSE_LDS_THREADS), lds, ctx->stream, d_status, cap_pairs, d_rec,
+            hipLaunchKernelGGL(k_pose_lds, dim3(listed ? wgs_sel : ctx->n_cu * (P.lds > 80 * 1024 ? 1 : pose_wgs_per_cu())), dim3(POSE_LDS_THREADS), P.lds, ctx->stream, d_status, cap_pairs, d_rec,
                                d_hi_cloud, scratch<double>(ctx, S_PG_PTS), scratch<int32_t>(ctx, S_PG_START), d_start16, G,
-                               l_hi_max, n_cloud, (float)reach, dd_lim, B, d_bits, scratch<int32_t>(ctx, S_COUNTS), d_sel);
-        else if (hi_in_lds)
-            hipLaunchKernelGGL(k_pose_lds32<true>, dim3(d_sel ? wgs_sel : ctx->n_cu), dim3(POSE_LDS_THREADS), lds32_hi, ctx->stream, d_status, cap_pairs, d_rec,
+                               l_hi_max, n_cloud, (float)reach, dd_lim, B, d_bits, scratch<int32_t>(ctx, S_COUNTS), d_sel, own);
+        else if (P.hi_in_lds)
+            hipLaunchKernelGGL(k_pose_lds32<true>, dim3(d_sel ? wgs_sel : ctx->n_cu), dim3(POSE_LDS_THREADS), P.lds32_hi, ctx->stream, d_status, cap_pairs, d_rec,
                                d_hi_cloud, scratch<double>(ctx, S_PG_PTS), scratch<float4>(ctx, S_PG_PTSF),
-                               scratch<int32_t>(ctx, S_PG_START), d_start16, G, n_cloud, l_hi_max, (float)reach, dd_lim, lim_in, lim_out, B, d_bits,
+                               scratch<int32_t>(ctx, S_PG_START), d_start16, G, n_cloud, l_hi_max, (float)reach, dd_lim, P.lim_in, P.lim_out, B, d_bits,
                                scratch<int32_t>(ctx, S_COUNTS), d_sel);
         else
-            hipLaunchKernelGGL(k_pose_lds32<false>, dim3(d_sel ? wgs_sel : ctx->n_cu), dim3(POSE_LDS_THREADS), lds32, ctx->stream, d_status, cap_pairs, d_rec,
+            hipLaunchKernelGGL(k_pose_lds32<false>, dim3(d_sel ? wgs_sel : ctx->n_cu), dim3(POSE_LDS_THREADS), P.lds32, ctx->stream, d_status, cap_pairs, d_rec,
                                d_hi_cloud, scratch<double>(ctx, S_PG_PTS), scratch<float4>(ctx, S_PG_PTSF),
-                               scratch<int32_t>(ctx, S_PG_START), d_start16, G, n_cloud, l_hi_max, (float)reach, dd_lim, lim_in, lim_out, B, d_bits,
+                               scratch<int32_t>(ctx, S_PG_START), d_start16, G, n_cloud, l_hi_max, (float)reach, dd_lim, P.lim_in, P.lim_out, B, d_bits,
                                scratch<int32_t>(ctx, S_COUNTS), d_sel);
         mad_timer_end(ctx, MAD_T_POSE);
         MAD_HIP(hipGetLastError());
@@ -2117,7 +2466,7 @@ static bool clouds_fit_lds(int64_t l_hi, int64_t l_lo) {      // with the larges
     // as pose_device sizes them (+ its 16-byte paddings): the float64 kernel carries a queue and two pair records per wave, the
     // float32 one a survivor stack
     const size_t cells = 15632 * 2 + 16 + 64;      // pose_device caps the grid at 25 cells per axis
-    const size_t fixed = cells + (POSE_LDS_THREADS / MAD_WAVE) * POSE_WAVE_LDS, fixed32 = cells + (POSE_LDS_THREADS / MAD_WAVE) * POSE_STACK * 2;
+    const size_t fixed = cells + (POSE_LDS_THREADS / MAD_WAVE) * POSE_WAVE_LDS + (size_t)POSE_OWN_CAP * 4, fixed32 = cells + (POSE_LDS_THREADS / MAD_WAVE) * POSE_STACK * 2;
     return ((size_t)(l_hi + l_lo) * 24 + (size_t)l_hi * 16 + fixed <= 150 * 1024 || (size_t)(l_lo + 1) * 16 + fixed32 <= 150 * 1024) && l_lo < 65535 &&
            l_hi < 65536;      // (the first alternative implies l_hi < 32768)
 }
@@ -2311,6 +2660,12 @@ extern "C" int mad_set_create(mad_ctx *ctx, mad_set **out) {
 extern "C" void mad_set_destroy(mad_ctx *ctx, mad_set *s) {
     if (!s) return;
     if (ctx) (void)mad_synchronize(ctx);
+    if (ctx) {      // results that still refer to this set (mad_match_fetch(counts), mad_match_results) are refused from now on
+        if (ctx->match.hi == s) ctx->match.hi = nullptr;
+        if (ctx->match.lo == s) ctx->match.lo = nullptr;
+        if (ctx->match.shard_hi == s) ctx->match.shard_hi = nullptr;
+        if (ctx->match.shard_lo == s) ctx->match.shard_lo = nullptr;
+    }
     DevBuf *bufs[] = {&s->anc_blob, &s->row_anchor, &s->row_main, &s->row_sec, &s->row_R, &s->row_Rinv, &s->row_meta, &s->dsc,
                       &s->dsc8, &s->norm, &s->row_perm, &s->cell_start, &s->cell_pts, &s->cell_ids};      // anc_* and dev_n are views
     for (DevBuf *b : bufs) mad_release(*b);
@@ -2362,6 +2717,7 @@ static int set_rows(mad_ctx *ctx, const mad_set *cs, int64_t *n_rows) {
 static int set_upload_anchors(mad_ctx *ctx, mad_set *s, const int32_t *anc_coords, const int32_t *anc_octave,
                               const double *anc_subv, const int32_t *anc_index, int n, int32_t rows0 = 0) {
     s->n_anchors = n;
+    s->gen++;
     const size_t m = (size_t)(n > 0 ? n : 1);
     const size_t o_subv = 64, o_coords = o_subv + m * 24, o_oct = o_coords + m * 12, o_idx = o_oct + m * 4, o_canon = o_idx + m * 4,
                  o_order = o_canon + m * 4, total = (o_order + m * 4 + 15) / 16 * 16;
@@ -2638,6 +2994,8 @@ struct MatchPlan {
     CellGrid G;
     double dist;
     bool no_small;      // the one-workgroup top-k over the pruned selection overflowed: use the general selection
+    bool pruned;        // this attempt's pose search was pruned by bounds (set when it is enqueued; per bracket and lane, not per lane)
+    PosePlan pose;      // made by match_enqueue_head (which also zeroes the bitmaps), used by match_enqueue_tail
 };
 
 // enqueue a11 + a12 + top-k (+ the result rows) of one (hi, lo) pair in the CURRENT lane; no host round trip.
@@ -2655,17 +3013,21 @@ static size_t tail_bytes(int64_t k) { return (size_t)k * (MAD_RESULT_COLS * 8 + 
 
 // A match is enqueued in two halves: what precedes the GEMM (waits, zeroed status, the GEMM's arguments) and what follows it.
 // Between them the caller launches the GEMM -- of this match alone, or of all matches of a bracket in one grid.
-static int match_enqueue_head(mad_ctx *ctx, const mad_set *hi, const mad_set *lo, double cc, const MatchPlan &P, GemmJob *job) {
+static int match_enqueue_head(mad_ctx *ctx, const mad_set *hi, const mad_set *lo, double cc, MatchPlan &P, GemmJob *job) {
     int32_t *st = zero_status(ctx);
     const Side H = side_of(hi), L = side_of(lo);
     // the sets may have been built on other lanes
     MAD_HIP(hipStreamWaitEvent(ctx->stream, hi->built, 0));
     MAD_HIP(hipStreamWaitEvent(ctx->stream, lo->built, 0));
-    mad_zero_words(ctx, st, zero_bytes(hi, lo));      // status, histogram and flags in one launch
+    // status, histograms and flags, and the occupancy bitmaps of the pose search, zeroed by ONE launch
+    pose_plan(ctx, hi->n_anchors, lo->n_anchors, lo->bb_min, lo->bb_max, !P.fits, P.dist, P.k, true, &P.pose);
+    const size_t bits_bytes = P.pose.fine_bytes + P.pose.coarse_bytes;
+    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_PG_BITS), bits_bytes + 16));
+    mad_zero_words3(ctx, st, zero_bytes(hi, lo), mad_sb(ctx, S_PG_BITS).p, bits_bytes, nullptr, 0);
     return correlate_reserve(ctx, H, L, hi->D, cc, st, P.cap_c, P.cap_pairs, job);
 }
 
-static int match_enqueue_tail(mad_ctx *ctx, const mad_set *hi, const mad_set *lo, double cc, double dist, const MatchPlan &P) {
+static int match_enqueue_tail(mad_ctx *ctx, const mad_set *hi, const mad_set *lo, double cc, double dist, MatchPlan &P) {
     int32_t *st = zero_status(ctx);
     int32_t *hist = zr_hist(st);
     uint8_t *used_hi = zr_used_hi(st, hi->n_anchors), *used_lo = zr_used_lo(st, hi->n_anchors);
@@ -2678,12 +3040,16 @@ static int match_enqueue_tail(mad_ctx *ctx, const mad_set *hi, const mad_set *lo
     G.used = used_lo;
     bool pruned = false;      // the caller gets k rows: pairs that cannot be among them need no exact count
     MAD_TRY(pose_device(ctx, H, L, st, P.cap_pairs, scratch<double>(ctx, S_HI_CLOUD), hi->n_anchors, (const double *)lo->anc_subv.p,
-                        lo->n_anchors, used_lo, lo->bb_min, lo->bb_max, P.fits ? nullptr : &G, dist, P.k, zr_hist2(st, hi->n_anchors), &pruned, &job));
-    ctx->lane_pruned[ctx->lane] = pruned;
+                        lo->n_anchors, used_lo, lo->bb_min, lo->bb_max, P.fits ? nullptr : &G, dist, P.k, zr_hist2(st, hi->n_anchors), &pruned, &job,
+                        &P.pose, true));
+    P.pruned = pruned;
     // A pruned search has listed every pair that can be among the k best (all others lie strictly below the k-th count): when the
     // previous match of this lane listed few enough, the k best are taken from that list by ONE workgroup instead of four
     // launches over all pairs.  Should the list outgrow the kernel (ST_FLAG_SEL), the match is repeated with the general selection.
     const int64_t hint = ctx->lane_sel_hint[ctx->lane];
+    const ResultArgs RA = {scratch<int32_t>(ctx, S_PAIR_HI), scratch<int32_t>(ctx, S_PAIR_LO), scratch<double>(ctx, S_PAIR_SCORE),
+                           scratch<int32_t>(ctx, S_COUNTS), H.p, H.R, H.meta, L.p, L.Rinv, L.meta, H.row_anchor, L.row_anchor,
+                           (double *)ctx->host_res[ctx->res_slot][ctx->lane], P.k};
     if (pruned && !P.no_small && hint > 0 && hint <= TKS_CAP / 2 && P.k <= TKS_CAP) {
         mad_timer_begin(ctx, MAD_T_TOPK);
         static bool attr_t = false;
@@ -2692,23 +3058,23 @@ static int match_enqueue_tail(mad_ctx *ctx, const mad_set *hi, const mad_set *lo
             attr_t = true;
         }
         hipLaunchKernelGGL(k_topk_selected, dim3(1), dim3(1024), (size_t)TKS_CAP * 8, ctx->stream, scratch<int32_t>(ctx, S_COUNTS),
-                           scratch<int32_t>(ctx, S_TMP_D), st, P.k, hi->n_anchors, scratch<int64_t>(ctx, S_SEL_OUT));
+                           scratch<int32_t>(ctx, S_TMP_D), st, P.k, hi->n_anchors, scratch<int64_t>(ctx, S_SEL_OUT), RA);
         mad_timer_end(ctx, MAD_T_TOPK);
     } else {
         MAD_TRY(topk_device(ctx, scratch<int32_t>(ctx, S_COUNTS), st, P.cap_pairs, P.k, hi->n_anchors, scratch<int64_t>(ctx, S_SEL_OUT), hist));
+        hipLaunchKernelGGL(k_results, dim3((unsigned)mad_ceil_div(P.k, 256)), dim3(256), 0, ctx->stream,
+                           scratch<int64_t>(ctx, S_SEL_OUT), st + ST_NKEYS, P.k, scratch<int32_t>(ctx, S_PAIR_HI),
+                           scratch<int32_t>(ctx, S_PAIR_LO), scratch<double>(ctx, S_PAIR_SCORE), scratch<int32_t>(ctx, S_COUNTS),
+                           st, H.p, H.R, H.meta, L.p, L.Rinv, L.meta, H.row_anchor, L.row_anchor, RA.out, 1);
     }
-    hipLaunchKernelGGL(k_results, dim3((unsigned)mad_ceil_div(P.k, 256)), dim3(256), 0, ctx->stream,
-                       scratch<int64_t>(ctx, S_SEL_OUT), st + ST_NKEYS, P.k, scratch<int32_t>(ctx, S_PAIR_HI),
-                       scratch<int32_t>(ctx, S_PAIR_LO), scratch<double>(ctx, S_PAIR_SCORE), scratch<int32_t>(ctx, S_COUNTS),
-                       st, H.p, H.R, H.meta, L.p, L.Rinv, L.meta, H.row_anchor, L.row_anchor, scratch<double>(ctx, S_RESULTS), 1);
     MAD_HIP(hipGetLastError());
-    // rows, pair ranks and status come back in ONE copy into pinned memory: the host is never blocked by it
-    MAD_HIP(hipMemcpyAsync(ctx->host_res[ctx->res_slot][ctx->lane], mad_sb(ctx, S_RESULTS).p, tail_bytes(P.k), hipMemcpyDeviceToHost, ctx->stream));
+    // rows, pair ranks and status words were written by the kernel straight into the pinned staging of this (bracket, lane): no copy
+    // engine, no blit kernel; the host reads them once the event has passed
     MAD_HIP(hipEventRecord(ctx->lane_done[ctx->res_slot][ctx->lane], ctx->stream));
     return MAD_OK;
 }
 
-static int match_enqueue(mad_ctx *ctx, const mad_set *hi, const mad_set *lo, double cc, double dist, const MatchPlan &P) {
+static int match_enqueue(mad_ctx *ctx, const mad_set *hi, const mad_set *lo, double cc, double dist, MatchPlan &P) {
     GemmJob job;
     MAD_TRY(match_enqueue_head(ctx, hi, lo, cc, P, &job));
     MAD_TRY(correlate_gemm(ctx, 1, &job, hi->D, cc));
@@ -2721,6 +3087,7 @@ static int match_prepare(mad_ctx *ctx, const mad_set *hi, const mad_set *lo, dou
     P->k = k < 1 ? 1 : k;
     P->dist = dist;
     P->no_small = false;
+    P->pruned = false;
     MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_ZERO), zero_bytes(hi, lo)));
     MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_HI_CLOUD), (size_t)hi->n_anchors * 24 + 24));
     MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_SEL_OUT), (size_t)(P->k + 8) * 8));
@@ -2794,10 +3161,10 @@ static int match_finish(mad_ctx *ctx, int lane, const mad_set *hi, const mad_set
     ctx->match.lane = lane;
     ctx->match.n_hi_anchors = hi->n_anchors;
     ctx->match.n_lo_anchors = lo->n_anchors;
-    ctx->match.pruned = ctx->lane_pruned[lane];
+    ctx->match.pruned = P->pruned;
     ctx->match.n_sel = ctx->match.pruned ? hs[ST_NSEL] : hs[ST_NPAIRS];
     ctx->lane_sel_hint[lane] = ctx->match.pruned ? std::max<int64_t>(hs[ST_NSEL], 1) : 0;
-    ctx->match.hi = hi; ctx->match.lo = lo; ctx->match.cap_pairs_used = P->cap_pairs; ctx->match.fits = P->fits; ctx->match.dist = P->dist;
+    ctx->match.hi = hi; ctx->match.lo = lo; ctx->match.hi_gen = hi->gen; ctx->match.lo_gen = lo->gen; ctx->match.cap_pairs_used = P->cap_pairs; ctx->match.fits = P->fits; ctx->match.dist = P->dist;
     const_cast<mad_set *>(hi)->n_rows_host = hs[ST_NHI];
     const_cast<mad_set *>(lo)->n_rows_host = hs[ST_NLO];
     const_cast<mad_set *>(hi)->rows_hint = hs[ST_NHI];
@@ -3157,7 +3524,9 @@ extern "C" int mad_match_shard_topk(mad_ctx *ctx, const mad_set *hi, const mad_s
 static int complete_counts(mad_ctx *ctx) {
     if (!ctx->match.pruned || ctx->match.n_pairs <= 0) return MAD_OK;
     const mad_set *hi = (const mad_set *)ctx->match.hi, *lo = (const mad_set *)ctx->match.lo;
-    if (!hi || !lo) return mad_fail(ctx, MAD_EINVAL, "match counts: the sets of the last match are unknown");
+    if (!hi || !lo) return mad_fail(ctx, MAD_EINVAL, "match counts: a set of the last match has been destroyed; its pruned pose search cannot be completed");
+    if (hi->gen != ctx->match.hi_gen || lo->gen != ctx->match.lo_gen)
+        return mad_fail(ctx, MAD_EINVAL, "match counts: a set of the last match has been rebuilt since; its pruned pose search cannot be completed");
     mad_use_lane(ctx, ctx->match.lane);
     int32_t *st = zero_status(ctx);
     const Side H = side_of(hi), L = side_of(lo);
@@ -3165,7 +3534,6 @@ static int complete_counts(mad_ctx *ctx) {
                         lo->n_anchors, zr_used_lo(st, hi->n_anchors), lo->bb_min, lo->bb_max, nullptr, ctx->match.dist));
     MAD_HIP(hipStreamSynchronize(ctx->stream));
     ctx->match.pruned = false;
-    ctx->lane_pruned[ctx->match.lane] = false;
     return MAD_OK;
 }
 

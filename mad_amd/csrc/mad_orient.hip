@@ -458,6 +458,61 @@ __global__ __launch_bounds__(256) void k_orient_rows(Batch<RowsArgs> B, int fan,
     if (A.row_meta) { A.row_meta[3 * row] = A.anc_index[a]; A.row_meta[3 * row + 1] = A.anc_octave[a]; A.row_meta[3 * row + 2] = mb; }
 }
 
+// k_orient_scan + k_orient_rows in ONE launch (round 3): every 1024-thread workgroup forms the exclusive scan of its job's
+// per-anchor row counts for itself, in LDS (n ints: a thread sums a run of consecutive anchors, one block scan over the runs), the
+// working-order offset of its first anchor by a block reduction, and then expands its 1024 / fan anchors.  A few microseconds of
+// redundant work per workgroup, all of them side by side, instead of a one-workgroup launch on the build's critical path.
+// Dynamic LDS: (max n + 1) ints.  The rows come out exactly as from the two-launch form.
+#define ORI_ROWS_MAX_N 30000      // anchors per job the one-launch form takes (LDS); beyond: k_orient_scan + k_orient_rows
+__global__ __launch_bounds__(1024) void k_orient_rows_scan(Batch<RowsArgs> B, int fan, int lim_main, const EqspDev *eq) {
+    extern __shared__ __align__(16) int s_off[];
+    __shared__ int wt[1024 / MAD_WAVE + 1];
+    __shared__ int s_perm[1024];
+    const int job = batch_job(B, (int)blockIdx.x);
+    const RowsArgs &A = B.job[job];
+    const int n = A.n, tid = (int)threadIdx.x;
+    const int per = (n + 1023) / 1024;
+    const int i0 = min(tid * per, n), i1 = min(i0 + per, n);
+    int sum = 0;
+    for (int i = i0; i < i1; i++) sum += A.slot_cnt[i];
+    int total;
+    int run = block_excl_scan(sum, wt, &total);
+    for (int i = i0; i < i1; i++) { s_off[i] = run; run += A.slot_cnt[i]; }
+    const int ppb = 1024 / fan;                                   // anchors per workgroup
+    const int p0 = ((int)blockIdx.x - B.first[job]) * ppb;        // its first position in working order
+    if (p0 == 0 && tid == 0) *A.n_rows = total;
+    // rows of the anchors that precede position p0 in working order, then of this workgroup's own anchors
+    int before = 0;
+    for (int q = tid; q < p0; q += 1024) before += A.slot_cnt[A.order ? A.order[q] : q];
+    int base;
+    (void)block_excl_scan(before, wt, &base);
+    const int mine = (tid < ppb && p0 + tid < n) ? A.slot_cnt[A.order ? A.order[p0 + tid] : p0 + tid] : 0;
+    int tot2;
+    const int ex = block_excl_scan(mine, wt, &tot2);
+    s_perm[tid] = base + ex;
+    __syncthreads();
+    const int pl = tid / fan, sl = tid % fan, pp = p0 + pl;
+    if (pl >= ppb || pp >= n) return;
+    const int a = A.order ? A.order[pp] : pp;
+    const int c = A.slot_cnt[a];
+    if (sl >= c) return;
+    const int64_t row = (int64_t)s_off[a] + sl;
+    if (A.order) A.row_perm[s_perm[pl] + sl] = (int32_t)row;
+    const int mb = A.slot_main[(size_t)a * fan + sl], sb = A.slot_sec[(size_t)a * fan + sl];
+    A.row_anchor[row] = a;
+    A.row_main[row] = mb;
+    A.row_sec[row] = sb;
+    double *o = A.row_R + 9 * row;
+    mad_rfinal(eq, mb, sb, o);
+    if (A.row_count) {
+        const int Z = eq->Z;
+        const int32_t *h = A.slot_hist + ((size_t)a * lim_main + A.slot_hidx[(size_t)a * fan + sl]) * Z;
+        for (int i = 0; i < Z; i++) A.row_count[row * Z + i] = h[i];
+    }
+    if (A.row_Rinv) mad_mat3_inv(o, A.row_Rinv + 9 * row);      // inv(lo.Rfinal) of MaD.py:438, once per row
+    if (A.row_meta) { A.row_meta[3 * row] = A.anc_index[a]; A.row_meta[3 * row + 1] = A.anc_octave[a]; A.row_meta[3 * row + 2] = mb; }
+}
+
 // Runs a1-a8 for the anchor lists of n_jobs structures (coordinates and octaves already on the device) in one k_orient
 // grid, one scan and one row-expansion launch, and writes each job's rows to its `out` (capacity n * lim_main * lim_sec rows).
 // Asynchronous: the row counts stay on the device.
@@ -480,6 +535,10 @@ static int orient_batch(mad_ctx *ctx, int n_jobs, const OrientJob *jobs, int r, 
     Batch<RowsArgs> R;
     B.n_jobs = R.n_jobs = n_jobs;
     int64_t a0 = 0, blk = 0;
+    int max_n = 0;
+    for (int j = 0; j < n_jobs; j++) max_n = std::max(max_n, jobs[j].n);
+    static const bool no_fuse = getenv("MAD_NO_FUSE") != nullptr;      // diagnostic switch: the launch-per-step form of round 2
+    const bool one_launch = !no_fuse && max_n <= ORI_ROWS_MAX_N && fan <= 1024;
     for (int j = 0; j < n_jobs; j++) {
         const OrientJob &J = jobs[j];
         OrientArgs &A = B.job[j];
@@ -507,7 +566,7 @@ static int orient_batch(mad_ctx *ctx, int n_jobs, const OrientJob *jobs, int r, 
         Q.order = A.order; Q.perm_off = scratch<int32_t>(ctx, S_PERM_OFF) + a0 + j; Q.row_perm = J.out.row_perm;
         R.first[j] = (int)blk;
         a0 += J.n;
-        blk += mad_ceil_div((int64_t)J.n * fan, 256);
+        blk += one_launch ? mad_ceil_div((int64_t)J.n, 1024 / fan) : mad_ceil_div((int64_t)J.n * fan, 256);
         if (J.out.d_n_reject && !J.out.counters_zeroed) MAD_HIP(hipMemsetAsync(J.out.d_n_reject, 0, 4, ctx->stream));
     }
     B.first[n_jobs] = (int)a0;
@@ -528,8 +587,17 @@ static int orient_batch(mad_ctx *ctx, int n_jobs, const OrientJob *jobs, int r, 
     if (gw) hipLaunchKernelGGL(k_orient<true>, dim3((unsigned)a0), dim3(ORI_THREADS), lds, ctx->stream, B);
     else hipLaunchKernelGGL(k_orient<false>, dim3((unsigned)a0), dim3(ORI_THREADS), lds, ctx->stream, B);
     mad_timer_end(ctx, MAD_T_ORIENT);
-    hipLaunchKernelGGL(k_orient_scan, dim3(n_jobs), dim3(1024), 0, ctx->stream, R);
-    hipLaunchKernelGGL(k_orient_rows, dim3((unsigned)blk), dim3(256), 0, ctx->stream, R, fan, lim_main, ctx->eq[0]);
+    if (one_launch) {
+        const size_t lds_r = (size_t)(max_n + 4) * 4;
+        if (lds_r > 48 * 1024) {
+            static bool attr_r = false;
+            if (!attr_r) { MAD_HIP(hipFuncSetAttribute((const void *)k_orient_rows_scan, hipFuncAttributeMaxDynamicSharedMemorySize, (ORI_ROWS_MAX_N + 4) * 4)); attr_r = true; }
+        }
+        hipLaunchKernelGGL(k_orient_rows_scan, dim3((unsigned)blk), dim3(1024), lds_r, ctx->stream, R, fan, lim_main, ctx->eq[0]);
+    } else {
+        hipLaunchKernelGGL(k_orient_scan, dim3(n_jobs), dim3(1024), 0, ctx->stream, R);
+        hipLaunchKernelGGL(k_orient_rows, dim3((unsigned)blk), dim3(256), 0, ctx->stream, R, fan, lim_main, ctx->eq[0]);
+    }
     MAD_HIP(hipGetLastError());
     return MAD_OK;
 }

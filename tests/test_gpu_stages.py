@@ -485,6 +485,31 @@ def test_anchors_with_identical_coordinates_count_once(lib, fields):
     np.testing.assert_allclose(top, res[order], rtol=1e-10, atol=1e-10)
 
 
+def test_counts_of_a_pruned_match_are_refused_once_a_set_is_gone(lib, fields):
+    """mad_match_topk prunes its pose search, so mad_match_fetch(counts) / mad_match_results have to search the other pairs
+    afterwards -- through the two sets.  A set destroyed or rebuilt in between must be refused, not dereferenced."""
+    from mad_amd._lib import MadBackendError
+    f = fields[1]
+    sets = []
+    for seed, n in ((51, 48), (52, 20)):
+        coords = synth.interior_anchors(f["shape"], n, 10, seed)
+        sets.append((coords, lib.set_build([-1, f["slot"]], coords, np.ones(n, np.int32), coords.astype(np.float64) * 1.5 + 0.2, np.arange(n))))
+    (lo_c, lo), (hi_c, hi) = sets
+    top, idx, st = lib.match_topk(hi, lo, 0.3, 4.0, 5)
+    assert st["n_pairs"] > 50 and lib.last_pose_selected() < st["n_pairs"]      # the search was pruned
+    full = lib.match_fetch(st["n_pairs"])[3]                                    # completes the counts: fine, both sets alive
+    assert len(full) == st["n_pairs"]
+    lib.match_topk(hi, lo, 0.3, 4.0, 5)
+    lib.set_build([-1, f["slot"]], hi_c, np.ones(len(hi_c), np.int32), hi_c.astype(np.float64) * 1.5 + 0.2, np.arange(len(hi_c)), into=hi)
+    with pytest.raises(MadBackendError, match="rebuilt"):
+        lib.match_fetch(st["n_pairs"])
+    lib.match_topk(hi, lo, 0.3, 4.0, 5)
+    hi.close()
+    with pytest.raises(MadBackendError, match="destroyed"):
+        lib.match_fetch(st["n_pairs"])
+    lo.close()
+
+
 def test_lanes_overlap_and_serial_give_identical_results(lib):
     """Builds and matches of several structures spread over the lanes (streams); serialising the lanes with
     mad_set_overlap(0) must not change a bit of the output."""
