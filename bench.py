@@ -44,14 +44,25 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-WORKLOADS = {
-    # name: map size N, voxel spacing, resolution, subunits, first seed, atoms per subunit, globule radius, lattice
-    "c3": dict(N=256, vs=1.2, res=7.0, n_sub=4, seed0=20, n_atoms=26000, radius=46.0, grid=(2, 2, 1), desc="C3: 256^3 map, 4 subunits, EQSP-112/16"),
-    "c4": dict(N=256, vs=1.2, res=7.0, n_sub=8, seed0=30, n_atoms=26000, radius=46.0, grid=(2, 2, 2), desc="C4: 256^3 map, 8 subunits (seeds 30-37), EQSP-112/16"),
-    "c2": dict(N=128, vs=1.5, res=8.0, n_sub=4, seed0=20, n_atoms=14000, radius=34.0, grid=(2, 2, 1), desc="C2: 128^3 tetramer map"),
-    "c5": dict(N=512, vs=1.0, res=6.0, n_sub=12, seed0=20, n_atoms=26000, radius=46.0, grid=(3, 2, 2), desc="C5: 512^3 map, 12 subunits, EQSP-112/16"),
-    "small": dict(N=64, vs=2.0, res=10.0, n_sub=2, seed0=20, n_atoms=1500, radius=16.0, grid=(2, 1, 1), desc="C1: 64^3 dimer map"),
-}
+def load_workloads():
+    """The workloads of SURVEY.md 8(d), frozen in bench/configs/*.json (seeds, atom counts, radii, lattice, noise): one file per
+    BASELINE.json config, plus c3clean (C3 without its noise: the workload rounds 1-2 were measured on)."""
+    out = {}
+    d = os.path.join(ROOT, "bench", "configs")
+    for fn in sorted(os.listdir(d)):
+        if fn.endswith(".json"):
+            with open(os.path.join(d, fn)) as fh:
+                c = json.load(fh)
+            c["n_sub"] = len(c["seeds"])                 # distinct subunits (sets matched against the map)
+            c["n_placed"] = c["n_sub"] * c["copies"]     # rigid copies in the map
+            c["grid"] = tuple(c["lattice"])
+            c["file"] = "bench/configs/" + fn
+            out[fn[:-5]] = c
+    out["small"] = out["c1"]
+    return out
+
+
+WORKLOADS = load_workloads()
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 I8_PEAK_TOPS = 5000.0      # dense int8 MFMA = 2x bf16 (~2.5 PF)
 ORIENT_BYTES = 58956       # SURVEY.md 8(d): 17^3 x 3 x f32 read per anchor
@@ -83,7 +94,7 @@ class Structure(object):
     """Device-resident fields + anchors of one structure: density simulation (a14-a15), MapSpace and Detector
      all through the library; nothing of it is inside the timed region."""
 
-    def __init__(self, lib, atoms, mass, res, vs, N=None, tag="sub"):
+    def __init__(self, lib, atoms, mass, res, vs, N=None, tag="sub", noise=0.0):
         from mad_amd.Detector import Detector
         from mad_amd.MapSpace import MapSpace
         grid, x0, y0, z0 = lib.structure_to_density(atoms, mass, res, vs)
@@ -95,6 +106,8 @@ class Structure(object):
             big[lo[0]:lo[0] + grid.shape[0], lo[1]:lo[1] + grid.shape[1], lo[2]:lo[2] + grid.shape[2]] = grid
             origin = origin - np.array(lo) * vs
             grid = big
+        if noise > 0.0:      # Gaussian noise sigma_n x max over the whole box, seeded
+            grid = (grid + np.random.default_rng(4321).normal(0.0, noise * float(grid.max()), grid.shape)).astype(np.float32)
         self.shape = grid.shape
         self.grid, self.origin, self.atoms, self.mass = grid, origin, atoms, mass
         ms = MapSpace(tag + ".pdb", resolution=res, voxelsp=vs)
@@ -130,23 +143,26 @@ class Structure(object):
 
 
 def build_inputs(lib, W, rank=0, world=1):
-    """-> (map, this rank's subunits, setup seconds).  The map (all n_sub subunits placed on a jittered lattice) is the same on
-    every rank; subunit s belongs to rank s % world (strong scaling: the workload does not grow with the ranks)."""
+    """-> (map, this rank's subunits, setup seconds).  The map (every subunit placed `copies` times on a jittered lattice, plus
+    the workload's Gaussian noise) is the same on every rank; subunit s belongs to rank s % world (strong scaling: the workload
+    does not grow with the ranks)."""
     from mad_amd import synth
     rng = np.random.default_rng(1234)
     subs, placed, placed_mass = [], [], []
     sp = 2.2 * W["radius"]
     cells = [(i, j, k) for i in range(W["grid"][0]) for j in range(W["grid"][1]) for k in range(W["grid"][2])]
+    assert len(cells) >= W["n_placed"], "lattice of %d cells for %d copies" % (len(cells), W["n_placed"])
     centre = (np.array(W["grid"]) - 1) * sp / 2
-    for s in range(W["n_sub"]):
-        atoms, names, elems = synth.random_globule(W["n_atoms"], W["radius"], seed=W["seed0"] + s)
-        placed.append(synth.place(atoms, synth.random_rotation(rng), np.array(cells[s]) * sp - centre + rng.normal(scale=2.0, size=3)))
-        placed_mass.append(synth.masses(elems))
+    for s, seed in enumerate(W["seeds"]):
+        atoms, names, elems = synth.random_globule(W["n_atoms"], W["radius"], seed=seed)
+        for c in range(W["copies"]):
+            placed.append(synth.place(atoms, synth.random_rotation(rng), np.array(cells[s * W["copies"] + c]) * sp - centre + rng.normal(scale=2.0, size=3)))
+            placed_mass.append(synth.masses(elems))
         if s % world == rank:
             subs.append((s, atoms, synth.masses(elems)))
     mass_all = np.concatenate(placed_mass)
     t0 = time.time()
-    the_map = Structure(lib, np.concatenate(placed), mass_all, W["res"], W["vs"], N=W["N"], tag="map")
+    the_map = Structure(lib, np.concatenate(placed), mass_all, W["res"], W["vs"], N=W["N"], tag="map", noise=W.get("noise", 0.0))
     sub_structs = []
     for s, a, m in subs:
         st = Structure(lib, a, m, W["res"], W["vs"])
@@ -459,10 +475,13 @@ def main():
     lib.set_eqsp(0, e112.sphere_eqsp, dom, adj)
     lib.set_eqsp(1, e16.sphere_eqsp)
 
+    # device peaks measured in this run (untimed): a streaming copy and the int8 MFMA issue rate
+    peak_copy_gbs, peak_i8_tops = lib.probe_peaks() if rank == 0 else (None, None)
+
     emu = args.emulate_rank_of if (world == 1 and args.emulate_rank_of > 1) else 0
     wl = args.workload if args.workload != "auto" else ("c4" if (world > 1 or emu) else "c3")
     W = WORKLOADS[wl]
-    cc, dist_thr, k = 0.6, 4.0, 60
+    cc, dist_thr, k = W["cc_threshold"], W["anchor_dist"], W["n_samples"] * W["copies"]      # k = n_samples x n_copies (MaD.py:502)
     the_map, subs, t_setup = build_inputs(lib, W, 0 if emu else rank, emu if emu else world)
     if world > 1:      # one anchor list for everybody: the shares of the map build are indices into it
         for arr in (the_map.coords, the_map.octave, the_map.subv, the_map.index):
@@ -566,6 +585,14 @@ def main():
     dt_serial = time.perf_counter() - t1
     lib.timing_enable(False)
     lib.set_overlap(not args.serial)
+
+    # how much of the pair list the pruned pose search had to search exactly, per subunit (untimed; one match at a time)
+    pose_sel = []
+    if rank == 0 and not sharded:
+        lo_x, his_x = enqueue_builds(lib, the_map, subs, sets)
+        for hi_x in his_x:
+            _, _, st_x = lib.match_topk(hi_x, lo_x, cc, dist_thr, k)
+            pose_sel.append((int(lib.last_pose_selected()), int(st_x["n_pairs"])))
 
     red_dev = "cuda" if (world == 1 or backend == "nccl") else "cpu"
     t_all = torch.tensor([dt], dtype=torch.float64, device=red_dev)
@@ -675,6 +702,10 @@ def main():
             roofs[gname] = dict(kernel=kname, bound=bound, achieved=work / (ms * 1e-3) / scale if ms > 0 else 0.0, peak=peak, unit=unit,
                                 traffic=traffic.get(gname), avg_launch_ms=ms, ms_per_step=groups[gname]["ms_total"] / n_serial)
             roofs[gname]["frac"] = roofs[gname]["achieved"] / peak
+            # against the peak MEASURED in this run on this device: a streaming copy for the HBM-bound kernels, the bare int8 MFMA loop for the GEMM
+            pm = peak_copy_gbs if bound == "hbm" else peak_i8_tops
+            roofs[gname]["peak_measured"] = pm
+            roofs[gname]["frac_of_measured"] = roofs[gname]["achieved"] / pm if pm else None
             if gname in valu_util:
                 roofs[gname]["valu_issue_share"] = round(valu_util[gname], 3)      # from the SQ counters of the profiled run (profiles/)
         # `roofline` = the HBM stage SURVEY.md 8(d) names as the binding roofline of the headline metric (the texel
@@ -693,6 +724,11 @@ def main():
         b_hbm = ORIENT_BYTES * (n_anchor_lo + anchors_hi) + DESCRIBE_BYTES * (rows_lo_built + rows_hi)
         roof["hbm_stage"] = dict(kernels="k_orient + k_describe", algorithmic_bytes_per_step=b_hbm, seconds_per_step=t_hbm,
                                  achieved=b_hbm / t_hbm / 1e9 if t_hbm > 0 else 0.0, unit="GB/s", frac=(b_hbm / t_hbm / 1e9) / HBM_PEAK_GBS if t_hbm > 0 else 0.0)
+        roof["hbm_stage"]["peak_measured"] = peak_copy_gbs
+        roof["hbm_stage"]["frac_of_measured"] = roof["hbm_stage"]["achieved"] / peak_copy_gbs if peak_copy_gbs else None
+        roof["peaks"] = dict(hbm_spec_GBs=HBM_PEAK_GBS, hbm_copy_measured_GBs=peak_copy_gbs, i8_mfma_spec_TOPs=I8_PEAK_TOPS, i8_mfma_measured_TOPs=peak_i8_tops,
+                             how="mad_probe_peaks, untimed, same process and device: a 1 GiB -> 1 GiB streaming copy kernel (read + write bytes) and "
+                                 "v_mfma_i32_16x16x64_i8 from registers, 8 independent accumulators per wave, 4 waves per SIMD; spec figures from MI355X_MICROARCH.md")
         roof["largest_share_of_device_time"] = max(groups, key=lambda g: groups[g]["ms_total"])
         roof["note"] = ("HBM traffic (PMC) is below the algorithmic bytes: anchors are worked on in Morton order, so neighbouring rows meet in "
                         "the XCD's L2 (88 % hits), no wasted re-reads; what the kernel waits for is not HBM but the scattered 16-byte texel "
@@ -731,10 +767,12 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "i8 (correlation, exact int32 accumulate) / f64 (binning, pose scoring)",
             "data": "synthetic",
-            "config": {"workload": W["desc"], "map": "%d^3 @ %.1f A/voxel, %.0f A" % (W["N"], W["vs"], W["res"]),
+            "config": {"workload": W["desc"], "workload_file": W["file"], "noise_sigma_of_max": W.get("noise", 0.0), "copies_per_subunit": W["copies"], "map": "%d^3 @ %.1f A/voxel, %.0f A" % (W["N"], W["vs"], W["res"]),
                        "subunits": W["n_sub"], "subunits_this_rank": len(subs), "map_anchors": len(the_map.coords), "map_rows": rows_lo,
                        "map_anchors_built_by_this_rank": n_anchor_lo, "map_rows_built_by_this_rank": rows_lo_built,
-                       "subunit_anchors_this_rank": anchors_hi, "subunit_rows_this_rank": rows_hi, "pairs_over_cc_this_rank": pairs,
+                       "subunit_anchors_this_rank": anchors_hi, "subunit_rows_this_rank": rows_hi, "pairs_over_cc_this_rank": pairs, "pairs_over_cc_per_correlation": pairs / corr if corr else None,
+                       "pose_selected_frac": (sum(a for a, _ in pose_sel) / max(sum(b for _, b in pose_sel), 1)) if pose_sel else None,
+                       "pose_selected_per_subunit": pose_sel or None,
                        "cc_threshold": cc, "top_k": k, "correlations_per_step": corr_total, "correlations_per_step_this_rank": corr,
                        "parallelism": ("1 process per GPU over RCCL: map anchors dealt round-robin (orient + describe), all-gather of the rows; "
                                        "subunits dealt round-robin (correlate + pose + top-k), all-gather of the top-k poses") if world > 1 else "single GPU",

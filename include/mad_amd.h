@@ -74,6 +74,14 @@ int mad_timing_get(mad_ctx *ctx, const char *what, double *total_ms, int64_t *la
 double mad_last_ms(mad_ctx *ctx, const char *what);
 
 /*
+ * Measurement aid (bench.py, SURVEY.md 8(d) "confirm with a device copy microbenchmark in the same run"): the rate of a
+ * streaming device copy of 1 GiB (read + write bytes per second, GB/s) and the issue rate of v_mfma_i32_16x16x64_i8 with
+ * register operands (the instruction of the correlation kernel, int8 TOP/s), measured on this ctx's device now.  Either
+ * pointer may be NULL.  No reference counterpart.
+ */
+int mad_probe_peaks(mad_ctx *ctx, double *copy_gbs, double *i8_tops);
+
+/*
  * EQSP zone tables.  which = 0: orientation sphere (Orientator.py:16, 112 zones);
  * which = 1: descriptor sphere (Descriptor.py:17, 16 zones).  bounds = Z x
  * [theta_min, phi_min, theta_max, phi_max] (eqsp.py:16-20).  For which = 0 also

@@ -19,7 +19,7 @@ ERRORS = {-22: "EINVAL", -12: "ENOMEM", -28: "ENOSPC", -19: "ENODEV", -33: "EDOM
 # every symbol include/mad_amd.h declares (tests check the library exports all of them)
 SYMBOLS = [
     "mad_init", "mad_destroy", "mad_last_error", "mad_synchronize", "mad_stream", "mad_set_overlap",
-    "mad_timing_enable", "mad_timing_reset", "mad_timing_get", "mad_last_ms",
+    "mad_timing_enable", "mad_timing_reset", "mad_timing_get", "mad_last_ms", "mad_probe_peaks",
     "mad_set_eqsp", "mad_upload_field", "mad_upload_field_device", "mad_free_field",
     "mad_set_orient_window", "mad_orient", "mad_describe", "mad_describe_sized", "mad_correlate", "mad_pose_score", "mad_topk",
     "mad_set_create", "mad_set_destroy", "mad_set_build", "mad_set_build_many", "mad_set_load", "mad_set_size", "mad_set_download",
@@ -341,6 +341,12 @@ class Lib(object):
     def set_option(self, name, value):
         """Tuning values that change speed, never results (`mad_set_option`)."""
         self._chk(self.dll.mad_set_option(self.ctx, name.encode(), C.c_double(float(value))))
+
+    def probe_peaks(self):
+        """(device copy GB/s, int8 MFMA TOP/s) measured now on this device (mad_probe_peaks)."""
+        c, m = C.c_double(0.0), C.c_double(0.0)
+        self._chk(self.dll.mad_probe_peaks(self.ctx, C.byref(c), C.byref(m)))
+        return c.value, m.value
 
     def timing_get(self, what):
         t = C.c_double(0)

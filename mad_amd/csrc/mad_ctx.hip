@@ -425,6 +425,97 @@ void mad_copy_words(mad_ctx *ctx, void *dst, const void *src, size_t bytes) {
 }
 
 // ---------------------------------------------------------------------------
+// device peaks measured on the spot (bench.py reports roofline fractions against these as well as against the spec figures)
+// ---------------------------------------------------------------------------
+
+// streaming copy, 16 bytes per lane, grid-stride: the HBM rate a kernel of this library can hope for (read + write counted)
+__global__ __launch_bounds__(256) void k_probe_copy(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n16) {
+    const size_t T = (size_t)gridDim.x * blockDim.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * T < n16; i += 4 * T) {      // four requests in flight per lane
+        const uint4 a = src[i], b = src[i + T], c = src[i + 2 * T], d = src[i + 3 * T];
+        dst[i] = a; dst[i + T] = b; dst[i + 2 * T] = c; dst[i + 3 * T] = d;
+    }
+    for (; i < n16; i += T) dst[i] = src[i];
+}
+// the same copy with one 16-byte element per thread (the form MI355X_MICROARCH.md quotes 6.29 TB/s for); the probe reports the better
+__global__ __launch_bounds__(256) void k_probe_copy1(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n16) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n16) dst[i] = src[i];
+}
+
+typedef int probe_v4i __attribute__((ext_vector_type(4)));
+// dense int8 MFMA issue rate: every wave keeps eight independent 16x16 accumulators busy with v_mfma_i32_16x16x64_i8 (the
+// instruction of k_corr_gemm2), operands in registers, nothing else in the loop
+__global__ __launch_bounds__(256) void k_probe_mfma_i8(int iters, int *__restrict__ sink) {
+    probe_v4i a = {(int)threadIdx.x, 1, 2, 3}, b = {4, 5, 6, (int)blockIdx.x};
+    probe_v4i c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0, c4 = c0, c5 = c0, c6 = c0, c7 = c0;
+    // (inline assembly: left to itself the compiler rotates the accumulators through v_accvgpr moves, 40 of them per trip)
+#define MAD_PROBE_MFMA(c) asm volatile("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b))
+    for (int it = 0; it < iters; it++) {
+        MAD_PROBE_MFMA(c0); MAD_PROBE_MFMA(c1); MAD_PROBE_MFMA(c2); MAD_PROBE_MFMA(c3);
+        MAD_PROBE_MFMA(c4); MAD_PROBE_MFMA(c5); MAD_PROBE_MFMA(c6); MAD_PROBE_MFMA(c7);
+    }
+#undef MAD_PROBE_MFMA
+    const probe_v4i t = c0 + c1 + c2 + c3 + c4 + c5 + c6 + c7;
+    const int v = t[0] + t[1] + t[2] + t[3];
+    if (v == 0x7fffffff) sink[0] = v;      // keeps the loop alive
+}
+
+extern "C" int mad_probe_peaks(mad_ctx *ctx, double *copy_gbs, double *i8_tops) {
+    if (!ctx) return MAD_EINVAL;
+    mad_use_lane(ctx, 0);
+    MAD_TRY(mad_synchronize(ctx));
+    hipEvent_t e0, e1;
+    MAD_HIP(hipEventCreate(&e0));
+    MAD_HIP(hipEventCreate(&e1));
+    float ms = 0.f;
+    if (copy_gbs) {
+        const size_t bytes = (size_t)1 << 30;      // 1 GiB in, 1 GiB out: far beyond the 256 MB of Infinity Cache
+        void *src = nullptr, *dst = nullptr;
+        if (hipMalloc(&src, bytes) != hipSuccess || hipMalloc(&dst, bytes) != hipSuccess) {
+            if (src) (void)hipFree(src);
+            (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+            return mad_fail(ctx, MAD_ENOMEM, "mad_probe_peaks: 2 GiB of probe buffers");
+        }
+        MAD_HIP(hipMemsetAsync(src, 1, bytes, ctx->stream));
+        double best = 0.0;
+        for (int rep = 0; rep < 7; rep++) {      // the first pass warms the page tables; then three of each form
+            MAD_HIP(hipEventRecord(e0, ctx->stream));
+            if (rep & 1) hipLaunchKernelGGL(k_probe_copy, dim3(ctx->n_cu * 16), dim3(256), 0, ctx->stream, (const uint4 *)src, (uint4 *)dst, bytes / 16);
+            else hipLaunchKernelGGL(k_probe_copy1, dim3((unsigned)(bytes / 16 / 256)), dim3(256), 0, ctx->stream, (const uint4 *)src, (uint4 *)dst, bytes / 16);
+            MAD_HIP(hipEventRecord(e1, ctx->stream));
+            MAD_HIP(hipEventSynchronize(e1));
+            MAD_HIP(hipEventElapsedTime(&ms, e0, e1));
+            if (rep > 0) best = std::max(best, 2.0 * (double)bytes / (ms * 1e-3) / 1e9);
+        }
+        *copy_gbs = best;
+        (void)hipFree(src);
+        (void)hipFree(dst);
+    }
+    if (i8_tops) {
+        int *sink = nullptr;
+        MAD_HIP(hipMalloc((void **)&sink, 64));
+        const int iters = 20000, wgs = ctx->n_cu * 4;      // 4 workgroups x 4 waves per CU: four waves per SIMD
+        double best = 0.0;
+        for (int rep = 0; rep < 3; rep++) {
+            MAD_HIP(hipEventRecord(e0, ctx->stream));
+            hipLaunchKernelGGL(k_probe_mfma_i8, dim3(wgs), dim3(256), 0, ctx->stream, iters, sink);
+            MAD_HIP(hipEventRecord(e1, ctx->stream));
+            MAD_HIP(hipEventSynchronize(e1));
+            MAD_HIP(hipEventElapsedTime(&ms, e0, e1));
+            const double ops = (double)wgs * 4 * (double)iters * 8 * (2.0 * 16 * 16 * 64);
+            if (rep > 0) best = std::max(best, ops / (ms * 1e-3) / 1e12);
+        }
+        *i8_tops = best;
+        (void)hipFree(sink);
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return MAD_OK;
+}
+
+// ---------------------------------------------------------------------------
 // exclusive prefix sum (three launches: chunk sums, scan of sums, apply)
 // ---------------------------------------------------------------------------
 

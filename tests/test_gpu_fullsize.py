@@ -101,7 +101,7 @@ def test_full_size_properties(lib, workload):
             st_.ms.release_device()
 
 
-@pytest.mark.parametrize("workload", ["c2", "c3", "c4", "c5"])
+@pytest.mark.parametrize("workload", ["c2", "c3", "c3clean", "c4", "c5"])
 def test_whole_workload_equals_the_oracle(lib, workload):
     """The benchmark's own workload (c3: 256^3 map, 4 subunits, every anchor of both octaves) through the CPU oracle on
     the host threads and through the device path: rows, descriptors, pair lists, match counts and top-k must be
