@@ -142,10 +142,10 @@ class Structure(object):
         return cache[octave]
 
 
-def build_inputs(lib, W, rank=0, world=1):
+def build_inputs(lib, W, rank=0, world=1, items=None):
     """-> (map, this rank's subunits, setup seconds).  The map (every subunit placed `copies` times on a jittered lattice, plus
     the workload's Gaussian noise) is the same on every rank; subunit s belongs to rank s % world (strong scaling: the workload
-    does not grow with the ranks)."""
+    does not grow with the ranks), or -- `items` -- the rank takes exactly the listed subunits, in that order (dist.plan_partition)."""
     from mad_amd import synth
     rng = np.random.default_rng(1234)
     subs, placed, placed_mass = [], [], []
@@ -158,8 +158,10 @@ def build_inputs(lib, W, rank=0, world=1):
         for c in range(W["copies"]):
             placed.append(synth.place(atoms, synth.random_rotation(rng), np.array(cells[s * W["copies"] + c]) * sp - centre + rng.normal(scale=2.0, size=3)))
             placed_mass.append(synth.masses(elems))
-        if s % world == rank:
+        if (s % world == rank) if items is None else (s in items):
             subs.append((s, atoms, synth.masses(elems)))
+    if items is not None:
+        subs.sort(key=lambda t: list(items).index(t[0]))
     mass_all = np.concatenate(placed_mass)
     t0 = time.time()
     the_map = Structure(lib, np.concatenate(placed), mass_all, W["res"], W["vs"], N=W["N"], tag="map", noise=W.get("noise", 0.0))
@@ -219,17 +221,30 @@ def enqueue_builds(lib, the_map, subs, sets):
     return lo, his
 
 
+PM = {"pm": None}      # dist.PartitionedMatch when some subunits' pair grids are split over groups of ranks (n_sub % ranks != 0)
+
+
+def begin_matches(lib, his, lo, cc, dist, k):
+    if PM["pm"] is not None:
+        return PM["pm"].begin(lib, his, lo, cc, dist, k)
+    return lib.match_topk_many_begin(his, lo, cc, dist, k)
+
+
 def collect(lib, handle, his):
     t0 = time.perf_counter()
-    corr, tops, stats = 0, [], []
-    for top, idx, st in lib.match_topk_many_finish(handle):
-        corr += st["n_corr"]
-        tops.append(top)
-        stats.append(st)
+    if PM["pm"] is not None:
+        corr, tops, stats = PM["pm"].finish(lib, handle)
+    else:
+        corr, tops, stats = 0, [], []
+        for top, idx, st in lib.match_topk_many_finish(handle):
+            corr += st["n_corr"]
+            tops.append(top)
+            stats.append(st)
     HOST_T["match_wait"] = HOST_T.get("match_wait", 0.0) + time.perf_counter() - t0
     for hi, st in zip(his, stats):
-        st["n_hi"], _ = hi.size()
-        st["n_lo"] = st["n_corr"] // max(st["n_hi"], 1)
+        if "n_hi" not in st:
+            st["n_hi"], _ = hi.size()
+            st["n_lo"] = st["n_corr"] // max(st["n_hi"], 1)
     return corr, tops, stats
 
 
@@ -237,7 +252,7 @@ def hot_path_step(lib, the_map, subs, cc, dist, k, sets):
     """One step, start to finish: returns (correlations, [top-k result rows per subunit], stats).  Everything is enqueued
     asynchronously; the only host round trip is the result read-back that ends each match."""
     lo, his = enqueue_builds(lib, the_map, subs, sets)
-    return collect(lib, lib.match_topk_many_begin(his, lo, cc, dist, k), his)
+    return collect(lib, begin_matches(lib, his, lo, cc, dist, k), his)
 
 
 def run_steps(lib, the_map, subs, cc, dist, k, set_groups, n_steps, after_step=None):
@@ -261,7 +276,7 @@ def run_steps(lib, the_map, subs, cc, dist, k, set_groups, n_steps, after_step=N
     for i in range(n_steps):
         lo, his = built
         t0 = time.perf_counter()
-        open_steps.append((lib.match_topk_many_begin(his, lo, cc, dist, k), his))
+        open_steps.append((begin_matches(lib, his, lo, cc, dist, k), his))
         HOST_T["match_enqueue"] = HOST_T.get("match_enqueue", 0.0) + time.perf_counter() - t0
         if i + 1 < n_steps:      # its group was last read by step i + 1 - depth, collected by now
             built = enqueue_builds(lib, the_map, subs, set_groups[(i + 1) % depth])
@@ -482,7 +497,16 @@ def main():
     wl = args.workload if args.workload != "auto" else ("c4" if (world > 1 or emu) else "c3")
     W = WORKLOADS[wl]
     cc, dist_thr, k = W["cc_threshold"], W["anchor_dist"], W["n_samples"] * W["copies"]      # k = n_samples x n_copies (MaD.py:502)
-    the_map, subs, t_setup = build_inputs(lib, W, 0 if emu else rank, emu if emu else world)
+    # Which pair grids this rank works on: whole subunits round-robin, and -- when the subunits do not divide by the ranks (C5: 12 on
+    # 8) -- blocks of map rows of the leftover ones inside groups of ranks (mad_amd/dist.py: plan_partition, PartitionedMatch)
+    n_ranks_part = emu if emu else world
+    pm = None
+    if n_ranks_part > 1 and W["n_sub"] % n_ranks_part != 0 and os.environ.get("MAD_NO_PARTITION", "0") != "1":
+        ident = (lambda f: np.asarray(f, dtype=np.uint8).copy(), lambda parts: [parts])      # a rehearsed rank has nobody to exchange with
+        pm = mdist.PartitionedMatch(W["n_sub"], 0 if emu else rank, n_ranks_part, make_group=None if emu else dist.new_group,
+                                    stand_ins=ident if emu else None)
+        PM["pm"] = pm
+    the_map, subs, t_setup = build_inputs(lib, W, 0 if emu else rank, emu if emu else world, items=pm.items if pm else None)
     if world > 1:      # one anchor list for everybody: the shares of the map build are indices into it
         for arr in (the_map.coords, the_map.octave, the_map.subv, the_map.index):
             t = torch.from_numpy(arr).to("cuda" if backend == "nccl" else "cpu")
@@ -603,6 +627,11 @@ def main():
         dist.all_reduce(c_all, op=dist.ReduceOp.SUM)
         dist.all_reduce(lat_all, op=dist.ReduceOp.MAX)
     t_max, corr_total = float(t_all.item()), float(c_all.item())
+    corr_by_rank = [float(corr)]
+    if world > 1:
+        each = [torch.zeros(1, dtype=torch.float64, device=red_dev) for _ in range(world)]
+        dist.all_gather(each, torch.tensor([float(corr)], dtype=torch.float64, device=red_dev))
+        corr_by_rank = [float(e.item()) for e in each]
 
     # N > 1: (a) the map set assembled from the ranks' shares must be the set one GPU builds from the whole anchor list, bit
     # for bit; (b) rank 0 then runs the WHOLE workload alone (all subunits, unsharded map build), outside the timed region:
@@ -618,6 +647,7 @@ def main():
         shard_check = bool(all(np.array_equal(a[f], b[f]) for f in ("anchor", "main", "sec", "R", "dsc")))
         ref_set.close()
         _, all_subs, _ = build_inputs(lib, W, 0, 1)
+        PM["pm"] = None      # (the whole workload on this one GPU: nothing is partitioned)
         was_batched = BATCHED["on"]      # the whole workload on one GPU in ITS best form: one launch per structure, three steps in flight
         BATCHED["on"] = False
         lib.set_batching(False)
@@ -634,8 +664,8 @@ def main():
         same = None
         if not emu:
             same = bool(len(gathered) == len(tops1) and all(np.array_equal(g, t) for g, t in zip(gathered, tops1)))
-        else:
-            same = bool(all(np.array_equal(tops1[s.item], t) for s, t in zip(subs, tops)))
+        else:      # (a rehearsed rank's blocks of leftover subunits have nobody to merge with: only its whole subunits are compared)
+            same = bool(all(np.array_equal(tops1[s.item], t) for s, t in list(zip(subs, tops))[:pm.n_whole if pm else len(subs)]))
         one_gpu = dict(value=corr1 * args.steps / dt1, unit="correlations/s", ms_per_step=1e3 * dt1 / args.steps,
                        topk_identical_to_sharded_run=same,
                        note="rank 0 running the whole workload alone after the timed region (same build, same box): the N = 1 point of this strong-scaling run")
@@ -703,9 +733,9 @@ def main():
                                 traffic=traffic.get(gname), avg_launch_ms=ms, ms_per_step=groups[gname]["ms_total"] / n_serial)
             roofs[gname]["frac"] = roofs[gname]["achieved"] / peak
             # against the peak MEASURED in this run on this device: a streaming copy for the HBM-bound kernels, the bare int8 MFMA loop for the GEMM
-            pm = peak_copy_gbs if bound == "hbm" else peak_i8_tops
-            roofs[gname]["peak_measured"] = pm
-            roofs[gname]["frac_of_measured"] = roofs[gname]["achieved"] / pm if pm else None
+            pk = peak_copy_gbs if bound == "hbm" else peak_i8_tops
+            roofs[gname]["peak_measured"] = pk
+            roofs[gname]["frac_of_measured"] = roofs[gname]["achieved"] / pk if pk else None
             if gname in valu_util:
                 roofs[gname]["valu_issue_share"] = round(valu_util[gname], 3)      # from the SQ counters of the profiled run (profiles/)
         # `roofline` = the HBM stage SURVEY.md 8(d) names as the binding roofline of the headline metric (the texel
@@ -776,6 +806,11 @@ def main():
                        "cc_threshold": cc, "top_k": k, "correlations_per_step": corr_total, "correlations_per_step_this_rank": corr,
                        "parallelism": ("1 process per GPU over RCCL: map anchors dealt round-robin (orient + describe), all-gather of the rows; "
                                        "subunits dealt round-robin (correlate + pose + top-k), all-gather of the top-k poses") if world > 1 else "single GPU",
+                       "partition": None if pm is None else dict(units_of_this_rank=[list(u) for u in pm.mine], groups=pm.groups, load_in_subunits=pm.load(),
+                                                                  note="whole subunits round-robin; each leftover subunit's pair grid split by blocks of map rows "
+                                                                       "inside a group of ranks (sharded_match: OR all-reduce of the cloud flags, all-gather + merge of the per-block top-k)"),
+                       "correlations_per_step_by_rank": corr_by_rank,
+                       "max_over_mean_rank_correlations": (max(corr_by_rank) / (sum(corr_by_rank) / len(corr_by_rank))) if sum(corr_by_rank) > 0 else None,
                        "pipelining": "%d steps in flight: the builds (and, with 3, the matches) of the next step are enqueued before the results of a step are awaited; every step does the full work" % args.in_flight,
                        "launches": ("batched: one launch per stage for all structures of a step, one GEMM grid for all its matches" if BATCHED["on"]
                                     else "one mad_set_build per structure and one GEMM per match, each on its own lane (batched alternative: --batched)"),

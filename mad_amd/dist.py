@@ -52,21 +52,26 @@ class TopkExchange(object):
     non-blocking copies on a side stream, so neither call blocks the host on anything but the collective itself; the
     staging sets are reused round-robin (at most three exchanges are ever in flight)."""
 
-    _pool = {}      # (bytes of one payload, world, device) -> [next set, [staging sets]]
+    _pool = {}      # (bytes of one payload, world, device) -> [staging sets]; a set is busy from the constructor to finish()
 
     @classmethod
     def _staging(cls, n, world, dev):
+        """A staging set that no unfinished exchange is using: the first idle one of the pool, or a new one.  (Round 2 handed the
+        sets out round-robin from a cursor that did not follow the appends: with three exchanges in flight the fourth took the
+        set of the second.)"""
         import torch
         key = (n, world, str(dev))
-        slot = cls._pool.setdefault(key, [0, []])
-        if len(slot[1]) < 3:
-            pin = dev != "cpu"
-            slot[1].append(dict(h_in=torch.empty(n, dtype=torch.float64, pin_memory=pin), h_out=torch.empty(world * n, dtype=torch.float64, pin_memory=pin),
-                                d_in=torch.empty(n, dtype=torch.float64, device=dev), d_out=torch.empty(world * n, dtype=torch.float64, device=dev),
-                                stream=torch.cuda.Stream() if pin else None, done=torch.cuda.Event() if pin else None))
-            return slot[1][-1]
-        slot[0] = (slot[0] + 1) % 3
-        return slot[1][slot[0]]
+        sets = cls._pool.setdefault(key, [])
+        for st in sets:
+            if not st["busy"]:
+                st["busy"] = True
+                return st
+        pin = dev != "cpu"
+        st = dict(h_in=torch.empty(n, dtype=torch.float64, pin_memory=pin), h_out=torch.empty(world * n, dtype=torch.float64, pin_memory=pin),
+                  d_in=torch.empty(n, dtype=torch.float64, device=dev), d_out=torch.empty(world * n, dtype=torch.float64, device=dev),
+                  stream=torch.cuda.Stream() if pin else None, done=torch.cuda.Event() if pin else None, busy=True)
+        sets.append(st)
+        return st
 
     def __init__(self, tops, k, n_items_total, rank, world, group=None, device=None):
         import torch
@@ -113,6 +118,7 @@ class TopkExchange(object):
             blk = out[r, :per_rank * k * RESULT_COLS].reshape(per_rank, k, RESULT_COLS)
             nv = int(out[r, per_rank * k * RESULT_COLS + slot])
             res.append(blk[slot, :nv].copy())
+        self.st["busy"] = False      # everything has been copied out of the staging set
         return res
 
 
@@ -122,6 +128,110 @@ def all_gather_topk(tops, k, n_items_total, rank, world, group=None, device=None
     tops: list of (<=k, 23) arrays for shard_round_robin(range(n_items_total), rank, world), in that order.
     Returns a list of n_items_total arrays (item order), identical on every rank."""
     return TopkExchange(tops, k, n_items_total, rank, world, group, device).finish()
+
+
+def plan_partition(n_items, world):
+    """How the pair grids of n_items subunits are dealt to `world` ranks so that no rank carries much more than the mean
+    (SURVEY.md 8(e) stages B-C; BASELINE configs[4] is 12 subunits on 8 GPUs: whole subunits alone leave four ranks with two and
+    four with one, a ceiling of 6.0x).
+
+    Whole rounds are dealt round-robin as whole subunits (item i -> rank i % world, no data-path collective).  Each of the
+    `left = n_items % world` remaining subunits is split by blocks of map rows over a GROUP of ranks (`sharded_match`: an OR
+    all-reduce of the cloud flags and an all-gather of the per-shard top-k inside the group): group j = ranks j, j + left,
+    j + 2 left, ... (all ranks when such groups would be too unequal), so that rank `item % world` -- the rank the top-k exchange
+    expects the item from -- belongs to it and reports.
+
+    -> (units, groups): units[r] = [("whole", item) | ("block", item, part, parts, group index)], groups = [[ranks]]."""
+    whole = (n_items // world) * world
+    left = n_items - whole
+
+    def deal(group_of):
+        units = [[("whole", it) for it in range(r, whole, world)] for r in range(world)]
+        groups = []
+        for j in range(left):
+            ranks = group_of(j)
+            groups.append(ranks)
+            for part, r in enumerate(ranks):
+                units[r].append(("block", whole + j, part, len(ranks), j))
+        return units, groups
+
+    units, groups = deal(lambda j: list(range(j, world, left)))
+    load = partition_load(units)
+    if left and max(load) > 1.1 * sum(load) / world:      # groups of unequal size (13 on 8): every leftover subunit over ALL ranks instead
+        units, groups = deal(lambda j: list(range(world)))
+    return units, groups
+
+
+def partition_load(units, rows=None):
+    """Pair-grid share of every rank under `units` in subunit equivalents (rows: optional per-item weights)."""
+    load = []
+    for mine in units:
+        t = 0.0
+        for u in mine:
+            w = 1.0 if rows is None else float(rows[u[1]])
+            t += w if u[0] == "whole" else w / u[3]
+        load.append(t)
+    return load
+
+
+class PartitionedMatch(object):
+    """The matches of one step on one rank under `plan_partition`: the rank's whole subunits through the asynchronous bracket
+    (`match_topk_many_begin` / `_finish`, no collective), then its blocks of leftover subunits through `sharded_match` inside their
+    group.  `begin` enqueues the bracket and runs the sharded matches (they are synchronous: two small collectives each, while the
+    bracket's kernels run on the other lanes); `finish` collects the bracket.
+
+        pm = PartitionedMatch(n_items, rank, world, make_group=torch.distributed.new_group)      # every rank, same order
+        st = pm.begin(lib, his, lo, cc, dist, k)        # his: the rank's device sets in the order of pm.items
+        corr, tops, stats = pm.finish(lib, st)          # tops: what this rank reports to the top-k exchange, in slot order
+    """
+
+    def __init__(self, n_items, rank, world, make_group=None, stand_ins=None):
+        self.n_items, self.rank, self.world = n_items, rank, world
+        self.units, self.groups = plan_partition(n_items, world)
+        self.mine = self.units[rank]
+        self.items = [u[1] for u in self.mine]
+        self.n_whole = sum(1 for u in self.mine if u[0] == "whole")
+        self.blocks = [u for u in self.mine if u[0] == "block"]
+        self.pg = {}
+        # stand_ins = (reduce_flags, gather): single-process stand-ins for the group collectives (rehearsals of one rank)
+        self.stand_ins = stand_ins
+        if make_group is not None and world > 1:
+            for j, ranks in enumerate(self.groups):      # collective: every rank creates every group, in the same order
+                g = make_group(ranks) if len(ranks) < world else None      # None = the default group (all ranks)
+                if rank in ranks:
+                    self.pg[j] = g
+
+    def load(self):
+        return partition_load(self.units)
+
+    def begin(self, lib, his, lo, cc, dist_thr, k):
+        handle = lib.match_topk_many_begin(list(his[:self.n_whole]), lo, cc, dist_thr, k)
+        done = []
+        for hi, (_, item, part, parts, j) in zip(his[self.n_whole:], self.blocks):
+            kw = {}
+            if self.stand_ins is not None:
+                kw = dict(reduce_flags=self.stand_ins[0], gather=self.stand_ins[1])
+            rows, cnt, prank = sharded_match(lib, hi, lo, cc, dist_thr, k, part, parts, group=self.pg.get(j), **kw)
+            n_lo, _ = lo.size()
+            n_hi, _ = hi.size()
+            b, e = lo_row_block(n_lo, part, parts)
+            done.append(dict(item=item, part=part, parts=parts, rows=rows, n_corr=int(n_hi) * int(e - b), n_hi=int(n_hi), n_lo=int(e - b)))
+        return handle, done
+
+    def finish(self, lib, state):
+        """-> (correlations of this rank, the top-k rows it reports (whole items, then the leftover item it reports for), stats)"""
+        handle, done = state
+        corr, tops, stats = 0, [], []
+        for top, idx, st in lib.match_topk_many_finish(handle):
+            corr += st["n_corr"]
+            tops.append(top)
+            stats.append(st)
+        for d in done:
+            corr += d["n_corr"]
+            if owner_of(d["item"], self.world) == self.rank:      # rank item % world reports the merged rows (identical on every rank of the group)
+                tops.append(d["rows"])
+            stats.append(dict(n_pairs=0, l_hi=0, l_lo=0, n_corr=d["n_corr"], n_hi=d["n_hi"], n_lo=d["n_lo"], block=(d["part"], d["parts"])))
+        return corr, tops, stats
 
 
 def merge_topk(shard_rows, shard_counts, shard_pair_rank, k):

@@ -235,3 +235,83 @@ def test_sharded_set_build_two_ranks(tmp_path):
         seen.append(int(o["cap"]))
     per_rank = [sum(i % 4 for i in range(r, 23, world)) for r in range(world)]
     assert seen[0] == seen[1] == max(per_rank) + max(per_rank) // 8 + 64
+
+
+class _FakePartLib(object):
+    """Stand-in for Lib in the host logic of PartitionedMatch: every "device set" of a subunit carries a fixed pair list
+    with match counts (a _FakeShardLib); whole matches return its unsharded top-k, block matches go through the shard calls."""
+
+    def match_topk_many_begin(self, his, lo, cc, dist, k):
+        return [(h, k) for h in his]
+
+    def match_topk_many_finish(self, handle):
+        out = []
+        for h, k in handle:
+            f = h.fake
+            order = np.lexsort((f.rank_all, -f.cnt_all.astype(np.int64)))[:k]
+            out.append((f.rows_all[order], f.rank_all[order], dict(n_pairs=len(f.rank_all), l_hi=0, l_lo=0, n_corr=h.n * lo_rows(h))))
+        return out
+
+    def match_shard_pairs(self, hi, lo, b, e, cc):
+        self.cur = hi.fake
+        return hi.fake.match_shard_pairs(hi, lo, b, e, cc)
+
+    def match_shard_topk(self, hi, lo, uh, ul, dist, k):
+        return self.cur.match_shard_topk(hi, lo, uh, ul, dist, k)
+
+
+def lo_rows(h):
+    return h.fake.n_lo
+
+
+def _part_worker(rank, world, port, n_items, out_dir):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    k, n_lo = 15, 101
+    pm = mdist.PartitionedMatch(n_items, rank, world, make_group=dist.new_group)
+    his = []
+    for item in pm.items:
+        h = _FakeSet(30 + item)
+        h.fake = _FakeShardLib(30 + item, n_lo, seed=40 + item)
+        his.append(h)
+    lib = _FakePartLib()
+    corr, tops, stats = pm.finish(lib, pm.begin(lib, his, _FakeSet(n_lo), 0.6, 4.0, k))
+    got = mdist.all_gather_topk(tops, k, n_items, rank, world)
+    np.savez(os.path.join(out_dir, "part%d.npz" % rank), corr=corr, load=np.array(pm.load()), **{"item%d" % i: g for i, g in enumerate(got)})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_items", [(2, 3), (3, 4)])
+def test_partitioned_match_balances_the_leftover_subunits(tmp_path, world, n_items):
+    """Subunits that do not divide by the ranks (BASELINE configs[4]: 12 on 8): whole subunits round-robin, the leftover ones
+    split by blocks of map rows inside groups of ranks -- every rank carries the same share of the pair grids (within 10 %) and
+    every subunit's merged top-k is the unsharded one, on every rank."""
+    import torch.multiprocessing as mp
+    k, n_lo = 15, 101
+    mp.spawn(_part_worker, args=(world, _free_port(), n_items, str(tmp_path)), nprocs=world, join=True)
+    outs = [np.load(os.path.join(str(tmp_path), "part%d.npz" % r)) for r in range(world)]
+    for item in range(n_items):
+        ref = _FakeShardLib(30 + item, n_lo, seed=40 + item)
+        order = np.lexsort((ref.rank_all, -ref.cnt_all.astype(np.int64)))[:k]
+        for o in outs:
+            np.testing.assert_array_equal(o["item%d" % item], ref.rows_all[order])
+    load = outs[0]["load"]
+    assert max(load) <= 1.1 * load.mean()
+    corr = np.array([float(o["corr"]) for o in outs])
+    assert corr.sum() >= sum((30 + i) * n_lo for i in range(n_items)) - world * 40      # every pair grid covered once (block edges round)
+    assert corr.max() <= 1.1 * corr.mean()
+
+
+def test_plan_partition_shapes():
+    for n, w in ((12, 8), (11, 8), (9, 8), (13, 8), (3, 2), (8, 8), (4, 8), (1, 1), (5, 1)):
+        units, groups = mdist.plan_partition(n, w)
+        load = mdist.partition_load(units)
+        assert abs(sum(load) - n) < 1e-9 and max(load) <= 1.1 * (n / w) + 1e-9
+        for j, ranks in enumerate(groups):
+            item = (n // w) * w + j
+            assert item % w in ranks      # the rank the top-k exchange expects the item from belongs to the group (and reports)
+        seen = sorted(u[1] for mine in units for u in mine if u[0] == "whole")
+        assert seen == list(range((n // w) * w))
