@@ -295,29 +295,24 @@ def refine_ccc_leg(lib, the_map, subs, tops, W, n_cand=8):
     lib.timing_reset()
     lib.synchronize()
     t0 = time.perf_counter()
-    n_done, n_conv, best, steps_total = 0, 0, [], 0
-    # all candidates of all subunits are refined in ONE launch
-    starts, owner = [], []
+    n_done, n_conv, best, steps_total, vox = 0, 0, [], 0, 0
+    # ONE device call for all subunits (mad_dock_refine_score): the poses of the n_cand best rows of each go in (MaD.py:451: hi point,
+    # lo point, rotation), the atoms are placed, refined, turned into densities and scored on the device; the coordinates stay there
+    hi_p, lo_p, rot, owner = [], [], [], []
     for si, (sub, top) in enumerate(zip(subs, tops)):
         m = min(n_cand, len(top))
         if m == 0:
             continue
-        R = top[:m, 14:23].reshape(m, 3, 3)
-        starts.append(np.einsum("aj,cij->cai", sub.atoms, R) + (top[:m, 11:14] - np.einsum("cij,cj->ci", R, top[:m, 8:11]))[:, None, :])
+        hi_p.append(top[:m, 8:11]); lo_p.append(top[:m, 11:14])
+        rot.append(np.swapaxes(top[:m, 14:23].reshape(m, 3, 3), 1, 2).reshape(m, 9))      # rows hold x' = R (x - hi) + lo: rotate_atoms takes R^T
         owner += [si] * m
-    vox = 0
-    if starts and len({len(s_.atoms) for s_ in subs}) == 1:
-        refined, conv, last = lib.refine(np.concatenate(starts))
-        per_sub = {}
-        owner = np.array(owner)
-        for si, sub in enumerate(subs):      # density simulation + CCC of a subunit's candidates: one call, device-resident
-            sel = np.flatnonzero(owner == si)
-            if len(sel):
-                per_sub[si] = lib.density_ccc(refined[sel], sub.mass, W["res"])
-                vox += len(sel) * int(np.prod(sub.shape))
+        vox += m * int(np.prod(sub.shape))
+    if owner:
+        _, conv, last, ccc = lib.dock_refine_score([s_.atoms for s_ in subs], [s_.mass for s_ in subs], np.concatenate(hi_p), np.concatenate(lo_p),
+                                                   np.concatenate(rot), W["res"], want_coords=False, cand_struct=np.array(owner, np.int32))
         n_done, n_conv = len(owner), int(np.sum(conv))
         steps_total = int(np.sum(np.asarray(last) + 1))
-        best = [float(np.max(v)) for _, v in sorted(per_sub.items())]
+        best = [float(np.max(ccc[np.array(owner) == si])) for si in sorted(set(owner))]
     lib.synchronize()
     dt = time.perf_counter() - t0
     ms = {g: lib.timing_get(g)[0] for g in ("refine", "density", "ccc")}
@@ -329,13 +324,14 @@ def refine_ccc_leg(lib, the_map, subs, tops, W, n_cand=8):
                                note="latency-bound by construction: <= 500 dependent steps per candidate, the gathers of one step are L2-resident")
     if ms["ccc"] > 0 and vox:
         a = CCC_BYTES * vox / (ms["ccc"] * 1e-3) / 1e9
-        roofs["ccc"] = dict(kernel="k_ccc", bound="hbm", achieved=a, peak=HBM_PEAK_GBS, unit="GB/s", frac=a / HBM_PEAK_GBS, voxels=vox)
+        roofs["ccc"] = dict(kernel="k_ccc_b", bound="hbm", achieved=a, peak=HBM_PEAK_GBS, unit="GB/s", frac=a / HBM_PEAK_GBS, voxels=vox)
     if ms["density"] > 0 and vox:      # splat + three separable blur passes (float64 read + write each) + float32 conversion
         a = (3 * 16 + 12) * vox / (ms["density"] * 1e-3) / 1e9
-        roofs["density"] = dict(kernel="k_splat + k_blur_axis x3 + k_to_f32", bound="hbm", achieved=a, peak=HBM_PEAK_GBS, unit="GB/s", frac=a / HBM_PEAK_GBS)
+        roofs["density"] = dict(kernel="k_splat_b + k_blur_b x3 + k_to_f32_b + k_norm_b (all candidates per launch)", bound="hbm", achieved=a, peak=HBM_PEAK_GBS, unit="GB/s", frac=a / HBM_PEAK_GBS)
     return dict(value=n_done / dt, unit="candidates/s", candidates=n_done, converged=n_conv, seconds=dt, atoms_per_candidate=n_atoms,
                 best_ccc_per_subunit=[round(float(b), 4) for b in best], kernel_ms=ms, roofline=roofs,
-                note="mad_refine + mad_density_ccc (one host round trip each per batch); not part of the headline metric")
+                note="mad_dock_refine_score, one call for the candidates of all subunits: placement, refinement, density simulation and CCC on the "
+                     "device, poses in and scores out (the refined coordinates are not fetched); not part of the headline metric")
 
 
 def cpu_baseline(the_map, subs, cc, dist, k, lib, n_lo_anchor=800, n_hi_anchor=250, threads=1, whole=False):

@@ -378,6 +378,24 @@ int mad_set_bind_lane(mad_ctx *ctx, mad_set *set, int lane);
 int mad_density_ccc(mad_ctx *ctx, const double *atoms, const double *mass, int n_cand, int64_t n,
                     double resolution, double density_isovalue, double ccc_isovalue, double *ccc);
 
+/*
+ * MaD._refine_filtered_solutions (MaD.py:556-629) for a batch of candidate poses, on the device from the poses to the scores -- what
+ * mad_refine + mad_density_ccc do with a host round trip of all coordinates in between.  The candidates may belong to several
+ * structures (the subunits of a run: the reference refines them one subunit after the other, MaD.py:165-190): structure s =
+ * base_atoms[first_atom[s] .. first_atom[s + 1]) (float64 xyz) with masses alongside, candidate c is a pose of structure cand_struct[c]:
+ *   start_c = (atoms - hi_p[c]) @ rot[c] + lo_p[c]             (MaD.py:566-569: translate_atoms(-hi), rotate_atoms(R), translate_atoms(lo);
+ *                                                               rot[c] row-major 3x3 in PDB.rotate_atoms' convention coords @ R)
+ *   refine_pdb(map, start_c, n_steps, max_step, min_step)      (structure_utils.py:58-161, against the map of mad_upload_density)
+ *   ccc[c] = map.get_CCC_with_grid(structure_to_density(refined_c, resolution, voxsp of the map, density_isovalue), ccc_isovalue)
+ * converged / last_step: refine_pdb's return values per candidate.  coords (nullable): the refined coordinates of candidate 0, 1, ...
+ * back to back; NULL leaves them on the device (15 doubles per candidate in and ~1.6 KB per candidate out cross the bus).  A
+ * candidate whose refinement ends in NaN coordinates (structure_utils.py:97-98) gets ccc = NaN.
+ */
+int mad_dock_refine_score(mad_ctx *ctx, int n_struct, const double *base_atoms, const double *mass, const int64_t *first_atom,
+                          int n_cand, const int32_t *cand_struct, const double *hi_p, const double *lo_p, const double *rot,
+                          int n_steps, double max_step, double min_step, double resolution, double density_isovalue,
+                          double ccc_isovalue, double *coords, int32_t *converged, int32_t *last_step, double *ccc);
+
 /* ---- next to the path, downstream: occupancy overlap for assembly building ------------ */
 
 /*

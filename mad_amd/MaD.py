@@ -8,6 +8,13 @@ the GPU), `_match_dsc` (int8-MFMA correlation, pose scoring, top-k on the GPU) a
 on the GPU).  `_filter_dsc_pairs` (the greedy cloud clustering that picks which poses
 get refined, MaD.py:456-553) is the "next" row and runs on the host in float64 numpy.
 
+Several GPUs (round 3): started under a launcher (`torchrun --nproc-per-node N run_MaD.py ...`: WORLD_SIZE / RANK / LOCAL_RANK in
+the environment), `run()` deals the structures to describe and then the subunits / ensemble frames to dock round-robin over the
+ranks -- the reference's loops over them are independent iterations (MaD.py:116-190) -- every rank works on its GPU, the
+solution files land in the one results folder rank 0 created, and the lists of solutions are all-gathered so that every rank
+ends with the reference's `buildable_subunits`; `build_assembly` runs on rank 0.  The exchanges are a few python objects over a
+gloo group (names, file lists): control plane, nothing of the data path crosses ranks.
+
 Kept from the reference: method names, argument order and defaults, the
 `results/<map>_<comps>_res..._iso...` folder layout, the `Solutions_refined_<k>.csv`
 header and the descriptor cache file name (MaD.py:118).  Replaced: the h5py cache
@@ -30,7 +37,7 @@ from .MapSpace import MapSpace
 from .math_utils import get_rototrans_SVD
 from .Orientator import Orientator
 from .PDB import PDB
-from .structure_utils import ccc_many, move_copy_structure, refine_many
+from .structure_utils import dock_refine_score_many, move_copy_structure
 
 try:      # optional: the reference's cache format
     import h5py
@@ -114,6 +121,19 @@ class MaD(object):
         self.map_name = os.path.splitext(os.path.split(input_map)[-1])[0]
         print("MaD> Added: density map %s, resolution %.2f A" % (self.map_name, self.resolution))
 
+    # ------------------------------------------------------------------ ranks
+    def _ranks(self):
+        """(rank, world, torch.distributed or None).  More than one rank only under a launcher (WORLD_SIZE > 1)."""
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        if world <= 1:
+            return 0, 1, None
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29544")
+            dist.init_process_group(os.environ.get("MAD_CONTROL_BACKEND", "gloo"))
+        return dist.get_rank(), dist.get_world_size(), dist
+
     # ------------------------------------------------------------------ driver
     def run(self, transform_subunits=False, detect_sigma=2.0, presmooth_sigma=1, ori_eqsp_size=112, dsc_eqsp_size=16,
             dsc_subregions=64, patch_size=16, cc_threshold=0.6, weight_threshold=4, n_samples=60):
@@ -132,7 +152,17 @@ class MaD(object):
             for k in self.input_subunits:
                 print("     > Subunit: %s" % k)
             return False      # the reference falls through and crashes later (MaD.py:104-113)
-        self._prep_files_folders()
+        rank, world, dist = self._ranks()
+        if world == 1:
+            self._prep_files_folders()
+            return True
+        # one results folder for the job: rank 0 prepares it, everybody learns its name and the processed inputs
+        state = [None]
+        if rank == 0:
+            self._prep_files_folders()
+            state = [(self.out_folder, self.processed_map, getattr(self, "voxsp", None), self.processed_subunits, self.processed_ensembles)]
+        dist.broadcast_object_list(state, src=0)
+        self.out_folder, self.processed_map, self.voxsp, self.processed_subunits, self.processed_ensembles = state[0]
         return True
 
     def _cache_name(self, key, detect_sigma, presmooth_sigma, patch_size, ori_eqsp_size, dsc_eqsp_size):
@@ -152,6 +182,27 @@ class MaD(object):
             self._save_descriptors(rows, name)
             return rows, name
 
+        rank, world, dist = self._ranks()
+        if world > 1:
+            # the structures to describe, in the reference's order, dealt round-robin; a rank describes its own (into the cache:
+            # dsc_db/ is the hand-over), then everybody loads the map's rows and refers to the others by cache name
+            jobs = [(self.map_name, self.processed_map, "map")] + [(k, v[0], "subunit") for k, v in self.processed_subunits.items()]
+            for ek in self.processed_ensembles:
+                jobs += [(fk, v[0], "frame") for fk, v in self.processed_ensembles[ek].items()]
+            names = {}
+            for i, (key, struct, what) in enumerate(jobs):
+                names[key] = self._cache_name(key, detect_sigma, presmooth_sigma, patch_size, ori_eqsp_size, dsc_eqsp_size)
+                if i % world == rank:
+                    described(key, struct, what)
+            dist.barrier()
+            self.map_dsc = self._load_descriptors(names[self.map_name])
+            for k in self.processed_subunits:
+                self.dsc_dict[k] = names[k]
+            for ek in self.processed_ensembles:
+                self.dsc_dict[ek] = {}
+                for fk in self.processed_ensembles[ek]:
+                    self.dsc_dict[fk] = names[fk]
+            return
         self.map_dsc, _ = described(self.map_name, self.processed_map, "map")
         for k in self.processed_subunits:
             self.dsc_dict[k], _ = described(k, self.processed_subunits[k][0], "subunit")
@@ -163,6 +214,34 @@ class MaD(object):
                 self.dsc_dict[fk] = name      # frames are re-loaded when matched (MaD.py:158-162)
 
     def get_solutions(self, cc_threshold=0.6, weight_threshold=4, n_samples=120):
+        rank, world, dist = self._ranks()
+        if world > 1:
+            # MaD.py:165-190: one independent docking per subunit / frame -> dealt round-robin (mad_amd.dist.shard_round_robin); the
+            # file lists come back in the reference's order on every rank
+            from .dist import shard_round_robin
+            jobs = [("sub", k, k) for k in self.processed_subunits]
+            for ek in self.processed_ensembles:
+                jobs += [("frame", ek, fk) for fk in self.processed_ensembles[ek]]
+            mine = {}
+            for kind, owner_key, key in shard_round_robin(jobs, rank, world):
+                pdbfile, n_copies = self.processed_subunits[key] if kind == "sub" else self.processed_ensembles[owner_key][key]
+                mine[(kind, owner_key, key)] = self._match_filter_refine(pdbfile, n_copies, key, cc_threshold, weight_threshold, n_samples)
+            everyone = [None] * world
+            dist.all_gather_object(everyone, mine)
+            files_of = {}
+            for part in everyone:
+                files_of.update(part)
+            for kind, owner_key, key in jobs:
+                files = files_of[(kind, owner_key, key)]
+                if kind == "sub":
+                    if len(files):
+                        self.buildable_subunits[key] = [self.processed_subunits[key][1], files]
+                else:
+                    ensemble = self.processed_ensembles[owner_key]
+                    if owner_key not in self.buildable_subunits:
+                        self.buildable_subunits[owner_key] = [ensemble[list(ensemble.keys())[0]][1], []]
+                    self.buildable_subunits[owner_key][1].extend(files)
+            return
         for k in self.processed_subunits:
             pdbfile, n_copies = self.processed_subunits[k]
             files = self._match_filter_refine(pdbfile, n_copies, k, cc_threshold, weight_threshold, n_samples)
@@ -179,6 +258,11 @@ class MaD(object):
     def build_assembly(self, max_models=10, max_overlap_complex=0.1):
         """MaD.py:192-222; the overlap table and the model CCCs are device calls (mad_amd/assembly.py)."""
         from . import assembly
+        rank, world, dist = self._ranks()
+        if world > 1:      # one rank builds the models (the combinatorics are sequential); the others wait for its files
+            out = assembly.build_assembly(self, max_models=max_models, max_overlap_complex=max_overlap_complex) if rank == 0 else None
+            dist.barrier()
+            return out
         return assembly.build_assembly(self, max_models=max_models, max_overlap_complex=max_overlap_complex)
 
     def _build_from_single(self, sub_key, homomultimer=False):
@@ -196,6 +280,8 @@ class MaD(object):
     def score_ensembles(self):
         if not self.processed_ensembles:
             print("MaD> No ensembles were provided and/or processed")
+            return
+        if self._ranks()[0] != 0:      # the tables are printed once
             return
         import csv
         for ek, ensemble in self.processed_ensembles.items():
@@ -375,18 +461,16 @@ class MaD(object):
         dmap = Dmap(self.processed_map)
         if not len(filtered_candidate_list):
             return []
-        starts = []
-        for cand in filtered_candidate_list:
-            hi_coord, lo_coord, R = cand[0], cand[1], cand[2]
-            hi_pdb.set_coords(hi_init)
-            hi_pdb.translate_atoms(-hi_coord)
-            hi_pdb.rotate_atoms(R)
-            hi_pdb.translate_atoms(lo_coord)
-            starts.append(hi_pdb.get_coords().copy())
-        coords, _, _ = refine_many(dmap, np.stack(starts), n_steps=500, max_step_size=1, min_step_size=0.1)
+        # placement, refinement, density simulation and CCC of every candidate in ONE device call (MaD.py:566-575, 613-616): the poses go
+        # in, the refined coordinates and one score per candidate come back
+        n_c = len(filtered_candidate_list)
+        coords, _, _, ccc_all = dock_refine_score_many(dmap, hi_init, hi_pdb.atom_masses(), np.array([c[0] for c in filtered_candidate_list]),
+                                                       np.array([c[1] for c in filtered_candidate_list]),
+                                                       np.array([c[2] for c in filtered_candidate_list]).reshape(n_c, 9), self.resolution,
+                                                       n_steps=500, max_step_size=1, min_step_size=0.1)
         tree = cKDTree(lo_cloud)
         refined = []
-        for cand, xyz in zip(filtered_candidate_list, coords):
+        for cand, xyz, ccc in zip(filtered_candidate_list, coords, ccc_all):
             weight, clustered = cand[4], cand[8]
             if np.any(np.isnan(xyz)):
                 continue
@@ -397,11 +481,9 @@ class MaD(object):
             if repeat > 0:
                 sol = deepcopy(hi_pdb)
                 sol.set_coords(xyz)
-                refined.append([sol, moved[dist < dmap.voxsp * 2], repeat, weight, clustered])
+                refined.append([sol, moved[dist < dmap.voxsp * 2], repeat, weight, clustered, float(ccc)])
         final = []
-        # density simulation + CCC of every surviving placement in one device-resident batch (MaD.py:613-616)
-        cccs = ccc_many(dmap, np.stack([r[0].coords for r in refined]), hi_pdb.atom_masses(), self.resolution) if refined else []
-        for (sol, corresp, repeat, weight, clustered), ccc in zip(refined, cccs):
+        for sol, corresp, repeat, weight, clustered, ccc in refined:
             if final:
                 rmsds = [sol.get_rmsdCA_with(f[0]) for f in final]
                 if np.min(rmsds) < 6:      # a clone of an earlier solution: merge (MaD.py:609-612)
@@ -409,7 +491,7 @@ class MaD(object):
                     final[j][3] += weight
                     final[j][5].extend(clustered)
                     continue
-            final.append([sol, corresp, repeat, weight, float(ccc), clustered])
+            final.append([sol, corresp, repeat, weight, ccc, clustered])
         for sol in final:
             sol.append(sol[2] * sol[3] * sol[4])
         return sorted(final, key=itemgetter(-1), reverse=True)

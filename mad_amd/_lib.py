@@ -26,7 +26,7 @@ SYMBOLS = [
     "mad_match_topk", "mad_match_topk_many", "mad_match_topk_many_begin", "mad_match_topk_many_finish", "mad_set_batching", "mad_set_option", "mad_last_pose_kernel", "mad_last_pose_selected", "mad_match_fetch", "mad_match_results", "mad_match_used",
     "mad_match_shard_pairs", "mad_match_shard_topk",
     "mad_set_wire_bytes", "mad_set_export", "mad_set_import", "mad_set_lane", "mad_set_stream", "mad_set_bind_lane",
-    "mad_upload_density", "mad_refine", "mad_structure_to_density", "mad_ccc", "mad_density_ccc", "mad_grid_overlap", "mad_overlap_matrix",
+    "mad_upload_density", "mad_refine", "mad_structure_to_density", "mad_ccc", "mad_density_ccc", "mad_dock_refine_score", "mad_grid_overlap", "mad_overlap_matrix",
     "mad_space_create", "mad_space_destroy", "mad_space_build", "mad_space_info", "mad_space_download",
     "mad_space_peaks", "mad_space_patches",
 ]
@@ -694,6 +694,41 @@ class Lib(object):
         self._chk(self.dll.mad_density_ccc(self.ctx, _p(c), _p(mass), C.c_int(n_cand), C.c_int64(n_atoms), C.c_double(resolution),
                                            C.c_double(density_isovalue), C.c_double(ccc_isovalue), _p(out)))
         return out
+
+    def dock_refine_score(self, base_atoms, mass, hi_p, lo_p, rot, resolution, n_steps=500, max_step=0.5, min_step=0.01,
+                          density_isovalue=0.0, ccc_isovalue=0.0, want_coords=True, cand_struct=None):
+        """Candidate poses -> (refined coords or None, converged, last_step, ccc), device-resident from the poses to the scores
+        (mad_dock_refine_score): start_c = (atoms - hi_p[c]) @ rot[c] + lo_p[c], refined against the uploaded map, turned into a
+        simulated density and scored by CCC.  One structure: base_atoms (n, 3), mass (n) -> coords (n_cand, n, 3).  Several: lists of
+        them + cand_struct[c] = the structure candidate c is a pose of -> coords = list of (n_of_c, 3) arrays."""
+        many = isinstance(base_atoms, (list, tuple))
+        bases = [_c(a, np.float64).reshape(-1, 3) for a in (base_atoms if many else [base_atoms])]
+        masses = [_c(m, np.float64).reshape(-1) for m in (mass if many else [mass])]
+        assert len(bases) == len(masses) and all(len(a) == len(m) for a, m in zip(bases, masses))
+        first = np.zeros(len(bases) + 1, np.int64)
+        first[1:] = np.cumsum([len(a) for a in bases])
+        base_all, mass_all = np.concatenate(bases), np.concatenate(masses)
+        hi_p, lo_p = _c(hi_p, np.float64).reshape(-1, 3), _c(lo_p, np.float64).reshape(-1, 3)
+        rot = _c(rot, np.float64).reshape(-1, 9)
+        n_cand = len(hi_p)
+        cs = np.zeros(n_cand, np.int32) if cand_struct is None else _c(cand_struct, np.int32).reshape(-1)
+        assert len(lo_p) == n_cand and len(rot) == n_cand and len(cs) == n_cand
+        sizes = (first[1:] - first[:-1])[cs] if n_cand else np.zeros(0, np.int64)
+        flat = np.zeros((int(sizes.sum()), 3)) if want_coords else None
+        conv, last = np.zeros(max(n_cand, 1), np.int32), np.zeros(max(n_cand, 1), np.int32)
+        ccc = np.zeros(max(n_cand, 1))
+        self._chk(self.dll.mad_dock_refine_score(self.ctx, C.c_int(len(bases)), _p(base_all), _p(mass_all), _p(first), C.c_int(n_cand), _p(cs),
+                                                 _p(hi_p), _p(lo_p), _p(rot), C.c_int(int(n_steps)), C.c_double(max_step), C.c_double(min_step),
+                                                 C.c_double(resolution), C.c_double(density_isovalue), C.c_double(ccc_isovalue),
+                                                 _p(flat) if want_coords else None, _p(conv), _p(last), _p(ccc)))
+        coords = None
+        if want_coords:
+            if many:
+                ends = np.cumsum(sizes)
+                coords = [flat[e - n:e] for e, n in zip(ends, sizes)]
+            else:
+                coords = flat.reshape(n_cand, len(bases[0]), 3)
+        return coords, conv[:n_cand].astype(bool), last[:n_cand], ccc[:n_cand]
 
     def grid_overlap(self, g1, o1, g2, o2, voxsp, isovalue=1e-8):
         """-> (common, positives of g1); both grids (writable C-contiguous float32) are clamped in place."""

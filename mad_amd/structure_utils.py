@@ -86,6 +86,22 @@ def ccc_many(dmap, coords, masses, resolution, isovalue=0):
     return out
 
 
+def dock_refine_score_many(dmap, base_coords, masses, hi_coords, lo_coords, rots, resolution, n_steps=500, max_step_size=0.5,
+                           min_step_size=0.01, isovalue=0, want_coords=True):
+    """MaD._refine_filtered_solutions' device work for all candidate poses of one structure in ONE call (`mad_dock_refine_score`):
+    placement (translate by -hi, rotate, translate by lo: MaD.py:566-569), `refine_pdb`, `structure_to_density` and
+    `get_CCC_with_grid` (MaD.py:613-616) without the coordinates ever leaving the device, unless asked for.
+    -> (coords (n_cand, n, 3) or None, converged, last_step, ccc).  Like get_CCC_with_grid, the map is left clamped at `isovalue`."""
+    lib = _lib.get_lib()
+    _ensure_density(lib, dmap)
+    out = lib.dock_refine_score(base_coords, masses, hi_coords, lo_coords, rots, resolution, n_steps=n_steps, max_step=max_step_size,
+                                min_step=min_step_size, density_isovalue=0.0, ccc_isovalue=isovalue, want_coords=want_coords)
+    if np.any(dmap.grid3d < isovalue):
+        dmap.grid3d[dmap.grid3d < isovalue] = 0
+        invalidate_density()
+    return out
+
+
 def move_structure(original_struct, t=None, a=0.375, b=1.735, c=2.452, suffix=""):
     moved = original_struct.replace(".pdb", "_moved%s.pdb" % suffix)
     pdb = PDB(original_struct)

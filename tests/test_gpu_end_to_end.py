@@ -72,3 +72,64 @@ def test_run_mad_docks_a_synthetic_dimer(tmp_path, monkeypatch, lib):
     with open(os.path.join(mad2.out_folder, "Solutions_refined_subunit.csv")) as fh:
         rows2 = list(csv.DictReader(fh))
     assert [r["Repeatability"] for r in rows2] == [r["Repeatability"] for r in rows]
+
+
+def _two_rank_worker(rank, world, port, folder):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK=str(rank), MAD_DEVICE="0")
+    os.chdir(folder)
+    from mad import MaD
+    mad = MaD.MaD()
+    mad.add_map("assembly.pdb", 10.0)
+    mad.add_subunit("subA.pdb")
+    mad.add_subunit("subB.pdb")
+    mad.run()
+    mad.build_assembly()
+    import torch.distributed as dist
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_run_mad_on_two_ranks_writes_what_one_rank_writes(tmp_path, monkeypatch, lib):
+    """run_MaD.py under a launcher: two ranks (here sharing the one GPU, a gloo control group) deal the structures to describe and
+    the subunits to dock; the results folder -- solution tables, solution files, model ranking -- is text for text the one a single
+    rank writes (MaD.py:116-190: independent iterations)."""
+    import socket
+    import torch.multiprocessing as mp
+    from mad_amd import _lib
+    rng = np.random.default_rng(21)
+    parts, all_names, all_elems = [], [], []
+    dirs = [str(tmp_path / "two"), str(tmp_path / "one")]
+    for d in dirs:
+        os.makedirs(d)
+    for name, seed, t in (("subA", 3, [0, 0, 0]), ("subB", 5, [40, 5, -6])):
+        coords, names, elems = synth.random_globule(1500, 16.0, seed=seed)
+        for d in dirs:
+            synth.write_pdb(os.path.join(d, name + ".pdb"), coords, names, elems)
+        parts.append(synth.place(coords, synth.random_rotation(rng), t))
+        all_names += names
+        all_elems += elems
+    for d in dirs:
+        synth.write_pdb(os.path.join(d, "assembly.pdb"), np.concatenate(parts), all_names, all_elems)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_two_rank_worker, args=(2, port, dirs[0]), nprocs=2, join=True)
+    monkeypatch.setattr(_lib, "_default", lib)
+    lib._eq_loaded = {}
+    monkeypatch.chdir(dirs[1])
+    from mad import MaD
+    mad = MaD.MaD()
+    mad.add_map("assembly.pdb", 10.0)
+    mad.add_subunit("subA.pdb")
+    mad.add_subunit("subB.pdb")
+    mad.run()
+    mad.build_assembly()
+    out = mad.out_folder
+    names = ["Solutions_refined_subA.csv", "Solutions_refined_subB.csv", "complex_ranking.csv"]
+    names += [os.path.join("individual_solutions", f) for f in sorted(os.listdir(os.path.join(out, "individual_solutions"))) if f.endswith(".pdb")]
+    names += [os.path.join("assembly_models", f) for f in sorted(os.listdir(os.path.join(out, "assembly_models"))) if f.endswith(".pdb")]
+    assert len(names) >= 6
+    for n in names:
+        with open(os.path.join(dirs[1], out, n)) as fa, open(os.path.join(dirs[0], out, n)) as fb:
+            assert fa.read() == fb.read(), n

@@ -405,6 +405,56 @@ def test_density_and_ccc_match_oracle(lib):
         assert a2[2, 3, 4] == 0.0
 
 
+def test_dock_refine_score_equals_the_separate_calls_and_the_oracle(lib):
+    """mad_dock_refine_score (poses in, scores out: placement, refinement, density simulation and CCC of all candidates on the device)
+    against (a) the oracle chain on the host-placed coordinates and (b) mad_refine + mad_density_ccc; candidates of two structures
+    of different sizes in one batch; a candidate that leaves the map; the batch reproduces itself bit for bit."""
+    from mad_amd.math_utils import euler_rod_mat
+    grid, origin, vs, truth, _ = _refine_case(4)
+    other, _, elems_o = synth.random_globule(700, 12.0, 9)
+    structs = [(truth, synth.masses(synth.random_globule(len(truth), 10.0, 4)[2])), (other + truth.mean(0), synth.masses(elems_o))]
+    lib.upload_density(grid, origin, vs)
+    rng = np.random.default_rng(12)
+    hi_p, lo_p, rot, owner, starts = [], [], [], [], []
+    for c, (st, ang, shift) in enumerate(((0, 0.10, 1.0), (0, 0.05, -0.8), (1, 0.2, 0.5), (0, 0.02, 60.0), (1, 0.0, 0.0))):
+        atoms = structs[st][0]
+        ax = rng.normal(size=3)
+        R = euler_rod_mat(ax / np.linalg.norm(ax), ang)
+        hi = atoms[rng.integers(len(atoms))] + 0.25
+        lo = hi + shift * np.array([0.6, -0.3, 0.5])
+        hi_p.append(hi); lo_p.append(lo); rot.append(R); owner.append(st)
+        starts.append((atoms - hi) @ R + lo)      # MaD.py:566-569
+    res = 8.0
+    coords, conv, last, ccc = lib.dock_refine_score([a for a, _ in structs], [m for _, m in structs], np.array(hi_p), np.array(lo_p),
+                                                   np.array(rot), res, n_steps=500, max_step=1.0, min_step=0.1, cand_struct=np.array(owner))
+    for c, st in enumerate(owner):
+        ref, rconv, rlast, _ = O.refine(grid, origin, vs, starts[c], n_steps=500, max_step=1.0, min_step=0.1)
+        assert (bool(conv[c]), int(last[c])) == (rconv, rlast)
+        np.testing.assert_allclose(coords[c], ref, rtol=0, atol=1e-6)
+        g2, x0, y0, z0 = O.structure_to_density(ref, structs[st][1], res, vs)
+        want = O.ccc(grid.copy(), origin, g2, np.array([x0, y0, z0]), vs)
+        if np.isnan(want):      # a box that misses every occupied voxel of the map: 0 / 0, as the reference (Dmap.py:249-254)
+            assert np.isnan(ccc[c]), (c, ccc[c])
+        else:
+            assert abs(ccc[c] - want) <= 1e-5 * max(abs(want), 1e-3), (c, ccc[c], want)
+    # the separate calls on one structure's candidates
+    sel = [c for c, st in enumerate(owner) if st == 0]
+    got, gconv, glast = lib.refine(np.stack([starts[c] for c in sel]), n_steps=500, max_step=1.0, min_step=0.1)
+    for j, c in enumerate(sel):
+        np.testing.assert_allclose(coords[c], got[j], rtol=0, atol=1e-6)
+        assert (bool(gconv[j]), int(glast[j])) == (bool(conv[c]), int(last[c]))
+    np.testing.assert_allclose(lib.density_ccc(got, structs[0][1], res), ccc[sel], rtol=1e-6, atol=1e-9, equal_nan=True)
+    # single-structure form, coordinates left on the device; and run-to-run reproducibility of the whole batch
+    _, c1, l1, ccc1 = lib.dock_refine_score(structs[0][0], structs[0][1], np.array(hi_p)[sel], np.array(lo_p)[sel], np.array(rot)[sel], res,
+                                            n_steps=500, max_step=1.0, min_step=0.1, want_coords=False)
+    np.testing.assert_allclose(ccc1, ccc[sel], rtol=1e-9, atol=0, equal_nan=True)
+    coords2, conv2, last2, ccc2 = lib.dock_refine_score([a for a, _ in structs], [m for _, m in structs], np.array(hi_p), np.array(lo_p),
+                                                       np.array(rot), res, n_steps=500, max_step=1.0, min_step=0.1, cand_struct=np.array(owner))
+    np.testing.assert_array_equal(ccc2, ccc)
+    for a, b in zip(coords, coords2):
+        np.testing.assert_array_equal(a, b)
+
+
 def test_set_pipeline_and_batched_match(lib, fields):
     """The device-resident pipeline (set_build + match_topk / match_topk_many) equals the stage-by-stage oracle chain."""
     sets, host = [], []
