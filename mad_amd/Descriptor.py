@@ -6,9 +6,11 @@ dsc_size=64).generate_descriptors(ms, df_list)` fills `lin_ar_subeqsp` (int16[10
 every oriented anchor and returns the list.  The arithmetic (step06,
 Descriptor.py:123-202) runs in the HIP kernel `k_describe` through `mad_describe`.
 
-Only the layout the reference actually uses is implemented on the device: 64 sub-cubes
-x 16 zones (`dsc_size` 27 / 8 / 1 exist in the reference's constructor but are never
-selected, MaD.py:362).
+MaD.run only ever constructs `Descriptor(dsc_radius=patch_size)` (MaD.py:362): 64 sub-cubes x 16 zones.  The constructor's other
+options run on the device too and are pinned by goldens from the reference: `dsc_size` 27 / 8 / 1 (g17; built for the default
+dsc_radius), `dsc_radius` 8 / 16 / 24 with 64 sub-cubes, and `subeqsp_size=112` -- the reference's other EQSP table, rows of
+64 x 112 = 7 168 counts (g18; default layout).  Rows whose counts exceed 127 (`dsc_size` 8 and 1 can) are described but refused
+by the int8 correlation (MAD_EDOM) rather than wrapped.
 """
 import sys
 
@@ -31,8 +33,10 @@ class Descriptor(object):
         if dsc_size not in (64, 27, 8, 1):
             print("MaD>> ERROR: invalid dsc size %i" % dsc_size)
             sys.exit(1)
-        if subeqsp_size != 16:
-            raise NotImplementedError("MaD> the device descriptor has 16 zones per sub-region (the only descriptor table the reference ships)")
+        if subeqsp_size not in (16, 112):
+            raise NotImplementedError("MaD> EQSP tables exist for 16 and 112 zones (eqsp.py:16): subeqsp_size=%r" % (subeqsp_size,))
+        if subeqsp_size != 16 and (dsc_size != 64 or self.dsc_radius != 8):
+            raise NotImplementedError("MaD> the 112-zone descriptor is built for the default layout (dsc_size 64, dsc_radius 16) only")
         if dsc_size != 64 and self.dsc_radius != 8:
             raise NotImplementedError("MaD> dsc_size 27, 8 and 1 are built for the default dsc_radius (16) only")
         dr = self.dsc_radius

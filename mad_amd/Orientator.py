@@ -13,8 +13,9 @@ Differences, all deliberate:
     arrays per row, Orientator.py:91,101); the 17^3 work arrays never leave the GPU;
   * `step1_reject` is initialised (the reference's border-reject path raises
     AttributeError, Orientator.py:133);
-  * only the default window is implemented on the device: gw_sig=0, magn_weighted=False
-    (the reference never passes anything else, MaD.py:361).
+  * `gw_sig` (Gaussian window, Orientator.py:49-54) runs on the device with zone sums in 2^-50 fixed point; `magn_weighted` is
+    stored and, as in the reference (Orientator.py:33 is its only use), never read; `eqsp_size` 112 (default) and 16 (the
+    reference's other table) -- goldens g17 / g18 from the reference.
 """
 import numpy as np
 

@@ -783,12 +783,14 @@ template <int S, int NSUB> __device__ __forceinline__ int sub_of_i(int i) {
 #ifndef DSC_OCC
 #define DSC_OCC 4         // workgroups per CU the register budget is set for
 #endif
-template <int S, int NSUB = 64>
+// ZMAX: zones of the descriptor sphere the histogram has room for -- 16 (Descriptor(subeqsp_size=16), what MaD.run uses) or 128
+// (subeqsp_size=112, the reference's other table, eqsp.py:16: rows of 64 x 112 = 7 168 counts)
+template <int S, int NSUB = 64, int ZMAX = 16>
 __global__ __launch_bounds__(DSC_THREADS, DSC_OCC) void k_describe(Batch<DescribeArgs> B) {
     const int job = batch_job(B, (int)blockIdx.x);
     const DescribeArgs &A = B.job[job];
     const int bid = (int)blockIdx.x - B.first[job], gdim = B.first[job + 1] - B.first[job];      // this job's part of the grid (multiples of 8)
-    __shared__ int hist[NSUB * 16];
+    __shared__ int hist[NSUB * ZMAX];
     __shared__ int s_oob, s_nq;
     __shared__ double sInv[9];
     __shared__ EqspFastLds fast;
@@ -1001,7 +1003,9 @@ int mad_describe_device_many(mad_ctx *ctx, int n_jobs, const DescribeJob *jobs, 
     if (dsc_size != 64 && (2 * r != 16 || (dsc_size != 27 && dsc_size != 8 && dsc_size != 1)))
         return mad_fail(ctx, MAD_EINVAL, "mad_describe: dsc_size %d (27, 8 and 1 are built for the default dsc_radius 16 only; 64 for 4 ... 16)", dsc_size);
     if (!ctx->eq_set[1]) return mad_fail(ctx, MAD_EINVAL, "mad_describe: descriptor EQSP table not set");
-    if (ctx->eq_host[1].Z != 16) return mad_fail(ctx, MAD_EINVAL, "mad_describe: kernel is built for 16 descriptor zones");
+    const int Zd = ctx->eq_host[1].Z;
+    if (Zd != 16 && !(Zd <= 128 && dsc_size == 64 && 2 * r == 16))
+        return mad_fail(ctx, MAD_EINVAL, "mad_describe: %d descriptor zones: 16 for every layout, up to 128 (the 112-zone table) for the default 64 regions and dsc_radius 16", Zd);
     if (r < 2 || r > 8 || (r % 2)) return mad_fail(ctx, MAD_EINVAL, "mad_describe: dsc radius %d must be 2, 4, 6 or 8", r);
     for (int j0 = 0; j0 < n_jobs; j0 += MAD_BATCH_MAX) {
         Batch<DescribeArgs> B;
@@ -1035,7 +1039,10 @@ int mad_describe_device_many(mad_ctx *ctx, int n_jobs, const DescribeJob *jobs, 
             case -27: hipLaunchKernelGGL((k_describe<16, 27>), dim3(nblk), dim3(DSC_THREADS), 0, ctx->stream, B); break;
             case -8: hipLaunchKernelGGL((k_describe<16, 8>), dim3(nblk), dim3(DSC_THREADS), 0, ctx->stream, B); break;
             case -1: hipLaunchKernelGGL((k_describe<16, 1>), dim3(nblk), dim3(DSC_THREADS), 0, ctx->stream, B); break;
-            default: hipLaunchKernelGGL(k_describe<16>, dim3(nblk), dim3(DSC_THREADS), 0, ctx->stream, B); break;
+            default:
+                if (Zd > 16) hipLaunchKernelGGL((k_describe<16, 64, 128>), dim3(nblk), dim3(DSC_THREADS), 0, ctx->stream, B);
+                else hipLaunchKernelGGL(k_describe<16>, dim3(nblk), dim3(DSC_THREADS), 0, ctx->stream, B);
+                break;
         }
         mad_timer_end(ctx, MAD_T_DESCRIBE);
         MAD_HIP(hipGetLastError());

@@ -16,7 +16,7 @@ Fixtures hold inputs and the reference's outputs only (numpy arrays).  Everythin
 seeded; re-running this script reproduces the files bit for bit on the same numpy /
 scipy build.
 
-Usage:  cd /root/repo && python tests/golden/make_golden.py [--only-g9 | --only-g10 | --only-g11 | --only-g12 | --only-g13 | --only-g14 | --only-g15 | --only-g16 | --only-g17]
+Usage:  cd /root/repo && python tests/golden/make_golden.py [--only-g9 | --only-g10 | --only-g11 | --only-g12 | --only-g13 | --only-g14 | --only-g15 | --only-g16 | --only-g17 | --only-g18]
 """
 import hashlib
 import os
@@ -456,6 +456,55 @@ def make_g17(R, synth):
     np.savez_compressed(os.path.join(OUT, "g17_options.npz"), **g17)
 
 
+def make_g18(R, synth):
+    """G18: the EQSP sizes the constructors take besides the defaults -- Orientator(eqsp_size=16) (the "coarse eqsp" of BASELINE
+    configs[0]; Orientator.py:13-21) and Descriptor(subeqsp_size=112) (Descriptor.py:14-30; the reference ships both tables,
+    eqsp.py:16) -- by the reference, on a smooth field, both octaves."""
+    from scipy.interpolate import RegularGridInterpolator as RGI
+    g18 = {}
+    for octave, shape, seed, margin in ((1, (44, 46, 48), 181, 10), (0, (62, 60, 64), 182, 18)):
+        vol = synth.blob_volume(shape, 50, seed, sigma=(1.5, 3.5), hollow=0.2)
+        grad = synth.gradient_field(vol).astype(np.float32)      # (X, Y, Z, 3)
+        ms = types.SimpleNamespace(grad_list=[grad, grad], rgi_space=[RGI(points=[np.arange(s_) for s_ in shape], values=grad, method="nearest")] * 2)
+        coords = synth.interior_anchors(shape, 30, margin, seed + 1)
+        coords[-1] = [2, 3, shape[2] - 3]      # an anchor the border test refuses (Orientator.py:131-135)
+        tag = "o%d_" % octave
+        g18[tag + "vol"] = vol      # the field is synth.gradient_field(vol) (np.gradient in float32): a third of the bytes
+        g18[tag + "coords"] = coords
+
+        def fresh(extra=None, n=None):
+            out = []
+            for i, c in enumerate(coords[:n]):
+                df = R.DF.DensityFeature()
+                df.set_detector_info(i, octave, [int(c[0]), int(c[1]), int(c[2])], np.zeros(3), np.zeros(3), 1.0)
+                if extra is not None:
+                    df.Rfinal = extra[i].copy()
+                out.append(df)
+            return out
+
+        ori = R.Ori.Orientator(eqsp_size=16)
+        ori.step1_reject = 0
+        rows = ori.assign_orientations(ms, fresh())
+        k = tag + "ori16_"
+        g18[k + "anchor"] = np.array([r.index for r in rows], np.int32)
+        g18[k + "main"] = np.array([r.main_bin for r in rows], np.int32)
+        g18[k + "sec"] = np.array([r.sec_bin for r in rows], np.int32)
+        g18[k + "count"] = np.array([r.ar_count for r in rows], np.int32)
+        g18[k + "R"] = np.array([r.Rfinal for r in rows])
+        g18[k + "reject"] = np.int32(ori.step1_reject)
+        print("g18 octave", octave, "Orientator(eqsp_size=16): rows", len(rows), "rejects", ori.step1_reject)
+        rr = np.random.default_rng(seed + 2)
+        n_d = len(coords) - 1      # (the border anchor's sample cube leaves the grid only partly: keep the rows the reference describes)
+        Rm = np.stack([np.identity(3)] * 4 + [synth.random_rotation(rr) for _ in range(n_d - 4)])
+        g18[tag + "dsc_R"] = Rm
+        dd = fresh(Rm, n_d)
+        R.Dsc.Descriptor(subeqsp_size=112).generate_descriptors(ms, dd)
+        g18[tag + "dsc112"] = np.array([d.lin_ar_subeqsp for d in dd], np.int16)
+        print("g18 octave", octave, "Descriptor(subeqsp_size=112): row length", g18[tag + "dsc112"].shape[1], "sum", int(g18[tag + "dsc112"].sum()),
+              "max", int(g18[tag + "dsc112"].max()))
+    np.savez_compressed(os.path.join(OUT, "g18_eqsp_sizes.npz"), **g18)
+
+
 def main():
     from scipy.interpolate import RegularGridInterpolator as RGI
     R = import_reference()
@@ -489,6 +538,9 @@ def main():
         return
     if "--only-g17" in sys.argv:
         make_g17(R, synth)
+        return
+    if "--only-g18" in sys.argv:
+        make_g18(R, synth)
         return
 
     # ---- G1: EQSP tables -----------------------------------------------------------

@@ -312,3 +312,49 @@ def test_stage_options_of_the_constructors(default_lib):
             np.testing.assert_array_equal(pl, wl)
             np.testing.assert_allclose(ps, ref[wh, wl], rtol=1e-12, atol=0)
         lib.free_field(slot)
+
+
+def test_the_other_eqsp_sizes(default_lib):
+    """Orientator(eqsp_size=16) ("coarse eqsp", BASELINE configs[0]) and Descriptor(subeqsp_size=112) (the reference ships both
+    tables, eqsp.py:16) through the drop-in classes against the reference's own outputs (g18): rows, bins, 16-zone histograms,
+    the border reject, and the 7 168-count descriptor rows identical; afterwards the default tables are back in place."""
+    from mad_amd import synth
+    from mad_amd.Descriptor import Descriptor
+    from mad_amd.Orientator import Orientator
+    g = load("g18_eqsp_sizes.npz")
+    lib = default_lib
+    for octave in (1, 0):
+        field = synth.gradient_field(g["o%d_vol" % octave])
+        ms = types.SimpleNamespace(grad_list=[field, field], oct_mode="both", name="g18")
+        slot = lib.new_slot()
+        lib.upload_field(slot, field)
+        ms.device_slots = lambda lib_, s=slot: [s, s]
+        coords = g["o%d_coords" % octave]
+        k = "o%d_ori16_" % octave
+        ori = Orientator(eqsp_size=16)
+        rows = ori.assign_orientations(ms, _anchors(coords, octave))
+        assert ori.step1_reject == int(g[k + "reject"]) == 1
+        np.testing.assert_array_equal([r.index for r in rows], g[k + "anchor"])
+        np.testing.assert_array_equal([r.main_bin for r in rows], g[k + "main"])
+        np.testing.assert_array_equal([r.sec_bin for r in rows], g[k + "sec"])
+        np.testing.assert_array_equal([r.ar_count for r in rows], g[k + "count"])
+        np.testing.assert_allclose([r.Rfinal for r in rows], g[k + "R"], rtol=0, atol=1e-14)
+        want = g["o%d_dsc112" % octave]
+        drows = []
+        for c, R in zip(coords[:len(want)], g["o%d_dsc_R" % octave]):
+            df = DensityFeature()
+            df.set_detector_info(0, octave, [int(v) for v in c], np.zeros(3), np.zeros(3), 1.0)
+            df.Rfinal = R
+            drows.append(df)
+        Descriptor(subeqsp_size=112).generate_descriptors(ms, drows)
+        np.testing.assert_array_equal(np.array([r.lin_ar_subeqsp for r in drows]), want)
+        # the defaults again: the tables are re-bound by the next default-constructed stage objects
+        plain = Orientator().assign_orientations(ms, _anchors(coords, octave))
+        assert plain and len(plain[0].ar_count) == 112
+        d16 = [DensityFeature() for _ in range(2)]
+        for df, c in zip(d16, coords[:2]):
+            df.set_detector_info(0, octave, [int(v) for v in c], np.zeros(3), np.zeros(3), 1.0)
+            df.Rfinal = np.identity(3)
+        Descriptor().generate_descriptors(ms, d16)
+        assert len(d16[0].lin_ar_subeqsp) == 1024
+        lib.free_field(slot)

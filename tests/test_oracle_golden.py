@@ -197,3 +197,29 @@ def test_g17_stage_options_of_the_constructors():
             want = g["o%d_dsc%d" % (octave, size)]
             assert want.shape[1] == size * 16 and want.sum() > 30000
             np.testing.assert_array_equal(O.describe(f[0], f[1], f[2], octave, coords, g["o%d_dsc_R" % octave], e16.sphere_eqsp, dsc_size=size), want)
+
+
+def test_g18_the_other_eqsp_sizes():
+    """Orientator(eqsp_size=16) -- the "coarse eqsp" of BASELINE configs[0] -- and Descriptor(subeqsp_size=112) (the reference ships
+    both tables, eqsp.py:16; tests/golden/make_golden.py::make_g18): the oracle on the reference's own outputs, both octaves, a
+    border reject included."""
+    from mad_amd import synth
+    from mad_amd.eqsp import EQSP_Sphere
+    from oracle import oracle as O
+    g = load("g18_eqsp_sizes.npz")
+    e112, e16 = EQSP_Sphere(112), EQSP_Sphere(16)
+    for octave in (1, 0):
+        f = np.ascontiguousarray(np.moveaxis(synth.gradient_field(g["o%d_vol" % octave]), -1, 0))
+        coords = g["o%d_coords" % octave]
+        k = "o%d_ori16_" % octave
+        rows = O.orient(f[0], f[1], f[2], octave, coords, e16.sphere_eqsp, e16.p_centers_eqsp)
+        assert len(g[k + "anchor"]) > 60 and rows["counts"].shape[1] == 16
+        assert rows["n_reject"] == int(g[k + "reject"]) == 1
+        np.testing.assert_array_equal(rows["anchor"], g[k + "anchor"])
+        np.testing.assert_array_equal(rows["main"], g[k + "main"])
+        np.testing.assert_array_equal(rows["sec"], g[k + "sec"])
+        np.testing.assert_array_equal(rows["counts"], g[k + "count"])
+        np.testing.assert_allclose(rows["R"], g[k + "R"], rtol=0, atol=1e-14)
+        want = g["o%d_dsc112" % octave]
+        assert want.shape[1] == 64 * 112 and want.sum() > 30000
+        np.testing.assert_array_equal(O.describe(f[0], f[1], f[2], octave, coords[:len(want)], g["o%d_dsc_R" % octave], e112.sphere_eqsp), want)
