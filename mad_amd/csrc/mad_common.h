@@ -45,6 +45,20 @@ struct __attribute__((aligned(16))) EqspFastLds {
     int tier2_ok;                     // every belt with more than one zone has zones narrower than 3 rad (else tier 2 is off)
 };
 
+// Table classifier of the 4-byte texels (k_describe, descriptor sphere only): belt from z through `zbelt`, zone inside the belt from
+// the pseudo-angle p = 1 - x / (|x| + |y|) (y >= 0) or 3 + x / (|x| + |y|) (y < 0), monotonic in theta, through `ptab`.  An entry is
+// a zone only where EVERY direction that can land in the bin -- the bin, its two neighbours and MAD_TAB_GUARD radians around them
+// (more than twice the 1.7e-3 rad three 10-bit components can be off together) -- lies strictly inside that zone; everything else is 255 =
+// "undecided", and the sample goes through the float32 / float64 tiers on its full texel.
+#define MAD_TAB_BELTS 4
+#define MAD_TAB_PBINS 2048
+#define MAD_TAB_ZBINS 2048
+#define MAD_TAB_GUARD 4e-3
+struct __attribute__((aligned(16))) EqspTabLds {
+    unsigned char zbelt[MAD_TAB_ZBINS];
+    unsigned char ptab[MAD_TAB_BELTS][MAD_TAB_PBINS];
+};
+
 #define MAD_T2_MARGIN64 1e-9      // >> the ~1e-15 rad of a float64 atan2 / acos
 #define MAD_T2_MARGIN32 2e-6      // >> the float32 rounding of theta, of theta + float32(2 pi) and of phi (<= 9e-7 rad together)
 
@@ -72,6 +86,8 @@ struct EqspDev {
     int belt_count32[MAD_MAX_BELT];
     float g32[MAD_MAX_Z][4];        // per zone: cos, sin of (theta_min + guard), cos, sin of (theta_max - guard)
     EqspFastLds image;              // the LDS copy of the above, byte for byte (mad_set_eqsp builds it, kernels copy it)
+    EqspTabLds tab;                 // table classifier of the 4-byte texels (valid when tab_ok)
+    int tab_ok;
 };
 
 #define MAD_EQSP_GUARD 1e-4
@@ -81,6 +97,10 @@ struct EqspDev {
 struct FieldDev {
     const float4 *tex;
     int nx, ny, nz;
+    // The same field as 4-byte texels (round 3): the unit direction in three signed 10-bit components + two flag bits (mad_tex4_encode).
+    // k_describe gathers THESE (a quarter of the bytes per sample) and classifies them through a table with a guard band wider than
+    // the quantisation; only the samples the table cannot decide (2-4 %) fetch the 16-byte texel.  Behind `tex` in the same allocation.
+    const unsigned *tex4;
 };
 
 // ---------------------------------------------------------------------------
@@ -471,6 +491,28 @@ __device__ __forceinline__ int cvt_round(float x) {
 }
 
 __device__ __forceinline__ void eqsp_fast_stage(const EqspDev *t, EqspFastLds *l) { stage_lds(l, &t->image, sizeof(EqspFastLds)); }
+
+// 4-byte texel of a gradient {x, y, z} with magnitude w (float32, as in the 16-byte texel): bits 0-9 / 10-19 / 20-29 = the unit
+// direction's components x 511, rounded, as signed 10-bit integers; bits 30-31: 0 = a direction, 3 = |g| < 1e-5 (the sample is not
+// counted, Descriptor.py:190), 2 = not finite (always decided by the exact tiers).
+__device__ __forceinline__ unsigned mad_tex4_encode(float x, float y, float z, float w) {
+    if (!(fabsf(x) <= 3.0e38f) || !(fabsf(y) <= 3.0e38f) || !(fabsf(z) <= 3.0e38f) || !(w <= 3.0e38f)) return 0x80000000u;
+    if (w < 1e-5f) return 0xC0000000u;
+    const float inv = 511.0f / w;
+    const int ix = min(max((int)rintf(x * inv), -511), 511), iy = min(max((int)rintf(y * inv), -511), 511), iz = min(max((int)rintf(z * inv), -511), 511);
+    return ((unsigned)ix & 0x3ffu) | (((unsigned)iy & 0x3ffu) << 10) | (((unsigned)iz & 0x3ffu) << 20);
+}
+
+// zone of the direction (x, y, z) -- z on the unit scale, x and y on any common scale -- or -1 (undecided); see EqspTabLds
+__device__ __forceinline__ int eqsp_tab32(const EqspTabLds *t, float x, float y, float z) {
+    const int bz = min(max(cvt_floor((z + 1.0f) * (0.5f * MAD_TAB_ZBINS)), 0), MAD_TAB_ZBINS - 1);
+    const int b = t->zbelt[bz];
+    const float xr = x * __builtin_amdgcn_rcpf(fmaxf(fabsf(x) + fabsf(y), 1e-30f));
+    const float p = y >= 0.f ? 1.0f - xr : 3.0f + xr;
+    const int bp = min(max(cvt_floor(p * (0.25f * MAD_TAB_PBINS)), 0), MAD_TAB_PBINS - 1);
+    const int zn = t->ptab[b & (MAD_TAB_BELTS - 1)][bp];
+    return (b | zn) >= 255 ? -1 : zn;      // (both are bytes: 255 in either means undecided)
+}
 
 // eqsp_classify on the LDS copy of the table
 template <class F>

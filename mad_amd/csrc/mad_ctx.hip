@@ -297,6 +297,39 @@ extern "C" int mad_set_eqsp(mad_ctx *ctx, int which, int Z, const double *bounds
             if (b + 1 < h.nbelt && h.ph_hi[b] != h.ph_lo[b + 1]) im.tier2_ok = 0;      // belts must share their bounds
         }
     }
+    {   // table classifier of the 4-byte texels (EqspTabLds): conservative by construction, see the struct
+        EqspTabLds &T = h.tab;
+        memset(&T, 255, sizeof(T));
+        static const bool no_tab = getenv("MAD_NO_TAB") != nullptr;      // diagnostic switch
+        h.tab_ok = (h.nbelt <= MAD_TAB_BELTS && !no_tab) ? 1 : 0;
+        const double g = MAD_TAB_GUARD, pi = 3.14159265358979323846;
+        for (int k = 0; h.tab_ok && k < MAD_TAB_ZBINS; k++) {
+            const double zlo = -1.0 + (k - 1) * (2.0 / MAD_TAB_ZBINS), zhi = -1.0 + (k + 2) * (2.0 / MAD_TAB_ZBINS);      // the bin and its neighbours
+            if (zlo <= -1.0 || zhi >= 1.0) continue;
+            const double ph_min = acos(zhi) - g, ph_max = acos(zlo) + g;
+            for (int b = 0; b < h.nbelt; b++)
+                if (ph_min > h.ph_lo[b] && ph_max < h.ph_hi[b]) T.zbelt[k] = (unsigned char)b;
+        }
+        auto theta_of = [&](double p) {      // inverse of eqsp_tab32's pseudo-angle
+            if (p <= 2.0) { const double xr = 1.0 - p; return atan2(1.0 - fabs(xr), xr); }
+            const double xr = p - 3.0;
+            return atan2(-(1.0 - fabs(xr)), xr) + 2.0 * pi;
+        };
+        for (int b = 0; h.tab_ok && b < h.nbelt; b++) {
+            const int a0 = h.belt_first[b], cnt = h.belt_count[b];
+            if (cnt == 1) { memset(T.ptab[b], a0, MAD_TAB_PBINS); continue; }      // a polar cap spans every azimuth
+            const double s_min = std::min(sin(h.ph_lo[b]), sin(h.ph_hi[b]));        // sin(phi) is concave on [0, pi]
+            if (!(s_min > 0.05)) continue;                                          // an angular error is an azimuth error / sin(phi)
+            const double gt = g / s_min;
+            for (int k = 2; k < MAD_TAB_PBINS - 2; k++) {                           // (the bins at the 0 / 2 pi seam stay undecided)
+                const double t0 = theta_of((k - 1) * (4.0 / MAD_TAB_PBINS)) - gt, t1 = theta_of((k + 2) * (4.0 / MAD_TAB_PBINS)) + gt;
+                for (int a = a0; a < a0 + cnt; a++) {
+                    const bool in = (t0 > h.th_lo[a] && t1 < h.th_hi[a]) || (t0 + 2.0 * pi > h.th_lo[a] && t1 + 2.0 * pi < h.th_hi[a]);
+                    if (in) T.ptab[b][k] = (unsigned char)a;
+                }
+            }
+        }
+    }
     if (to_dom) memcpy(h.to_dom, to_dom, sizeof(double) * 9 * Z);
     if (adj_sec) memcpy(h.adj_sec, adj_sec, sizeof(double) * 9 * Z);
     MAD_HIP(hipMemcpyAsync(ctx->eq[which], &h, sizeof(EqspDev), hipMemcpyHostToDevice, ctx->stream));
@@ -311,13 +344,15 @@ extern "C" int mad_set_eqsp(mad_ctx *ctx, int which, int Z, const double *bounds
 
 // planar {gx,gy,gz} -> texel {gx,gy,gz,|g|}; |g| with one float32 rounding per operation
 __global__ __launch_bounds__(256) void k_pack_field(const float *__restrict__ gx, const float *__restrict__ gy,
-                                                    const float *__restrict__ gz, float4 *__restrict__ tex, size_t n) {
+                                                    const float *__restrict__ gz, float4 *__restrict__ tex, unsigned *__restrict__ tex4, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t step = (size_t)gridDim.x * blockDim.x;
     for (; i < n; i += step) {
         const float x = gx[i], y = gy[i], z = gz[i];
         const float s = __fadd_rn(__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)), __fmul_rn(z, z));
-        tex[i] = make_float4(x, y, z, sqrtf(s));      // sqrtf is correctly rounded here; the "_rn" sqrt intrinsic is NOT (1 ulp off for 15 % of inputs, measured)
+        const float w = sqrtf(s);      // sqrtf is correctly rounded here; the "_rn" sqrt intrinsic is NOT (1 ulp off for 15 % of inputs, measured)
+        tex[i] = make_float4(x, y, z, w);
+        tex4[i] = mad_tex4_encode(x, y, z, w);
     }
 }
 
@@ -334,12 +369,12 @@ int mad_field_alloc(mad_ctx *ctx, int slot, int nx, int ny, int nz, size_t *n_ou
         ctx->field_mem[slot] = nullptr;
         ctx->fields[slot] = FieldDev{nullptr, 0, 0, 0};
     }
-    hipError_t e = hipMalloc(&ctx->field_mem[slot], n * sizeof(float4));
+    hipError_t e = hipMalloc(&ctx->field_mem[slot], n * (sizeof(float4) + sizeof(unsigned)));      // the 16-byte texels, then the 4-byte ones
     if (e != hipSuccess) {
         ctx->field_mem[slot] = nullptr;
         return mad_fail(ctx, MAD_ENOMEM, "field of %zu texels: %s", n, hipGetErrorString(e));
     }
-    ctx->fields[slot] = FieldDev{(const float4 *)ctx->field_mem[slot], nx, ny, nz};
+    ctx->fields[slot] = FieldDev{(const float4 *)ctx->field_mem[slot], nx, ny, nz, (const unsigned *)((const float4 *)ctx->field_mem[slot] + n)};
     *n_out = n;
     return MAD_OK;
 }
@@ -350,7 +385,7 @@ extern "C" int mad_upload_field_device(mad_ctx *ctx, int slot, const float *g3, 
     MAD_TRY(mad_field_alloc(ctx, slot, nx, ny, nz, &n));
     const int blocks = (int)std::min<size_t>(mad_ceil_div((int64_t)n, 256), (size_t)ctx->n_cu * 16);
     hipLaunchKernelGGL(k_pack_field, dim3(blocks), dim3(256), 0, ctx->stream, g3, g3 + n, g3 + 2 * n,
-                       (float4 *)ctx->field_mem[slot], n);
+                       (float4 *)ctx->field_mem[slot], (unsigned *)((float4 *)ctx->field_mem[slot] + n), n);
     MAD_HIP(hipGetLastError());
     MAD_HIP(hipStreamSynchronize(ctx->stream));
     return MAD_OK;

@@ -785,7 +785,18 @@ template <int S, int NSUB> __device__ __forceinline__ int sub_of_i(int i) {
 #endif
 // ZMAX: zones of the descriptor sphere the histogram has room for -- 16 (Descriptor(subeqsp_size=16), what MaD.run uses) or 128
 // (subeqsp_size=112, the reference's other table, eqsp.py:16: rows of 64 x 112 = 7 168 counts)
-template <int S, int NSUB = 64, int ZMAX = 16>
+// TAB (round 3): the samples are gathered from the field's 4-byte texels (a unit direction in 3 x 10 bits, FieldDev::tex4) and
+// classified through the conservative tables of EqspTabLds -- a quarter of the bytes per gather, ~25 vector instructions per
+// sample instead of ~65 for normalisation + rotation + eqsp_fast32, a quarter of the registers for the texels in flight.  What the
+// table cannot decide (the bins a zone edge crosses +- MAD_TAB_GUARD, 2-4 % of the samples) is queued BY TEXEL INDEX and goes
+// through the former tiers -- float32 with its 1e-4 guard, then float64 -- on the full 16-byte texel, in full lanes.  The result
+// is the same descriptor, bit for bit: every tier only ever answers when the exact arithmetic is certain to agree.
+#define DSC_QUEUE_TAB 768
+#ifdef MAD_PROBE_TAB      // diagnostic build: what the table tier did with every sample of the first row of a launch
+__device__ int dbg_tab[4096 * 4];
+extern "C" int mad_debug_tab(int *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(dbg_tab), sizeof(int) * 4096 * 4) == hipSuccess ? 0 : -1; }
+#endif
+template <int S, int NSUB = 64, int ZMAX = 16, bool TAB = false>
 __global__ __launch_bounds__(DSC_THREADS, DSC_OCC) void k_describe(Batch<DescribeArgs> B) {
     const int job = batch_job(B, (int)blockIdx.x);
     const DescribeArgs &A = B.job[job];
@@ -794,8 +805,12 @@ __global__ __launch_bounds__(DSC_THREADS, DSC_OCC) void k_describe(Batch<Describ
     __shared__ int s_oob, s_nq;
     __shared__ double sInv[9];
     __shared__ EqspFastLds fast;
-    __shared__ float4 qv[DSC_QUEUE];         // texels the fast classifier could not decide
-    __shared__ int qsub[DSC_QUEUE];
+    __shared__ float4 qv[TAB ? 1 : DSC_QUEUE];         // texels the fast classifier could not decide
+    __shared__ int qsub[TAB ? 1 : DSC_QUEUE];
+    __shared__ typename std::conditional<TAB, EqspTabLds, int>::type tab;
+    __shared__ unsigned qidx[TAB ? DSC_QUEUE_TAB : 1];             // TAB: texel indices of the samples the table could not decide
+    __shared__ unsigned short qsub16[TAB ? DSC_QUEUE_TAB : 1];
+    constexpr int QCAP = TAB ? DSC_QUEUE_TAB : DSC_QUEUE;
     // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs (b and b + 8 share one), so give
     // each XCD a contiguous run of rows.  Consecutive rows belong to the same anchor (fan-out ~5) or to
     // neighbours in the anchor list and sample the same neighbourhood: running side by side on ONE XCD
@@ -823,6 +838,7 @@ __global__ __launch_bounds__(DSC_THREADS, DSC_OCC) void k_describe(Batch<Describ
     int64_t row = work;
     if (A.row_perm) row = (int64_t)__builtin_amdgcn_readfirstlane(A.row_perm[work]);
     eqsp_fast_stage(A.eq, &fast);
+    if (TAB) stage_lds(&tab, &A.eq->tab, sizeof(EqspTabLds));
     int a = (int)row;
     if (A.row_anchor) a = __builtin_amdgcn_readfirstlane(A.row_anchor[row]);
     int oct = A.uniform_octave;
@@ -830,6 +846,7 @@ __global__ __launch_bounds__(DSC_THREADS, DSC_OCC) void k_describe(Batch<Describ
     const FieldDev F0 = A.f[0], F1 = A.f[1];
     FieldDev F;
     F.tex = oct == 1 ? F1.tex : F0.tex; F.nx = oct == 1 ? F1.nx : F0.nx; F.ny = oct == 1 ? F1.ny : F0.ny; F.nz = oct == 1 ? F1.nz : F0.nz;
+    F.tex4 = oct == 1 ? F1.tex4 : F0.tex4;
     const int Z = A.eq->Z;
     const int D = NSUB * Z;            // S = 2 r samples per axis (16), NSUB sub-regions of Z zones each
 
@@ -882,7 +899,8 @@ __global__ __launch_bounds__(DSC_THREADS, DSC_OCC) void k_describe(Batch<Describ
         const int sub_jk = sub_of_jk<S, NSUB>(j, k);      // Descriptor.py:44-93
 #pragma unroll
         for (int pass = 0; pass < NP; pass++) {
-            float4 t[PS];
+            float4 t[TAB ? 1 : PS];
+            unsigned q4[TAB ? PS : 1], qi[TAB ? PS : 1];      // TAB: the 4-byte texels and where they came from
             unsigned unsure = 0;      // bit i: the float32 guess of sample i of this pass is too close to a tie to be trusted
             auto guess = [&](auto border) {
                 const float fc0 = (float)ic0, fc1 = (float)ic1, fc2 = (float)ic2;
@@ -900,7 +918,9 @@ __global__ __launch_bounds__(DSC_THREADS, DSC_OCC) void k_describe(Batch<Describ
                         safe &= (q0 > 1e-3f) & (q0 < lim0) & (q1 > 1e-3f) & (q1 < lim1) & (q2 > 1e-3f) & (q2 < lim2);
                         n0 = min(max(n0, 0), F.nx - 1); n1 = min(max(n1, 0), F.ny - 1); n2 = min(max(n2, 0), F.nz - 1);
                     }
-                    t[i] = F.tex[mad_u24(mad_u24((unsigned)n0, (unsigned)F.ny, (unsigned)n1), (unsigned)F.nz, (unsigned)n2)];      // nx ny < 2^24 (checked at allocation)
+                    const unsigned at = mad_u24(mad_u24((unsigned)n0, (unsigned)F.ny, (unsigned)n1), (unsigned)F.nz, (unsigned)n2);      // nx ny < 2^24 (checked at allocation)
+                    if (TAB) { qi[i] = at; q4[i] = F.tex4[at]; }
+                    else t[i] = F.tex[at];
                     unsure |= safe ? 0u : (1u << i);
                 }
             };
@@ -908,7 +928,11 @@ __global__ __launch_bounds__(DSC_THREADS, DSC_OCC) void k_describe(Batch<Describ
             if (unsure) {      // rare: the reference's float64 expression for those samples, and their texels again
 #pragma unroll
                 for (int i = 0; i < PS; i++)
-                    if (unsure & (1u << i)) t[i] = F.tex[lattice_index_exact(lbase + lstep * (pass * PS + i), l1, l2, sInv, c0, c1, c2, F, &oob)];
+                    if (unsure & (1u << i)) {
+                        const unsigned at = lattice_index_exact(lbase + lstep * (pass * PS + i), l1, l2, sInv, c0, c1, c2, F, &oob);
+                        if (TAB) { qi[i] = at; q4[i] = F.tex4[at]; }
+                        else t[i] = F.tex[at];
+                    }
             }
             // DSC_CHUNK points at a time: first their zones, in straight-line code (approximate unit direction, rotated in
             // float32: a guess, verified with guard bands inside eqsp_fast32), so that the table reads of different points
@@ -917,14 +941,40 @@ __global__ __launch_bounds__(DSC_THREADS, DSC_OCC) void k_describe(Batch<Describ
             // what its pass counted in the meantime is never written.)
             unsigned undecided = 0;
             // (the rotation is converted here, behind the requests: nine registers fewer while the texels are in flight)
+            // (TAB: the third row carries the 1 / 511 of the texel's components: z on the unit scale, x and y on any common one)
+            const float zs = TAB ? (1.0f / 511.0f) : 1.0f;
             const float f0 = (float)Rrow[0], f1 = (float)Rrow[1], f2 = (float)Rrow[2], f3 = (float)Rrow[3], f4 = (float)Rrow[4], f5 = (float)Rrow[5],
-                        f6 = (float)Rrow[6], f7 = (float)Rrow[7], f8 = (float)Rrow[8];
+                        f6 = (float)Rrow[6] * zs, f7 = (float)Rrow[7] * zs, f8 = (float)Rrow[8] * zs;
 #pragma unroll
             for (int i0 = 0; i0 < PS; i0 += DSC_CHUNK) {
                 int zone[DSC_CHUNK];
 #pragma unroll
                 for (int u = 0; u < DSC_CHUNK; u++) {
                     if (i0 + u >= PS) { zone[u] = -2; continue; }      // S = 4, 12: the last chunk is short
+                    if (TAB) {
+                        const unsigned q = q4[i0 + u];
+                        // (the builtin's return type is unsigned: without the cast to int a negative component converts as 4e9)
+                        const float gx = (float)(int)__builtin_amdgcn_sbfe(q, 0, 10), gy = (float)(int)__builtin_amdgcn_sbfe(q, 10, 10),
+                                    gz = (float)(int)__builtin_amdgcn_sbfe(q, 20, 10);
+                        const float rx = fmaf(gz, f2, fmaf(gy, f1, gx * f0));
+                        const float ry = fmaf(gz, f5, fmaf(gy, f4, gx * f3));
+                        const float rz = fmaf(gz, f8, fmaf(gy, f7, gx * f6));
+                        const int zn = eqsp_tab32((const EqspTabLds *)&tab, rx, ry, rz);
+                        const unsigned fl = q >> 30;      // 0 a direction, 2 not finite (-> the exact tiers), 3 below the magnitude cut-off (not counted)
+                        zone[u] = fl == 3u ? -2 : (fl == 0u ? zn : -1);
+#ifdef MAD_PROBE_TAB
+                        if (work == 0 && A.dsc8 == nullptr) {
+                            int *o = dbg_tab + ((tid * S) + pass * PS + i0 + u) * 4;
+                            const EqspTabLds *tt = (const EqspTabLds *)&tab;
+                            const int bz_ = min(max(cvt_floor((rz + 1.0f) * 512.f), 0), 1023);
+                            const float xr_ = rx * __builtin_amdgcn_rcpf(fmaxf(fabsf(rx) + fabsf(ry), 1e-30f));
+                            const float p_ = ry >= 0.f ? 1.0f - xr_ : 3.0f + xr_;
+                            const int bp_ = min(max(cvt_floor(p_ * 256.f), 0), 1023);
+                            o[0] = zone[u]; o[1] = (int)q; o[2] = bz_ | (bp_ << 10) | ((int)tt->zbelt[bz_] << 20) | ((int)tt->ptab[tt->zbelt[bz_] & 3][bp_] << 24); o[3] = __float_as_int(p_);
+                        }
+#endif
+                        continue;
+                    }
                     const float4 tx = t[i0 + u];
                     const float inv = __builtin_amdgcn_rcpf(fmaxf(tx.w, 1e-30f));
                     const float gx = tx.x * inv, gy = tx.y * inv, gz = tx.z * inv;
@@ -941,12 +991,34 @@ __global__ __launch_bounds__(DSC_THREADS, DSC_OCC) void k_describe(Batch<Describ
                     undecided |= zone[u] == -1 ? (1u << (i0 + u)) : 0u;
                 }
             }
-            if (undecided) {      // decide later with the exact arithmetic, with full lanes
+            if (TAB) {
+                // The table leaves 3-6 % of the samples open: ~200 per row.  ONE queue reservation per wave (a scan of the lanes' counts;
+                // every thread of an S = 16 row is active) -- a returning LDS atomic per sample on one address serialises the CU.
+                const int cnt = __popc(undecided), ln = (int)lane_id();
+                int inc = cnt;
+#pragma unroll
+                for (int o = 1; o < MAD_WAVE; o <<= 1) {
+                    const int up = __shfl_up(inc, o, MAD_WAVE);
+                    if (ln >= o) inc += up;
+                }
+                const int total = __shfl(inc, MAD_WAVE - 1, MAD_WAVE);
+                if (total) {      // (wave-uniform)
+                    int base = 0;
+                    if (ln == MAD_WAVE - 1) base = atomicAdd(&s_nq, total);
+                    int off = __shfl(base, MAD_WAVE - 1, MAD_WAVE) + inc - cnt;
+#pragma unroll
+                    for (int i = 0; i < PS; i++)
+                        if (undecided & (1u << i)) {
+                            if (off < QCAP) { qidx[off] = qi[i]; qsub16[off] = (unsigned short)(sub_jk + sub_of_i<S, NSUB>(pass * PS + i)); }
+                            off++;
+                        }
+                }
+            } else if (undecided) {      // decide later with the exact arithmetic, with full lanes
 #pragma unroll
                 for (int i = 0; i < PS; i++)
                     if (undecided & (1u << i)) {
                         const int slot = atomicAdd(&s_nq, 1);
-                        if (slot < DSC_QUEUE) { qv[slot] = t[i]; qsub[slot] = sub_jk + sub_of_i<S, NSUB>(pass * PS + i); }
+                        if (slot < QCAP) { qv[slot] = t[i]; qsub[slot] = sub_jk + sub_of_i<S, NSUB>(pass * PS + i); }
                     }
             }
         }
@@ -962,7 +1034,7 @@ __global__ __launch_bounds__(DSC_THREADS, DSC_OCC) void k_describe(Batch<Describ
         return;
     }
     __syncthreads();
-    if (s_nq > DSC_QUEUE) {
+    if (s_nq > QCAP) {
         // more undecided points than the queue holds (not seen in practice): redo the whole row with the exact arithmetic
         __syncthreads();
         for (int i = tid; i < D; i += DSC_THREADS) hist[i] = 0;
@@ -974,6 +1046,20 @@ __global__ __launch_bounds__(DSC_THREADS, DSC_OCC) void k_describe(Batch<Describ
                 if (tx.w < 1e-5f) continue;
                 atomicAdd(&hist[(sub_of_jk<S, NSUB>(j, k) + sub_of_i<S, NSUB>(i)) * Z + describe_exact(&fast, tx, Rrow)], 1);
             }
+    } else if (TAB) {
+        // the samples the table left open: their 16-byte texels, the float32 tier with its 1e-4 guard, the float64 tier behind it
+        const int nq = s_nq;
+        const float f0 = (float)Rrow[0], f1 = (float)Rrow[1], f2 = (float)Rrow[2], f3 = (float)Rrow[3], f4 = (float)Rrow[4], f5 = (float)Rrow[5],
+                    f6 = (float)Rrow[6], f7 = (float)Rrow[7], f8 = (float)Rrow[8];
+        for (int e = tid; e < nq; e += DSC_THREADS) {
+            const float4 tx = F.tex[qidx[e]];
+            if (tx.w < 1e-5f) continue;      // (cannot happen for a queued sample: such texels carry flag 3; kept for symmetry with the slow path)
+            const float inv = __builtin_amdgcn_rcpf(fmaxf(tx.w, 1e-30f));
+            const float gx = tx.x * inv, gy = tx.y * inv, gz = tx.z * inv;
+            int zn = eqsp_fast32(&fast, fmaf(gz, f2, fmaf(gy, f1, gx * f0)), fmaf(gz, f5, fmaf(gy, f4, gx * f3)), fmaf(gz, f8, fmaf(gy, f7, gx * f6)));
+            if (zn < 0) zn = describe_exact(&fast, tx, Rrow);
+            atomicAdd(&hist[(int)qsub16[e] * Z + zn], 1);
+        }
     } else {
         const int nq = s_nq;
         for (int qi = tid; qi < nq; qi += DSC_THREADS) atomicAdd(&hist[qsub[qi] * Z + describe_exact(&fast, qv[qi], Rrow)], 1);
@@ -1032,6 +1118,8 @@ int mad_describe_device_many(mad_ctx *ctx, int n_jobs, const DescribeJob *jobs, 
         B.first[B.n_jobs] = (int)blk;
         const unsigned nblk = (unsigned)blk;
         mad_timer_begin(ctx, MAD_T_DESCRIBE);
+        // the default layout takes the 4-byte texels and the table classifier when the descriptor table has them (MAD_NO_TAB: never)
+        const bool tab = Zd == 16 && ctx->eq_host[1].tab_ok;
         switch (dsc_size == 64 ? 2 * r : -dsc_size) {
             case 4: hipLaunchKernelGGL(k_describe<4>, dim3(nblk), dim3(DSC_THREADS), 0, ctx->stream, B); break;
             case 8: hipLaunchKernelGGL(k_describe<8>, dim3(nblk), dim3(DSC_THREADS), 0, ctx->stream, B); break;
@@ -1041,6 +1129,7 @@ int mad_describe_device_many(mad_ctx *ctx, int n_jobs, const DescribeJob *jobs, 
             case -1: hipLaunchKernelGGL((k_describe<16, 1>), dim3(nblk), dim3(DSC_THREADS), 0, ctx->stream, B); break;
             default:
                 if (Zd > 16) hipLaunchKernelGGL((k_describe<16, 64, 128>), dim3(nblk), dim3(DSC_THREADS), 0, ctx->stream, B);
+                else if (tab) hipLaunchKernelGGL((k_describe<16, 64, 16, true>), dim3(nblk), dim3(DSC_THREADS), 0, ctx->stream, B);
                 else hipLaunchKernelGGL(k_describe<16>, dim3(nblk), dim3(DSC_THREADS), 0, ctx->stream, B);
                 break;
         }

@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256) void k_log_gauss(const T *__restrict__ s01, co
 
 // np.gradient of the smoothed volume (unit spacing, edge_order 1) -> texel {gx, gy, gz, |g|} in float32
 template <typename T>
-__global__ __launch_bounds__(256) void k_grad_tex(const T *__restrict__ g, Dims d, float4 *__restrict__ tex) {
+__global__ __launch_bounds__(256) void k_grad_tex(const T *__restrict__ g, Dims d, float4 *__restrict__ tex, unsigned *__restrict__ tex4) {
     const size_t total = d.count();
     const size_t sx = (size_t)d.n[1] * d.n[2], sy = (size_t)d.n[2];
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -181,7 +181,9 @@ __global__ __launch_bounds__(256) void k_grad_tex(const T *__restrict__ g, Dims 
         if (z == 0) gz = g[i + 1] - g[i]; else if (z == d.n[2] - 1) gz = g[i] - g[i - 1]; else gz = (g[i + 1] - g[i - 1]) / (T)2;
         const float fx = (float)gx, fy = (float)gy, fz = (float)gz;
         const float s = __fadd_rn(__fadd_rn(__fmul_rn(fx, fx), __fmul_rn(fy, fy)), __fmul_rn(fz, fz));
-        tex[i] = make_float4(fx, fy, fz, sqrtf(s));      // correctly rounded (see k_pack_field)
+        const float w = sqrtf(s);      // correctly rounded (see k_pack_field)
+        tex[i] = make_float4(fx, fy, fz, w);
+        tex4[i] = mad_tex4_encode(fx, fy, fz, w);
     }
 }
 
@@ -307,7 +309,8 @@ static int build_octave(mad_ctx *ctx, Octave &O, int R, const double *d_g0, cons
     if (slot >= 0) {
         size_t cnt = 0;
         MAD_TRY(mad_field_alloc(ctx, slot, O.d.n[0], O.d.n[1], O.d.n[2], &cnt));
-        hipLaunchKernelGGL((k_grad_tex<T>), dim3(nb), dim3(256), 0, ctx->stream, (const T *)O.gauss, O.d, (float4 *)ctx->field_mem[slot]);
+        hipLaunchKernelGGL((k_grad_tex<T>), dim3(nb), dim3(256), 0, ctx->stream, (const T *)O.gauss, O.d, (float4 *)ctx->field_mem[slot],
+                           (unsigned *)((float4 *)ctx->field_mem[slot] + cnt));
         MAD_HIP(hipGetLastError());
     }
     MAD_HIP(hipStreamSynchronize(ctx->stream));      // the arena goes away
