@@ -505,13 +505,14 @@ __device__ __forceinline__ unsigned mad_tex4_encode(float x, float y, float z, f
 
 // zone of the direction (x, y, z) -- z on the unit scale, x and y on any common scale -- or -1 (undecided); see EqspTabLds
 __device__ __forceinline__ int eqsp_tab32(const EqspTabLds *t, float x, float y, float z) {
-    const int bz = min(max(cvt_floor((z + 1.0f) * (0.5f * MAD_TAB_ZBINS)), 0), MAD_TAB_ZBINS - 1);
+    const int bz = min(max(cvt_floor(fmaf(z, 0.5f * MAD_TAB_ZBINS, 0.5f * MAD_TAB_ZBINS)), 0), MAD_TAB_ZBINS - 1);
     const int b = t->zbelt[bz];
     const float xr = x * __builtin_amdgcn_rcpf(fmaxf(fabsf(x) + fabsf(y), 1e-30f));
-    const float p = y >= 0.f ? 1.0f - xr : 3.0f + xr;
-    const int bp = min(max(cvt_floor(p * (0.25f * MAD_TAB_PBINS)), 0), MAD_TAB_PBINS - 1);
+    // p = 1 - xr (y >= 0) or 3 + xr (y < 0) = 2 - copysign(1 + xr, y); scaled to bins: 2 B/4 - copysign((1 + xr) B/4, y)
+    const float u = copysignf(fmaf(xr, 0.25f * MAD_TAB_PBINS, 0.25f * MAD_TAB_PBINS), y);
+    const int bp = min(max(cvt_floor(0.5f * MAD_TAB_PBINS - u), 0), MAD_TAB_PBINS - 1);
     const int zn = t->ptab[b & (MAD_TAB_BELTS - 1)][bp];
-    return (b | zn) >= 255 ? -1 : zn;      // (both are bytes: 255 in either means undecided)
+    return (b | zn) >= 255 ? -1 : zn;      // (both are bytes, zones stay below 128: 255 in either means undecided)
 }
 
 // eqsp_classify on the LDS copy of the table

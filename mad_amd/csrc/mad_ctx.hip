@@ -301,7 +301,7 @@ extern "C" int mad_set_eqsp(mad_ctx *ctx, int which, int Z, const double *bounds
         EqspTabLds &T = h.tab;
         memset(&T, 255, sizeof(T));
         static const bool no_tab = getenv("MAD_NO_TAB") != nullptr;      // diagnostic switch
-        h.tab_ok = (h.nbelt <= MAD_TAB_BELTS && !no_tab) ? 1 : 0;
+        h.tab_ok = (h.nbelt <= MAD_TAB_BELTS && Z <= 127 && !no_tab) ? 1 : 0;
         const double g = MAD_TAB_GUARD, pi = 3.14159265358979323846;
         for (int k = 0; h.tab_ok && k < MAD_TAB_ZBINS; k++) {
             const double zlo = -1.0 + (k - 1) * (2.0 / MAD_TAB_ZBINS), zhi = -1.0 + (k + 2) * (2.0 / MAD_TAB_ZBINS);      // the bin and its neighbours
@@ -317,7 +317,8 @@ extern "C" int mad_set_eqsp(mad_ctx *ctx, int which, int Z, const double *bounds
         };
         for (int b = 0; h.tab_ok && b < h.nbelt; b++) {
             const int a0 = h.belt_first[b], cnt = h.belt_count[b];
-            if (cnt == 1) { memset(T.ptab[b], a0, MAD_TAB_PBINS); continue; }      // a polar cap spans every azimuth
+            unsigned char *row = T.ptab[b];
+            if (cnt == 1) { memset(row, a0, MAD_TAB_PBINS); continue; }      // a polar cap spans every azimuth
             const double s_min = std::min(sin(h.ph_lo[b]), sin(h.ph_hi[b]));        // sin(phi) is concave on [0, pi]
             if (!(s_min > 0.05)) continue;                                          // an angular error is an azimuth error / sin(phi)
             const double gt = g / s_min;
@@ -325,7 +326,7 @@ extern "C" int mad_set_eqsp(mad_ctx *ctx, int which, int Z, const double *bounds
                 const double t0 = theta_of((k - 1) * (4.0 / MAD_TAB_PBINS)) - gt, t1 = theta_of((k + 2) * (4.0 / MAD_TAB_PBINS)) + gt;
                 for (int a = a0; a < a0 + cnt; a++) {
                     const bool in = (t0 > h.th_lo[a] && t1 < h.th_hi[a]) || (t0 + 2.0 * pi > h.th_lo[a] && t1 + 2.0 * pi < h.th_hi[a]);
-                    if (in) T.ptab[b][k] = (unsigned char)a;
+                    if (in) row[k] = (unsigned char)a;
                 }
             }
         }

@@ -796,15 +796,24 @@ template <int S, int NSUB> __device__ __forceinline__ int sub_of_i(int i) {
 __device__ int dbg_tab[4096 * 4];
 extern "C" int mad_debug_tab(int *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(dbg_tab), sizeof(int) * 4096 * 4) == hipSuccess ? 0 : -1; }
 #endif
+#ifndef DSC_OCC_TAB
+#define DSC_OCC_TAB 4     // ... of the TAB form (5: 96 registers, 32 of them spilled, 88 -> 102 us per launch)
+#endif
 template <int S, int NSUB = 64, int ZMAX = 16, bool TAB = false>
-__global__ __launch_bounds__(DSC_THREADS, DSC_OCC) void k_describe(Batch<DescribeArgs> B) {
+__global__ __launch_bounds__(DSC_THREADS, TAB ? DSC_OCC_TAB : DSC_OCC) void k_describe(Batch<DescribeArgs> B) {
     const int job = batch_job(B, (int)blockIdx.x);
     const DescribeArgs &A = B.job[job];
     const int bid = (int)blockIdx.x - B.first[job], gdim = B.first[job + 1] - B.first[job];      // this job's part of the grid (multiples of 8)
     __shared__ int hist[NSUB * ZMAX];
     __shared__ int s_oob, s_nq;
     __shared__ double sInv[9];
-    __shared__ EqspFastLds fast;
+    // TAB: the float32 / float64 tiers see 3-4 % of the samples, at the end, in full lanes: they read their tables from global
+    // memory (cache-resident, shared by every workgroup) and the 12 KB image is not staged per row
+    // (TAB: only what eqsp_fast32 reads -- the head of the image: g32, zlut, belt_f, belt_i -- is staged; the float64 tier, a few
+    // samples per row, reads its tables from global memory)
+    __shared__ typename std::conditional<TAB, uint4[(offsetof(EqspFastLds, th_lo) + 15) / 16], EqspFastLds>::type fast_s;
+    const EqspFastLds *const fastp = (const EqspFastLds *)&fast_s;                             // float32 tier
+    const EqspFastLds *const exactp = TAB ? &A.eq->image : (const EqspFastLds *)&fast_s;       // float64 tier
     __shared__ float4 qv[TAB ? 1 : DSC_QUEUE];         // texels the fast classifier could not decide
     __shared__ int qsub[TAB ? 1 : DSC_QUEUE];
     __shared__ typename std::conditional<TAB, EqspTabLds, int>::type tab;
@@ -837,8 +846,8 @@ __global__ __launch_bounds__(DSC_THREADS, DSC_OCC) void k_describe(Batch<Describ
     // dependent fetch from the kernel arguments): both fields' descriptors are read up front and one is selected.
     int64_t row = work;
     if (A.row_perm) row = (int64_t)__builtin_amdgcn_readfirstlane(A.row_perm[work]);
-    eqsp_fast_stage(A.eq, &fast);
-    if (TAB) stage_lds(&tab, &A.eq->tab, sizeof(EqspTabLds));
+    if (TAB) { stage_lds(&tab, &A.eq->tab, sizeof(EqspTabLds)); stage_lds(&fast_s, &A.eq->image, sizeof(fast_s)); }
+    else eqsp_fast_stage(A.eq, (EqspFastLds *)&fast_s);
     int a = (int)row;
     if (A.row_anchor) a = __builtin_amdgcn_readfirstlane(A.row_anchor[row]);
     int oct = A.uniform_octave;
@@ -911,7 +920,7 @@ __global__ __launch_bounds__(DSC_THREADS, DSC_OCC) void k_describe(Batch<Describ
                     const float a0 = fmaf(m0, h0, b0), a1 = fmaf(m0, h3, b1), a2 = fmaf(m0, h6, b2);
                     // nearest voxel = floor(a + 0.5) unless the fraction is within 2e-4 of the tie (then the float64 expression decides)
                     const float fr0 = __builtin_amdgcn_fractf(a0), fr1 = __builtin_amdgcn_fractf(a1), fr2 = __builtin_amdgcn_fractf(a2);
-                    bool safe = (fabsf(fr0 - 0.5f) > 2e-4f) & (fabsf(fr1 - 0.5f) > 2e-4f) & (fabsf(fr2 - 0.5f) > 2e-4f);
+                    bool safe = fminf(fminf(fabsf(fr0 - 0.5f), fabsf(fr1 - 0.5f)), fabsf(fr2 - 0.5f)) > 2e-4f;      // (three subtractions, one v_min3 with |.| modifiers, one compare)
                     int n0 = ic0 + cvt_round(a0), n1 = ic1 + cvt_round(a1), n2 = ic2 + cvt_round(a2);
                     if (decltype(border)::value) {
                         const float q0 = a0 + fc0, q1 = a1 + fc1, q2 = a2 + fc2;
@@ -948,6 +957,7 @@ __global__ __launch_bounds__(DSC_THREADS, DSC_OCC) void k_describe(Batch<Describ
 #pragma unroll
             for (int i0 = 0; i0 < PS; i0 += DSC_CHUNK) {
                 int zone[DSC_CHUNK];
+                unsigned any_flag = 0;      // TAB: the texels of this chunk or-ed together -- bit 31 says "some texel carries a flag"
 #pragma unroll
                 for (int u = 0; u < DSC_CHUNK; u++) {
                     if (i0 + u >= PS) { zone[u] = -2; continue; }      // S = 4, 12: the last chunk is short
@@ -960,8 +970,8 @@ __global__ __launch_bounds__(DSC_THREADS, DSC_OCC) void k_describe(Batch<Describ
                         const float ry = fmaf(gz, f5, fmaf(gy, f4, gx * f3));
                         const float rz = fmaf(gz, f8, fmaf(gy, f7, gx * f6));
                         const int zn = eqsp_tab32((const EqspTabLds *)&tab, rx, ry, rz);
-                        const unsigned fl = q >> 30;      // 0 a direction, 2 not finite (-> the exact tiers), 3 below the magnitude cut-off (not counted)
-                        zone[u] = fl == 3u ? -2 : (fl == 0u ? zn : -1);
+                        zone[u] = zn;      // (flags: below, once per chunk and only where there are any)
+                        any_flag |= q;
 #ifdef MAD_PROBE_TAB
                         if (work == 0 && A.dsc8 == nullptr) {
                             int *o = dbg_tab + ((tid * S) + pass * PS + i0 + u) * 4;
@@ -981,8 +991,16 @@ __global__ __launch_bounds__(DSC_THREADS, DSC_OCC) void k_describe(Batch<Describ
                     const float rx = fmaf(gz, f2, fmaf(gy, f1, gx * f0));
                     const float ry = fmaf(gz, f5, fmaf(gy, f4, gx * f3));
                     const float rz = fmaf(gz, f8, fmaf(gy, f7, gx * f6));
-                    const int zn = eqsp_fast32(&fast, rx, ry, rz);
+                    const int zn = eqsp_fast32(fastp, rx, ry, rz);
                     zone[u] = tx.w < 1e-5f ? -2 : zn;                         // -2: Descriptor.py:190 (zone -1, not counted)
+                }
+                if (TAB && (int)any_flag < 0) {      // rare: 2 = not finite -> the exact tiers, 3 = below the magnitude cut-off, not counted (Descriptor.py:190)
+#pragma unroll
+                    for (int u = 0; u < DSC_CHUNK; u++) {
+                        if (i0 + u >= PS) continue;
+                        const unsigned fl = q4[TAB ? i0 + u : 0] >> 30;
+                        zone[u] = fl == 3u ? -2 : (fl == 0u ? zone[u] : -1);
+                    }
                 }
 #pragma unroll
                 for (int u = 0; u < DSC_CHUNK; u++) {
@@ -1044,7 +1062,7 @@ __global__ __launch_bounds__(DSC_THREADS, DSC_OCC) void k_describe(Batch<Describ
                 bool none = false;
                 const float4 tx = F.tex[lattice_index_exact(lbase + lstep * i, l1, l2, sInv, c0, c1, c2, F, &none)];
                 if (tx.w < 1e-5f) continue;
-                atomicAdd(&hist[(sub_of_jk<S, NSUB>(j, k) + sub_of_i<S, NSUB>(i)) * Z + describe_exact(&fast, tx, Rrow)], 1);
+                atomicAdd(&hist[(sub_of_jk<S, NSUB>(j, k) + sub_of_i<S, NSUB>(i)) * Z + describe_exact(exactp, tx, Rrow)], 1);
             }
     } else if (TAB) {
         // the samples the table left open: their 16-byte texels, the float32 tier with its 1e-4 guard, the float64 tier behind it
@@ -1056,13 +1074,13 @@ __global__ __launch_bounds__(DSC_THREADS, DSC_OCC) void k_describe(Batch<Describ
             if (tx.w < 1e-5f) continue;      // (cannot happen for a queued sample: such texels carry flag 3; kept for symmetry with the slow path)
             const float inv = __builtin_amdgcn_rcpf(fmaxf(tx.w, 1e-30f));
             const float gx = tx.x * inv, gy = tx.y * inv, gz = tx.z * inv;
-            int zn = eqsp_fast32(&fast, fmaf(gz, f2, fmaf(gy, f1, gx * f0)), fmaf(gz, f5, fmaf(gy, f4, gx * f3)), fmaf(gz, f8, fmaf(gy, f7, gx * f6)));
-            if (zn < 0) zn = describe_exact(&fast, tx, Rrow);
+            int zn = eqsp_fast32(fastp, fmaf(gz, f2, fmaf(gy, f1, gx * f0)), fmaf(gz, f5, fmaf(gy, f4, gx * f3)), fmaf(gz, f8, fmaf(gy, f7, gx * f6)));
+            if (zn < 0) zn = describe_exact(exactp, tx, Rrow);
             atomicAdd(&hist[(int)qsub16[e] * Z + zn], 1);
         }
     } else {
         const int nq = s_nq;
-        for (int qi = tid; qi < nq; qi += DSC_THREADS) atomicAdd(&hist[qsub[qi] * Z + describe_exact(&fast, qv[qi], Rrow)], 1);
+        for (int qi = tid; qi < nq; qi += DSC_THREADS) atomicAdd(&hist[qsub[qi] * Z + describe_exact(exactp, qv[qi], Rrow)], 1);
     }
     __syncthreads();
     int ss = 0;      // counts <= 64, 1024 of them: the sum of squares is exact in int32
