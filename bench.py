@@ -704,7 +704,7 @@ def main():
             return max(keys, key=lambda k_: pj[k_].get("total_us", 0.0)) if keys else None
 
         for kn, gname in (("k_pose_bounds", "pose"), ("k_describe", "describe"), ("k_orient", "orient"), ("k_corr_gemm", "correlate"),
-                          ("k_pair_emit", "pairs")):
+                          ("k_pair_emit2", "pairs")):
             kn = summary_of(kn)
             if kn in pj and "fetch_size_bytes_avg" in pj[kn]:
                 traffic[gname] = pj[kn]["fetch_size_bytes_avg"] + pj[kn].get("write_size_bytes_avg", 0.0)
@@ -718,7 +718,7 @@ def main():
             "correlate": ("k_corr_gemm2", "mfma", 2.0 * 1024 * corr, I8_PEAK_TOPS, "TOP/s", 1e12),
             # pose scoring reads a pair (8 B) and writes a count (4 B); its real limit is float64 VALU + LDS latency
             "pose": ("k_pose_bounds + k_pose_lds", "hbm", 12.0 * pairs, HBM_PEAK_GBS, "GB/s", 1e9),
-            "pairs": ("k_pair_count+k_pair_emit", "hbm", 8.0 * corr + 16.0 * pairs, HBM_PEAK_GBS, "GB/s", 1e9),
+            "pairs": ("k_pair_count + k_pair_emit2", "hbm", 8.0 * corr + 16.0 * pairs, HBM_PEAK_GBS, "GB/s", 1e9),
             "topk": ("top-k kernels", "hbm", 12.0 * pairs, HBM_PEAK_GBS, "GB/s", 1e9),
         }
         roofs = {}
@@ -756,10 +756,11 @@ def main():
                              how="mad_probe_peaks, untimed, same process and device: a 1 GiB -> 1 GiB streaming copy kernel (read + write bytes) and "
                                  "v_mfma_i32_16x16x64_i8 from registers, 8 independent accumulators per wave, 4 waves per SIMD; spec figures from MI355X_MICROARCH.md")
         roof["largest_share_of_device_time"] = max(groups, key=lambda g: groups[g]["ms_total"])
-        roof["note"] = ("HBM traffic (PMC) is below the algorithmic bytes: anchors are worked on in Morton order, so neighbouring rows meet in "
-                        "the XCD's L2 (88 % hits), no wasted re-reads; what the kernel waits for is not HBM but the scattered 16-byte texel "
-                        "requests between a CU and its L2 (~4 clocks per lane-load per CU whatever the texel size: a 4-byte-texel probe build "
-                        "runs only 14 % faster), and its own arithmetic takes about half of the SIMD issue cycles (DESIGN.md section 6b)")
+        roof["note"] = ("achieved = SURVEY 8(d)'s ALGORITHMIC 51 200 B per row (4 096 samples x 12 B gathered + 2 048 B written) over the launch time. "
+                        "Since round 3 the kernel gathers 4-byte texels (a quantised unit direction; 16 KB per row) and fetches the 16-byte texel "
+                        "only for the 3-4 % of samples its table classifier leaves open, so the bytes it really moves are about a third of the "
+                        "algorithmic figure; anchors are worked on in Morton order and neighbouring rows meet in the XCD's L2.  What it waits for is "
+                        "not HBM but the per-lane request path of fully divergent loads and the chain of phases of a row (DESIGN.md section 6c)")
         l_hi_mean = float(np.mean([s["l_hi"] for s in stats])) if stats else 0.0
         pts = pairs * l_hi_mean      # transformed hi-cloud points per step
         t_pose = groups["pose"]["ms_total"] / n_serial * 1e-3
