@@ -223,6 +223,7 @@ struct mad_set {
     // per row
     DevBuf row_anchor, row_main, row_sec, row_R, row_Rinv, row_meta, dsc, dsc8, norm;
     DevBuf row_perm;             // k-th row in working order (rows of spatially neighbouring anchors next to each other)
+    DevBuf row_rec;              // DscRowRec of the k-th row in working order
     DevBuf dev_n;                // view: int32[4] on the device = {rows, rows out of int8 range, rejects, describe overflow}
     int64_t n_rows_host = -1;    // host copy of dev_n[0]; -1 until the asynchronous read-back has been waited for
     bool range_bad = false;      // a loaded row held a count outside the int8 range
@@ -230,7 +231,7 @@ struct mad_set {
     // what mad_set_build needs to repeat the describe stage when the hint was too small
     FieldDev last_f[2];
     int last_r = 0;
-    bool last_perm = false;
+    bool last_perm = false, last_rec = false;
     int pinned_slot = 0;
     hipEvent_t ready = nullptr;  // recorded behind mad_set_export: a rebuild on another lane (mad_set_build_many) waits for that read
     // cell list over ALL anchors (cell = dist), only built when a cloud does not fit LDS
@@ -288,6 +289,18 @@ int mad_scan_i32(mad_ctx *ctx, const int32_t *in, int32_t *out, int64_t n);
 // single-launch exclusive scan for n <= 65536 with the length read on the device; out[*n] = total, also to *total_out
 void mad_scan_small(mad_ctx *ctx, const int32_t *in, int32_t *out, const int32_t *d_n, int32_t *total_out, int n_host = 0);
 
+// What k_describe starts a row from, as one 128-byte record in WORKING order (the k-th record belongs to the k-th row the kernel
+// takes): written with the rows by k_orient_rows*, fetched with one vector load a row ahead.
+struct alignas(16) DscRowRec {
+    int32_t row;           // the row (where its descriptor goes)
+    int32_t c[3];          // voxel coordinates of its anchor
+    int32_t octave;
+    int32_t pad0[3];
+    double inv[9];         // inv(Rfinal) (np.linalg.inv of Descriptor.py:132, by cofactors)
+    int32_t pad1[6];
+};
+static_assert(sizeof(DscRowRec) == 128, "DscRowRec is read as 32 dwords");
+
 // implemented in mad_orient.hip; used by the set API in mad_match.hip.  Both are fully asynchronous.
 struct OrientOut {
     int32_t *row_anchor, *row_main, *row_sec;
@@ -300,6 +313,7 @@ struct OrientOut {
     // nullable: the anchors in working order (a permutation of 0 .. n-1) and, written with the rows, the rows in that order
     const int32_t *anc_order = nullptr;
     int32_t *row_perm = nullptr;
+    DscRowRec *row_rec = nullptr;      // nullable: the rows' records for k_describe, in working order
     bool counters_zeroed = false;      // the caller has already enqueued the zeroing of d_n_rows / d_n_reject
     int32_t *d_n_rows;       // device: number of rows produced
     int32_t *d_n_reject;     // device, nullable: anchors refused at the border
@@ -322,6 +336,7 @@ struct DescribeJob {
     const int32_t *d_row_anchor;
     const double *d_row_R, *d_row_Rinv;
     const int32_t *d_row_perm = nullptr;      // nullable: workgroup k describes row d_row_perm[k]
+    const DscRowRec *d_row_rec = nullptr;     // nullable: the same rows' records (k_orient_rows* wrote them), in that order
     const int32_t *d_n_rows;
     int64_t grid_rows;
     int32_t *d_overflow;
@@ -361,15 +376,34 @@ static inline int64_t mad_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / 
 // ---------------------------------------------------------------------------
 #ifdef __HIPCC__
 
-__device__ __forceinline__ int wave_sum_i32(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, MAD_WAVE);
+// Wave-wide integer collectives on the DPP data path (row shifts, row broadcasts: vector-ALU instructions) rather than
+// ds_bpermute: a shuffle is an LDS instruction, and six dependent ones queue behind whatever the workgroup has in flight there
+// (3 500 cycles for the scan of k_describe's queue reservation, measured with MAD_PROBE_STAMPS).  Integer sums and maxima are
+// order-independent, so the results are those of the shuffle forms.
+template <int CTRL, int ROW_MASK, bool BOUND> __device__ __forceinline__ int dpp_i32(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, BOUND);      // lanes without a source (or masked out) read 0
+}
+// inclusive prefix sum over the 64 lanes
+__device__ __forceinline__ int wave_incl_scan_i32(int v) {
+    v += dpp_i32<0x111, 0xf, true>(v);      // row_shr:1
+    v += dpp_i32<0x112, 0xf, true>(v);      // row_shr:2
+    v += dpp_i32<0x114, 0xf, true>(v);      // row_shr:4
+    v += dpp_i32<0x118, 0xf, true>(v);      // row_shr:8   -- inclusive within each row of 16
+    v += dpp_i32<0x142, 0xa, false>(v);     // row_bcast:15 into rows 1 and 3
+    v += dpp_i32<0x143, 0xc, false>(v);     // row_bcast:31 into rows 2 and 3
     return v;
 }
-__device__ __forceinline__ int wave_max_i32(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, MAD_WAVE));
-    return v;
+__device__ __forceinline__ int wave_sum_i32(int v) {
+    return __builtin_amdgcn_readlane(wave_incl_scan_i32(v), MAD_WAVE - 1);
+}
+__device__ __forceinline__ int wave_max_i32(int v) {      // (values >= INT_MIN: lanes without a source contribute the lane's own value)
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x111, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x112, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x114, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x118, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x142, 0xa, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x143, 0xc, 0xf, false));
+    return __builtin_amdgcn_readlane(v, MAD_WAVE - 1);
 }
 __device__ __forceinline__ double wave_sum_f64(double v) {
 #pragma unroll
@@ -389,12 +423,7 @@ __device__ __forceinline__ unsigned long long lanemask_lt() { return (1ull << la
 // *total gets the block sum.
 __device__ __forceinline__ int block_excl_scan(int v, int *warp_tot, int *total) {
     const int lane = lane_id(), w = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    int inc = v;
-#pragma unroll
-    for (int o = 1; o < MAD_WAVE; o <<= 1) {
-        int t = __shfl_up(inc, o, MAD_WAVE);
-        if (lane >= o) inc += t;
-    }
+    const int inc = wave_incl_scan_i32(v);
     if (lane == MAD_WAVE - 1) warp_tot[w] = inc;
     __syncthreads();
     if (threadIdx.x == 0) {

@@ -2667,7 +2667,7 @@ extern "C" void mad_set_destroy(mad_ctx *ctx, mad_set *s) {
         if (ctx->match.shard_lo == s) ctx->match.shard_lo = nullptr;
     }
     DevBuf *bufs[] = {&s->anc_blob, &s->row_anchor, &s->row_main, &s->row_sec, &s->row_R, &s->row_Rinv, &s->row_meta, &s->dsc,
-                      &s->dsc8, &s->norm, &s->row_perm, &s->cell_start, &s->cell_pts, &s->cell_ids};      // anc_* and dev_n are views
+                      &s->dsc8, &s->norm, &s->row_perm, &s->row_rec, &s->cell_start, &s->cell_pts, &s->cell_ids};      // anc_* and dev_n are views
     for (DevBuf *b : bufs) mad_release(*b);
     if (s->host_stage) (void)hipHostFree(s->host_stage);
     if (s->ready) (void)hipEventDestroy(s->ready);
@@ -2695,6 +2695,7 @@ static int set_rows(mad_ctx *ctx, const mad_set *cs, int64_t *n_rows) {
             J.d_anc_coords = (const int32_t *)s->anc_coords.p; J.d_anc_octave = (const int32_t *)s->anc_octave.p; J.uniform_octave = 0;
             J.d_row_anchor = (const int32_t *)s->row_anchor.p; J.d_row_R = (const double *)s->row_R.p; J.d_row_Rinv = (const double *)s->row_Rinv.p;
             J.d_row_perm = s->last_perm ? (const int32_t *)s->row_perm.p : nullptr;
+            J.d_row_rec = s->last_rec ? (const DscRowRec *)s->row_rec.p : nullptr;
             J.d_n_rows = (const int32_t *)s->dev_n.p; J.grid_rows = s->cap_rows; J.d_overflow = (int32_t *)s->dev_n.p + 3;
             J.d_dsc = (int16_t *)s->dsc.p; J.d_dsc8 = (int8_t *)s->dsc8.p; J.d_norm = (double *)s->norm.p;
             MAD_TRY(mad_describe_device_many(ctx, 1, &J, s->last_r));
@@ -2825,6 +2826,7 @@ static int set_reserve_rows(mad_ctx *ctx, mad_set *s, int64_t cap) {
     MAD_TRY(mad_reserve(ctx, s->dsc8, (size_t)cap_pad * s->D));
     MAD_TRY(mad_reserve(ctx, s->norm, (size_t)cap_pad * 8));
     MAD_TRY(mad_reserve(ctx, s->row_perm, (size_t)cap_pad * 4));
+    MAD_TRY(mad_reserve(ctx, s->row_rec, (size_t)cap_pad * sizeof(DscRowRec)));
     return MAD_OK;
 }
 
@@ -2898,12 +2900,15 @@ extern "C" int mad_set_build_many(mad_ctx *ctx, int n_sets, mad_set *const *sets
         out.anc_index = (const int32_t *)s->anc_index.p; out.anc_octave = (const int32_t *)s->anc_octave.p;
         out.anc_order = ctx->spatial_order ? (const int32_t *)s->anc_order.p : nullptr;
         out.row_perm = ctx->spatial_order ? (int32_t *)s->row_perm.p : nullptr;
+        out.row_rec = (DscRowRec *)s->row_rec.p;
         out.counters_zeroed = true;
         DescribeJob &Q = dj[i];
         Q.f[0] = J.f[0]; Q.f[1] = J.f[1];
         Q.d_anc_coords = J.d_coords; Q.d_anc_octave = J.d_octave; Q.uniform_octave = 0;
         Q.d_row_anchor = out.row_anchor; Q.d_row_R = out.row_R; Q.d_row_Rinv = out.row_Rinv; Q.d_row_perm = out.row_perm; Q.d_n_rows = out.d_n_rows;
+        Q.d_row_rec = out.row_rec;
         s->last_perm = out.row_perm != nullptr;
+        s->last_rec = out.row_rec != nullptr;
         // the describe launch is sized from the row count of this set's previous build when there is one
         Q.grid_rows = n <= 0 ? 0 : (s->rows_hint > 0 ? std::min<int64_t>(s->cap_rows, s->rows_hint + s->rows_hint / 8 + 64) : s->cap_rows);
         Q.d_overflow = (int32_t *)s->dev_n.p + 3;

@@ -390,7 +390,23 @@ struct RowsArgs {
     const int32_t *order;          // nullable: anchors in working order
     int32_t *perm_off;             // with order: n + 1 row offsets in working order
     int32_t *row_perm;             // with order: the rows in working order
+    DscRowRec *row_rec;            // nullable: what k_describe starts a row from, in working order
+    const int32_t *coords;         // with row_rec: the anchors' voxel coordinates
+    int uniform_octave;            // ... and their octave when anc_octave is null
 };
+
+// the record of one row (k_describe reads it with one 128-byte load)
+__device__ __forceinline__ void put_row_rec(const RowsArgs &A, int64_t pos, int row, int a, const double *R) {
+    DscRowRec &q = A.row_rec[pos];
+    q.row = row;
+    q.c[0] = A.coords[3 * a]; q.c[1] = A.coords[3 * a + 1]; q.c[2] = A.coords[3 * a + 2];
+    q.octave = A.anc_octave ? A.anc_octave[a] : A.uniform_octave;
+    if (A.row_Rinv) {
+        for (int i = 0; i < 9; i++) q.inv[i] = A.row_Rinv[9 * (int64_t)row + i];      // (just written by this thread)
+    } else {
+        mad_mat3_inv(R, q.inv);
+    }
+}
 
 // row offsets of every job: exclusive scan of its anchors' row counts, one workgroup per job
 __global__ __launch_bounds__(1024) void k_orient_scan(Batch<RowsArgs> B) {
@@ -456,6 +472,7 @@ __global__ __launch_bounds__(256) void k_orient_rows(Batch<RowsArgs> B, int fan,
     }
     if (A.row_Rinv) mad_mat3_inv(o, A.row_Rinv + 9 * row);      // inv(lo.Rfinal) of MaD.py:438, once per row
     if (A.row_meta) { A.row_meta[3 * row] = A.anc_index[a]; A.row_meta[3 * row + 1] = A.anc_octave[a]; A.row_meta[3 * row + 2] = mb; }
+    if (A.row_rec) put_row_rec(A, A.order ? A.perm_off[p] + s : row, (int)row, a, o);
 }
 
 // k_orient_scan + k_orient_rows in ONE launch (round 3): every 1024-thread workgroup forms the exclusive scan of its job's
@@ -511,6 +528,7 @@ __global__ __launch_bounds__(1024) void k_orient_rows_scan(Batch<RowsArgs> B, in
     }
     if (A.row_Rinv) mad_mat3_inv(o, A.row_Rinv + 9 * row);      // inv(lo.Rfinal) of MaD.py:438, once per row
     if (A.row_meta) { A.row_meta[3 * row] = A.anc_index[a]; A.row_meta[3 * row + 1] = A.anc_octave[a]; A.row_meta[3 * row + 2] = mb; }
+    if (A.row_rec) put_row_rec(A, A.order ? s_perm[pl] + sl : row, (int)row, a, o);
 }
 
 // Runs a1-a8 for the anchor lists of n_jobs structures (coordinates and octaves already on the device) in one k_orient
@@ -564,6 +582,8 @@ static int orient_batch(mad_ctx *ctx, int n_jobs, const OrientJob *jobs, int r, 
         Q.anc_index = J.out.anc_index; Q.anc_octave = J.out.anc_octave;
         Q.n_rows = J.out.d_n_rows;
         Q.order = A.order; Q.perm_off = scratch<int32_t>(ctx, S_PERM_OFF) + a0 + j; Q.row_perm = J.out.row_perm;
+        Q.row_rec = J.out.row_rec; Q.coords = J.d_coords; Q.uniform_octave = J.uniform_octave;
+        if (!Q.anc_octave) Q.anc_octave = J.d_octave;
         R.first[j] = (int)blk;
         a0 += J.n;
         blk += one_launch ? mad_ceil_div((int64_t)J.n, 1024 / fan) : mad_ceil_div((int64_t)J.n * fan, 256);
@@ -712,8 +732,9 @@ struct DescribeArgs {
     const double *row_R;           // n_rows x 9
     const double *row_Rinv;        // n_rows x 9: inv(Rfinal) by cofactors (mad_mat3_inv), or nullptr -> formed here
     const int32_t *row_perm;       // nullable: the k-th workgroup takes row row_perm[k] (rows of neighbouring anchors side by side)
+    const DscRowRec *row_rec;      // nullable: the k-th record = everything the k-th row in working order starts from
     const int32_t *n_rows;         // device: number of rows
-    int32_t *overflow;             // device: set when the grid was too small for *n_rows
+    int32_t *overflow;             // device: set when the launch was sized for fewer rows than *n_rows
     int r;
     const EqspDev *eq;
     int16_t *dsc;                  // n_rows x 64*Z
@@ -796,6 +817,15 @@ template <int S, int NSUB> __device__ __forceinline__ int sub_of_i(int i) {
 __device__ int dbg_tab[4096 * 4];
 extern "C" int mad_debug_tab(int *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(dbg_tab), sizeof(int) * 4096 * 4) == hipSuccess ? 0 : -1; }
 #endif
+#ifdef MAD_PROBE_STAMPS      // diagnostic build: s_memtime at the phases of every row's workgroup (tools/probe_describe.py)
+__device__ long long dsc_stamps[16384 * 8];
+#define DSC_STAMP(k) do { __builtin_amdgcn_sched_barrier(0); if (threadIdx.x == 0 && blockIdx.x < 16384) dsc_stamps[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+extern "C" int mad_debug_dsc_stamps(long long *out, int n) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(dsc_stamps), (size_t)n * 8) == hipSuccess ? 0 : -1;
+}
+#else
+#define DSC_STAMP(k) do { } while (0)
+#endif
 #ifndef DSC_OCC_TAB
 #define DSC_OCC_TAB 4     // ... of the TAB form (5: 96 registers, 32 of them spilled, 88 -> 102 us per launch)
 #endif
@@ -806,7 +836,8 @@ __global__ __launch_bounds__(DSC_THREADS, TAB ? DSC_OCC_TAB : DSC_OCC) void k_de
     const int bid = (int)blockIdx.x - B.first[job], gdim = B.first[job + 1] - B.first[job];      // this job's part of the grid (multiples of 8)
     __shared__ int hist[NSUB * ZMAX];
     __shared__ int s_oob, s_nq;
-    __shared__ double sInv[9];
+    __shared__ int s_part[DSC_THREADS / MAD_WAVE];
+    __shared__ __align__(16) int s_rec[32];      // the row's DscRowRec
     // TAB: the float32 / float64 tiers see 3-4 % of the samples, at the end, in full lanes: they read their tables from global
     // memory (cache-resident, shared by every workgroup) and the 12 KB image is not staged per row
     // (TAB: only what eqsp_fast32 reads -- the head of the image: g32, zlut, belt_f, belt_i -- is staged; the float64 tier, a few
@@ -841,54 +872,75 @@ __global__ __launch_bounds__(DSC_THREADS, TAB ? DSC_OCC_TAB : DSC_OCC) void k_de
     }
     const int64_t work = (int64_t)(bid & 7) * chunk + (bid >> 3);
     if ((int64_t)(bid >> 3) >= chunk || work >= n_rows) return;
-    // row -> anchor -> octave, coordinates: a chain of dependent loads before the first texel can be asked for.  Written so that
-    // every link is a SCALAR load (the conditional-pointer forms compiled into flat vector loads, and the field into a
-    // dependent fetch from the kernel arguments): both fields' descriptors are read up front and one is selected.
-    int64_t row = work;
-    if (A.row_perm) row = (int64_t)__builtin_amdgcn_readfirstlane(A.row_perm[work]);
+    DSC_STAMP(0);
     if (TAB) { stage_lds(&tab, &A.eq->tab, sizeof(EqspTabLds)); stage_lds(&fast_s, &A.eq->image, sizeof(fast_s)); }
     else eqsp_fast_stage(A.eq, (EqspFastLds *)&fast_s);
-    int a = (int)row;
-    if (A.row_anchor) a = __builtin_amdgcn_readfirstlane(A.row_anchor[row]);
-    int oct = A.uniform_octave;
-    if (A.anc_octave) oct = __builtin_amdgcn_readfirstlane(A.anc_octave[a]);
     const FieldDev F0 = A.f[0], F1 = A.f[1];
+    const int Z = A.eq->Z;
+    const int D = NSUB * Z;            // S = 2 r samples per axis (16), NSUB sub-regions of Z zones each
+    for (int i = tid; i < D; i += DSC_THREADS) hist[i] = 0;
+    // What a row starts from -- its index, its anchor's coordinates and octave, inv(Rfinal) -- is one 128-byte record (DscRowRec,
+    // written with the rows by k_orient_rows* in WORKING order) that 32 lanes fetch with one vector load and park in LDS, next
+    // to the staging of the tables.  Before (round 2) it was a chain of dependent scalar loads, row_perm -> row_anchor -> octave,
+    // coordinates, inv(R): with the staging 7 700 of a row's 35 600 cycles (MAD_PROBE_STAMPS).  Without records (mad_describe
+    // on rows of the caller) thread 0 walks that chain and forms the record itself.
+    // (Round 3 also built this kernel as a loop -- 4 workgroups per CU walking the rows, tables staged once, the next row's
+    // record fetched a row ahead: 13 % fewer vector instructions and 20 % MORE time per launch at any grid size, with and
+    // without staggered starts.  Not understood; dropped.)
+    const int32_t *const p_perm = A.row_perm, *const p_anchor = A.row_anchor, *const p_coords = A.anc_coords, *const p_octave = A.anc_octave;
+    const double *const p_R = A.row_R, *const p_Rinv = A.row_Rinv;
+    const int uni_octave = A.uniform_octave;
+    auto chain_record = [=](int64_t w, int *rec) {      // thread 0 only
+        const int r = p_perm ? p_perm[w] : (int)w;
+        const int an = p_anchor ? p_anchor[r] : r;
+        rec[0] = r;
+        rec[1] = p_coords[3 * an]; rec[2] = p_coords[3 * an + 1]; rec[3] = p_coords[3 * an + 2];
+        rec[4] = p_octave ? p_octave[an] : uni_octave;
+        double *inv = (double *)(rec + 8);
+        // Rfinal's inverse (np.linalg.inv, Descriptor.py:132; cofactors)
+        if (p_Rinv) {
+            for (int i = 0; i < 9; i++) inv[i] = p_Rinv[9 * (int64_t)r + i];
+        } else {
+            double m[9];
+            mad_mat3_inv(p_R + 9 * (int64_t)r, m);
+            for (int i = 0; i < 9; i++) inv[i] = m[i];
+        }
+    };
+    const int *const recs = (const int *)A.row_rec;
+    if (recs) {
+        if (tid < 32) s_rec[tid] = recs[work * 32 + tid];
+    } else if (tid == 0) chain_record(work, s_rec);
+    if (tid == 0) { s_oob = 0; s_nq = 0; }
+    __syncthreads();      // the histogram is zero, the flags are reset, the record is there
+    const int64_t row = __builtin_amdgcn_readfirstlane(s_rec[0]);
+    const int oct = __builtin_amdgcn_readfirstlane(s_rec[4]);
+    const double *const sInv = (const double *)&s_rec[8];
     FieldDev F;
     F.tex = oct == 1 ? F1.tex : F0.tex; F.nx = oct == 1 ? F1.nx : F0.nx; F.ny = oct == 1 ? F1.ny : F0.ny; F.nz = oct == 1 ? F1.nz : F0.nz;
     F.tex4 = oct == 1 ? F1.tex4 : F0.tex4;
-    const int Z = A.eq->Z;
-    const int D = NSUB * Z;            // S = 2 r samples per axis (16), NSUB sub-regions of Z zones each
-
-    // Rfinal and its inverse (np.linalg.inv, Descriptor.py:132; cofactors): the row is uniform over the workgroup, so these
-    // are scalar loads; nobody waits for a thread 0 to publish them through LDS
     const double *Rrow = A.row_R + 9 * row;
-    double inv9[9];
-    if (A.row_Rinv) {
-        for (int i = 0; i < 9; i++) inv9[i] = A.row_Rinv[9 * row + i];
-    } else {
-        mad_mat3_inv(Rrow, inv9);
-    }
-    if (tid == 0) {
-        s_oob = 0; s_nq = 0;
-        for (int i = 0; i < 9; i++) sInv[i] = inv9[i];      // the rare float64 paths read it from here, not from 18 live registers
-    }
-    for (int i = tid; i < D; i += DSC_THREADS) hist[i] = 0;
-    __syncthreads();
+    DSC_STAMP(1);
 
-    const int ic0 = __builtin_amdgcn_readfirstlane(A.anc_coords[3 * a]), ic1 = __builtin_amdgcn_readfirstlane(A.anc_coords[3 * a + 1]),
-              ic2 = __builtin_amdgcn_readfirstlane(A.anc_coords[3 * a + 2]);
-    const double c0 = (double)ic0, c1 = (double)ic1, c2 = (double)ic2;
-    const float h0 = (float)inv9[0], h1 = (float)inv9[1], h2 = (float)inv9[2], h3 = (float)inv9[3], h4 = (float)inv9[4], h5 = (float)inv9[5],
-                h6 = (float)inv9[6], h7 = (float)inv9[7], h8 = (float)inv9[8];
+    const int ic0 = __builtin_amdgcn_readfirstlane(s_rec[1]), ic1 = __builtin_amdgcn_readfirstlane(s_rec[2]),
+              ic2 = __builtin_amdgcn_readfirstlane(s_rec[3]);
+    const float h0 = (float)sInv[0], h1 = (float)sInv[1], h2 = (float)sInv[2], h3 = (float)sInv[3], h4 = (float)sInv[4], h5 = (float)sInv[5],
+                h6 = (float)sInv[6], h7 = (float)sInv[7], h8 = (float)sInv[8];
     // this thread's (j, k) column of the S^3 lattice; threads beyond S*S idle (S <= 16)
     const int j = tid / S, k = tid % S;
     const bool active = tid < S * S;
     // lattice coordinate along an axis = lbase + lstep * index (Descriptor.py:34-35)
-    const double lbase = oct == 0 ? (double)(-2 * A.r + 1) : -A.r + 0.5, lstep = oct == 0 ? 2.0 : 1.0;
-    const double l1 = lbase + lstep * j, l2 = lbase + lstep * k;
+    // (float32 here: half-integers below 32, exact.  The float64 forms the rare exact paths need are made inside those paths, from
+    // values the optimiser cannot see through, so that they do not occupy registers outside them)
+    const float lbf = oct == 0 ? (float)(-2 * A.r + 1) : (float)-A.r + 0.5f, lsf = oct == 0 ? 2.0f : 1.0f;
+    auto exact_index = [&](int i, bool *left) -> unsigned {
+        float lb = lbf, ls = lsf;
+        asm volatile("" : "+v"(lb), "+v"(ls));
+        const double lbase = (double)lb, lstep = (double)ls;
+        return lattice_index_exact(lbase + lstep * i, lbase + lstep * j, lbase + lstep * k, sInv, (double)ic0, (double)ic1, (double)ic2, F, left);
+    };
     // The rotated lattice stays within `reach` voxels of the anchor.  When that ball lies inside the grid with a voxel to
     // spare (every row of an anchor the Orientator accepted, unless it hugs the border) no sample can leave the grid.
-    const int reach = (int)(1.7320508 * fabs(lbase)) + 2;
+    const int reach = (int)(1.7320508 * fabs((double)lbf)) + 2;
     const bool interior = ic0 - reach >= 1 && ic0 + reach <= F.nx - 2 && ic1 - reach >= 1 && ic1 + reach <= F.ny - 2 &&
                           ic2 - reach >= 1 && ic2 + reach <= F.nz - 2;      // uniform over the workgroup
     // The S samples of a thread go through in DSC_PASSES passes: the texel requests of a pass all go out before its first texel is
@@ -902,9 +954,8 @@ __global__ __launch_bounds__(DSC_THREADS, TAB ? DSC_OCC_TAB : DSC_OCC) void k_de
         // Straight-line code: the (j, k) part of inv(R) l is formed once, every sample adds one fused multiply-add per
         // axis, and the texel requests go out as the indices appear (clamped into the grid in a border row: a sample that
         // needed the clamp is marked unsure and fetched again below).
-        const float m1 = (float)l1, m2 = (float)l2;
+        const float m1 = lbf + lsf * (float)j, m2 = lbf + lsf * (float)k;      // exact
         const float b0 = fmaf(m1, h1, m2 * h2), b1 = fmaf(m1, h4, m2 * h5), b2 = fmaf(m1, h7, m2 * h8);
-        const float lbf = (float)lbase, lsf = (float)lstep;
         const int sub_jk = sub_of_jk<S, NSUB>(j, k);      // Descriptor.py:44-93
 #pragma unroll
         for (int pass = 0; pass < NP; pass++) {
@@ -934,11 +985,12 @@ __global__ __launch_bounds__(DSC_THREADS, TAB ? DSC_OCC_TAB : DSC_OCC) void k_de
                 }
             };
             if (interior) guess(std::false_type()); else guess(std::true_type());
+            DSC_STAMP(2);
             if (unsure) {      // rare: the reference's float64 expression for those samples, and their texels again
 #pragma unroll
                 for (int i = 0; i < PS; i++)
                     if (unsure & (1u << i)) {
-                        const unsigned at = lattice_index_exact(lbase + lstep * (pass * PS + i), l1, l2, sInv, c0, c1, c2, F, &oob);
+                        const unsigned at = exact_index(pass * PS + i, &oob);
                         if (TAB) { qi[i] = at; q4[i] = F.tex4[at]; }
                         else t[i] = F.tex[at];
                     }
@@ -1009,21 +1061,17 @@ __global__ __launch_bounds__(DSC_THREADS, TAB ? DSC_OCC_TAB : DSC_OCC) void k_de
                     undecided |= zone[u] == -1 ? (1u << (i0 + u)) : 0u;
                 }
             }
+            DSC_STAMP(3);
             if (TAB) {
                 // The table leaves 3-6 % of the samples open: ~200 per row.  ONE queue reservation per wave (a scan of the lanes' counts;
                 // every thread of an S = 16 row is active) -- a returning LDS atomic per sample on one address serialises the CU.
-                const int cnt = __popc(undecided), ln = (int)lane_id();
-                int inc = cnt;
-#pragma unroll
-                for (int o = 1; o < MAD_WAVE; o <<= 1) {
-                    const int up = __shfl_up(inc, o, MAD_WAVE);
-                    if (ln >= o) inc += up;
-                }
-                const int total = __shfl(inc, MAD_WAVE - 1, MAD_WAVE);
+                const int cnt = __popc(undecided);
+                const int inc = wave_incl_scan_i32(cnt);      // (DPP: a shuffle is an LDS instruction and waits behind the histogram's atomics)
+                const int total = __builtin_amdgcn_readlane(inc, MAD_WAVE - 1);
                 if (total) {      // (wave-uniform)
                     int base = 0;
-                    if (ln == MAD_WAVE - 1) base = atomicAdd(&s_nq, total);
-                    int off = __shfl(base, MAD_WAVE - 1, MAD_WAVE) + inc - cnt;
+                    if (lane_id() == 0) base = atomicAdd(&s_nq, total);
+                    int off = __builtin_amdgcn_readfirstlane(base) + inc - cnt;
 #pragma unroll
                     for (int i = 0; i < PS; i++)
                         if (undecided & (1u << i)) {
@@ -1041,18 +1089,18 @@ __global__ __launch_bounds__(DSC_THREADS, TAB ? DSC_OCC_TAB : DSC_OCC) void k_de
             }
         }
     }
+    DSC_STAMP(4);
     if (oob) s_oob = 1;
     __syncthreads();
-    if (s_oob) {      // Descriptor.py:142-149: the whole descriptor is zero
+    DSC_STAMP(5);
+    const bool dead = s_oob != 0;      // Descriptor.py:142-149: a sample left the grid -> the whole descriptor is zero
+    if (dead) {
         for (int i = tid; i < D; i += DSC_THREADS) A.dsc[row * D + i] = 0;
         if (A.dsc8) {
             for (int i = tid; i < D; i += DSC_THREADS) A.dsc8[row * D + i] = 0;
             if (tid == 0) A.norm[row] = 0.0;
         }
-        return;
-    }
-    __syncthreads();
-    if (s_nq > QCAP) {
+    } else if (s_nq > QCAP) {
         // more undecided points than the queue holds (not seen in practice): redo the whole row with the exact arithmetic
         __syncthreads();
         for (int i = tid; i < D; i += DSC_THREADS) hist[i] = 0;
@@ -1060,7 +1108,7 @@ __global__ __launch_bounds__(DSC_THREADS, TAB ? DSC_OCC_TAB : DSC_OCC) void k_de
         if (active)
             for (int i = 0; i < S; i++) {      // not unrolled: indices again from the float64 expression
                 bool none = false;
-                const float4 tx = F.tex[lattice_index_exact(lbase + lstep * i, l1, l2, sInv, c0, c1, c2, F, &none)];
+                const float4 tx = F.tex[exact_index(i, &none)];
                 if (tx.w < 1e-5f) continue;
                 atomicAdd(&hist[(sub_of_jk<S, NSUB>(j, k) + sub_of_i<S, NSUB>(i)) * Z + describe_exact(exactp, tx, Rrow)], 1);
             }
@@ -1083,24 +1131,26 @@ __global__ __launch_bounds__(DSC_THREADS, TAB ? DSC_OCC_TAB : DSC_OCC) void k_de
         for (int qi = tid; qi < nq; qi += DSC_THREADS) atomicAdd(&hist[qsub[qi] * Z + describe_exact(exactp, qv[qi], Rrow)], 1);
     }
     __syncthreads();
+    DSC_STAMP(6);
     int ss = 0;      // counts <= 64, 1024 of them: the sum of squares is exact in int32
     for (int i = tid; i < D; i += DSC_THREADS) {
         const int v = hist[i];
+        if (dead) continue;
         A.dsc[row * D + i] = (int16_t)v;
         if (A.dsc8) A.dsc8[row * D + i] = (int8_t)v;
         ss += v * v;
     }
-    if (A.dsc8) {
+    if (A.dsc8 && !dead) {
         ss = wave_sum_i32(ss);
-        __syncthreads();
-        if (lane_id() == 0) hist[tid >> 6] = ss;
+        if (lane_id() == 0) s_part[tid >> 6] = ss;
         __syncthreads();
         if (tid == 0) {
             int tot = 0;
-            for (int w = 0; w < DSC_THREADS / MAD_WAVE; w++) tot += hist[w];
+            for (int w = 0; w < DSC_THREADS / MAD_WAVE; w++) tot += s_part[w];
             A.norm[row] = sqrt((double)tot);
         }
     }
+    DSC_STAMP(7);
 }
 
 int mad_describe_device_many(mad_ctx *ctx, int n_jobs, const DescribeJob *jobs, int r, int dsc_size) {
@@ -1111,6 +1161,7 @@ int mad_describe_device_many(mad_ctx *ctx, int n_jobs, const DescribeJob *jobs, 
     if (Zd != 16 && !(Zd <= 128 && dsc_size == 64 && 2 * r == 16))
         return mad_fail(ctx, MAD_EINVAL, "mad_describe: %d descriptor zones: 16 for every layout, up to 128 (the 112-zone table) for the default 64 regions and dsc_radius 16", Zd);
     if (r < 2 || r > 8 || (r % 2)) return mad_fail(ctx, MAD_EINVAL, "mad_describe: dsc radius %d must be 2, 4, 6 or 8", r);
+    const bool tab = Zd == 16 && ctx->eq_host[1].tab_ok && dsc_size == 64 && 2 * r == 16;
     for (int j0 = 0; j0 < n_jobs; j0 += MAD_BATCH_MAX) {
         Batch<DescribeArgs> B;
         B.n_jobs = 0;
@@ -1127,7 +1178,7 @@ int mad_describe_device_many(mad_ctx *ctx, int n_jobs, const DescribeJob *jobs, 
             A.f[0] = J.f[0]; A.f[1] = J.f[1];
             A.anc_coords = J.d_anc_coords; A.anc_octave = J.d_anc_octave; A.uniform_octave = J.uniform_octave;
             A.row_anchor = J.d_row_anchor; A.row_R = J.d_row_R; A.row_Rinv = J.d_row_Rinv; A.row_perm = J.d_row_perm; A.n_rows = J.d_n_rows; A.overflow = J.d_overflow;
-            A.r = r; A.eq = ctx->eq[1]; A.dsc = J.d_dsc; A.dsc8 = J.d_dsc8; A.norm = J.d_norm;
+            A.r = r; A.eq = ctx->eq[1]; A.dsc = J.d_dsc; A.dsc8 = J.d_dsc8; A.norm = J.d_norm; A.row_rec = J.d_row_rec;
             B.first[B.n_jobs++] = (int)blk;
             blk += ((J.grid_rows + 7) / 8) * 8 + 8;      // one workgroup per possible row, a multiple of 8 per job (one share per XCD)
             if (blk > INT32_MAX) return mad_fail(ctx, MAD_EINVAL, "mad_describe: %lld rows in one batch", (long long)blk);
@@ -1137,7 +1188,6 @@ int mad_describe_device_many(mad_ctx *ctx, int n_jobs, const DescribeJob *jobs, 
         const unsigned nblk = (unsigned)blk;
         mad_timer_begin(ctx, MAD_T_DESCRIBE);
         // the default layout takes the 4-byte texels and the table classifier when the descriptor table has them (MAD_NO_TAB: never)
-        const bool tab = Zd == 16 && ctx->eq_host[1].tab_ok;
         switch (dsc_size == 64 ? 2 * r : -dsc_size) {
             case 4: hipLaunchKernelGGL(k_describe<4>, dim3(nblk), dim3(DSC_THREADS), 0, ctx->stream, B); break;
             case 8: hipLaunchKernelGGL(k_describe<8>, dim3(nblk), dim3(DSC_THREADS), 0, ctx->stream, B); break;
