@@ -34,15 +34,16 @@ struct __attribute__((aligned(16))) EqspFastLds {
     unsigned char zlut[MAD_ZLUT];
     float4 belt_f[MAD_MAX_BELT];      // (z_in_lo, z_in_hi, belt_lo0, belt_inv_w): one 16-byte read per lookup
     int2 belt_i[MAD_MAX_BELT];        // (first zone, zone count)
-    // the exact float64 bounds as well: the fallback walks them serially, and an LDS read is several times
-    // closer than the L1/L2 path of a global table
-    double th_lo[MAD_MAX_Z], th_hi[MAD_MAX_Z], ph_lo[MAD_MAX_BELT], ph_hi[MAD_MAX_BELT];
     // second tier (eqsp_tier2): float64 edge directions of every zone and z thresholds of every belt, with which a
     // direction that is not within MAD_T2_* radians of a bound is classified by four cross products instead of atan2 / acos
     double dir[MAD_MAX_Z][4];         // cos, sin of theta_min; cos, sin of theta_max
     double zthr[MAD_MAX_BELT][4];     // inside the belt needs z < [0] and z > [1] (float64 semantics), z < [2] and z > [3] (float32 semantics)
     int nbelt;
     int tier2_ok;                     // every belt with more than one zone has zones narrower than 3 rad (else tier 2 is off)
+    // LAST: the exact float64 bounds the atan2 / acos fallback walks (eqsp_classify_lds; ~1e-8 of the samples get that far).
+    // Kernels that stage a prefix of this image -- k_describe's table form up to `dir`, k_orient up to here -- hand the fallback the
+    // image in global memory instead.
+    double th_lo[MAD_MAX_Z], th_hi[MAD_MAX_Z], ph_lo[MAD_MAX_BELT], ph_hi[MAD_MAX_BELT];
 };
 
 // Table classifier of the 4-byte texels (k_describe, descriptor sphere only): belt from z through `zbelt`, zone inside the belt from
@@ -90,7 +91,9 @@ struct EqspDev {
     int tab_ok;
 };
 
+#ifndef MAD_EQSP_GUARD
 #define MAD_EQSP_GUARD 1e-4
+#endif
 
 // One octave's gradient field: a texel is {gx, gy, gz, |g|} (|g| in float32 exactly
 // as numpy forms it: sqrt((gx*gx + gy*gy) + gz*gz), Orientator.py:139).

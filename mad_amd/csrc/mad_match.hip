@@ -351,25 +351,42 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_corr_gemm2(GemmBatch G) {
             G2_STAMP(2);
             issue(0);
             if (n_k > 1) issue(1);
-            for (int s = 0; s < n_k; s++) {
-                if (s == 1) G2_STAMP(3);
-                // stage s has landed (this wave's part: six instructions per stage, the next stage's six may stay in flight)
-                if (s + 1 < n_k) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+            // One stage: wait for its bytes, barrier, the twelve fragment reads up front (48 registers), then the 32 MFMAs with the
+            // six LDS-DMA pieces of stage s + 2 spread between them.  The order is pinned with sched_group_barrier: left alone the
+            // compiler keeps two A fragments live, waits for lgkmcnt(0) five times a stage, and issues the six pieces in a burst
+            // right behind the barrier, next to the reads, where a piece costs most to issue (1 640 clocks per stage for the two
+            // workgroups of a CU against 1 024 of MFMA issue, in-kernel stamps).
+            auto stage = [&](int s, auto more) {
+                if (decltype(more)::value || s + 1 < n_k) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();      // ... and everybody's; and everybody has read stage s - 1, whose slot is filled next
-                if (s + 2 < n_k) issue(s + 2);
+                __builtin_amdgcn_s_barrier();      // stage s has landed for everybody; everybody has read stage s - 1, whose slot is filled next
                 const int8_t *slot = g2_smem + (s % G2_NSTAGE) * G2_STAGE;
                 v4i fa[8], fb[4];
 #pragma unroll
                 for (int n = 0; n < 4; n++) fb[n] = *(const v4i *)(slot + (16 + wn * 4 + n) * 1024 + rd_off);
 #pragma unroll
                 for (int m = 0; m < 8; m++) fa[m] = *(const v4i *)(slot + (wm * 8 + m) * 1024 + rd_off);
+                if (decltype(more)::value) issue(s + 2);
 #pragma unroll
                 for (int m = 0; m < 8; m++)
 #pragma unroll
                     for (int n = 0; n < 4; n++)
                         acc[m][n] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[m], fb[n], acc[m][n], 0, 0, 0);
+                // the B fragments and the first two of A, then per A fragment: its four MFMAs, the read of the fragment after next, a piece
+                __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+#pragma unroll
+                for (int m = 0; m < 8; m++) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                   // MFMA
+                    if (m + 2 < 8) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                    // DS read
+                    if (decltype(more)::value && m < 6) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // one LDS-DMA piece (VMEM read)
+                }
+            };
+            for (int s = 0; s + 2 < n_k; s++) {
+                if (s == 1) G2_STAMP(3);
+                stage(s, std::true_type());
             }
+            stage(n_k - 2, std::false_type());      // (K is a multiple of 128: at least two stages)
+            stage(n_k - 1, std::false_type());
             G2_STAMP(4);
             // Epilogue, as in k_corr_gemm: a candidate bit per entry (float32 test with a margin: a superset of the reference's
             // float64 test), the int32 dot product stored for candidates only, mask words assembled on the scalar unit.

@@ -14,8 +14,11 @@
 
 #include "mad_common.h"
 
+#ifndef ORI_THREADS
 #define ORI_THREADS 512
+#endif
 #define ORI_MAX_FAN 64          // lim_main * lim_sec must not exceed this
+#define ORI_QUEUE 512           // directions the float32 classifier hands to the exact one, per pass (more: classified in place)
 #define ORI_MAX_MAIN 8
 
 // ---------------------------------------------------------------------------
@@ -85,27 +88,50 @@ struct OrientArgs {
 __device__ __forceinline__ int hist_count(int v) { return v; }
 __device__ __forceinline__ int hist_count(unsigned long long v) { return (int)(v >> ORI_WFIX_BITS); }
 
-template <class H>
-__device__ __forceinline__ int quantise_wave0(const H *hist, int *q, int Z) {
+template <class H, class Q>
+__device__ __forceinline__ int quantise_wave0(const H *hist, Q *q, int Z) {
     const int lane = lane_id();
     const int c0 = lane < Z ? hist_count(hist[lane]) : 0;
     const int c1 = lane + 64 < Z ? hist_count(hist[lane + 64]) : 0;
     const int mx = wave_max_i32(max(c0, c1));
-    if (lane < Z) q[lane] = mx ? (int)((double)c0 / (double)mx * 50.0) : c0;
-    if (lane + 64 < Z) q[lane + 64] = mx ? (int)((double)c1 / (double)mx * 50.0) : c1;
+    if (lane < Z) q[lane] = (Q)(mx ? (int)((double)c0 / (double)mx * 50.0) : c0);
+    if (lane + 64 < Z) q[lane + 64] = (Q)(mx ? (int)((double)c1 / (double)mx * 50.0) : c1);
     return mx;
+}
+
+// The atan2 / acos test against the table's bounds -- the reference's own arithmetic, float64 (Descriptor.py:176-187) or with its
+// float32 roundings (sem32: Orientator.py:317-331) -- OUT OF LINE: one direction in 1e8 gets this far, and inlined (three times
+// in k_orient, twice in k_describe) the polynomial constants of the two functions were materialised, and at k_orient's 80
+// registers spilled, on the common path.  Returns the matching zones, ascending, as bytes (zone + 1; at most three can match).
+__device__ __noinline__ unsigned eqsp_trig_zones(const EqspFastLds *trig, double x, double y, double z, int sem32) {
+    unsigned out = 0;
+    int n = 0;
+    auto take = [&](int zn) { if (n < 4) out |= (unsigned)(zn + 1) << (8 * n); n++; };
+    if (sem32) {
+        const float two_pi_f = (float)MAD_TWO_PI;
+        float th = (float)atan2(y, x);
+        if (th < 0.0f) th = __fadd_rn(th, two_pi_f);
+        const float sth = __fadd_rn(th, two_pi_f);
+        z = z > 1.0 ? 1.0 : (z < -1.0 ? -1.0 : z);
+        const float ph = (float)acos(z);
+        eqsp_classify_lds(trig, (double)th, (double)sth, (double)ph, take);
+    } else {
+        double th = atan2(y, x);
+        if (th < 0) th += MAD_TWO_PI;
+        const double sth = th + MAD_TWO_PI;
+        z = z > 1.0 ? 1.0 : (z < -1.0 ? -1.0 : z);
+        const double ph = acos(z);
+        eqsp_classify_lds(trig, th, sth, ph, take);
+    }
+    return out;
 }
 
 // exact zone test of one rotated direction in float64 (the reference's arithmetic); f(zone) per match
 template <class F>
-__device__ __forceinline__ void classify_exact64(const EqspFastLds *eq, double rx, double ry, double rz, F &&f) {
+__device__ __forceinline__ void classify_exact64(const EqspFastLds *eq, const EqspFastLds *trig, double rx, double ry, double rz, F &&f) {
+    // eq: the image up to th_lo at least (LDS); trig: a whole image (the bounds the angle test walks: global memory will do)
     if (eqsp_tier2(eq, rx, ry, rz, false, f)) return;      // decided without atan2 / acos (all but ~1e-8 of the calls)
-    double th = atan2(ry, rx);
-    if (th < 0) th += MAD_TWO_PI;
-    const double sth = th + MAD_TWO_PI;
-    rz = rz > 1.0 ? 1.0 : (rz < -1.0 ? -1.0 : rz);
-    const double ph = acos(rz);
-    eqsp_classify_lds(eq, th, sth, ph, f);
+    for (unsigned zs = eqsp_trig_zones(trig, rx, ry, rz, 0); zs; zs >>= 8) f((int)(zs & 255u) - 1);
 }
 
 #ifdef MAD_PROBE_STAMPS      // diagnostic build: s_memtime at the phases of every anchor's workgroup (tools/probe_orient.py)
@@ -119,7 +145,11 @@ extern "C" int mad_debug_ori_stamps(long long *out, int n) {
 #endif
 
 template <bool GW>
-__global__ __launch_bounds__(ORI_THREADS) void k_orient(Batch<OrientArgs> B) {
+#ifndef ORI_WPE
+#define ORI_WPE 6
+#endif
+// (registers for three workgroups per CU -- 6 waves per SIMD, 80 registers -- where the LDS allows three: the unweighted form)
+__global__ __launch_bounds__(ORI_THREADS, GW ? 4 : ORI_WPE) void k_orient(Batch<OrientArgs> B) {
     ORI_STAMP(0);
     const int job = batch_job(B, (int)blockIdx.x);
     const OrientArgs &A = B.job[job];
@@ -127,20 +157,25 @@ __global__ __launch_bounds__(ORI_THREADS) void k_orient(Batch<OrientArgs> B) {
     float *vx = (float *)smem;
     float *vy = vx + A.nmask;
     float *vz = vy + A.nmask;
-    int *queue = (int *)(vz + A.nmask);                 // (voxel | candidate << 16) the fast classifier could not decide
+    int *queue = (int *)(vz + A.nmask);                 // (voxel | candidate << 16) the fast classifier could not decide: ORI_QUEUE entries
     // GW (Gaussian window): the kept voxels' squared offsets and the weight table, behind the queue
-    unsigned short *vw = (unsigned short *)(queue + A.nmask);
-    unsigned long long *wl = (unsigned long long *)(smem + (((size_t)A.nmask * 18 + 15) & ~(size_t)15));
+    unsigned short *vw = (unsigned short *)(queue + ORI_QUEUE);
+    unsigned long long *wl = (unsigned long long *)(smem + (((size_t)A.nmask * 14 + ORI_QUEUE * 4 + 15) & ~(size_t)15));
     using H = typename std::conditional<GW, unsigned long long, int>::type;
     __shared__ H hist[ORI_MAX_MAIN + 1][MAD_MAX_Z];     // [0]: first pass; [1 + c]: main-bin candidate c
-    __shared__ int qz[ORI_MAX_MAIN + 1][MAD_MAX_Z];     // quantised counts, same indexing
+    __shared__ short qz[ORI_MAX_MAIN + 1][MAD_MAX_Z];   // quantised counts (<= 50), same indexing
     __shared__ int main_list[MAD_MAX_Z];
     __shared__ int sec_list[ORI_MAX_MAIN][ORI_MAX_FAN];
     __shared__ int sec_cnt[ORI_MAX_MAIN];
     __shared__ int s_nvox, s_nmain, s_mx, s_nq;
     __shared__ double s_dom[ORI_MAX_MAIN][9];
     __shared__ float s_domf[ORI_MAX_MAIN][9];
-    __shared__ EqspFastLds fast;
+    // The classifier's tables without their last part, the float64 bounds of the atan2 / acos fallback (one direction in 1e8 gets
+    // that far: it reads them from the image in global memory).  With the queue cut to ORI_QUEUE entries and the quantised counts
+    // as int16 an anchor's workgroup needs 52 KB of LDS instead of 65: three per CU instead of two.
+    __shared__ uint4 fast_s[(offsetof(EqspFastLds, th_lo) + 15) / 16];
+    const EqspFastLds &fast = *(const EqspFastLds *)fast_s;
+    const EqspFastLds *const trig = &A.eq->image;
 
     // anchor -> octave, coordinates -> texel addresses: every link a scalar load, the field selected from both descriptors
     // (as in k_describe: the conditional-pointer forms compile into flat vector loads and a dependent fetch)
@@ -176,7 +211,7 @@ __global__ __launch_bounds__(ORI_THREADS) void k_orient(Batch<OrientArgs> B) {
     // and five such trips in a row were a quarter of the anchor's time.  The first batch goes out BEFORE the tables are staged
     // and the histograms zeroed, so that those ~1.5 us run under the texels' flight.
     const float cutoff = 1e-5f;
-    constexpr int ORI_TRIPS = 5;      // r = 8: 2 517 voxels in the sphere; larger boxes take the loop below more than once
+    constexpr int ORI_TRIPS = 2560 / ORI_THREADS;      // r = 8: 2 517 voxels in the sphere; larger boxes take the loop below more than once
     int packed[ORI_TRIPS];
     float4 tx[ORI_TRIPS];
     auto request = [&](int m00) {
@@ -199,7 +234,7 @@ __global__ __launch_bounds__(ORI_THREADS) void k_orient(Batch<OrientArgs> B) {
     for (int i = tid; i < (ORI_MAX_MAIN + 1) * MAD_MAX_Z; i += ORI_THREADS) (&hist[0][0])[i] = 0;
     if (GW)
         for (int i = tid; i <= 3 * r * r; i += ORI_THREADS) wl[i] = A.wfix[i];
-    eqsp_fast_stage(A.eq, &fast);
+    stage_lds(fast_s, &A.eq->image, sizeof(fast_s));
     // one count (or one weight) of voxel v for zone zn of histogram h
     auto tally = [&](int h, int zn, int v) {
         if (GW) atomicAdd(&hist[h][zn], (H)wl[vw[v]]);
@@ -238,10 +273,17 @@ __global__ __launch_bounds__(ORI_THREADS) void k_orient(Batch<OrientArgs> B) {
 
     // step02: first binning on the float32 box (Orientator.py:307-334).  Directions well inside a zone
     // take the guard-banded float32 path; the few near a bound are queued for the exact test.
+    // the reference's float32 arithmetic for one direction of the first pass (Orientator.py:317-331)
+    auto exact_first = [&](int v) {
+        if (eqsp_tier2(&fast, (double)vx[v], (double)vy[v], (double)vz[v], true, [&](int zn) { tally(0, zn, v); })) return;
+        for (unsigned zs = eqsp_trig_zones(trig, (double)vx[v], (double)vy[v], (double)vz[v], 1); zs; zs >>= 8) tally(0, (int)(zs & 255u) - 1, v);
+    };
     for (int v = tid; v < nvox; v += ORI_THREADS) {
         const int zn = eqsp_fast32<true>(&fast, vx[v], vy[v], vz[v]);
-        if (zn >= 0) tally(0, zn, v);
-        else queue[atomicAdd(&s_nq, 1)] = v;
+        if (zn >= 0) { tally(0, zn, v); continue; }
+        const int slot = atomicAdd(&s_nq, 1);
+        if (slot < ORI_QUEUE) queue[slot] = v;
+        else exact_first(v);      // queue full (only if nearly every direction sat on a bound): in place
     }
     __syncthreads();
     ORI_STAMP(3);
@@ -249,20 +291,9 @@ __global__ __launch_bounds__(ORI_THREADS) void k_orient(Batch<OrientArgs> B) {
     // (the reference's float32 arithmetic), the quantisation, the main bins and their rotations -- four barrier-separated
     // phases before, a third of the anchor's time for a handful of lanes' work.
     if (tid < MAD_WAVE) {
-        const float two_pi_f = (float)MAD_TWO_PI;
-        const int nq = s_nq;
+        const int nq = min(s_nq, ORI_QUEUE);
         const int lane = lane_id();
-        for (int qi = lane; qi < nq; qi += MAD_WAVE) {
-            const int v = queue[qi];
-            if (eqsp_tier2(&fast, (double)vx[v], (double)vy[v], (double)vz[v], true, [&](int zn) { tally(0, zn, v); })) continue;
-            float th = (float)atan2((double)vy[v], (double)vx[v]);
-            if (th < 0.0f) th = __fadd_rn(th, two_pi_f);
-            const float sth = __fadd_rn(th, two_pi_f);
-            double cz = (double)vz[v];
-            cz = cz > 1.0 ? 1.0 : (cz < -1.0 ? -1.0 : cz);
-            const float ph = (float)acos(cz);
-            eqsp_classify_lds(&fast, (double)th, (double)sth, (double)ph, [&](int zn) { tally(0, zn, v); });
-        }
+        for (int qi = lane; qi < nq; qi += MAD_WAVE) exact_first(queue[qi]);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // the wave's own LDS atomics above before its reads below
         const int mx = quantise_wave0(hist[0], qz[0], Z);
         // main bins: quantised count > 0.8 * max (Orientator.py:181)
@@ -305,18 +336,18 @@ __global__ __launch_bounds__(ORI_THREADS) void k_orient(Batch<OrientArgs> B) {
             const int zn = eqsp_fast32<true>(&fast, rx, ry, rz);
             if (zn >= 0) { tally(1 + c, zn, v); continue; }
             const int slot = atomicAdd(&s_nq, 1);
-            if (slot < A.nmask) { queue[slot] = v | (c << 16); continue; }
+            if (slot < ORI_QUEUE) { queue[slot] = v | (c << 16); continue; }
             // queue full (only if nearly every direction sat on a bound): exact test in place
             const double *dd = s_dom[c];
             const double e0 = g0, e1 = g1, e2 = g2;
-            classify_exact64(&fast, e0 * dd[0] + e1 * dd[1] + e2 * dd[2], e0 * dd[3] + e1 * dd[4] + e2 * dd[5],
+            classify_exact64(&fast, trig, e0 * dd[0] + e1 * dd[1] + e2 * dd[2], e0 * dd[3] + e1 * dd[4] + e2 * dd[5],
                              e0 * dd[6] + e1 * dd[7] + e2 * dd[8], [&](int z2) { tally(1 + c, z2, v); });
         }
     }
     __syncthreads();
     ORI_STAMP(7);
     {
-        const int nq = min(s_nq, A.nmask);      // ~0.1 % of nvox * nmain in practice; capacity is nmask
+        const int nq = min(s_nq, ORI_QUEUE);      // ~0.1 % of nvox * nmain in practice
         for (int qi = tid; qi < nq; qi += ORI_THREADS) {
             const int v = queue[qi] & 0xffff, c = queue[qi] >> 16;
             const double *d = s_dom[c];
@@ -324,7 +355,7 @@ __global__ __launch_bounds__(ORI_THREADS) void k_orient(Batch<OrientArgs> B) {
             const double rx = g0 * d[0] + g1 * d[1] + g2 * d[2];
             const double ry = g0 * d[3] + g1 * d[4] + g2 * d[5];
             const double rz = g0 * d[6] + g1 * d[7] + g2 * d[8];
-            classify_exact64(&fast, rx, ry, rz, [&](int zn) { tally(1 + c, zn, v); });
+            classify_exact64(&fast, trig, rx, ry, rz, [&](int zn) { tally(1 + c, zn, v); });
         }
     }
     __syncthreads();
@@ -332,7 +363,7 @@ __global__ __launch_bounds__(ORI_THREADS) void k_orient(Batch<OrientArgs> B) {
     // quantise + step04 (Orientator.py:228-239) per candidate, one wave each
     for (int c = tid >> 6; c < nmain; c += ORI_THREADS / MAD_WAVE) {
         const int lane = lane_id();
-        int *q1 = qz[1 + c];
+        short *q1 = qz[1 + c];
         if (main_list[c] != 0) quantise_wave0(hist[1 + c], q1, Z);
         else { if (lane < Z) q1[lane] = qz[0][lane]; if (lane + 64 < Z) q1[lane + 64] = qz[0][lane + 64]; }
         const int i0 = lane, i1 = lane + 64;
@@ -594,7 +625,8 @@ static int orient_batch(mad_ctx *ctx, int n_jobs, const OrientJob *jobs, int r, 
     mad_timer_begin(ctx, MAD_T_ORIENT);
     // unit gradients (SoA) + the undecided-voxel queue; with a window also the voxels' squared offsets and the weight table
     const bool gw = ctx->gw_sig != 0.0;
-    const size_t lds = gw ? ((((size_t)ctx->mask_n * 18 + 15) & ~(size_t)15) + (size_t)(3 * r * r + 1) * 8) : (size_t)ctx->mask_n * 4 * sizeof(float);
+    const size_t lds = gw ? ((((size_t)ctx->mask_n * 14 + ORI_QUEUE * 4 + 15) & ~(size_t)15) + (size_t)(3 * r * r + 1) * 8)
+                          : (size_t)ctx->mask_n * 3 * sizeof(float) + ORI_QUEUE * 4;
     if (lds > 48 * 1024) {      // boxes beyond r = 8 (Orientator(ori_radius > 16)): more dynamic LDS than a kernel gets by default
         static bool attr = false;
         if (!attr) {
@@ -752,7 +784,7 @@ __device__ __forceinline__ int describe_exact(const EqspFastLds *eq, float4 t, c
     const double ry = g0 * R[3] + g1 * R[4] + g2 * R[5];
     const double rz = g0 * R[6] + g1 * R[7] + g2 * R[8];
     int zone = 0;
-    classify_exact64(eq, rx, ry, rz, [&](int zn) { zone = zn; });
+    classify_exact64(eq, eq, rx, ry, rz, [&](int zn) { zone = zn; });
     return zone;
 }
 
@@ -842,7 +874,7 @@ __global__ __launch_bounds__(DSC_THREADS, TAB ? DSC_OCC_TAB : DSC_OCC) void k_de
     // memory (cache-resident, shared by every workgroup) and the 12 KB image is not staged per row
     // (TAB: only what eqsp_fast32 reads -- the head of the image: g32, zlut, belt_f, belt_i -- is staged; the float64 tier, a few
     // samples per row, reads its tables from global memory)
-    __shared__ typename std::conditional<TAB, uint4[(offsetof(EqspFastLds, th_lo) + 15) / 16], EqspFastLds>::type fast_s;
+    __shared__ typename std::conditional<TAB, uint4[(offsetof(EqspFastLds, dir) + 15) / 16], EqspFastLds>::type fast_s;
     const EqspFastLds *const fastp = (const EqspFastLds *)&fast_s;                             // float32 tier
     const EqspFastLds *const exactp = TAB ? &A.eq->image : (const EqspFastLds *)&fast_s;       // float64 tier
     __shared__ float4 qv[TAB ? 1 : DSC_QUEUE];         // texels the fast classifier could not decide
