@@ -916,9 +916,12 @@ __global__ __launch_bounds__(DSC_THREADS, TAB ? DSC_OCC_TAB : DSC_OCC) void k_de
     // to the staging of the tables.  Before (round 2) it was a chain of dependent scalar loads, row_perm -> row_anchor -> octave,
     // coordinates, inv(R): with the staging 7 700 of a row's 35 600 cycles (MAD_PROBE_STAMPS).  Without records (mad_describe
     // on rows of the caller) thread 0 walks that chain and forms the record itself.
-    // (Round 3 also built this kernel as a loop -- 4 workgroups per CU walking the rows, tables staged once, the next row's
-    // record fetched a row ahead: 13 % fewer vector instructions and 20 % MORE time per launch at any grid size, with and
-    // without staggered starts.  Not understood; dropped.)
+    // (Round 3 also built this kernel as a loop, twice -- workgroups that fill the chip walk the rows, statically dealt or by
+    // tickets from a counter per XCD, tables staged once, the next row's record fetched a row ahead.  Fewer instructions (-13 %)
+    // and MORE time: with the registers of this form (80, six workgroups per CU) the same binary took 0.46 ms per C3 step run one
+    // row per workgroup and 0.58 looping; its waves spend 60 % of their cycles parked at waits and barriers against 43 %
+    // (SQ_WAIT_ANY), L2 misses +26 %.  Neither staggered starts, nor an LDS-only barrier at the top of a row, nor the ticket behind
+    // that barrier changed it.  Not understood; dropped.)
     const int32_t *const p_perm = A.row_perm, *const p_anchor = A.row_anchor, *const p_coords = A.anc_coords, *const p_octave = A.anc_octave;
     const double *const p_R = A.row_R, *const p_Rinv = A.row_Rinv;
     const int uni_octave = A.uniform_octave;

@@ -36,8 +36,8 @@ def main():
         st = out.reshape(n, 8).astype(np.float64)
         ok = (st[:, 7] > 0) & (st[:, 0] > 0)
         st = st[ok]
-        st = st[np.argsort(st[:, 0])]      # the slots keep the stamps of earlier launches: take the last launch (no 20 us = 50 000 shader-clock gap between its starts)
-        gaps = np.nonzero(np.diff(st[:, 0]) > 50000)[0]
+        st = st[np.argsort(st[:, 7])]      # the slots keep the stamps of earlier launches: take the last launch (no 40 us gap between its workgroups' ends)
+        gaps = np.nonzero(np.diff(st[:, 7]) > 100000)[0]
         if len(gaps):
             st = st[gaps[-1] + 1:]
         d = np.diff(st, axis=1)
@@ -46,6 +46,8 @@ def main():
             print("  %-58s %8.0f %8.0f %8.0f" % (name, np.median(d[:, k]), np.percentile(d[:, k], 10), np.percentile(d[:, k], 90)))
         tot = st[:, 7] - st[:, 0]
         print("  workgroup total %.0f (median); kernel span %.0f ticks" % (np.median(tot), st[:, 7].max() - st[:, 0].min()))
+        e = st[:, 7] - st[:, 7].min()
+        print("  ends of the workgroups' last rows, ticks after the first one to end: p10 %.0f  p50 %.0f  p90 %.0f  max %.0f" % tuple(np.percentile(e, q) for q in (10, 50, 90, 100)))
 
 
 if __name__ == "__main__":
