@@ -426,17 +426,13 @@ struct RowsArgs {
     int uniform_octave;            // ... and their octave when anc_octave is null
 };
 
-// the record of one row (k_describe reads it with one 128-byte load)
-__device__ __forceinline__ void put_row_rec(const RowsArgs &A, int64_t pos, int row, int a, const double *R) {
+// the record of one row (k_describe reads it with one 128-byte load); inv = inv(Rfinal), still in the thread's registers
+__device__ __forceinline__ void put_row_rec(const RowsArgs &A, int64_t pos, int row, int a, const double *inv) {
     DscRowRec &q = A.row_rec[pos];
     q.row = row;
     q.c[0] = A.coords[3 * a]; q.c[1] = A.coords[3 * a + 1]; q.c[2] = A.coords[3 * a + 2];
     q.octave = A.anc_octave ? A.anc_octave[a] : A.uniform_octave;
-    if (A.row_Rinv) {
-        for (int i = 0; i < 9; i++) q.inv[i] = A.row_Rinv[9 * (int64_t)row + i];      // (just written by this thread)
-    } else {
-        mad_mat3_inv(R, q.inv);
-    }
+    for (int i = 0; i < 9; i++) q.inv[i] = inv[i];
 }
 
 // row offsets of every job: exclusive scan of its anchors' row counts, one workgroup per job
@@ -494,16 +490,19 @@ __global__ __launch_bounds__(256) void k_orient_rows(Batch<RowsArgs> B, int fan,
     A.row_anchor[row] = a;
     A.row_main[row] = mb;
     A.row_sec[row] = sb;
-    double *o = A.row_R + 9 * row;
-    mad_rfinal(eq, mb, sb, o);
+    double R9[9], inv9[9];      // in registers: the inverse is formed from what was computed, not from what was just stored
+    mad_rfinal(eq, mb, sb, R9);
+    for (int i = 0; i < 9; i++) A.row_R[9 * row + i] = R9[i];
     if (A.row_count) {
         const int Z = eq->Z;
         const int32_t *h = A.slot_hist + ((size_t)a * lim_main + A.slot_hidx[(size_t)a * fan + s]) * Z;
         for (int i = 0; i < Z; i++) A.row_count[row * Z + i] = h[i];
     }
-    if (A.row_Rinv) mad_mat3_inv(o, A.row_Rinv + 9 * row);      // inv(lo.Rfinal) of MaD.py:438, once per row
+    if (A.row_Rinv || A.row_rec) mad_mat3_inv(R9, inv9);      // inv(lo.Rfinal) of MaD.py:438, once per row
+    if (A.row_Rinv)
+        for (int i = 0; i < 9; i++) A.row_Rinv[9 * row + i] = inv9[i];
     if (A.row_meta) { A.row_meta[3 * row] = A.anc_index[a]; A.row_meta[3 * row + 1] = A.anc_octave[a]; A.row_meta[3 * row + 2] = mb; }
-    if (A.row_rec) put_row_rec(A, A.order ? A.perm_off[p] + s : row, (int)row, a, o);
+    if (A.row_rec) put_row_rec(A, A.order ? A.perm_off[p] + s : row, (int)row, a, inv9);
 }
 
 // k_orient_scan + k_orient_rows in ONE launch (round 3): every 1024-thread workgroup forms the exclusive scan of its job's
@@ -550,16 +549,19 @@ __global__ __launch_bounds__(1024) void k_orient_rows_scan(Batch<RowsArgs> B, in
     A.row_anchor[row] = a;
     A.row_main[row] = mb;
     A.row_sec[row] = sb;
-    double *o = A.row_R + 9 * row;
-    mad_rfinal(eq, mb, sb, o);
+    double R9[9], inv9[9];      // in registers: the inverse is formed from what was computed, not from what was just stored
+    mad_rfinal(eq, mb, sb, R9);
+    for (int i = 0; i < 9; i++) A.row_R[9 * row + i] = R9[i];
     if (A.row_count) {
         const int Z = eq->Z;
         const int32_t *h = A.slot_hist + ((size_t)a * lim_main + A.slot_hidx[(size_t)a * fan + sl]) * Z;
         for (int i = 0; i < Z; i++) A.row_count[row * Z + i] = h[i];
     }
-    if (A.row_Rinv) mad_mat3_inv(o, A.row_Rinv + 9 * row);      // inv(lo.Rfinal) of MaD.py:438, once per row
+    if (A.row_Rinv || A.row_rec) mad_mat3_inv(R9, inv9);      // inv(lo.Rfinal) of MaD.py:438, once per row
+    if (A.row_Rinv)
+        for (int i = 0; i < 9; i++) A.row_Rinv[9 * row + i] = inv9[i];
     if (A.row_meta) { A.row_meta[3 * row] = A.anc_index[a]; A.row_meta[3 * row + 1] = A.anc_octave[a]; A.row_meta[3 * row + 2] = mb; }
-    if (A.row_rec) put_row_rec(A, A.order ? s_perm[pl] + sl : row, (int)row, a, o);
+    if (A.row_rec) put_row_rec(A, A.order ? s_perm[pl] + sl : row, (int)row, a, inv9);
 }
 
 // Runs a1-a8 for the anchor lists of n_jobs structures (coordinates and octaves already on the device) in one k_orient
