@@ -3353,6 +3353,11 @@ extern "C" int mad_set_option(mad_ctx *ctx, const char *name, double value) {
         ctx->pose_split = value < 0 ? -1 : (value != 0 ? 1 : 0);
         return MAD_OK;
     }
+    if (!strcmp(name, "ori_queue") || !strcmp(name, "dsc_queue")) {      // test hooks: a small cap drives the kernels' full-queue paths
+        if (!(value >= 0) || !(value < 1e9)) return mad_fail(ctx, MAD_EINVAL, "mad_set_option: %s = %g", name, value);
+        (name[0] == 'o' ? ctx->ori_queue_cap : ctx->dsc_queue_cap) = (int)value;
+        return MAD_OK;
+    }
     return mad_fail(ctx, MAD_EINVAL, "mad_set_option: unknown option '%s'", name);
 }
 

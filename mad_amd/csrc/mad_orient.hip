@@ -77,6 +77,7 @@ struct OrientArgs {
     // Orientator(gw_sig != 0): weight of a voxel at squared offset d2 from the anchor, exp(-d2 / (2 sigma^2)) in 2^-50 units
     // (Orientator.py:49-54); nullptr = every voxel of the sphere counts 1
     const unsigned long long *wfix;
+    int queue_cap;                 // <= ORI_QUEUE: entries of the undecided-direction queue in use (mad_set_option "ori_queue": tests of the full-queue path)
 };
 #define ORI_WFIX_BITS 50
 
@@ -282,7 +283,7 @@ __global__ __launch_bounds__(ORI_THREADS, GW ? 4 : ORI_WPE) void k_orient(Batch<
         const int zn = eqsp_fast32<true>(&fast, vx[v], vy[v], vz[v]);
         if (zn >= 0) { tally(0, zn, v); continue; }
         const int slot = atomicAdd(&s_nq, 1);
-        if (slot < ORI_QUEUE) queue[slot] = v;
+        if (slot < A.queue_cap) queue[slot] = v;
         else exact_first(v);      // queue full (only if nearly every direction sat on a bound): in place
     }
     __syncthreads();
@@ -291,7 +292,7 @@ __global__ __launch_bounds__(ORI_THREADS, GW ? 4 : ORI_WPE) void k_orient(Batch<
     // (the reference's float32 arithmetic), the quantisation, the main bins and their rotations -- four barrier-separated
     // phases before, a third of the anchor's time for a handful of lanes' work.
     if (tid < MAD_WAVE) {
-        const int nq = min(s_nq, ORI_QUEUE);
+        const int nq = min(s_nq, A.queue_cap);
         const int lane = lane_id();
         for (int qi = lane; qi < nq; qi += MAD_WAVE) exact_first(queue[qi]);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // the wave's own LDS atomics above before its reads below
@@ -336,7 +337,7 @@ __global__ __launch_bounds__(ORI_THREADS, GW ? 4 : ORI_WPE) void k_orient(Batch<
             const int zn = eqsp_fast32<true>(&fast, rx, ry, rz);
             if (zn >= 0) { tally(1 + c, zn, v); continue; }
             const int slot = atomicAdd(&s_nq, 1);
-            if (slot < ORI_QUEUE) { queue[slot] = v | (c << 16); continue; }
+            if (slot < A.queue_cap) { queue[slot] = v | (c << 16); continue; }
             // queue full (only if nearly every direction sat on a bound): exact test in place
             const double *dd = s_dom[c];
             const double e0 = g0, e1 = g1, e2 = g2;
@@ -347,7 +348,7 @@ __global__ __launch_bounds__(ORI_THREADS, GW ? 4 : ORI_WPE) void k_orient(Batch<
     __syncthreads();
     ORI_STAMP(7);
     {
-        const int nq = min(s_nq, ORI_QUEUE);      // ~0.1 % of nvox * nmain in practice
+        const int nq = min(s_nq, A.queue_cap);      // ~0.1 % of nvox * nmain in practice
         for (int qi = tid; qi < nq; qi += ORI_THREADS) {
             const int v = queue[qi] & 0xffff, c = queue[qi] >> 16;
             const double *d = s_dom[c];
@@ -605,6 +606,7 @@ static int orient_batch(mad_ctx *ctx, int n_jobs, const OrientJob *jobs, int r, 
         A.slot_hist = J.out.row_count ? scratch<int32_t>(ctx, S_SLOT_HIST) + a0 * lim_main * Z : nullptr;
         A.slot_hidx = scratch<int32_t>(ctx, S_TMP_A) + a0 * fan;
         A.wfix = ctx->gw_sig != 0.0 ? ctx->gw_tab : nullptr;
+        A.queue_cap = std::min(std::max(ctx->ori_queue_cap, 0), ORI_QUEUE);
         B.first[j] = (int)a0;
         RowsArgs &Q = R.job[j];
         Q.slot_cnt = A.slot_cnt; Q.slot_main = A.slot_main; Q.slot_sec = A.slot_sec; Q.slot_hist = A.slot_hist; Q.slot_hidx = A.slot_hidx;
@@ -767,6 +769,7 @@ struct DescribeArgs {
     const double *row_Rinv;        // n_rows x 9: inv(Rfinal) by cofactors (mad_mat3_inv), or nullptr -> formed here
     const int32_t *row_perm;       // nullable: the k-th workgroup takes row row_perm[k] (rows of neighbouring anchors side by side)
     const DscRowRec *row_rec;      // nullable: the k-th record = everything the k-th row in working order starts from
+    int queue_cap;                 // entries of the undecided-sample queue in use (<= its size)
     const int32_t *n_rows;         // device: number of rows
     int32_t *overflow;             // device: set when the launch was sized for fewer rows than *n_rows
     int r;
@@ -884,7 +887,7 @@ __global__ __launch_bounds__(DSC_THREADS, TAB ? DSC_OCC_TAB : DSC_OCC) void k_de
     __shared__ typename std::conditional<TAB, EqspTabLds, int>::type tab;
     __shared__ unsigned qidx[TAB ? DSC_QUEUE_TAB : 1];             // TAB: texel indices of the samples the table could not decide
     __shared__ unsigned short qsub16[TAB ? DSC_QUEUE_TAB : 1];
-    constexpr int QCAP = TAB ? DSC_QUEUE_TAB : DSC_QUEUE;
+    const int QCAP = min(TAB ? DSC_QUEUE_TAB : DSC_QUEUE, A.queue_cap);      // (mad_set_option "dsc_queue": tests of the full-queue path)
     // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs (b and b + 8 share one), so give
     // each XCD a contiguous run of rows.  Consecutive rows belong to the same anchor (fan-out ~5) or to
     // neighbours in the anchor list and sample the same neighbourhood: running side by side on ONE XCD
@@ -1216,6 +1219,7 @@ int mad_describe_device_many(mad_ctx *ctx, int n_jobs, const DescribeJob *jobs, 
             A.anc_coords = J.d_anc_coords; A.anc_octave = J.d_anc_octave; A.uniform_octave = J.uniform_octave;
             A.row_anchor = J.d_row_anchor; A.row_R = J.d_row_R; A.row_Rinv = J.d_row_Rinv; A.row_perm = J.d_row_perm; A.n_rows = J.d_n_rows; A.overflow = J.d_overflow;
             A.r = r; A.eq = ctx->eq[1]; A.dsc = J.d_dsc; A.dsc8 = J.d_dsc8; A.norm = J.d_norm; A.row_rec = J.d_row_rec;
+            A.queue_cap = std::max(ctx->dsc_queue_cap, 0);
             B.first[B.n_jobs++] = (int)blk;
             blk += ((J.grid_rows + 7) / 8) * 8 + 8;      // one workgroup per possible row, a multiple of 8 per job (one share per XCD)
             if (blk > INT32_MAX) return mad_fail(ctx, MAD_EINVAL, "mad_describe: %lld rows in one batch", (long long)blk);

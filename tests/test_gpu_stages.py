@@ -953,3 +953,35 @@ def test_pruned_pose_search_returns_the_rows_of_the_full_search(lib, k, n_hi_a):
         np.testing.assert_array_equal(top3, top)
     hi.close()
     lo.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ori_cap, dsc_cap", [(0, 1 << 20), (3, 1 << 20), (1 << 20, 0), (1 << 20, 5), (2, 7)])
+def test_full_queues_of_undecided_directions_change_nothing(lib, fields, ori_cap, dsc_cap):
+    """k_orient hands the directions its float32 classifier cannot decide to the exact one through a queue of 512 entries and
+    classifies in place beyond; k_describe's table tier queues 768 texel indices and redoes the whole row with the exact arithmetic
+    beyond.  With the queues cut to a few entries (mad_set_option "ori_queue" / "dsc_queue") those paths run for every anchor and
+    row, and the set comes out bit for bit as with the full queues."""
+    f0, f1 = fields[0], fields[1]
+    a0 = _anchors(f0["shape"], 0, 40, 71)
+    a1 = _anchors(f1["shape"], 1, 50, 72)
+    coords = np.concatenate([a0, a1]).astype(np.int32)
+    octave = np.concatenate([np.zeros(len(a0), np.int32), np.ones(len(a1), np.int32)])
+    subv = coords * np.where(octave[:, None] == 0, 0.75, 1.5)
+    job = ([f0["slot"], f1["slot"]], coords, octave, subv, np.arange(len(coords), dtype=np.int32))
+    ref = lib.set_build(*job)
+    want = ref.download()
+    assert ref.size()[0] > 100
+    try:
+        lib.set_option("ori_queue", ori_cap)
+        lib.set_option("dsc_queue", dsc_cap)
+        got = lib.set_build(*job)
+        have = got.download()
+    finally:
+        lib.set_option("ori_queue", 1 << 20)
+        lib.set_option("dsc_queue", 1 << 20)
+    assert got.size() == ref.size()
+    for key in ("anchor", "main", "sec", "R", "dsc"):
+        np.testing.assert_array_equal(have[key], want[key], err_msg=key)
+    got.close()
+    ref.close()
