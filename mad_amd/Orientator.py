@@ -59,6 +59,12 @@ class Orientator(object):
         print("MaD> Orienting %i anchors..." % (len(df_list)))
         lib = _lib.get_lib()
         self._bind(lib)
+        try:
+            return self._assign(lib, ms, df_list)
+        finally:
+            lib.set_orient_window(0.0)      # the window is state of the context: do not leave this object's behind
+
+    def _assign(self, lib, ms, df_list):
         slots = ms.device_slots(lib)
         oriented = {}
         for octave in sorted(set(df.oct_scale for df in df_list)):

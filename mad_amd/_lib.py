@@ -468,9 +468,12 @@ class Lib(object):
         return order[:k]
 
     # -- device-resident pipeline -------------------------------------------------------
-    def set_build(self, slots, anc_coords, anc_octave, anc_subv, anc_index, r=8, lim_main=6, lim_sec=6, into=None):
+    def set_build(self, slots, anc_coords, anc_octave, anc_subv, anc_index, r=8, lim_main=6, lim_sec=6, into=None, gw_sig=0.0):
         """Orient + describe the anchors into a device-resident set.  Asynchronous; pass `into` to rebuild an
-        existing set in place (its device buffers are reused)."""
+        existing set in place (its device buffers are reused).  `gw_sig`: the Gaussian window of Orientator(gw_sig) for THIS
+        build (the window is state of the context: it is set here for every build, so that an Orientator object used earlier on
+        the same context cannot leak its window into a set)."""
+        self.set_orient_window(gw_sig)
         s = into if into is not None else DeviceSet(self)
         slots = (C.c_int * 2)(int(slots[0]), int(slots[1]))
         anc_coords = _c(anc_coords, np.int32).reshape(-1, 3)
@@ -488,7 +491,8 @@ class Lib(object):
         Prepared once, run every step: the argument arrays are converted and pinned down here."""
         return BuildBatch(self, jobs, r, lim_main, lim_sec)
 
-    def set_build_many(self, jobs, r=8, lim_main=6, lim_sec=6):
+    def set_build_many(self, jobs, r=8, lim_main=6, lim_sec=6, gw_sig=0.0):
+        self.set_orient_window(gw_sig)
         return self.prepare_build_many(jobs, r, lim_main, lim_sec).run()
 
     def set_load(self, row_anchor, row_main, row_R, dsc, anc_subv, anc_index, anc_octave):

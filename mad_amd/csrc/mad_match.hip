@@ -1410,11 +1410,11 @@ __global__ __launch_bounds__(PB_THREADS) void k_pose_bounds(const int32_t *__res
             __syncthreads();
         }
         if (phase == 2 && b_star == 0) return;      // everything went through in phase 1
-        if (phase == 2 && k_stop > 0) {
-            int need;
-            t_stop = max(topk_threshold(hist, nbins, k_stop, t_wt, t_sh, &need), 0);
-            __syncthreads();
-        }
+        // T_stop: what phase 1 left in hist[nbins + 1] (its last workgroup, below) -- NOT derived here from the histogram, into which
+        // the workgroups of this very launch flush their own lower bounds as they finish: a workgroup that starts late (the lanes
+        // overlap: a CU may be busy with another match) would see a higher threshold and abandon other pairs than in the run
+        // before.  The top-k does not depend on it, the selected count and the launch sizes derived from it did.
+        if (phase == 2 && k_stop > 0) t_stop = hist[nbins + 1];
     }
     // histogram of the lower bounds (k_prune_select takes its threshold from it): per workgroup in LDS, flushed once at the end
     int *lh = (int *)(smem + pad16((size_t)C.n_words * 4) + pad16((size_t)(l_hi + 4) * 16) + (size_t)(PB_THREADS / MAD_WAVE) * ((NB + 1) * MAD_WAVE) * 2);
@@ -1571,8 +1571,30 @@ __global__ __launch_bounds__(PB_THREADS) void k_pose_bounds(const int32_t *__res
         p = pa;
     }
     __syncthreads();
+    const bool leave_t = SPLIT && phase == 1 && k_stop > 0;
+    int came_back = 0;
     for (int i = threadIdx.x; i < nbins; i += PB_THREADS)
-        if (lh[i]) atomicAdd(&hist[i], lh[i]);
+        if (lh[i]) {
+            if (leave_t) came_back += atomicAdd(&hist[i], lh[i]);      // returning: the add has been performed when the value is here
+            else atomicAdd(&hist[i], lh[i]);
+        }
+    if (leave_t) {
+        // The workgroup that finishes last takes T_stop = the k_stop-th largest lower bound of phase 1 for phase 2.  Atomics only,
+        // no fence: a workgroup's adds have come back before its ticket goes out, the last one reads the bins with agent-scope
+        // loads.  (A __threadfence() here -- an agent-scope release -- writes the L2 back in every workgroup: +60 us per match.)
+        asm volatile("" :: "v"(came_back));
+        __syncthreads();
+        if (threadIdx.x == 0) t_sh[0] = atomicAdd(&hist[nbins + 2], 1) == (int)gridDim.x - 1;
+        __syncthreads();
+        if (t_sh[0]) {      // (uniform)
+            __syncthreads();
+            for (int i = threadIdx.x; i < nbins; i += PB_THREADS) lh[i] = __hip_atomic_load(&hist[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            int need;
+            const int T = max(topk_threshold(lh, nbins, k_stop, t_wt, t_sh, &need), 0);
+            if (threadIdx.x == 0) hist[nbins + 1] = T;
+        }
+    }
 }
 
 // T = the k-th largest lower bound (from its histogram; 0 when there are fewer than k pairs), then the pairs whose upper bound
@@ -2399,7 +2421,7 @@ static int pose_device(mad_ctx *ctx, const Side &hi, const Side &lo, int32_t *d_
                        (const double *)scratch<double>(ctx, S_PAIR_SCORE), pb_phase, target_a, pb_stop)
             for (int pass = 0; pass < (split ? 2 : 1); pass++) {
                 const int pb_phase = split ? pass + 1 : 0;
-                const int64_t pb_stop = pass == 1 ? prune_k : 0;
+                const int64_t pb_stop = split ? prune_k : 0;      // phase 1 leaves T_stop for phase 2 (hist2[nbins + 1]; [nbins + 2]: its workgroups' tickets)
                 if (split) {
                     if (nbv == 2) MAD_PB_LAUNCH(2, true);
                     else if (nbv == 4) MAD_PB_LAUNCH(4, true);
