@@ -850,10 +850,6 @@ template <int S, int NSUB> __device__ __forceinline__ int sub_of_i(int i) {
 // through the former tiers -- float32 with its 1e-4 guard, then float64 -- on the full 16-byte texel, in full lanes.  The result
 // is the same descriptor, bit for bit: every tier only ever answers when the exact arithmetic is certain to agree.
 #define DSC_QUEUE_TAB 768
-#ifdef MAD_PROBE_TAB      // diagnostic build: what the table tier did with every sample of the first row of a launch
-__device__ int dbg_tab[4096 * 4];
-extern "C" int mad_debug_tab(int *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(dbg_tab), sizeof(int) * 4096 * 4) == hipSuccess ? 0 : -1; }
-#endif
 #ifdef MAD_PROBE_STAMPS      // diagnostic build: s_memtime at the phases of every row's workgroup (tools/probe_describe.py)
 __device__ long long dsc_stamps[16384 * 8];
 #define DSC_STAMP(k) do { __builtin_amdgcn_sched_barrier(0); if (threadIdx.x == 0 && blockIdx.x < 16384) dsc_stamps[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
@@ -1064,17 +1060,6 @@ __global__ __launch_bounds__(DSC_THREADS, TAB ? DSC_OCC_TAB : DSC_OCC) void k_de
                         const int zn = eqsp_tab32((const EqspTabLds *)&tab, rx, ry, rz);
                         zone[u] = zn;      // (flags: below, once per chunk and only where there are any)
                         any_flag |= q;
-#ifdef MAD_PROBE_TAB
-                        if (work == 0 && A.dsc8 == nullptr) {
-                            int *o = dbg_tab + ((tid * S) + pass * PS + i0 + u) * 4;
-                            const EqspTabLds *tt = (const EqspTabLds *)&tab;
-                            const int bz_ = min(max(cvt_floor((rz + 1.0f) * 512.f), 0), 1023);
-                            const float xr_ = rx * __builtin_amdgcn_rcpf(fmaxf(fabsf(rx) + fabsf(ry), 1e-30f));
-                            const float p_ = ry >= 0.f ? 1.0f - xr_ : 3.0f + xr_;
-                            const int bp_ = min(max(cvt_floor(p_ * 256.f), 0), 1023);
-                            o[0] = zone[u]; o[1] = (int)q; o[2] = bz_ | (bp_ << 10) | ((int)tt->zbelt[bz_] << 20) | ((int)tt->ptab[tt->zbelt[bz_] & 3][bp_] << 24); o[3] = __float_as_int(p_);
-                        }
-#endif
                         continue;
                     }
                     const float4 tx = t[i0 + u];
