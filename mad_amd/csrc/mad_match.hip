@@ -3455,7 +3455,6 @@ extern "C" int mad_match_shard_pairs(mad_ctx *ctx, const mad_set *hi, const mad_
     const int64_t nb = lo_end - lo_begin;
     MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_ZERO), zero_bytes(hi, lo)));
     int32_t *st = zero_status(ctx);
-    int32_t *hist = zr_hist(st);
     uint8_t *d_used_hi = zr_used_hi(st, hi->n_anchors), *d_used_lo = zr_used_lo(st, hi->n_anchors);
     MAD_HIP(hipStreamWaitEvent(ctx->stream, hi->built, 0));
     MAD_HIP(hipStreamWaitEvent(ctx->stream, lo->built, 0));

@@ -181,7 +181,6 @@ __global__ __launch_bounds__(MAXA > 0 ? RF_THREADS_REG : RF_THREADS) void k_refi
     __shared__ double red[RF_WAVES * 7 + 7];
     __shared__ double s_rot[9], s_trans[3], s_upd[12];      // s_upd: step translation (3) or step rotation (9) + centre
     __shared__ double s_step;
-    __shared__ int s_flag;      // 1 = NaN abort, 2 = converged
     const int cand = blockIdx.x / A.G, grp = blockIdx.x % A.G;
     const int tid = threadIdx.x;
     const int64_t first = (int64_t)grp * blockDim.x + tid, stride = (int64_t)A.G * blockDim.x;      // this thread's atoms: first, first + stride, ...
@@ -222,7 +221,6 @@ __global__ __launch_bounds__(MAXA > 0 ? RF_THREADS_REG : RF_THREADS) void k_refi
         for (int i = 0; i < 9; i++) s_rot[i] = (i % 4 == 0) ? 1.0 : 0.0;
         s_trans[0] = s_trans[1] = s_trans[2] = 0;
         s_step = A.max_step;
-        s_flag = 0;
     }
     __syncthreads();
 
