@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """k_corr_gemm2 against the number of 256 x 128 tiles: the same hi rows against lo sets of 7 936 ... 9 216 rows (496 ... 576 tiles on
-512 resident workgroups), timed through the library's timers.   python tools/probe_gemm_sizes.py"""
+512 resident workgroups), timed through the library's timers.   python tools/probe_gemm_sizes.py [n_hi n_lo ...]"""
 import os
 import sys
 import time
@@ -22,8 +22,10 @@ def rows(n, seed):
 
 def main():
     lib = _lib.Lib(0)
-    hi = rows(2048, 1)
-    for n_lo in (7936, 8192, 8448, 9088, 9216, 16384, 16512):
+    n_hi = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+    sizes = [int(a) for a in sys.argv[2:]] or [7936, 8192, 8448, 9088, 9216, 16384, 16512]
+    hi = rows(n_hi, 1)
+    for n_lo in sizes:
         lo = rows(n_lo, 2)
         lib.correlate(hi, lo, 0.9)
         lib.synchronize()
@@ -34,7 +36,7 @@ def main():
             lib.synchronize()
             t.append(time.perf_counter() - t0)
         tm = lib.timers() if hasattr(lib, "timers") else {}
-        print("n_lo %5d  tiles %4d  call %.3f ms  timers %s" % (n_lo, 8 * ((n_lo + 127) // 128), 1e3 * min(t), {k: round(v, 4) for k, v in tm.items()} if tm else ""), flush=True)
+        print("n_lo %5d  tiles %4d  call %.3f ms  timers %s" % (n_lo, ((n_hi + 255) // 256) * ((n_lo + 127) // 128), 1e3 * min(t), {k: round(v, 4) for k, v in tm.items()} if tm else ""), flush=True)
 
 
 if __name__ == "__main__":
