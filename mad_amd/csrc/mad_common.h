@@ -106,6 +106,17 @@ struct FieldDev {
     const unsigned *tex4;
 };
 
+// k_describe_ball takes a base-octave anchor when its ball of texels (radius 13 voxels) lies inside the grid with a voxel to spare:
+// the condition under which k_describe knows that no sample of the anchor's rows can leave the grid.  The host sorts anchors with
+// this expression (set_upload_anchors), the kernel checks it.
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+static inline bool mad_ball_interior(int c0, int c1, int c2, int nx, int ny, int nz) {
+    const int reach = 14;
+    return c0 - reach >= 1 && c0 + reach <= nx - 2 && c1 - reach >= 1 && c1 + reach <= ny - 2 && c2 - reach >= 1 && c2 + reach <= nz - 2;
+}
+
 // ---------------------------------------------------------------------------
 // host-side context
 // ---------------------------------------------------------------------------
@@ -181,6 +192,8 @@ struct mad_ctx {
     int8_t *mask_off = nullptr;              // sphere-mask offsets for the current r
     int mask_r = -1;
     int mask_n = 0;
+    int16_t *ball_colbase = nullptr;         // k_describe_ball: LDS offset of every (x, y) column of the base-octave sample ball (device)
+    bool dsc_ball = true;                    // base-octave rows described anchor by anchor from a ball of texels in LDS (MAD_NO_BALL / "dsc_ball": per row, as octave 0)
     // named grow-only scratch buffers
     DevBuf scratch[64 * MAD_LANES];   // MAD_LANES independent copies: matches in flight do not share scratch
     int lane = 0;                    // the copy the current call works in
@@ -228,6 +241,11 @@ struct mad_set {
     DevBuf row_anchor, row_main, row_sec, row_R, row_Rinv, row_meta, dsc, dsc8, norm;
     DevBuf row_perm;             // k-th row in working order (rows of spatially neighbouring anchors next to each other)
     DevBuf row_rec;              // DscRowRec of the k-th row in working order
+    DevBuf anc_rows;             // per anchor IN WORKING ORDER: {position of its first row in working order, rows} (k_orient_rows* write it)
+    int n_rowwise = 0;           // anchors k_describe takes row by row (octave 0, and base-octave ones near the border): they come first in
+                                 // working order; the others go through k_describe_ball
+    int ball_dims[3] = {0, 0, 0};      // the base-octave grid the anchors were sorted for (0: no anchor was set apart)
+    int last_fan = 0;            // lim_main x lim_sec of the last build
     DevBuf dev_n;                // view: int32[4] on the device = {rows, rows out of int8 range, rejects, describe overflow}
     int64_t n_rows_host = -1;    // host copy of dev_n[0]; -1 until the asynchronous read-back has been waited for
     bool range_bad = false;      // a loaded row held a count outside the int8 range
@@ -293,8 +311,9 @@ int mad_scan_i32(mad_ctx *ctx, const int32_t *in, int32_t *out, int64_t n);
 // single-launch exclusive scan for n <= 65536 with the length read on the device; out[*n] = total, also to *total_out
 void mad_scan_small(mad_ctx *ctx, const int32_t *in, int32_t *out, const int32_t *d_n, int32_t *total_out, int n_host = 0);
 
-// What k_describe starts a row from, as one 128-byte record in WORKING order (the k-th record belongs to the k-th row the kernel
-// takes): written with the rows by k_orient_rows*, fetched with one vector load a row ahead.
+// What k_describe starts a row from, as one record in WORKING order (the k-th record belongs to the k-th row the kernel takes):
+// written with the rows by k_orient_rows*.  k_describe fetches its first 128 bytes with one vector load; k_describe_ball reads the
+// float32 copies behind them with scalar loads (they are what every thread of k_describe forms from the float64 values).
 struct alignas(16) DscRowRec {
     int32_t row;           // the row (where its descriptor goes)
     int32_t c[3];          // voxel coordinates of its anchor
@@ -302,8 +321,12 @@ struct alignas(16) DscRowRec {
     int32_t pad0[3];
     double inv[9];         // inv(Rfinal) (np.linalg.inv of Descriptor.py:132, by cofactors)
     int32_t pad1[6];
+    float hf[9];           // (float)inv[i]
+    float rf[9];           // (float)Rfinal[i], the third row times 1 / 511 (the scale of a 4-byte texel's components)
+    int32_t pad2[2];
 };
-static_assert(sizeof(DscRowRec) == 128, "DscRowRec is read as 32 dwords");
+#define MAD_ROWREC_WORDS ((int)(sizeof(DscRowRec) / 4))
+static_assert(sizeof(DscRowRec) == 208 && offsetof(DscRowRec, hf) == 128, "k_describe reads the first 32 dwords of a DscRowRec");
 
 // implemented in mad_orient.hip; used by the set API in mad_match.hip.  Both are fully asynchronous.
 struct OrientOut {
@@ -318,6 +341,7 @@ struct OrientOut {
     const int32_t *anc_order = nullptr;
     int32_t *row_perm = nullptr;
     DscRowRec *row_rec = nullptr;      // nullable: the rows' records for k_describe, in working order
+    int32_t *anc_rows = nullptr;       // nullable (with anc_order): per anchor in working order {first row position, rows}
     bool counters_zeroed = false;      // the caller has already enqueued the zeroing of d_n_rows / d_n_reject
     int32_t *d_n_rows;       // device: number of rows produced
     int32_t *d_n_reject;     // device, nullable: anchors refused at the border
@@ -341,6 +365,10 @@ struct DescribeJob {
     const double *d_row_R, *d_row_Rinv;
     const int32_t *d_row_perm = nullptr;      // nullable: workgroup k describes row d_row_perm[k]
     const DscRowRec *d_row_rec = nullptr;     // nullable: the same rows' records (k_orient_rows* wrote them), in that order
+    // nullable: {first row position, rows} per anchor in working order; with it, n_anchors, n_rowwise (the anchors k_describe takes: the
+    // first ones in working order) and fan (rows per anchor at most), the other anchors -- base octave, interior -- go through k_describe_ball
+    const int32_t *d_anc_rows = nullptr;
+    int n_anchors = 0, n_rowwise = 0, fan = 0;
     const int32_t *d_n_rows;
     int64_t grid_rows;
     int32_t *d_overflow;
@@ -515,6 +543,11 @@ __device__ __forceinline__ int cvt_floor(float x) {
 __device__ __forceinline__ unsigned mad_u24(unsigned a, unsigned b, unsigned c) {
     unsigned r;
     asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ int mad_i24(int a, int b, int c) {      // the same for signed values within 24 bits
+    int r;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
 __device__ __forceinline__ int cvt_round(float x) {

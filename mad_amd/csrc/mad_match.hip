@@ -2706,7 +2706,7 @@ extern "C" void mad_set_destroy(mad_ctx *ctx, mad_set *s) {
         if (ctx->match.shard_lo == s) ctx->match.shard_lo = nullptr;
     }
     DevBuf *bufs[] = {&s->anc_blob, &s->row_anchor, &s->row_main, &s->row_sec, &s->row_R, &s->row_Rinv, &s->row_meta, &s->dsc,
-                      &s->dsc8, &s->norm, &s->row_perm, &s->row_rec, &s->cell_start, &s->cell_pts, &s->cell_ids};      // anc_* and dev_n are views
+                      &s->dsc8, &s->norm, &s->row_perm, &s->row_rec, &s->anc_rows, &s->cell_start, &s->cell_pts, &s->cell_ids};      // anc_* and dev_n are views
     for (DevBuf *b : bufs) mad_release(*b);
     if (s->host_stage) (void)hipHostFree(s->host_stage);
     if (s->ready) (void)hipEventDestroy(s->ready);
@@ -2735,12 +2735,17 @@ static int set_rows(mad_ctx *ctx, const mad_set *cs, int64_t *n_rows) {
             J.d_row_anchor = (const int32_t *)s->row_anchor.p; J.d_row_R = (const double *)s->row_R.p; J.d_row_Rinv = (const double *)s->row_Rinv.p;
             J.d_row_perm = s->last_perm ? (const int32_t *)s->row_perm.p : nullptr;
             J.d_row_rec = s->last_rec ? (const DscRowRec *)s->row_rec.p : nullptr;
+            if (s->last_perm && s->last_rec && s->anc_rows.p && s->ball_dims[0] > 0 && s->ball_dims[0] == s->last_f[1].nx &&
+                s->ball_dims[1] == s->last_f[1].ny && s->ball_dims[2] == s->last_f[1].nz) {
+                J.d_anc_rows = (const int32_t *)s->anc_rows.p; J.n_anchors = s->n_anchors; J.n_rowwise = s->n_rowwise; J.fan = s->last_fan;
+            }
             J.d_n_rows = (const int32_t *)s->dev_n.p; J.grid_rows = s->cap_rows; J.d_overflow = (int32_t *)s->dev_n.p + 3;
             J.d_dsc = (int16_t *)s->dsc.p; J.d_dsc8 = (int8_t *)s->dsc8.p; J.d_norm = (double *)s->norm.p;
             MAD_TRY(mad_describe_device_many(ctx, 1, &J, s->last_r));
             MAD_HIP(hipEventRecord(s->built, ctx->stream));
             MAD_HIP(hipMemcpyAsync(&ctx->pinned[s->pinned_slot], s->dev_n.p, 16, hipMemcpyDeviceToHost, ctx->stream));
             MAD_HIP(hipStreamSynchronize(ctx->stream));
+            if (h[3]) return mad_fail(ctx, MAD_EINVAL, "mad_set_build: the describe stage could not be completed (flag %d)", h[3]);
         }
         if (h[3] && s->last_r == 0) {      // an imported set (mad_set_import) that could not be completed
             if (h[3] < 0) return mad_fail(ctx, MAD_EINVAL, "mad_set_import: malformed wire image (size, capacity or anchor ids do not match)");
@@ -2754,9 +2759,12 @@ static int set_rows(mad_ctx *ctx, const mad_set *cs, int64_t *n_rows) {
     return MAD_OK;
 }
 
+// ball_dims (nullable): the base-octave grid; base-octave anchors whose sample ball lies inside it (mad_ball_interior) are sorted
+// behind all others in working order -- k_describe_ball takes them, s->n_rowwise anchors stay with k_describe
 static int set_upload_anchors(mad_ctx *ctx, mad_set *s, const int32_t *anc_coords, const int32_t *anc_octave,
-                              const double *anc_subv, const int32_t *anc_index, int n, int32_t rows0 = 0) {
+                              const double *anc_subv, const int32_t *anc_index, int n, int32_t rows0 = 0, const int *ball_dims = nullptr) {
     s->n_anchors = n;
+    const int bd[3] = {ball_dims && anc_coords ? ball_dims[0] : 0, ball_dims && anc_coords ? ball_dims[1] : 0, ball_dims && anc_coords ? ball_dims[2] : 0};
     s->gen++;
     const size_t m = (size_t)(n > 0 ? n : 1);
     const size_t o_subv = 64, o_coords = o_subv + m * 24, o_oct = o_coords + m * 12, o_idx = o_oct + m * 4, o_canon = o_idx + m * 4,
@@ -2784,6 +2792,7 @@ static int set_upload_anchors(mad_ctx *ctx, mad_set *s, const int32_t *anc_coord
     // The same anchors as last time (a set rebuilt in place, step after step): the staging buffer and the device copy already
     // hold them -- only the counters are reset.  Decided by comparing the bytes, not by trusting the caller.
     const bool same = n > 0 && s->staged_n == n && s->staged_coords == (anc_coords != nullptr) && blob_before == s->anc_blob.p &&
+                      bd[0] == s->ball_dims[0] && bd[1] == s->ball_dims[1] && bd[2] == s->ball_dims[2] &&
                       memcmp(h + o_subv, anc_subv, (size_t)n * 24) == 0 && (!anc_coords || memcmp(h + o_coords, anc_coords, (size_t)n * 12) == 0) &&
                       memcmp(h + o_oct, anc_octave, (size_t)n * 4) == 0 && memcmp(h + o_idx, anc_index, (size_t)n * 4) == 0;
     memset(h, 0, 64);      // the device counters start from zero
@@ -2796,6 +2805,8 @@ static int set_upload_anchors(mad_ctx *ctx, mad_set *s, const int32_t *anc_coord
         return MAD_OK;
     }
     s->staged_n = n; s->staged_coords = anc_coords != nullptr;
+    s->ball_dims[0] = bd[0]; s->ball_dims[1] = bd[1]; s->ball_dims[2] = bd[2];
+    s->n_rowwise = n;
     if (n > 0) {
         memcpy(h + o_subv, anc_subv, (size_t)n * 24);
         if (anc_coords) memcpy(h + o_coords, anc_coords, (size_t)n * 12);
@@ -2832,7 +2843,11 @@ static int set_upload_anchors(mad_ctx *ctx, mad_set *s, const int32_t *anc_coord
                 const int sh = anc_octave[i] == 0 ? 1 : 0;      // the same physical cell size in both octaves
                 const uint64_t x = (uint64_t)std::max(anc_coords[3 * i], 0) >> sh, y = (uint64_t)std::max(anc_coords[3 * i + 1], 0) >> sh,
                                z = (uint64_t)std::max(anc_coords[3 * i + 2], 0) >> sh;
-                key[i] = ((uint64_t)(anc_octave[i] != 0) << 63) | spread(x) << 2 | spread(y) << 1 | spread(z);
+                // (bit 62: a base-octave anchor whose ball of samples lies inside the grid -- k_describe_ball's, behind all others)
+                const bool ball = bd[0] > 0 && anc_octave[i] == 1 &&
+                                  mad_ball_interior(anc_coords[3 * i], anc_coords[3 * i + 1], anc_coords[3 * i + 2], bd[0], bd[1], bd[2]);
+                if (ball) s->n_rowwise--;
+                key[i] = ((uint64_t)ball << 63) | ((uint64_t)(anc_octave[i] != 0) << 62) | ((spread(x) << 2 | spread(y) << 1 | spread(z)) & ~(3ull << 62));
             }
             std::sort(work, work + n, [&](int32_t a, int32_t b) { return key[a] != key[b] ? key[a] < key[b] : a < b; });
         }
@@ -2926,9 +2941,14 @@ extern "C" int mad_set_build_many(mad_ctx *ctx, int n_sets, mad_set *const *sets
     for (int i = 0; i < n_sets; i++) {
         mad_set *s = sets[i];
         const int n = n_anchors[i];
-        MAD_TRY(set_upload_anchors(ctx, s, anc_coords[i], anc_octave[i], anc_subv[i], anc_index[i], n));
+        // (r = 8, the default patch: the only size k_describe_ball is built for)
+        const int bdims[3] = {oj[i].f[1].nx, oj[i].f[1].ny, oj[i].f[1].nz};
+        const bool sort_ball = r == 8 && oj[i].f[1].tex4 != nullptr && ctx->spatial_order;
+        MAD_TRY(set_upload_anchors(ctx, s, anc_coords[i], anc_octave[i], anc_subv[i], anc_index[i], n, 0, sort_ball ? bdims : nullptr));
         s->D = 64 * ctx->eq_host[1].Z;
         MAD_TRY(set_reserve_rows(ctx, s, (int64_t)n * lim_main * lim_sec));
+        MAD_TRY(mad_reserve(ctx, s->anc_rows, (size_t)(n > 0 ? n : 1) * 8));
+        s->last_fan = lim_main * lim_sec;
         OrientJob &J = oj[i];
         J.d_coords = (const int32_t *)s->anc_coords.p; J.d_octave = (const int32_t *)s->anc_octave.p; J.uniform_octave = 0; J.n = n;
         OrientOut &out = J.out;
@@ -2940,12 +2960,17 @@ extern "C" int mad_set_build_many(mad_ctx *ctx, int n_sets, mad_set *const *sets
         out.anc_order = ctx->spatial_order ? (const int32_t *)s->anc_order.p : nullptr;
         out.row_perm = ctx->spatial_order ? (int32_t *)s->row_perm.p : nullptr;
         out.row_rec = (DscRowRec *)s->row_rec.p;
+        out.anc_rows = out.anc_order ? (int32_t *)s->anc_rows.p : nullptr;
         out.counters_zeroed = true;
         DescribeJob &Q = dj[i];
         Q.f[0] = J.f[0]; Q.f[1] = J.f[1];
         Q.d_anc_coords = J.d_coords; Q.d_anc_octave = J.d_octave; Q.uniform_octave = 0;
         Q.d_row_anchor = out.row_anchor; Q.d_row_R = out.row_R; Q.d_row_Rinv = out.row_Rinv; Q.d_row_perm = out.row_perm; Q.d_n_rows = out.d_n_rows;
         Q.d_row_rec = out.row_rec;
+        // the anchors sorted behind n_rowwise go through k_describe_ball (when the sort was made for this base-octave grid)
+        if (out.anc_rows && s->ball_dims[0] == bdims[0] && s->ball_dims[1] == bdims[1] && s->ball_dims[2] == bdims[2] && s->ball_dims[0] > 0) {
+            Q.d_anc_rows = out.anc_rows; Q.n_anchors = n; Q.n_rowwise = s->n_rowwise; Q.fan = lim_main * lim_sec;
+        }
         s->last_perm = out.row_perm != nullptr;
         s->last_rec = out.row_rec != nullptr;
         // the describe launch is sized from the row count of this set's previous build when there is one
@@ -3378,6 +3403,10 @@ extern "C" int mad_set_option(mad_ctx *ctx, const char *name, double value) {
     if (!strcmp(name, "ori_queue") || !strcmp(name, "dsc_queue")) {      // test hooks: a small cap drives the kernels' full-queue paths
         if (!(value >= 0) || !(value < 1e9)) return mad_fail(ctx, MAD_EINVAL, "mad_set_option: %s = %g", name, value);
         (name[0] == 'o' ? ctx->ori_queue_cap : ctx->dsc_queue_cap) = (int)value;
+        return MAD_OK;
+    }
+    if (!strcmp(name, "dsc_ball")) {      // 1 (default): the base-octave anchors through k_describe_ball; 0: every row through k_describe
+        ctx->dsc_ball = value != 0;
         return MAD_OK;
     }
     return mad_fail(ctx, MAD_EINVAL, "mad_set_option: unknown option '%s'", name);

@@ -423,17 +423,21 @@ struct RowsArgs {
     int32_t *perm_off;             // with order: n + 1 row offsets in working order
     int32_t *row_perm;             // with order: the rows in working order
     DscRowRec *row_rec;            // nullable: what k_describe starts a row from, in working order
+    int32_t *anc_rows;             // nullable: per anchor in working order {position of its first row in working order, rows}
     const int32_t *coords;         // with row_rec: the anchors' voxel coordinates
     int uniform_octave;            // ... and their octave when anc_octave is null
 };
 
 // the record of one row (k_describe reads it with one 128-byte load); inv = inv(Rfinal), still in the thread's registers
-__device__ __forceinline__ void put_row_rec(const RowsArgs &A, int64_t pos, int row, int a, const double *inv) {
+__device__ __forceinline__ void put_row_rec(const RowsArgs &A, int64_t pos, int row, int a, const double *inv, const double *R) {
     DscRowRec &q = A.row_rec[pos];
     q.row = row;
     q.c[0] = A.coords[3 * a]; q.c[1] = A.coords[3 * a + 1]; q.c[2] = A.coords[3 * a + 2];
     q.octave = A.anc_octave ? A.anc_octave[a] : A.uniform_octave;
     for (int i = 0; i < 9; i++) q.inv[i] = inv[i];
+    // the float32 values k_describe's threads form for themselves, once per row (k_describe_ball takes them with scalar loads)
+    for (int i = 0; i < 9; i++) q.hf[i] = (float)inv[i];
+    for (int i = 0; i < 9; i++) q.rf[i] = i < 6 ? (float)R[i] : (float)R[i] * (1.0f / 511.0f);
 }
 
 // row offsets of every job: exclusive scan of its anchors' row counts, one workgroup per job
@@ -484,6 +488,7 @@ __global__ __launch_bounds__(256) void k_orient_rows(Batch<RowsArgs> B, int fan,
     if (p >= A.n) return;
     const int a = A.order ? A.order[p] : p;
     const int c = A.slot_cnt[a];
+    if (s == 0 && A.anc_rows) { A.anc_rows[2 * p] = A.order ? A.perm_off[p] : A.row_off[a]; A.anc_rows[2 * p + 1] = c; }
     if (s >= c) return;
     const int64_t row = (int64_t)A.row_off[a] + s;
     if (A.order) A.row_perm[A.perm_off[p] + s] = (int32_t)row;
@@ -503,7 +508,7 @@ __global__ __launch_bounds__(256) void k_orient_rows(Batch<RowsArgs> B, int fan,
     if (A.row_Rinv)
         for (int i = 0; i < 9; i++) A.row_Rinv[9 * row + i] = inv9[i];
     if (A.row_meta) { A.row_meta[3 * row] = A.anc_index[a]; A.row_meta[3 * row + 1] = A.anc_octave[a]; A.row_meta[3 * row + 2] = mb; }
-    if (A.row_rec) put_row_rec(A, A.order ? A.perm_off[p] + s : row, (int)row, a, inv9);
+    if (A.row_rec) put_row_rec(A, A.order ? A.perm_off[p] + s : row, (int)row, a, inv9, R9);
 }
 
 // k_orient_scan + k_orient_rows in ONE launch (round 3): every 1024-thread workgroup forms the exclusive scan of its job's
@@ -543,6 +548,7 @@ __global__ __launch_bounds__(1024) void k_orient_rows_scan(Batch<RowsArgs> B, in
     if (pl >= ppb || pp >= n) return;
     const int a = A.order ? A.order[pp] : pp;
     const int c = A.slot_cnt[a];
+    if (sl == 0 && A.anc_rows) { A.anc_rows[2 * pp] = s_perm[pl]; A.anc_rows[2 * pp + 1] = c; }
     if (sl >= c) return;
     const int64_t row = (int64_t)s_off[a] + sl;
     if (A.order) A.row_perm[s_perm[pl] + sl] = (int32_t)row;
@@ -562,7 +568,7 @@ __global__ __launch_bounds__(1024) void k_orient_rows_scan(Batch<RowsArgs> B, in
     if (A.row_Rinv)
         for (int i = 0; i < 9; i++) A.row_Rinv[9 * row + i] = inv9[i];
     if (A.row_meta) { A.row_meta[3 * row] = A.anc_index[a]; A.row_meta[3 * row + 1] = A.anc_octave[a]; A.row_meta[3 * row + 2] = mb; }
-    if (A.row_rec) put_row_rec(A, A.order ? s_perm[pl] + sl : row, (int)row, a, inv9);
+    if (A.row_rec) put_row_rec(A, A.order ? s_perm[pl] + sl : row, (int)row, a, inv9, R9);
 }
 
 // Runs a1-a8 for the anchor lists of n_jobs structures (coordinates and octaves already on the device) in one k_orient
@@ -618,6 +624,7 @@ static int orient_batch(mad_ctx *ctx, int n_jobs, const OrientJob *jobs, int r, 
         Q.n_rows = J.out.d_n_rows;
         Q.order = A.order; Q.perm_off = scratch<int32_t>(ctx, S_PERM_OFF) + a0 + j; Q.row_perm = J.out.row_perm;
         Q.row_rec = J.out.row_rec; Q.coords = J.d_coords; Q.uniform_octave = J.uniform_octave;
+        Q.anc_rows = J.out.anc_rows;
         if (!Q.anc_octave) Q.anc_octave = J.d_octave;
         R.first[j] = (int)blk;
         a0 += J.n;
@@ -771,6 +778,7 @@ struct DescribeArgs {
     const DscRowRec *row_rec;      // nullable: the k-th record = everything the k-th row in working order starts from
     int queue_cap;                 // entries of the undecided-sample queue in use (<= its size)
     const int32_t *n_rows;         // device: number of rows
+    const int32_t *row_limit;      // device, nullable: this launch takes the first *row_limit rows in working order only (the rest: k_describe_ball)
     int32_t *overflow;             // device: set when the launch was sized for fewer rows than *n_rows
     int r;
     const EqspDev *eq;
@@ -793,22 +801,30 @@ __device__ __forceinline__ int describe_exact(const EqspFastLds *eq, float4 t, c
     return zone;
 }
 
-// Nearest voxel of lattice point l (in the anchor's frame) with the reference's float64 expression; *oob is set when the
+// Nearest voxel of lattice point l (in the anchor's frame) with the reference's float64 expression; false when the
 // point leaves the grid (scipy's RegularGridInterpolator, bounds_error=True, MapSpace.py:189).
-__device__ __forceinline__ unsigned lattice_index_exact(double l0, double l1, double l2, const double *inv, double c0, double c1, double c2,
-                                                        const FieldDev &F, bool *oob) {
+__device__ __forceinline__ bool lattice_voxel_exact(double l0, double l1, double l2, const double *inv, double c0, double c1, double c2,
+                                                    const FieldDev &F, int *v0, int *v1, int *v2) {
     const double p0 = (l0 * inv[0] + l1 * inv[1] + l2 * inv[2]) + c0;      // Descriptor.py:132-133
     const double p1 = (l0 * inv[3] + l1 * inv[4] + l2 * inv[5]) + c1;
     const double p2 = (l0 * inv[6] + l1 * inv[7] + l2 * inv[8]) + c2;
     if (!(p0 >= 0.0) || !(p0 <= (double)(F.nx - 1)) || !(p1 >= 0.0) || !(p1 <= (double)(F.ny - 1)) || !(p2 >= 0.0) ||
-        !(p2 <= (double)(F.nz - 1))) {
+        !(p2 <= (double)(F.nz - 1)))
+        return false;
+    int a0i = min((int)floor(p0), F.nx - 2), a1i = min((int)floor(p1), F.ny - 2), a2i = min((int)floor(p2), F.nz - 2);
+    *v0 = (p0 - (double)a0i <= 0.5) ? a0i : a0i + 1;
+    *v1 = (p1 - (double)a1i <= 0.5) ? a1i : a1i + 1;
+    *v2 = (p2 - (double)a2i <= 0.5) ? a2i : a2i + 1;
+    return true;
+}
+// ... as a texel index; *oob is set when the point leaves the grid
+__device__ __forceinline__ unsigned lattice_index_exact(double l0, double l1, double l2, const double *inv, double c0, double c1, double c2,
+                                                        const FieldDev &F, bool *oob) {
+    int a0i, a1i, a2i;
+    if (!lattice_voxel_exact(l0, l1, l2, inv, c0, c1, c2, F, &a0i, &a1i, &a2i)) {
         *oob = true;
         return 0;
     }
-    int a0i = min((int)floor(p0), F.nx - 2), a1i = min((int)floor(p1), F.ny - 2), a2i = min((int)floor(p2), F.nz - 2);
-    a0i = (p0 - (double)a0i <= 0.5) ? a0i : a0i + 1;
-    a1i = (p1 - (double)a1i <= 0.5) ? a1i : a1i + 1;
-    a2i = (p2 - (double)a2i <= 0.5) ? a2i : a2i + 1;
     return (unsigned)(((size_t)a0i * F.ny + a1i) * F.nz + a2i);
 }
 
@@ -889,7 +905,8 @@ __global__ __launch_bounds__(DSC_THREADS, TAB ? DSC_OCC_TAB : DSC_OCC) void k_de
     // neighbours in the anchor list and sample the same neighbourhood: running side by side on ONE XCD
     // they meet in its L2.  The row count lives on the device; the grid is an upper bound of it.
     const int64_t n_rows = *A.n_rows;
-    const int64_t chunk = (n_rows + 7) / 8;
+    const int64_t n_work = A.row_limit ? (int64_t)*A.row_limit : n_rows;
+    const int64_t chunk = (n_work + 7) / 8;
     const int tid = threadIdx.x;
     if (8 * chunk > (int64_t)gdim) {      // the launch was sized from a stale hint: tell the host
         if (bid == 0 && tid == 0) *A.overflow = 1;
@@ -904,7 +921,7 @@ __global__ __launch_bounds__(DSC_THREADS, TAB ? DSC_OCC_TAB : DSC_OCC) void k_de
         }
     }
     const int64_t work = (int64_t)(bid & 7) * chunk + (bid >> 3);
-    if ((int64_t)(bid >> 3) >= chunk || work >= n_rows) return;
+    if ((int64_t)(bid >> 3) >= chunk || work >= n_work) return;
     DSC_STAMP(0);
     if (TAB) { stage_lds(&tab, &A.eq->tab, sizeof(EqspTabLds)); stage_lds(&fast_s, &A.eq->image, sizeof(fast_s)); }
     else eqsp_fast_stage(A.eq, (EqspFastLds *)&fast_s);
@@ -944,7 +961,7 @@ __global__ __launch_bounds__(DSC_THREADS, TAB ? DSC_OCC_TAB : DSC_OCC) void k_de
     };
     const int *const recs = (const int *)A.row_rec;
     if (recs) {
-        if (tid < 32) s_rec[tid] = recs[work * 32 + tid];
+        if (tid < 32) s_rec[tid] = recs[work * MAD_ROWREC_WORDS + tid];
     } else if (tid == 0) chain_record(work, s_rec);
     if (tid == 0) { s_oob = 0; s_nq = 0; }
     __syncthreads();      // the histogram is zero, the flags are reset, the record is there
@@ -1178,6 +1195,358 @@ __global__ __launch_bounds__(DSC_THREADS, TAB ? DSC_OCC_TAB : DSC_OCC) void k_de
     DSC_STAMP(7);
 }
 
+// ---------------------------------------------------------------------------
+// descriptor kernel of the base octave: the anchor's ball of 4-byte texels in LDS (round 4)
+// ---------------------------------------------------------------------------
+// k_describe runs at the rate its gathers are accepted: ~3.3 clocks per scattered lane-load per CU, whatever the lanes' addresses have
+// in common, 4 096 of them per row.  In the base octave (Descriptor.py:35: lattice -7.5 .. 7.5 voxels) every
+// sample of every row of an anchor lies within 7.5 sqrt(3) = 12.99 voxels of it, so its nearest voxel d satisfies
+// sum_i max(|d_i| - 0.5, 0)^2 <= 168.75: 11 027 texels = 43 KB as 4-byte texels.  One 1 024-thread workgroup per (anchor, run of
+// DSCB_RPB rows) fetches that ball ONCE with coalesced loads (z-runs of up to 27 consecutive texels) and samples the rows from LDS:
+// a thread owns four samples of a row -- one (j, k) column, a quarter of the i axis = one sub-region -- and the rows go through
+// one after the other, one barrier each: histogram of row r (packed, two 16-bit counters per word: a count is <= 64) | barrier |
+// the samples the table left open (their 16-byte texels from global memory, the float32 / float64 tiers, as in k_describe) and,
+// by one wave, the write-out of row r - 1.  Same arithmetic per sample as k_describe<16, 64, 16, true>: same descriptors, bit for bit.
+// (The upsampled octave's ball is 53^3 texels: it does not fit, and stays with k_describe.)
+#define DSCB_THREADS 1024
+#define DSCB_M 13
+#define DSCB_SIDE (2 * DSCB_M + 1)
+#define DSCB_COLS (DSCB_SIDE * DSCB_SIDE)
+#define DSCB_E2MAX 676                  // voxel d is in the ball iff sum_i max(2 |d_i| - 1, 0)^2 <= 4 (7.5 sqrt(3) + 0.01)^2 = 676.04
+#define DSCB_NBALL 11027
+#define DSCB_QCAP 512
+#ifndef DSCB_RPB
+#define DSCB_RPB 4                      // rows of an anchor one workgroup takes (an anchor of n rows: ceil(n / DSCB_RPB) workgroups, each with its own ball)
+#endif
+#define DSCB_FAST_BYTES ((offsetof(EqspFastLds, dir) + 15) / 16 * 16)
+#define DSCB_OFF_TAB ((DSCB_NBALL + 3) / 4 * 16)
+#define DSCB_OFF_FAST (DSCB_OFF_TAB + sizeof(EqspTabLds))
+#define DSCB_OFF_COL (DSCB_OFF_FAST + DSCB_FAST_BYTES)
+#define DSCB_COL_BYTES ((DSCB_COLS * 2 + 15) / 16 * 16)
+#define DSCB_OFF_HIST (DSCB_OFF_COL + DSCB_COL_BYTES)
+#define DSCB_OFF_Q (DSCB_OFF_HIST + 3 * 512 * 4)
+#define DSCB_OFF_FLAGS (DSCB_OFF_Q + 2 * DSCB_QCAP * 2)
+#define DSCB_LDS_BYTES (DSCB_OFF_FLAGS + 32)
+static_assert(DSCB_LDS_BYTES <= 80 * 1024, "two workgroups of k_describe_ball per CU");
+
+// half-length of the z-run of column (cx, cy) of the ball (its voxels: z = DSCB_M - h .. DSCB_M + h), or -1
+__host__ __device__ __forceinline__ int dscb_col_h(int cx, int cy) {
+    const int ax = cx > DSCB_M ? cx - DSCB_M : DSCB_M - cx, ay = cy > DSCB_M ? cy - DSCB_M : DSCB_M - cy;
+    const int ex = ax > 0 ? 2 * ax - 1 : 0, ey = ay > 0 ? 2 * ay - 1 : 0;
+    const int rem = DSCB_E2MAX - ex * ex - ey * ey;
+    if (rem < 0) return -1;
+    const int sq = (int)__builtin_sqrtf((float)rem + 0.5f);      // floor(sqrt(rem)): rem <= 676, the square root is correctly rounded
+    return (sq + 1) >> 1;                                         // max(2 |dz| - 1, 0) <= sq
+}
+
+
+// The rare float64 paths of k_describe_ball, out of line: inlined, their float64 temporaries (and the loop invariants the optimiser
+// hoists for them) would set the register count of a kernel that has 64 registers per thread.
+// Nearest voxel of lattice point (i, j, k) of a base-octave row with the reference's float64 expression (Descriptor.py:132-133), as
+// local coordinates of the anchor's ball (3 x 5 bits), or ~0u when the point leaves the grid.
+__device__ __noinline__ unsigned dscb_exact_voxel(const double *inv, int ic0, int ic1, int ic2, int nx, int ny, int nz, int i, int j, int k) {
+    FieldDev F;
+    F.tex = nullptr; F.tex4 = nullptr; F.nx = nx; F.ny = ny; F.nz = nz;
+    int v0, v1, v2;
+    if (!lattice_voxel_exact(-7.5 + (double)i, -7.5 + (double)j, -7.5 + (double)k, inv, (double)ic0, (double)ic1, (double)ic2, F, &v0, &v1, &v2)) return ~0u;
+    return (unsigned)(v0 - ic0 + 13) | (unsigned)(v1 - ic1 + 13) << 5 | (unsigned)(v2 - ic2 + 13) << 10;
+}
+__device__ __noinline__ int dscb_describe_exact(const EqspFastLds *eq, float tx, float ty, float tz, float tw, const double *R) {
+    return describe_exact(eq, make_float4(tx, ty, tz, tw), R);
+}
+typedef const __attribute__((address_space(4))) DscRowRec *dscb_rec_t;      // records and rotations were written by earlier launches:
+typedef const __attribute__((address_space(4))) double *dscb_f64_t;         // constant for this kernel -> scalar loads
+
+struct DescribeBallArgs {
+    FieldDev f;                    // the base octave's field
+    const DscRowRec *row_rec;      // the rows' records in working order
+    const int32_t *anc_rows;       // per anchor in working order: {position of its first row, rows}
+    const double *row_R;           // n_rows x 9
+    int n_base, n_rowwise;            // base-octave anchors, and the (octave-0) anchors before them in working order
+    int queue_cap;
+    const EqspDev *eq;
+    int32_t *overflow;             // device: -2 when an anchor that is not interior arrives here
+    const int16_t *colbase;        // mad_ctx::ball_colbase
+    int16_t *dsc;                  // n_rows x 1024
+    int8_t *dsc8;                  // nullable
+    double *norm;
+};
+
+__global__ __launch_bounds__(DSCB_THREADS, 8) void k_describe_ball(Batch<DescribeBallArgs> B, int chunks) {
+    extern __shared__ __align__(16) unsigned char dscb_lds[];
+    const int job = batch_job(B, (int)blockIdx.x);
+    const DescribeBallArgs &A = B.job[job];
+    const int bid = (int)blockIdx.x - B.first[job];
+    // workgroup -> (run of rows, anchor): the FIRST runs of all anchors come first in the grid (most anchors have no second one), and
+    // within a run the anchors are dealt so that each XCD (workgroups b, b + 8, ...) gets a contiguous stretch of the Morton order
+    const int per = (A.n_base + 7) / 8, nbp = per * 8;
+    const int ch = bid / nbp, bi = bid - ch * nbp;
+    const int slot = (bi & 7) * per + (bi >> 3);
+    if (ch >= chunks || slot >= A.n_base) return;
+    const int p = A.n_rowwise + slot;
+    const int pos0 = __builtin_amdgcn_readfirstlane(A.anc_rows[2 * p]), cnt = __builtin_amdgcn_readfirstlane(A.anc_rows[2 * p + 1]);
+    const int r_begin = ch * DSCB_RPB;
+    if (r_begin >= cnt) return;
+    const int r_end = min(cnt, r_begin + DSCB_RPB);
+
+    unsigned *const ball = (unsigned *)dscb_lds;
+    const EqspTabLds *const tab = (const EqspTabLds *)(dscb_lds + DSCB_OFF_TAB);
+    const EqspFastLds *const fastp = (const EqspFastLds *)(dscb_lds + DSCB_OFF_FAST);      // float32 tier (the head of the image)
+    const EqspFastLds *const exactp = &A.eq->image;                                          // float64 tier: global memory, a few samples per row
+    short *const colb = (short *)(dscb_lds + DSCB_OFF_COL);
+    const short *const colc = colb + DSCB_M * (DSCB_SIDE + 1);      // indexed by r0 * 27 + r1 with the offsets r = -13 .. 13 from the anchor voxel
+    unsigned *const hist = (unsigned *)(dscb_lds + DSCB_OFF_HIST);      // three rows in flight x 512 words of two 16-bit counters
+    unsigned short *const qent = (unsigned short *)(dscb_lds + DSCB_OFF_Q);      // two rows x DSCB_QCAP undecided samples: thread | u << 10
+    int *const s_nq = (int *)(dscb_lds + DSCB_OFF_FLAGS), *const s_oob = s_nq + 4;      // four rows each
+    const int tid = (int)threadIdx.x;
+    const FieldDev F = A.f;
+    const dscb_rec_t recs = (dscb_rec_t)(A.row_rec + pos0);
+    const int ic0 = recs[r_begin].c[0], ic1 = recs[r_begin].c[1], ic2 = recs[r_begin].c[2];
+    const int QCAP = min(DSCB_QCAP, A.queue_cap);
+    // as in k_describe: when the ball lies inside the grid with a voxel to spare no sample can leave it
+    // Only anchors whose ball lies inside the grid with a voxel to spare come here (no sample of theirs can leave the grid, as in
+    // k_describe's `interior`); the host sorts the others in front of `n_rowwise` with the same expression (mad_ball_interior).
+    if (!mad_ball_interior(ic0, ic1, ic2, F.nx, F.ny, F.nz)) {
+        if (tid == 0) *A.overflow = -2;      // refused, loudly: the set's describe stage reports the flag
+        return;
+    }
+
+    // ---- tables, counters, and the ball: half a wave per column, eight columns of a thread in flight ----
+    stage_lds((void *)tab, &A.eq->tab, sizeof(EqspTabLds));
+    stage_lds((void *)fastp, &A.eq->image, DSCB_FAST_BYTES);
+    stage_lds((void *)colb, A.colbase, DSCB_COL_BYTES);
+    for (int i = tid; i < 3 * 512; i += DSCB_THREADS) hist[i] = 0;
+    if (tid < 8) s_nq[tid] = 0;
+    {
+        const int hw = tid >> 5, zl = tid & 31;
+        for (int c0 = hw; c0 < DSCB_COLS; c0 += 32 * 8) {
+            unsigned v[8];
+            int dst[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int c = c0 + 32 * u, cc = min(c, DSCB_COLS - 1);
+                const int cx = cc / DSCB_SIDE, cy = cc - cx * DSCB_SIDE;
+                const int h = dscb_col_h(cx, cy);
+                const bool ok = c < DSCB_COLS && h >= 0 && zl <= 2 * h;
+                // (a border anchor's ball is filled with the grid's outermost texels where it leaves the grid: a sample there is
+                // never trusted, see `border` below)
+                const int gx = min(max(ic0 - DSCB_M + cx, 0), F.nx - 1), gy = min(max(ic1 - DSCB_M + cy, 0), F.ny - 1),
+                          gz = min(max(ic2 - h + zl, 0), F.nz - 1);
+                v[u] = F.tex4[mad_u24(mad_u24((unsigned)gx, (unsigned)F.ny, (unsigned)gy), (unsigned)F.nz, (unsigned)gz)];
+                dst[u] = ok ? (int)A.colbase[cc] - h + zl : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (dst[u] >= 0) ball[dst[u]] = v[u];
+        }
+    }
+    __syncthreads();
+
+    // this thread's samples of every row: column (j, k), i = 4 iq .. 4 iq + 3 -- all in sub-region `sub` (Descriptor.py:44-64)
+    const int iq = tid >> 8, j = (tid >> 4) & 15, k = tid & 15;
+    const int sub = (j >> 2) * 16 + (k >> 2) + 4 * iq;
+    const float lbf = -7.5f;      // Descriptor.py:35, dsc_radius 16: the lattice -7.5 .. 7.5
+    const float m1 = lbf + (float)j, m2 = lbf + (float)k;
+
+    // float32 guess of sample i of column (jj, kk): offset from the anchor voxel exactly as k_describe forms it -- the nearest voxel is
+    // cvt_round(a) unless a fraction is within 2e-4 of the 0.5 tie (`unsure`: the reference's float64 expression decides)
+    // (an interior anchor: no sample can leave the grid, no edge test)
+    auto accumulate = [&](int rr, int r) {
+        const dscb_rec_t rec = recs + r;
+        const float h0 = rec->hf[0], h1 = rec->hf[1], h2 = rec->hf[2], h3 = rec->hf[3], h4 = rec->hf[4], h5 = rec->hf[5], h6 = rec->hf[6],
+                    h7 = rec->hf[7], h8 = rec->hf[8];      // (float)inv(Rfinal): scalar registers
+        const float b0 = fmaf(m1, h1, m2 * h2), b1 = fmaf(m1, h4, m2 * h5), b2 = fmaf(m1, h7, m2 * h8);
+        unsigned q[4], unsure = 0;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const float m0 = lbf + (float)(4 * iq + u);
+            const float a0 = fmaf(m0, h0, b0), a1 = fmaf(m0, h3, b1), a2 = fmaf(m0, h6, b2);
+            const float fr0 = __builtin_amdgcn_fractf(a0), fr1 = __builtin_amdgcn_fractf(a1), fr2 = __builtin_amdgcn_fractf(a2);
+            const bool safe = fminf(fminf(fabsf(fr0 - 0.5f), fabsf(fr1 - 0.5f)), fabsf(fr2 - 0.5f)) > 2e-4f;
+            // |a| <= 12.991, so the voxel lies in the ball; the clamp of the LDS index keeps a corrupt record from reading outside it
+            const int col = mad_i24(cvt_round(a0), DSCB_SIDE, cvt_round(a1));      // (+ 13 * 28: in the table's address)
+            const int li = (int)colc[col] + cvt_round(a2);                           // (+ 13: in the table's values)
+            q[u] = ball[min(max(li, 0), DSCB_NBALL - 1)];
+            unsure |= safe ? 0u : (1u << u);
+        }
+        bool oob = false;
+        if (unsure) {      // rare: the reference's float64 expression for those samples, their texels from global memory
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (unsure & (1u << u)) {
+                    const unsigned loc = dscb_exact_voxel(A.row_rec[pos0 + r].inv, ic0, ic1, ic2, F.nx, F.ny, F.nz, 4 * iq + u, j, k);
+                    if (loc == ~0u) {      // (cannot happen for an interior anchor; kept: the row would be zero, Descriptor.py:142-149)
+                        oob = true;
+                        continue;
+                    }
+                    const int v0 = ic0 - DSCB_M + (int)(loc & 31u), v1 = ic1 - DSCB_M + (int)((loc >> 5) & 31u), v2 = ic2 - DSCB_M + (int)((loc >> 10) & 31u);
+                    q[u] = F.tex4[mad_u24(mad_u24((unsigned)v0, (unsigned)F.ny, (unsigned)v1), (unsigned)F.nz, (unsigned)v2)];
+                }
+        }
+        // zones of the four samples in straight-line code (4-byte texel -> float32 rotation -> table: k_describe's TAB tier)
+        // (float)Rfinal, the third row with the 1 / 511 of the texel's components: z on the unit scale, x and y on any common one
+        const float f0 = rec->rf[0], f1 = rec->rf[1], f2 = rec->rf[2], f3 = rec->rf[3], f4 = rec->rf[4], f5 = rec->rf[5], f6 = rec->rf[6],
+                    f7 = rec->rf[7], f8 = rec->rf[8];
+        int zone[4];
+        unsigned any_flag = 0;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const unsigned t = q[u];
+            const float gx = (float)(int)__builtin_amdgcn_sbfe(t, 0, 10), gy = (float)(int)__builtin_amdgcn_sbfe(t, 10, 10),
+                        gz = (float)(int)__builtin_amdgcn_sbfe(t, 20, 10);
+            const float rx = fmaf(gz, f2, fmaf(gy, f1, gx * f0));
+            const float ry = fmaf(gz, f5, fmaf(gy, f4, gx * f3));
+            const float rz = fmaf(gz, f8, fmaf(gy, f7, gx * f6));
+            zone[u] = eqsp_tab32(tab, rx, ry, rz);
+            any_flag |= t;
+        }
+        if ((int)any_flag < 0) {      // rare: 2 = not finite -> the exact tiers, 3 = below the magnitude cut-off, not counted (Descriptor.py:190)
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const unsigned fl = q[u] >> 30;
+                zone[u] = fl == 3u ? -2 : (fl == 0u ? zone[u] : -1);
+            }
+        }
+        unsigned *const H = hist + (rr % 3) * 512;
+        unsigned undecided = 0;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (zone[u] >= 0) atomicAdd(&H[sub * 8 + (zone[u] >> 1)], 1u << ((zone[u] & 1) << 4));
+            undecided |= zone[u] == -1 ? (1u << u) : 0u;
+        }
+        // one queue reservation per wave (a scan of the lanes' counts on the DPP path), as in k_describe; an entry names the
+        // sample (thread, u): whoever takes it forms its voxel again
+        const int cn = __popc(undecided);
+        const int inc = wave_incl_scan_i32(cn);
+        const int total = __builtin_amdgcn_readlane(inc, MAD_WAVE - 1);
+        if (total) {
+            int base = 0;
+            if (lane_id() == 0) base = atomicAdd(&s_nq[rr & 3], total);
+            int off = __builtin_amdgcn_readfirstlane(base) + inc - cn;
+            unsigned short *const Q = qent + (rr & 1) * DSCB_QCAP;
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (undecided & (1u << u)) {
+                    if (off < QCAP) Q[off] = (unsigned short)(tid | u << 10);
+                    off++;
+                }
+        }
+        if (oob) s_oob[rr & 3] = 1;
+    };
+
+    // the samples the table left open: their 16-byte texels, the float32 tier with its 1e-4 guard, the float64 tier behind it
+    auto drain = [&](int rr, int r) {
+        const int nq = s_nq[rr & 3];
+        unsigned *const H = hist + (rr % 3) * 512;
+        const int64_t row = recs[r].row;
+        const double *const Rrow = A.row_R + 9 * row;
+        if (nq > QCAP) {
+            // more undecided samples than the queue holds (not seen in practice): the whole row again with the exact arithmetic
+            // (uniform over the workgroup: every thread passes this barrier)
+            for (int i = tid; i < 512; i += DSCB_THREADS) H[i] = 0;
+            __syncthreads();
+            for (int u = 0; u < 4; u++) {
+                const unsigned loc = dscb_exact_voxel(A.row_rec[pos0 + r].inv, ic0, ic1, ic2, F.nx, F.ny, F.nz, 4 * iq + u, j, k);
+                if (loc == ~0u) continue;      // (the row is dead: accumulate has seen the same sample leave the grid)
+                const int v0 = ic0 - DSCB_M + (int)(loc & 31u), v1 = ic1 - DSCB_M + (int)((loc >> 5) & 31u), v2 = ic2 - DSCB_M + (int)((loc >> 10) & 31u);
+                const float4 tx = F.tex[mad_u24(mad_u24((unsigned)v0, (unsigned)F.ny, (unsigned)v1), (unsigned)F.nz, (unsigned)v2)];
+                if (tx.w < 1e-5f) continue;
+                const int zn = dscb_describe_exact(exactp, tx.x, tx.y, tx.z, tx.w, Rrow);
+                atomicAdd(&H[sub * 8 + (zn >> 1)], 1u << ((zn & 1) << 4));
+            }
+            return;
+        }
+        const int e = DSCB_THREADS - 1 - tid;      // (the last waves: the first ones write rows out)
+        if (e < nq) {
+            const unsigned ent = qent[(rr & 1) * DSCB_QCAP + e];
+            const int et = (int)(ent & 1023u), ei = 4 * (et >> 8) + (int)(ent >> 10), ej = (et >> 4) & 15, ek = et & 15;
+            const int sb = (ej >> 2) * 16 + (ek >> 2) + 4 * (et >> 8);
+            // the sample's voxel again: the same float32 guess, the same float64 decision next to a tie
+            const dscb_rec_t rec = recs + r;
+            const float e1 = lbf + (float)ej, e2 = lbf + (float)ek, e0 = lbf + (float)ei;
+            const float a0 = fmaf(e0, rec->hf[0], fmaf(e1, rec->hf[1], e2 * rec->hf[2])), a1 = fmaf(e0, rec->hf[3], fmaf(e1, rec->hf[4], e2 * rec->hf[5])),
+                        a2 = fmaf(e0, rec->hf[6], fmaf(e1, rec->hf[7], e2 * rec->hf[8]));
+            const bool safe = fminf(fminf(fabsf(__builtin_amdgcn_fractf(a0) - 0.5f), fabsf(__builtin_amdgcn_fractf(a1) - 0.5f)), fabsf(__builtin_amdgcn_fractf(a2) - 0.5f)) > 2e-4f;
+            int v0 = ic0 + cvt_round(a0), v1 = ic1 + cvt_round(a1), v2 = ic2 + cvt_round(a2);
+            bool gone = false;
+            if (!safe) {
+                const unsigned loc = dscb_exact_voxel(A.row_rec[pos0 + r].inv, ic0, ic1, ic2, F.nx, F.ny, F.nz, ei, ej, ek);
+                gone = loc == ~0u;
+                v0 = ic0 - DSCB_M + (int)(loc & 31u); v1 = ic1 - DSCB_M + (int)((loc >> 5) & 31u); v2 = ic2 - DSCB_M + (int)((loc >> 10) & 31u);
+            }
+            // (the clamps never act for an interior anchor: they keep a corrupt record inside the texture)
+            v0 = min(max(v0, 0), F.nx - 1); v1 = min(max(v1, 0), F.ny - 1); v2 = min(max(v2, 0), F.nz - 1);
+            const float4 tx = F.tex[mad_u24(mad_u24((unsigned)v0, (unsigned)F.ny, (unsigned)v1), (unsigned)F.nz, (unsigned)v2)];
+            if (!gone && tx.w >= 1e-5f) {      // (always: texels below the cut-off carry flag 3 and are never queued)
+                const dscb_f64_t Rc = (dscb_f64_t)Rrow;
+                const float f0 = (float)Rc[0], f1 = (float)Rc[1], f2 = (float)Rc[2], f3 = (float)Rc[3], f4 = (float)Rc[4], f5 = (float)Rc[5],
+                            f6 = (float)Rc[6], f7 = (float)Rc[7], f8 = (float)Rc[8];
+                const float inv = __builtin_amdgcn_rcpf(fmaxf(tx.w, 1e-30f));
+                const float gx = tx.x * inv, gy = tx.y * inv, gz = tx.z * inv;
+                int zn = eqsp_fast32(fastp, fmaf(gz, f2, fmaf(gy, f1, gx * f0)), fmaf(gz, f5, fmaf(gy, f4, gx * f3)), fmaf(gz, f8, fmaf(gy, f7, gx * f6)));
+                if (zn < 0) zn = dscb_describe_exact(exactp, tx.x, tx.y, tx.z, tx.w, Rrow);
+                atomicAdd(&H[sb * 8 + (zn >> 1)], 1u << ((zn & 1) << 4));
+            }
+        }
+    };
+
+    // one wave: the 1 024 counts of a finished row as int16 (the packed words ARE the row) and int8, its norm; the histogram zeroed
+    auto write_out = [&](int rr, int r) {
+        const int l = (int)lane_id();
+        const bool dead = s_oob[rr & 3] != 0;      // Descriptor.py:142-149: a sample left the grid -> the whole descriptor is zero
+        uint4 *const H4 = (uint4 *)(hist + (rr % 3) * 512);
+        uint4 w0 = H4[2 * l], w1 = H4[2 * l + 1];
+        H4[2 * l] = make_uint4(0, 0, 0, 0);
+        H4[2 * l + 1] = make_uint4(0, 0, 0, 0);
+        if (dead) w0 = w1 = make_uint4(0, 0, 0, 0);
+        const int64_t row = recs[r].row;
+        uint4 *const o16 = (uint4 *)(A.dsc + row * 1024);
+        o16[2 * l] = w0;
+        o16[2 * l + 1] = w1;
+        if (A.dsc8) {
+            auto b2 = [](unsigned x) { return (x & 0xffu) | ((x >> 8) & 0xff00u); };      // two counts -> two bytes
+            auto sq = [](unsigned x) { const int a = (int)(x & 0xffffu), b = (int)(x >> 16); return a * a + b * b; };
+            ((uint4 *)(A.dsc8 + row * 1024))[l] = make_uint4(b2(w0.x) | b2(w0.y) << 16, b2(w0.z) | b2(w0.w) << 16, b2(w1.x) | b2(w1.y) << 16, b2(w1.z) | b2(w1.w) << 16);
+            int ss = sq(w0.x) + sq(w0.y) + sq(w0.z) + sq(w0.w) + sq(w1.x) + sq(w1.y) + sq(w1.z) + sq(w1.w);      // counts <= 64: exact in int32
+            ss = wave_sum_i32(ss);
+            if (l == 0) A.norm[row] = sqrt((double)ss);
+        }
+    };
+
+    // Row rr = r - r_begin lives in histogram rr % 3, queue rr & 1, flags rr & 3.  Between two barriers: the table tier of row rr
+    // | barrier rr | the open samples of row rr, the write-out (and zeroing) of row rr - 1, the flags of row rr + 2 reset.  A
+    // histogram is written again three barriers after its write-out, a queue two after its drain, a flag two after its last reader.
+    const int wave = tid >> 6;
+    for (int r = r_begin; r <= r_end; r++) {
+        const int rr = r - r_begin;
+        if (r < r_end) {
+            accumulate(rr, r);
+        }
+        __syncthreads();
+        if (r < r_end && tid == 0) { s_nq[(rr + 2) & 3] = 0; s_oob[(rr + 2) & 3] = 0; }
+        if (rr > 0 && wave == ((rr - 1) & 7)) write_out(rr - 1, r - 1);
+        if (r < r_end) drain(rr, r);
+    }
+}
+
+static int ensure_ball(mad_ctx *ctx) {
+    if (ctx->ball_colbase) return MAD_OK;
+    int16_t h[DSCB_COL_BYTES / 2];
+    memset(h, 0, sizeof(h));
+    int base = 0;
+    for (int c = 0; c < DSCB_COLS; c++) {
+        const int hh = dscb_col_h(c / DSCB_SIDE, c % DSCB_SIDE);
+        if (hh < 0) continue;
+        h[c] = (int16_t)(base + hh);      // LDS index of the voxel dz = -hh .. hh of column (cx, cy) = h[c] + dz
+        base += 2 * hh + 1;
+    }
+    if (base != DSCB_NBALL) return mad_fail(ctx, MAD_EINVAL, "k_describe_ball: the ball has %d texels, built for %d", base, DSCB_NBALL);
+    MAD_HIP(hipMalloc((void **)&ctx->ball_colbase, sizeof(h)));
+    MAD_HIP(hipMemcpy(ctx->ball_colbase, h, sizeof(h), hipMemcpyHostToDevice));
+    MAD_HIP(hipFuncSetAttribute((const void *)k_describe_ball, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DSCB_LDS_BYTES));
+    return MAD_OK;
+}
+
 int mad_describe_device_many(mad_ctx *ctx, int n_jobs, const DescribeJob *jobs, int r, int dsc_size) {
     if (dsc_size != 64 && (2 * r != 16 || (dsc_size != 27 && dsc_size != 8 && dsc_size != 1)))
         return mad_fail(ctx, MAD_EINVAL, "mad_describe: dsc_size %d (27, 8 and 1 are built for the default dsc_radius 16 only; 64 for 4 ... 16)", dsc_size);
@@ -1187,10 +1556,16 @@ int mad_describe_device_many(mad_ctx *ctx, int n_jobs, const DescribeJob *jobs, 
         return mad_fail(ctx, MAD_EINVAL, "mad_describe: %d descriptor zones: 16 for every layout, up to 128 (the 112-zone table) for the default 64 regions and dsc_radius 16", Zd);
     if (r < 2 || r > 8 || (r % 2)) return mad_fail(ctx, MAD_EINVAL, "mad_describe: dsc radius %d must be 2, 4, 6 or 8", r);
     const bool tab = Zd == 16 && ctx->eq_host[1].tab_ok && dsc_size == 64 && 2 * r == 16;
+    static const bool no_ball = getenv("MAD_NO_BALL") != nullptr;      // diagnostic switch: every row through k_describe, as in round 3
+    const bool ball_ok = tab && ctx->dsc_ball && !no_ball;
+    if (ball_ok) MAD_TRY(ensure_ball(ctx));
     for (int j0 = 0; j0 < n_jobs; j0 += MAD_BATCH_MAX) {
         Batch<DescribeArgs> B;
+        Batch<DescribeBallArgs> BB;      // the base-octave anchors of the same jobs (k_describe_ball)
         B.n_jobs = 0;
-        int64_t blk = 0;
+        BB.n_jobs = 0;
+        int64_t blk = 0, bblk = 0;
+        int max_fan = 1;
         for (int j = j0; j < n_jobs && j < j0 + MAD_BATCH_MAX; j++) {
             const DescribeJob &J = jobs[j];
             if (J.grid_rows <= 0) continue;
@@ -1199,15 +1574,32 @@ int mad_describe_device_many(mad_ctx *ctx, int n_jobs, const DescribeJob *jobs, 
                 if (f.tex && ((size_t)f.nx * f.ny * f.nz >= (size_t)1 << 32 || (size_t)f.nx * f.ny >= (size_t)1 << 24 || f.nz >= 1 << 24))
                     return mad_fail(ctx, MAD_EINVAL, "mad_describe: field of %dx%dx%d texels exceeds 2^32 (or 2^24 per x-y plane)", f.nx, f.ny, f.nz);
             }
+            // the anchors of the base octave (behind those of octave 0 in working order) go through the ball kernel when the set
+            // pipeline has told where each anchor's rows lie
+            const int n_base = J.n_anchors - J.n_rowwise;
+            const bool ball = ball_ok && J.d_anc_rows && J.d_row_rec && J.d_row_perm && n_base > 0 && J.n_rowwise >= 0 && J.fan > 0 && J.f[1].tex4;
             DescribeArgs &A = B.job[B.n_jobs];
             A.f[0] = J.f[0]; A.f[1] = J.f[1];
             A.anc_coords = J.d_anc_coords; A.anc_octave = J.d_anc_octave; A.uniform_octave = J.uniform_octave;
             A.row_anchor = J.d_row_anchor; A.row_R = J.d_row_R; A.row_Rinv = J.d_row_Rinv; A.row_perm = J.d_row_perm; A.n_rows = J.d_n_rows; A.overflow = J.d_overflow;
             A.r = r; A.eq = ctx->eq[1]; A.dsc = J.d_dsc; A.dsc8 = J.d_dsc8; A.norm = J.d_norm; A.row_rec = J.d_row_rec;
             A.queue_cap = std::max(ctx->dsc_queue_cap, 0);
+            A.row_limit = ball ? J.d_anc_rows + 2 * (int64_t)J.n_rowwise : nullptr;      // first row position of the first base-octave anchor
             B.first[B.n_jobs++] = (int)blk;
-            blk += ((J.grid_rows + 7) / 8) * 8 + 8;      // one workgroup per possible row, a multiple of 8 per job (one share per XCD)
+            // one workgroup per possible row, a multiple of 8 per job (one share per XCD).  With the ball kernel this grid only has
+            // the octave-0 rows to cover: their share of the hint by anchors, with room (a launch that falls short raises `overflow`)
+            int64_t rows_here = J.grid_rows;
+            if (ball) rows_here = std::min<int64_t>(J.grid_rows, (int64_t)((double)J.grid_rows * J.n_rowwise / J.n_anchors * 1.3) + 64);
+            blk += ((rows_here + 7) / 8) * 8 + 8;
             if (blk > INT32_MAX) return mad_fail(ctx, MAD_EINVAL, "mad_describe: %lld rows in one batch", (long long)blk);
+            if (ball) {
+                DescribeBallArgs &Q = BB.job[BB.n_jobs];
+                Q.f = J.f[1]; Q.row_rec = J.d_row_rec; Q.anc_rows = J.d_anc_rows; Q.row_R = J.d_row_R;
+                Q.n_base = n_base; Q.n_rowwise = J.n_rowwise; Q.queue_cap = std::max(ctx->dsc_queue_cap, 0);
+                Q.eq = ctx->eq[1]; Q.overflow = J.d_overflow; Q.colbase = ctx->ball_colbase; Q.dsc = J.d_dsc; Q.dsc8 = J.d_dsc8; Q.norm = J.d_norm;
+                BB.first[BB.n_jobs++] = (int)bblk;
+                max_fan = std::max(max_fan, J.fan);
+            }
         }
         if (B.n_jobs == 0) continue;
         B.first[B.n_jobs] = (int)blk;
@@ -1226,6 +1618,19 @@ int mad_describe_device_many(mad_ctx *ctx, int n_jobs, const DescribeJob *jobs, 
                 else if (tab) hipLaunchKernelGGL((k_describe<16, 64, 16, true>), dim3(nblk), dim3(DSC_THREADS), 0, ctx->stream, B);
                 else hipLaunchKernelGGL(k_describe<16>, dim3(nblk), dim3(DSC_THREADS), 0, ctx->stream, B);
                 break;
+        }
+        if (BB.n_jobs > 0) {
+            // every job's grid: `chunks` runs of DSCB_RPB rows x its base-octave anchors rounded up to 8 (an anchor has at most fan rows;
+            // the workgroups of runs an anchor does not have return at once)
+            const int chunks = (max_fan + DSCB_RPB - 1) / DSCB_RPB;
+            int64_t at = 0;
+            for (int q = 0; q < BB.n_jobs; q++) {
+                BB.first[q] = (int)at;
+                at += (int64_t)chunks * ((BB.job[q].n_base + 7) / 8 * 8);
+                if (at > INT32_MAX) return mad_fail(ctx, MAD_EINVAL, "mad_describe: %lld ball workgroups in one batch", (long long)at);
+            }
+            BB.first[BB.n_jobs] = (int)at;
+            hipLaunchKernelGGL(k_describe_ball, dim3((unsigned)at), dim3(DSCB_THREADS), DSCB_LDS_BYTES, ctx->stream, BB, chunks);
         }
         mad_timer_end(ctx, MAD_T_DESCRIBE);
         MAD_HIP(hipGetLastError());

@@ -985,3 +985,60 @@ def test_full_queues_of_undecided_directions_change_nothing(lib, fields, ori_cap
         np.testing.assert_array_equal(have[key], want[key], err_msg=key)
     got.close()
     ref.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dsc_cap", [1 << 20, 3])
+def test_base_octave_rows_from_a_ball_in_lds_equal_rows_described_one_by_one(lib, dsc_cap):
+    """k_describe_ball (round 4): the base-octave anchors whose ball of samples lies inside the grid are described anchor by anchor
+    from 11 027 4-byte texels staged in LDS, the others (octave 0, anchors near the border) row by row by k_describe.  The set is
+    bit for bit the set k_describe alone makes (mad_set_option "dsc_ball" = 0), and its descriptors are the oracle's
+    (Descriptor.py:123-202) -- anchors with 1 .. 20+ rows (several runs of rows per anchor), border anchors, rejected anchors,
+    both octaves in one set, and the full-queue path (dsc_cap = 3: every row again with the exact arithmetic)."""
+    shape1, shape0 = (64, 64, 60), (60, 64, 70)
+    _, gx1, gy1, gz1 = _field(shape1, 31)
+    _, gx0, gy0, gz0 = _field(shape0, 32)
+    s1, s0 = lib.new_slot(), lib.new_slot()
+    lib.upload_field(s1, np.stack([gx1, gy1, gz1]))
+    lib.upload_field(s0, np.stack([gx0, gy0, gz0]))
+    a1 = _anchors(shape1, 1, 70, 73)      # interior ones (ball inside the grid), ones within 14 voxels of the border, rejected ones
+    a0 = _anchors(shape0, 0, 12, 74)
+    coords = np.concatenate([a1[:30], a0, a1[30:]]).astype(np.int32)
+    octave = np.concatenate([np.ones(30, np.int32), np.zeros(len(a0), np.int32), np.ones(len(a1) - 30, np.int32)])
+    subv = coords * np.where(octave[:, None] == 0, 0.75, 1.5)
+    job = ([s0, s1], coords, octave, subv, np.arange(len(coords), dtype=np.int32))
+    inside = np.all((a1 - 14 >= 1) & (a1 + 14 <= np.array(shape1) - 2), axis=1)
+    assert inside.sum() >= 20 and (~inside).sum() >= 10, "the anchors must exercise both kernels"
+    try:
+        lib.set_option("dsc_queue", dsc_cap)
+        ball = lib.set_build(*job)
+        have = ball.download()
+        lib.set_option("dsc_ball", 0)
+        rowwise = lib.set_build(*job)
+        want = rowwise.download()
+    finally:
+        lib.set_option("dsc_ball", 1)
+        lib.set_option("dsc_queue", 1 << 20)
+    assert ball.size() == rowwise.size() and ball.size()[0] > 200
+    for key in ("anchor", "main", "sec", "R", "dsc"):
+        np.testing.assert_array_equal(have[key], want[key], err_msg=key)
+    fan = np.bincount(have["anchor"], minlength=len(coords))
+    assert fan[octave == 1].max() > 4, "no anchor with more rows than one workgroup takes"
+    # ... and the oracle's descriptors, octave by octave
+    for o, (gx, gy, gz) in ((1, (gx1, gy1, gz1)), (0, (gx0, gy0, gz0))):
+        rows = np.nonzero(octave[have["anchor"]] == o)[0]
+        ref = O.describe(gx, gy, gz, o, coords[have["anchor"][rows]], have["R"][rows], E16.sphere_eqsp)
+        np.testing.assert_array_equal(have["dsc"][rows], ref, err_msg="octave %d" % o)
+    # a set rebuilt in place with the same anchors (the unchanged-anchors path keeps the sorting), then with other anchors
+    lib.set_build(*job, into=ball)
+    np.testing.assert_array_equal(ball.download()["dsc"], want["dsc"])
+    job2 = ([s0, s1], coords[::-1].copy(), octave[::-1].copy(), subv[::-1].copy(), np.arange(len(coords), dtype=np.int32))
+    lib.set_build(*job2, into=ball)
+    lib.set_option("dsc_ball", 0)
+    try:
+        lib.set_build(*job2, into=rowwise)
+    finally:
+        lib.set_option("dsc_ball", 1)
+    np.testing.assert_array_equal(ball.download()["dsc"], rowwise.download()["dsc"])
+    ball.close()
+    rowwise.close()
