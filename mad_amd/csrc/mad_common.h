@@ -192,7 +192,7 @@ struct mad_ctx {
     int8_t *mask_off = nullptr;              // sphere-mask offsets for the current r
     int mask_r = -1;
     int mask_n = 0;
-    int16_t *ball_colbase = nullptr;         // k_describe_ball: LDS offset of every (x, y) column of the base-octave sample ball (device)
+    unsigned *ball_colinfo = nullptr;        // k_describe_ball: LDS offset and half-length of every (x, y) column of the base-octave sample ball (device)
     bool dsc_ball = true;                    // base-octave rows described anchor by anchor from a ball of texels in LDS (MAD_NO_BALL / "dsc_ball": per row, as octave 0)
     // named grow-only scratch buffers
     DevBuf scratch[64 * MAD_LANES];   // MAD_LANES independent copies: matches in flight do not share scratch
@@ -241,7 +241,7 @@ struct mad_set {
     DevBuf row_anchor, row_main, row_sec, row_R, row_Rinv, row_meta, dsc, dsc8, norm;
     DevBuf row_perm;             // k-th row in working order (rows of spatially neighbouring anchors next to each other)
     DevBuf row_rec;              // DscRowRec of the k-th row in working order
-    DevBuf anc_rows;             // per anchor IN WORKING ORDER: {position of its first row in working order, rows} (k_orient_rows* write it)
+    DevBuf anc_rows;             // per anchor IN WORKING ORDER: MAD_ANCROW_WORDS ints {position of its first row in working order, rows, voxel coordinates} (k_orient_rows* write it)
     int n_rowwise = 0;           // anchors k_describe takes row by row (octave 0, and base-octave ones near the border): they come first in
                                  // working order; the others go through k_describe_ball
     int ball_dims[3] = {0, 0, 0};      // the base-octave grid the anchors were sorted for (0: no anchor was set apart)
@@ -323,10 +323,12 @@ struct alignas(16) DscRowRec {
     int32_t pad1[6];
     float hf[9];           // (float)inv[i]
     float rf[9];           // (float)Rfinal[i], the third row times 1 / 511 (the scale of a 4-byte texel's components)
-    int32_t pad2[2];
+    float ru[3];           // (float)Rfinal[6 .. 8] as they are (the tiers on the 16-byte texel)
+    int32_t pad2[3];
 };
 #define MAD_ROWREC_WORDS ((int)(sizeof(DscRowRec) / 4))
-static_assert(sizeof(DscRowRec) == 208 && offsetof(DscRowRec, hf) == 128, "k_describe reads the first 32 dwords of a DscRowRec");
+#define MAD_ANCROW_WORDS 8      // mad_set::anc_rows, per anchor in working order: {position of its first row, rows, voxel coordinates x 3, -, -, -}
+static_assert(sizeof(DscRowRec) == 224 && offsetof(DscRowRec, hf) == 128, "k_describe reads the first 32 dwords of a DscRowRec");
 
 // implemented in mad_orient.hip; used by the set API in mad_match.hip.  Both are fully asynchronous.
 struct OrientOut {

@@ -2947,7 +2947,7 @@ extern "C" int mad_set_build_many(mad_ctx *ctx, int n_sets, mad_set *const *sets
         MAD_TRY(set_upload_anchors(ctx, s, anc_coords[i], anc_octave[i], anc_subv[i], anc_index[i], n, 0, sort_ball ? bdims : nullptr));
         s->D = 64 * ctx->eq_host[1].Z;
         MAD_TRY(set_reserve_rows(ctx, s, (int64_t)n * lim_main * lim_sec));
-        MAD_TRY(mad_reserve(ctx, s->anc_rows, (size_t)(n > 0 ? n : 1) * 8));
+        MAD_TRY(mad_reserve(ctx, s->anc_rows, (size_t)(n > 0 ? n : 1) * MAD_ANCROW_WORDS * 4));
         s->last_fan = lim_main * lim_sec;
         OrientJob &J = oj[i];
         J.d_coords = (const int32_t *)s->anc_coords.p; J.d_octave = (const int32_t *)s->anc_octave.p; J.uniform_octave = 0; J.n = n;

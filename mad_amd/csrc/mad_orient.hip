@@ -423,7 +423,7 @@ struct RowsArgs {
     int32_t *perm_off;             // with order: n + 1 row offsets in working order
     int32_t *row_perm;             // with order: the rows in working order
     DscRowRec *row_rec;            // nullable: what k_describe starts a row from, in working order
-    int32_t *anc_rows;             // nullable: per anchor in working order {position of its first row in working order, rows}
+    int32_t *anc_rows;             // nullable: per anchor in working order MAD_ANCROW_WORDS ints {position of its first row in working order, rows, voxel coordinates}
     const int32_t *coords;         // with row_rec: the anchors' voxel coordinates
     int uniform_octave;            // ... and their octave when anc_octave is null
 };
@@ -438,6 +438,7 @@ __device__ __forceinline__ void put_row_rec(const RowsArgs &A, int64_t pos, int 
     // the float32 values k_describe's threads form for themselves, once per row (k_describe_ball takes them with scalar loads)
     for (int i = 0; i < 9; i++) q.hf[i] = (float)inv[i];
     for (int i = 0; i < 9; i++) q.rf[i] = i < 6 ? (float)R[i] : (float)R[i] * (1.0f / 511.0f);
+    for (int i = 0; i < 3; i++) q.ru[i] = (float)R[6 + i];
 }
 
 // row offsets of every job: exclusive scan of its anchors' row counts, one workgroup per job
@@ -488,7 +489,10 @@ __global__ __launch_bounds__(256) void k_orient_rows(Batch<RowsArgs> B, int fan,
     if (p >= A.n) return;
     const int a = A.order ? A.order[p] : p;
     const int c = A.slot_cnt[a];
-    if (s == 0 && A.anc_rows) { A.anc_rows[2 * p] = A.order ? A.perm_off[p] : A.row_off[a]; A.anc_rows[2 * p + 1] = c; }
+    if (s == 0 && A.anc_rows) {
+        int32_t *q = A.anc_rows + MAD_ANCROW_WORDS * (int64_t)p;
+        q[0] = A.order ? A.perm_off[p] : A.row_off[a]; q[1] = c; q[2] = A.coords[3 * a]; q[3] = A.coords[3 * a + 1]; q[4] = A.coords[3 * a + 2];
+    }
     if (s >= c) return;
     const int64_t row = (int64_t)A.row_off[a] + s;
     if (A.order) A.row_perm[A.perm_off[p] + s] = (int32_t)row;
@@ -548,7 +552,10 @@ __global__ __launch_bounds__(1024) void k_orient_rows_scan(Batch<RowsArgs> B, in
     if (pl >= ppb || pp >= n) return;
     const int a = A.order ? A.order[pp] : pp;
     const int c = A.slot_cnt[a];
-    if (sl == 0 && A.anc_rows) { A.anc_rows[2 * pp] = s_perm[pl]; A.anc_rows[2 * pp + 1] = c; }
+    if (sl == 0 && A.anc_rows) {
+        int32_t *q = A.anc_rows + MAD_ANCROW_WORDS * (int64_t)pp;
+        q[0] = s_perm[pl]; q[1] = c; q[2] = A.coords[3 * a]; q[3] = A.coords[3 * a + 1]; q[4] = A.coords[3 * a + 2];
+    }
     if (sl >= c) return;
     const int64_t row = (int64_t)s_off[a] + sl;
     if (A.order) A.row_perm[s_perm[pl] + sl] = (int32_t)row;
@@ -1214,19 +1221,19 @@ __global__ __launch_bounds__(DSC_THREADS, TAB ? DSC_OCC_TAB : DSC_OCC) void k_de
 #define DSCB_COLS (DSCB_SIDE * DSCB_SIDE)
 #define DSCB_E2MAX 676                  // voxel d is in the ball iff sum_i max(2 |d_i| - 1, 0)^2 <= 4 (7.5 sqrt(3) + 0.01)^2 = 676.04
 #define DSCB_NBALL 11027
-#define DSCB_QCAP 512
-#ifndef DSCB_RPB
-#define DSCB_RPB 4                      // rows of an anchor one workgroup takes (an anchor of n rows: ceil(n / DSCB_RPB) workgroups, each with its own ball)
-#endif
+#define DSCB_RPB 4                      // rows of an anchor one workgroup takes, four waves each (an anchor of n rows: ceil(n / 4) workgroups, each with its own ball)
 #define DSCB_FAST_BYTES ((offsetof(EqspFastLds, dir) + 15) / 16 * 16)
 #define DSCB_OFF_TAB ((DSCB_NBALL + 3) / 4 * 16)
 #define DSCB_OFF_FAST (DSCB_OFF_TAB + sizeof(EqspTabLds))
 #define DSCB_OFF_COL (DSCB_OFF_FAST + DSCB_FAST_BYTES)
 #define DSCB_COL_BYTES ((DSCB_COLS * 2 + 15) / 16 * 16)
 #define DSCB_OFF_HIST (DSCB_OFF_COL + DSCB_COL_BYTES)
-#define DSCB_OFF_Q (DSCB_OFF_HIST + 3 * 512 * 4)
-#define DSCB_OFF_FLAGS (DSCB_OFF_Q + 2 * DSCB_QCAP * 2)
-#define DSCB_LDS_BYTES (DSCB_OFF_FLAGS + 32)
+#define DSCB_OFF_Q (DSCB_OFF_HIST + DSCB_RPB * 512 * 4)
+#define DSCB_OFF_FLAGS (DSCB_OFF_Q + DSCB_RPB * 256 * 4)
+#define DSCB_ROWC 24                    // floats of a row's constants in LDS (21 used)
+#define DSCB_OFF_ROWC (DSCB_OFF_FLAGS + 64)      // (wtot: one int per wave)
+#define DSCB_OFF_ROWD (DSCB_OFF_ROWC + DSCB_RPB * DSCB_ROWC * 4 + 16)      // behind the constants: the rows' indices (4 ints)
+#define DSCB_LDS_BYTES (DSCB_OFF_ROWD + DSCB_RPB * 9 * 8)
 static_assert(DSCB_LDS_BYTES <= 80 * 1024, "two workgroups of k_describe_ball per CU");
 
 // half-length of the z-run of column (cx, cy) of the ball (its voxels: z = DSCB_M - h .. DSCB_M + h), or -1
@@ -1240,17 +1247,8 @@ __host__ __device__ __forceinline__ int dscb_col_h(int cx, int cy) {
 }
 
 
-// The rare float64 paths of k_describe_ball, out of line: inlined, their float64 temporaries (and the loop invariants the optimiser
+// The float64 tier of k_describe_ball, out of line: inlined, its float64 temporaries (and the loop invariants the optimiser
 // hoists for them) would set the register count of a kernel that has 64 registers per thread.
-// Nearest voxel of lattice point (i, j, k) of a base-octave row with the reference's float64 expression (Descriptor.py:132-133), as
-// local coordinates of the anchor's ball (3 x 5 bits), or ~0u when the point leaves the grid.
-__device__ __noinline__ unsigned dscb_exact_voxel(const double *inv, int ic0, int ic1, int ic2, int nx, int ny, int nz, int i, int j, int k) {
-    FieldDev F;
-    F.tex = nullptr; F.tex4 = nullptr; F.nx = nx; F.ny = ny; F.nz = nz;
-    int v0, v1, v2;
-    if (!lattice_voxel_exact(-7.5 + (double)i, -7.5 + (double)j, -7.5 + (double)k, inv, (double)ic0, (double)ic1, (double)ic2, F, &v0, &v1, &v2)) return ~0u;
-    return (unsigned)(v0 - ic0 + 13) | (unsigned)(v1 - ic1 + 13) << 5 | (unsigned)(v2 - ic2 + 13) << 10;
-}
 __device__ __noinline__ int dscb_describe_exact(const EqspFastLds *eq, float tx, float ty, float tz, float tw, const double *R) {
     return describe_exact(eq, make_float4(tx, ty, tz, tw), R);
 }
@@ -1262,16 +1260,36 @@ struct DescribeBallArgs {
     const DscRowRec *row_rec;      // the rows' records in working order
     const int32_t *anc_rows;       // per anchor in working order: {position of its first row, rows}
     const double *row_R;           // n_rows x 9
-    int n_base, n_rowwise;            // base-octave anchors, and the (octave-0) anchors before them in working order
-    int queue_cap;
+    int n_base, n_rowwise;         // anchors of this kernel, and the anchors before them in working order (k_describe's)
     const EqspDev *eq;
     int32_t *overflow;             // device: -2 when an anchor that is not interior arrives here
-    const int16_t *colbase;        // mad_ctx::ball_colbase
+    const unsigned *colinfo;       // mad_ctx::ball_colinfo
     int16_t *dsc;                  // n_rows x 1024
     int8_t *dsc8;                  // nullable
     double *norm;
 };
 
+#ifdef MAD_PROBE_STAMPS      // diagnostic build: s_memtime at the phases of every workgroup (tools/probe_ball.py)
+__device__ long long dscb_stamps[16384 * 8];
+__device__ int dscb_stamp_rows[16384];
+__device__ int dscb_stamp_n;
+__device__ int dscb_dbg[16384 * 4];      // per workgroup: longest dscb_exact_voxel / dscb_describe_exact call of the drain (ticks), calls of each
+extern "C" int mad_debug_dscb_dbg(int *out, int n) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(dscb_dbg), (size_t)n * 16) == hipSuccess ? 0 : -1; }
+__device__ long long dscb_real[16384 * 2];      // s_memrealtime (100 MHz, one clock for the whole device) at a workgroup's start and end
+extern "C" int mad_debug_dscb_real(long long *out, int n) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(dscb_real), (size_t)n * 16) == hipSuccess ? 0 : -1; }
+#define DSCB_STAMP(k) do { __builtin_amdgcn_sched_barrier(0); if (threadIdx.x == 0 && st_slot < 16384) dscb_stamps[st_slot * 8 + (k)] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+extern "C" int mad_debug_dscb_stamps(long long *out, int *rows, int n) {
+    int used = 0;
+    if (hipMemcpyFromSymbol(&used, HIP_SYMBOL(dscb_stamp_n), 4) != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(dscb_stamps), (size_t)n * 64) != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(rows, HIP_SYMBOL(dscb_stamp_rows), (size_t)n * 4) != hipSuccess) return -1;
+    const int zero = 0;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(dscb_stamp_n), &zero, 4) != hipSuccess) return -1;
+    return used;
+}
+#else
+#define DSCB_STAMP(k) do { } while (0)
+#endif
 __global__ __launch_bounds__(DSCB_THREADS, 8) void k_describe_ball(Batch<DescribeBallArgs> B, int chunks) {
     extern __shared__ __align__(16) unsigned char dscb_lds[];
     const int job = batch_job(B, (int)blockIdx.x);
@@ -1283,11 +1301,23 @@ __global__ __launch_bounds__(DSCB_THREADS, 8) void k_describe_ball(Batch<Describ
     const int ch = bid / nbp, bi = bid - ch * nbp;
     const int slot = (bi & 7) * per + (bi >> 3);
     if (ch >= chunks || slot >= A.n_base) return;
-    const int p = A.n_rowwise + slot;
-    const int pos0 = __builtin_amdgcn_readfirstlane(A.anc_rows[2 * p]), cnt = __builtin_amdgcn_readfirstlane(A.anc_rows[2 * p + 1]);
+    // one scalar load: where the anchor's rows lie and where the anchor is (written by k_orient_rows* of this build: constant here)
+    typedef const __attribute__((address_space(4))) int32_t *ci32_t;
+    const ci32_t an = (ci32_t)(A.anc_rows + MAD_ANCROW_WORDS * (int64_t)(A.n_rowwise + slot));
+    const int pos0 = an[0], cnt = an[1], ic0 = an[2], ic1 = an[3], ic2 = an[4];
     const int r_begin = ch * DSCB_RPB;
     if (r_begin >= cnt) return;
-    const int r_end = min(cnt, r_begin + DSCB_RPB);
+    const int n_here = min(cnt - r_begin, DSCB_RPB);      // rows of this workgroup: r_begin .. r_begin + n_here - 1 of the anchor
+#ifdef MAD_PROBE_STAMPS
+    __shared__ int st_slot_s;
+    if (threadIdx.x == 0) { st_slot_s = atomicAdd(&dscb_stamp_n, 1); if (st_slot_s < 16384) dscb_stamp_rows[st_slot_s] = n_here; }
+    __syncthreads();
+    const int st_slot = st_slot_s;
+    __shared__ int dbg_s[4];
+    if (threadIdx.x < 4) dbg_s[threadIdx.x] = 0;
+    if (threadIdx.x == 0 && st_slot < 16384) dscb_real[2 * st_slot] = __builtin_amdgcn_s_memrealtime();
+#endif
+    DSCB_STAMP(0);
 
     unsigned *const ball = (unsigned *)dscb_lds;
     const EqspTabLds *const tab = (const EqspTabLds *)(dscb_lds + DSCB_OFF_TAB);
@@ -1295,15 +1325,17 @@ __global__ __launch_bounds__(DSCB_THREADS, 8) void k_describe_ball(Batch<Describ
     const EqspFastLds *const exactp = &A.eq->image;                                          // float64 tier: global memory, a few samples per row
     short *const colb = (short *)(dscb_lds + DSCB_OFF_COL);
     const short *const colc = colb + DSCB_M * (DSCB_SIDE + 1);      // indexed by r0 * 27 + r1 with the offsets r = -13 .. 13 from the anchor voxel
-    unsigned *const hist = (unsigned *)(dscb_lds + DSCB_OFF_HIST);      // three rows in flight x 512 words of two 16-bit counters
-    unsigned short *const qent = (unsigned short *)(dscb_lds + DSCB_OFF_Q);      // two rows x DSCB_QCAP undecided samples: thread | u << 10
-    int *const s_nq = (int *)(dscb_lds + DSCB_OFF_FLAGS), *const s_oob = s_nq + 4;      // four rows each
+    unsigned *const hist = (unsigned *)(dscb_lds + DSCB_OFF_HIST);      // per row of the run: 512 words of two 16-bit counters
+    // per row and column: which of its 16 samples are open (the table could not decide them, or their voxel is next to a tie), and
+    // the running count of open samples up to and including the column
+    unsigned short *const omask = (unsigned short *)(dscb_lds + DSCB_OFF_Q), *const ocum = omask + DSCB_RPB * 256;
+    int *const wtot = (int *)(dscb_lds + DSCB_OFF_FLAGS);                // per wave: its open samples
+    float *const rowc = (float *)(dscb_lds + DSCB_OFF_ROWC);            // per row: hf[9], rf[9], ru[3] of its record
+    int *const rowi = (int *)(rowc + DSCB_RPB * DSCB_ROWC);             // ... and its row index
+    double *const rowd = (double *)(dscb_lds + DSCB_OFF_ROWD);          // ... and inv(Rfinal) in float64 (the voxel of a sample next to a tie)
     const int tid = (int)threadIdx.x;
     const FieldDev F = A.f;
-    const dscb_rec_t recs = (dscb_rec_t)(A.row_rec + pos0);
-    const int ic0 = recs[r_begin].c[0], ic1 = recs[r_begin].c[1], ic2 = recs[r_begin].c[2];
-    const int QCAP = min(DSCB_QCAP, A.queue_cap);
-    // as in k_describe: when the ball lies inside the grid with a voxel to spare no sample can leave it
+    const DscRowRec *const grec = A.row_rec + pos0 + r_begin;           // the records of this run
     // Only anchors whose ball lies inside the grid with a voxel to spare come here (no sample of theirs can leave the grid, as in
     // k_describe's `interior`); the host sorts the others in front of `n_rowwise` with the same expression (mad_ball_interior).
     if (!mad_ball_interior(ic0, ic1, ic2, F.nx, F.ny, F.nz)) {
@@ -1311,195 +1343,244 @@ __global__ __launch_bounds__(DSCB_THREADS, 8) void k_describe_ball(Batch<Describ
         return;
     }
 
-    // ---- tables, counters, and the ball: half a wave per column, eight columns of a thread in flight ----
-    stage_lds((void *)tab, &A.eq->tab, sizeof(EqspTabLds));
-    stage_lds((void *)fastp, &A.eq->image, DSCB_FAST_BYTES);
-    stage_lds((void *)colb, A.colbase, DSCB_COL_BYTES);
-    for (int i = tid; i < 3 * 512; i += DSCB_THREADS) hist[i] = 0;
-    if (tid < 8) s_nq[tid] = 0;
+    // ---- tables (one 16-byte piece per thread) and the ball's column list first; then half a wave per x-plane of the ball: the 27
+    // ---- columns' texels of a thread all requested before the first is stored (z-runs of up to 27 consecutive texels)
+    unsigned *const cinfo = (unsigned *)omask;      // (the open-sample lists are not in use yet) per column: LDS offset of its first texel | half-length << 16 (31: none)
     {
-        const int hw = tid >> 5, zl = tid & 31;
-        for (int c0 = hw; c0 < DSCB_COLS; c0 += 32 * 8) {
-            unsigned v[8];
-            int dst[8];
+        constexpr int N_TAB = (int)sizeof(EqspTabLds) / 16, N_FAST = (int)DSCB_FAST_BYTES / 16;
+        static_assert(N_TAB + N_FAST <= DSCB_THREADS && DSCB_COLS <= DSCB_THREADS && DSCB_RPB * 256 * 4 >= DSCB_COLS * 4, "one table piece per thread");
+        const uint4 *src = (const uint4 *)&A.eq->tab;      // (a valid address for every thread; stored only where dst4 is set)
+        uint4 *dst4 = nullptr;
+        if (tid < N_TAB) { src = (const uint4 *)&A.eq->tab + tid; dst4 = (uint4 *)tab + tid; }
+        else if (tid < N_TAB + N_FAST) { src = (const uint4 *)&A.eq->image + (tid - N_TAB); dst4 = (uint4 *)fastp + (tid - N_TAB); }
+        const uint4 tv = *src;
+        const unsigned ci = A.colinfo[min(tid, DSCB_COLS - 1)];
+        const int rq = tid / DSCB_ROWC, ri = tid - rq * DSCB_ROWC;
+        const bool has_rc = rq < n_here && ri < 21;
+        const float rcv = ((const float *)grec[has_rc ? rq : 0].hf)[has_rc ? ri : 0];      // hf, rf, ru are contiguous
+        const int riv = grec[tid < n_here ? tid : 0].row;
+        const bool has_rd = tid < 9 * n_here;
+        const double rdv = grec[has_rd ? tid / 9 : 0].inv[has_rd ? tid % 9 : 0];
+        if (dst4) *dst4 = tv;
+        if (has_rd) rowd[tid] = rdv;
+        if (tid < DSCB_COLS) {
+            cinfo[tid] = ci;
+            colb[tid] = (short)((ci & 0xffffu) + (ci >> 16));      // the column's middle texel: what a sample's dz is added to
+        }
+        if (has_rc) rowc[tid] = rcv;
+        if (tid < n_here) rowi[tid] = riv;
+        for (int i = tid; i < DSCB_RPB * 512; i += DSCB_THREADS) hist[i] = 0;
+        __syncthreads();
+        const int hw = tid >> 5, zl = tid & 31;      // half-wave hw: the plane x = ic0 - 13 + hw; lane zl: the zl-th texel of a column's run
+        if (hw < DSCB_SIDE) {
+            unsigned v[DSCB_SIDE];
+            const unsigned plane = mad_u24((unsigned)(ic0 - DSCB_M + hw), (unsigned)F.ny, (unsigned)(ic1 - DSCB_M));
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const int c = c0 + 32 * u, cc = min(c, DSCB_COLS - 1);
-                const int cx = cc / DSCB_SIDE, cy = cc - cx * DSCB_SIDE;
-                const int h = dscb_col_h(cx, cy);
-                const bool ok = c < DSCB_COLS && h >= 0 && zl <= 2 * h;
-                // (a border anchor's ball is filled with the grid's outermost texels where it leaves the grid: a sample there is
-                // never trusted, see `border` below)
-                const int gx = min(max(ic0 - DSCB_M + cx, 0), F.nx - 1), gy = min(max(ic1 - DSCB_M + cy, 0), F.ny - 1),
-                          gz = min(max(ic2 - h + zl, 0), F.nz - 1);
-                v[u] = F.tex4[mad_u24(mad_u24((unsigned)gx, (unsigned)F.ny, (unsigned)gy), (unsigned)F.nz, (unsigned)gz)];
-                dst[u] = ok ? (int)A.colbase[cc] - h + zl : -1;
+            for (int u = 0; u < DSCB_SIDE; u++) {
+                const int h = (int)(cinfo[hw * DSCB_SIDE + u] >> 16);
+                // (the ball lies inside the grid; the clamp keeps the lanes beyond a column's run, or of no column, inside the texture)
+                const int gz = min(max(ic2 - h + zl, 0), F.nz - 1);
+                v[u] = F.tex4[mad_u24(plane + (unsigned)u, (unsigned)F.nz, (unsigned)gz)];
             }
 #pragma unroll
-            for (int u = 0; u < 8; u++)
-                if (dst[u] >= 0) ball[dst[u]] = v[u];
+            for (int u = 0; u < DSCB_SIDE; u++) {
+                const unsigned c2 = cinfo[hw * DSCB_SIDE + u];
+                const int h = (int)(c2 >> 16);
+                if (h != 31 && zl <= 2 * h) ball[(c2 & 0xffffu) + zl] = v[u];
+            }
         }
     }
     __syncthreads();
+    DSCB_STAMP(1);
 
-    // this thread's samples of every row: column (j, k), i = 4 iq .. 4 iq + 3 -- all in sub-region `sub` (Descriptor.py:44-64)
-    const int iq = tid >> 8, j = (tid >> 4) & 15, k = tid & 15;
-    const int sub = (j >> 2) * 16 + (k >> 2) + 4 * iq;
+    // Four waves per row, the rows of the run side by side: wave w belongs to row g = w / 4; its thread owns column (j, k) of that
+    // row's lattice and walks i = 0 .. 15 four samples at a time -- a sub-region (Descriptor.py:44-64) per trip.
+    const int g = tid >> 8, col = tid & 255, j = col >> 4, k = col & 15;
+    const bool live = g < n_here;      // (uniform per wave)
+    const int sub_jk = (j >> 2) * 16 + (k >> 2);
     const float lbf = -7.5f;      // Descriptor.py:35, dsc_radius 16: the lattice -7.5 .. 7.5
     const float m1 = lbf + (float)j, m2 = lbf + (float)k;
+    const float *const rcp = rowc + (live ? g : 0) * DSCB_ROWC;
+    auto rc = [&](int i) {      // constant i of this wave's row: the same value in every lane -> a scalar register
+        return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, rcp[i])));
+    };
+    unsigned *const H = hist + g * 512;
 
-    // float32 guess of sample i of column (jj, kk): offset from the anchor voxel exactly as k_describe forms it -- the nearest voxel is
-    // cvt_round(a) unless a fraction is within 2e-4 of the 0.5 tie (`unsure`: the reference's float64 expression decides)
-    // (an interior anchor: no sample can leave the grid, no edge test)
-    auto accumulate = [&](int rr, int r) {
-        const dscb_rec_t rec = recs + r;
-        const float h0 = rec->hf[0], h1 = rec->hf[1], h2 = rec->hf[2], h3 = rec->hf[3], h4 = rec->hf[4], h5 = rec->hf[5], h6 = rec->hf[6],
-                    h7 = rec->hf[7], h8 = rec->hf[8];      // (float)inv(Rfinal): scalar registers
-        const float b0 = fmaf(m1, h1, m2 * h2), b1 = fmaf(m1, h4, m2 * h5), b2 = fmaf(m1, h7, m2 * h8);
-        unsigned q[4], unsure = 0;
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const float m0 = lbf + (float)(4 * iq + u);
-            const float a0 = fmaf(m0, h0, b0), a1 = fmaf(m0, h3, b1), a2 = fmaf(m0, h6, b2);
-            const float fr0 = __builtin_amdgcn_fractf(a0), fr1 = __builtin_amdgcn_fractf(a1), fr2 = __builtin_amdgcn_fractf(a2);
-            const bool safe = fminf(fminf(fabsf(fr0 - 0.5f), fabsf(fr1 - 0.5f)), fabsf(fr2 - 0.5f)) > 2e-4f;
-            // |a| <= 12.991, so the voxel lies in the ball; the clamp of the LDS index keeps a corrupt record from reading outside it
-            const int col = mad_i24(cvt_round(a0), DSCB_SIDE, cvt_round(a1));      // (+ 13 * 28: in the table's address)
-            const int li = (int)colc[col] + cvt_round(a2);                           // (+ 13: in the table's values)
-            q[u] = ball[min(max(li, 0), DSCB_NBALL - 1)];
-            unsure |= safe ? 0u : (1u << u);
-        }
-        bool oob = false;
-        if (unsure) {      // rare: the reference's float64 expression for those samples, their texels from global memory
-#pragma unroll
-            for (int u = 0; u < 4; u++)
-                if (unsure & (1u << u)) {
-                    const unsigned loc = dscb_exact_voxel(A.row_rec[pos0 + r].inv, ic0, ic1, ic2, F.nx, F.ny, F.nz, 4 * iq + u, j, k);
-                    if (loc == ~0u) {      // (cannot happen for an interior anchor; kept: the row would be zero, Descriptor.py:142-149)
-                        oob = true;
-                        continue;
-                    }
-                    const int v0 = ic0 - DSCB_M + (int)(loc & 31u), v1 = ic1 - DSCB_M + (int)((loc >> 5) & 31u), v2 = ic2 - DSCB_M + (int)((loc >> 10) & 31u);
-                    q[u] = F.tex4[mad_u24(mad_u24((unsigned)v0, (unsigned)F.ny, (unsigned)v1), (unsigned)F.nz, (unsigned)v2)];
-                }
-        }
-        // zones of the four samples in straight-line code (4-byte texel -> float32 rotation -> table: k_describe's TAB tier)
+    // ---- table tier.  The float32 guess of a sample's offset from the anchor voxel is formed exactly as in k_describe: the nearest
+    // ---- voxel is cvt_round(a) unless a fraction is within 2e-4 of the 0.5 tie -- such a sample is left open with the ones the
+    // ---- table cannot decide, and whoever takes it from the row's list lets the reference's float64 expression choose the voxel.
+    unsigned openmask = 0;      // bit i: sample i of this thread is open
+    int open_inc = 0;
+    if (live) {
+        const float h0 = rc(0), h1 = rc(1), h2 = rc(2), h3 = rc(3), h4 = rc(4), h5 = rc(5), h6 = rc(6), h7 = rc(7), h8 = rc(8);      // (float)inv(Rfinal)
         // (float)Rfinal, the third row with the 1 / 511 of the texel's components: z on the unit scale, x and y on any common one
-        const float f0 = rec->rf[0], f1 = rec->rf[1], f2 = rec->rf[2], f3 = rec->rf[3], f4 = rec->rf[4], f5 = rec->rf[5], f6 = rec->rf[6],
-                    f7 = rec->rf[7], f8 = rec->rf[8];
-        int zone[4];
-        unsigned any_flag = 0;
+        const float f0 = rc(9), f1 = rc(10), f2 = rc(11), f3 = rc(12), f4 = rc(13), f5 = rc(14), f6 = rc(15), f7 = rc(16), f8 = rc(17);
+        const float b0 = fmaf(m1, h1, m2 * h2), b1 = fmaf(m1, h4, m2 * h5), b2 = fmaf(m1, h7, m2 * h8);
+        // A row whose rotation keeps a grid axis (nearly) fixed has EVERY sample next to a tie along that axis: the lattice sits on
+        // half-integers (Descriptor.py:35), and the reference's float64 expression has to place each sample (scipy: a fraction <= 0.5
+        // takes the lower voxel).  These are the rows of main bin 0 / 111 -- the poles: Rfinal is a turn about z -- about one row in
+        // a hundred.  Such a row takes that expression for all its samples here, in line, instead of leaving 4 096 samples open.
+        // (Which rows take this path changes their cost, never their result: both paths place a sample with the float64 expression
+        // whenever float32 cannot.)
+        auto tiny = [](float x) { return fabsf(x) < 2e-5f ? 1 : 0; };
+        const bool tie_row = tiny(h0) + tiny(h1) + tiny(h2) >= 2 || tiny(h3) + tiny(h4) + tiny(h5) >= 2 || tiny(h6) + tiny(h7) + tiny(h8) >= 2;
+        const double *const dinv = rowd + 9 * g;
+#pragma unroll 1
+        for (int i0 = 0; i0 < 16; i0 += 4) {
+            unsigned q[4], open = 0;
+            if (tie_row) {      // (uniform per wave)
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const unsigned t = q[u];
-            const float gx = (float)(int)__builtin_amdgcn_sbfe(t, 0, 10), gy = (float)(int)__builtin_amdgcn_sbfe(t, 10, 10),
-                        gz = (float)(int)__builtin_amdgcn_sbfe(t, 20, 10);
-            const float rx = fmaf(gz, f2, fmaf(gy, f1, gx * f0));
-            const float ry = fmaf(gz, f5, fmaf(gy, f4, gx * f3));
-            const float rz = fmaf(gz, f8, fmaf(gy, f7, gx * f6));
-            zone[u] = eqsp_tab32(tab, rx, ry, rz);
-            any_flag |= t;
-        }
-        if ((int)any_flag < 0) {      // rare: 2 = not finite -> the exact tiers, 3 = below the magnitude cut-off, not counted (Descriptor.py:190)
+                for (int u = 0; u < 4; u++) {
+                    const double l0 = -7.5 + (double)(i0 + u), l1 = -7.5 + (double)j, l2 = -7.5 + (double)k;
+                    int r[3];
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const unsigned fl = q[u] >> 30;
-                zone[u] = fl == 3u ? -2 : (fl == 0u ? zone[u] : -1);
-            }
-        }
-        unsigned *const H = hist + (rr % 3) * 512;
-        unsigned undecided = 0;
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            if (zone[u] >= 0) atomicAdd(&H[sub * 8 + (zone[u] >> 1)], 1u << ((zone[u] & 1) << 4));
-            undecided |= zone[u] == -1 ? (1u << u) : 0u;
-        }
-        // one queue reservation per wave (a scan of the lanes' counts on the DPP path), as in k_describe; an entry names the
-        // sample (thread, u): whoever takes it forms its voxel again
-        const int cn = __popc(undecided);
-        const int inc = wave_incl_scan_i32(cn);
-        const int total = __builtin_amdgcn_readlane(inc, MAD_WAVE - 1);
-        if (total) {
-            int base = 0;
-            if (lane_id() == 0) base = atomicAdd(&s_nq[rr & 3], total);
-            int off = __builtin_amdgcn_readfirstlane(base) + inc - cn;
-            unsigned short *const Q = qent + (rr & 1) * DSCB_QCAP;
-#pragma unroll
-            for (int u = 0; u < 4; u++)
-                if (undecided & (1u << u)) {
-                    if (off < QCAP) Q[off] = (unsigned short)(tid | u << 10);
-                    off++;
+                    for (int ax = 0; ax < 3; ax++) {
+                        const int ic = ax == 0 ? ic0 : (ax == 1 ? ic1 : ic2), nmax = ax == 0 ? F.nx : (ax == 1 ? F.ny : F.nz);
+                        const double pp = (l0 * dinv[3 * ax] + l1 * dinv[3 * ax + 1] + l2 * dinv[3 * ax + 2]) + (double)ic;      // Descriptor.py:132-133
+                        const int lo = min((int)floor(pp), nmax - 2);
+                        r[ax] = ((pp - (double)lo <= 0.5) ? lo : lo + 1) - ic;
+                    }
+                    const int li = (int)colc[mad_i24(r[0], DSCB_SIDE, r[1])] + r[2];
+                    q[u] = ball[min(max(li, 0), DSCB_NBALL - 1)];
                 }
-        }
-        if (oob) s_oob[rr & 3] = 1;
-    };
-
-    // the samples the table left open: their 16-byte texels, the float32 tier with its 1e-4 guard, the float64 tier behind it
-    auto drain = [&](int rr, int r) {
-        const int nq = s_nq[rr & 3];
-        unsigned *const H = hist + (rr % 3) * 512;
-        const int64_t row = recs[r].row;
-        const double *const Rrow = A.row_R + 9 * row;
-        if (nq > QCAP) {
-            // more undecided samples than the queue holds (not seen in practice): the whole row again with the exact arithmetic
-            // (uniform over the workgroup: every thread passes this barrier)
-            for (int i = tid; i < 512; i += DSCB_THREADS) H[i] = 0;
-            __syncthreads();
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const float m0 = lbf + (float)(i0 + u);
+                    const float a0 = fmaf(m0, h0, b0), a1 = fmaf(m0, h3, b1), a2 = fmaf(m0, h6, b2);
+                    const float fr0 = __builtin_amdgcn_fractf(a0), fr1 = __builtin_amdgcn_fractf(a1), fr2 = __builtin_amdgcn_fractf(a2);
+                    const bool safe = fminf(fminf(fabsf(fr0 - 0.5f), fabsf(fr1 - 0.5f)), fabsf(fr2 - 0.5f)) > 2e-4f;
+                    // |a| <= 12.991, so the voxel lies in the ball; the clamp of the LDS index keeps a corrupt record from reading outside it
+                    const int cidx = mad_i24(cvt_round(a0), DSCB_SIDE, cvt_round(a1));
+                    const int li = (int)colc[cidx] + cvt_round(a2);
+                    q[u] = ball[min(max(li, 0), DSCB_NBALL - 1)];
+                    open |= safe ? 0u : (1u << u);
+                }
+            }
+            // zones of the four samples in straight-line code (4-byte texel -> float32 rotation -> table: k_describe's TAB tier)
+            int zone[4];
+            unsigned any_flag = 0;
+#pragma unroll
             for (int u = 0; u < 4; u++) {
-                const unsigned loc = dscb_exact_voxel(A.row_rec[pos0 + r].inv, ic0, ic1, ic2, F.nx, F.ny, F.nz, 4 * iq + u, j, k);
-                if (loc == ~0u) continue;      // (the row is dead: accumulate has seen the same sample leave the grid)
-                const int v0 = ic0 - DSCB_M + (int)(loc & 31u), v1 = ic1 - DSCB_M + (int)((loc >> 5) & 31u), v2 = ic2 - DSCB_M + (int)((loc >> 10) & 31u);
-                const float4 tx = F.tex[mad_u24(mad_u24((unsigned)v0, (unsigned)F.ny, (unsigned)v1), (unsigned)F.nz, (unsigned)v2)];
-                if (tx.w < 1e-5f) continue;
-                const int zn = dscb_describe_exact(exactp, tx.x, tx.y, tx.z, tx.w, Rrow);
-                atomicAdd(&H[sub * 8 + (zn >> 1)], 1u << ((zn & 1) << 4));
+                const unsigned t = q[u];
+                const float gx = (float)(int)__builtin_amdgcn_sbfe(t, 0, 10), gy = (float)(int)__builtin_amdgcn_sbfe(t, 10, 10),
+                            gz = (float)(int)__builtin_amdgcn_sbfe(t, 20, 10);
+                const float rx = fmaf(gz, f2, fmaf(gy, f1, gx * f0));
+                const float ry = fmaf(gz, f5, fmaf(gy, f4, gx * f3));
+                const float rz = fmaf(gz, f8, fmaf(gy, f7, gx * f6));
+                zone[u] = eqsp_tab32(tab, rx, ry, rz);
+                any_flag |= t;
             }
-            return;
+            if ((int)any_flag < 0) {      // rare: 2 = not finite -> the exact tiers, 3 = below the magnitude cut-off, not counted (Descriptor.py:190)
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const unsigned fl = q[u] >> 30;
+                    zone[u] = fl == 3u ? -2 : (fl == 0u ? zone[u] : -1);
+                }
+            }
+            const int sub8 = (sub_jk + i0) * 8;      // sub-region of these four samples: i0 / 4 along i = + 4 (i0 / 4), x 8 words
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const bool op = (open >> u) & 1u;      // voxel not certain: whatever the guessed texel said does not count
+                if (zone[u] >= 0 && !op) atomicAdd(&H[sub8 + (zone[u] >> 1)], 1u << ((zone[u] & 1) << 4));
+                open |= zone[u] == -1 ? (1u << u) : 0u;
+            }
+            openmask |= open << i0;
         }
-        const int e = DSCB_THREADS - 1 - tid;      // (the last waves: the first ones write rows out)
-        if (e < nq) {
-            const unsigned ent = qent[(rr & 1) * DSCB_QCAP + e];
-            const int et = (int)(ent & 1023u), ei = 4 * (et >> 8) + (int)(ent >> 10), ej = (et >> 4) & 15, ek = et & 15;
-            const int sb = (ej >> 2) * 16 + (ek >> 2) + 4 * (et >> 8);
-            // the sample's voxel again: the same float32 guess, the same float64 decision next to a tie
-            const dscb_rec_t rec = recs + r;
-            const float e1 = lbf + (float)ej, e2 = lbf + (float)ek, e0 = lbf + (float)ei;
-            const float a0 = fmaf(e0, rec->hf[0], fmaf(e1, rec->hf[1], e2 * rec->hf[2])), a1 = fmaf(e0, rec->hf[3], fmaf(e1, rec->hf[4], e2 * rec->hf[5])),
-                        a2 = fmaf(e0, rec->hf[6], fmaf(e1, rec->hf[7], e2 * rec->hf[8]));
-            const bool safe = fminf(fminf(fabsf(__builtin_amdgcn_fractf(a0) - 0.5f), fabsf(__builtin_amdgcn_fractf(a1) - 0.5f)), fabsf(__builtin_amdgcn_fractf(a2) - 0.5f)) > 2e-4f;
-            int v0 = ic0 + cvt_round(a0), v1 = ic1 + cvt_round(a1), v2 = ic2 + cvt_round(a2);
-            bool gone = false;
-            if (!safe) {
-                const unsigned loc = dscb_exact_voxel(A.row_rec[pos0 + r].inv, ic0, ic1, ic2, F.nx, F.ny, F.nz, ei, ej, ek);
-                gone = loc == ~0u;
-                v0 = ic0 - DSCB_M + (int)(loc & 31u); v1 = ic1 - DSCB_M + (int)((loc >> 5) & 31u); v2 = ic2 - DSCB_M + (int)((loc >> 10) & 31u);
-            }
-            // (the clamps never act for an interior anchor: they keep a corrupt record inside the texture)
-            v0 = min(max(v0, 0), F.nx - 1); v1 = min(max(v1, 0), F.ny - 1); v2 = min(max(v2, 0), F.nz - 1);
-            const float4 tx = F.tex[mad_u24(mad_u24((unsigned)v0, (unsigned)F.ny, (unsigned)v1), (unsigned)F.nz, (unsigned)v2)];
-            if (!gone && tx.w >= 1e-5f) {      // (always: texels below the cut-off carry flag 3 and are never queued)
-                const dscb_f64_t Rc = (dscb_f64_t)Rrow;
-                const float f0 = (float)Rc[0], f1 = (float)Rc[1], f2 = (float)Rc[2], f3 = (float)Rc[3], f4 = (float)Rc[4], f5 = (float)Rc[5],
-                            f6 = (float)Rc[6], f7 = (float)Rc[7], f8 = (float)Rc[8];
-                const float inv = __builtin_amdgcn_rcpf(fmaxf(tx.w, 1e-30f));
-                const float gx = tx.x * inv, gy = tx.y * inv, gz = tx.z * inv;
-                int zn = eqsp_fast32(fastp, fmaf(gz, f2, fmaf(gy, f1, gx * f0)), fmaf(gz, f5, fmaf(gy, f4, gx * f3)), fmaf(gz, f8, fmaf(gy, f7, gx * f6)));
-                if (zn < 0) zn = dscb_describe_exact(exactp, tx.x, tx.y, tx.z, tx.w, Rrow);
-                atomicAdd(&H[sb * 8 + (zn >> 1)], 1u << ((zn & 1) << 4));
-            }
-        }
-    };
+        // where this thread's open samples stand in the row's list: a scan over the wave now, the waves before it after the barrier
+        open_inc = wave_incl_scan_i32(__popc(openmask));
+        if (lane_id() == MAD_WAVE - 1) wtot[tid >> 6] = open_inc;
+    }
+    DSCB_STAMP(2);
+    __syncthreads();
+    DSCB_STAMP(3);
 
-    // one wave: the 1 024 counts of a finished row as int16 (the packed words ARE the row) and int8, its norm; the histogram zeroed
-    auto write_out = [&](int rr, int r) {
+    // ---- the open samples of each row (~4 % of a row; up to most of it where the directions hug a zone's edge), dealt evenly to
+    // ---- the row's 256 threads whatever their number: the columns' masks and running counts in LDS, the e-th open sample found by
+    // ---- a binary search.  Per sample: its voxel again (float64 next to a tie: Descriptor.py:132-133, scipy's rule), its 16-byte
+    // ---- texel, the float32 tier with its 1e-4 guard, the float64 tier behind it -- as k_describe's queue phase.
+    if (live) {
+        int before = 0;
+        for (int w = g * 4; w < (tid >> 6); w++) before += wtot[w];
+        ocum[g * 256 + col] = (unsigned short)(open_inc + before);
+        omask[g * 256 + col] = (unsigned short)openmask;
+    }
+    __syncthreads();
+    auto settle = [&](int ei, int ej, int ek) {
+        const float e1 = lbf + (float)ej, e2 = lbf + (float)ek, e0 = lbf + (float)ei;
+        const float a0 = fmaf(e0, rcp[0], fmaf(e1, rcp[1], e2 * rcp[2])), a1 = fmaf(e0, rcp[3], fmaf(e1, rcp[4], e2 * rcp[5])),
+                    a2 = fmaf(e0, rcp[6], fmaf(e1, rcp[7], e2 * rcp[8]));
+        const bool safe = fminf(fminf(fabsf(__builtin_amdgcn_fractf(a0) - 0.5f), fabsf(__builtin_amdgcn_fractf(a1) - 0.5f)), fabsf(__builtin_amdgcn_fractf(a2) - 0.5f)) > 2e-4f;
+        int r0 = cvt_round(a0), r1 = cvt_round(a1), r2 = cvt_round(a2);      // the voxel's offset from the anchor's
+        const int sb8 = (((ej >> 2) * 16 + (ek >> 2)) + (ei & ~3)) * 8;
+        if (!safe) {
+            // Next to a tie the reference's own float64 expression decides (Descriptor.py:132-133; scipy's nearest rule: a fraction
+            // <= 0.5 takes the lower voxel).  Rows turned by a multiple of 90 degrees have EVERY sample there (the lattice sits on
+            // half-integers), so this is straight-line code, an axis at a time, not a call.  The ball lies inside the grid.
+            const double *const dinv = rowd + 9 * g;
+            const double l0 = -7.5 + (double)ei, l1 = -7.5 + (double)ej, l2 = -7.5 + (double)ek;
+            auto nearest = [&](int ax, int ic, int nmax) {
+                const double pp = (l0 * dinv[3 * ax] + l1 * dinv[3 * ax + 1] + l2 * dinv[3 * ax + 2]) + (double)ic;
+                const int lo = min((int)floor(pp), nmax - 2);
+                const int v = (pp - (double)lo <= 0.5) ? lo : lo + 1;
+                return min(max(v - ic, -DSCB_M), DSCB_M);      // (the clamp never acts: |offset| <= 12.991)
+            };
+            r0 = nearest(0, ic0, F.nx); r1 = nearest(1, ic1, F.ny); r2 = nearest(2, ic2, F.nz);
+            // the voxel is settled, its 4-byte texel is in the ball: the table tier, as for every other sample
+            const unsigned t = ball[min(max((int)colc[mad_i24(r0, DSCB_SIDE, r1)] + r2, 0), DSCB_NBALL - 1)];
+            const unsigned fl = t >> 30;
+            if (fl == 3u) return;      // below the magnitude cut-off: not counted (Descriptor.py:190)
+            if (fl == 0u) {
+                const float gx = (float)(int)__builtin_amdgcn_sbfe(t, 0, 10), gy = (float)(int)__builtin_amdgcn_sbfe(t, 10, 10),
+                            gz = (float)(int)__builtin_amdgcn_sbfe(t, 20, 10);
+                const int zn = eqsp_tab32(tab, fmaf(gz, rcp[11], fmaf(gy, rcp[10], gx * rcp[9])), fmaf(gz, rcp[14], fmaf(gy, rcp[13], gx * rcp[12])),
+                                          fmaf(gz, rcp[17], fmaf(gy, rcp[16], gx * rcp[15])));
+                if (zn >= 0) {
+                    atomicAdd(&H[sb8 + (zn >> 1)], 1u << ((zn & 1) << 4));
+                    return;
+                }
+            }
+        }
+        // the 16-byte texel: the float32 tier with its 1e-4 guard, the float64 tier behind it
+        const float4 tx = F.tex[mad_u24(mad_u24((unsigned)(ic0 + r0), (unsigned)F.ny, (unsigned)(ic1 + r1)), (unsigned)F.nz, (unsigned)(ic2 + r2))];
+        if (tx.w < 1e-5f) return;      // (not counted, Descriptor.py:190 -- such texels carry flag 3 and never get here)
+        const float inv = __builtin_amdgcn_rcpf(fmaxf(tx.w, 1e-30f));
+        const float gx = tx.x * inv, gy = tx.y * inv, gz = tx.z * inv;
+        int zn = eqsp_fast32(fastp, fmaf(gz, rcp[11], fmaf(gy, rcp[10], gx * rcp[9])), fmaf(gz, rcp[14], fmaf(gy, rcp[13], gx * rcp[12])),
+                             fmaf(gz, rcp[20], fmaf(gy, rcp[19], gx * rcp[18])));
+#ifdef MAD_PROBE_STAMPS
+        if (zn < 0) atomicAdd(&dbg_s[3], 1);
+#endif
+        if (zn < 0) zn = dscb_describe_exact(exactp, tx.x, tx.y, tx.z, tx.w, A.row_R + 9 * (int64_t)rowi[g]);
+        atomicAdd(&H[sb8 + (zn >> 1)], 1u << ((zn & 1) << 4));
+    };
+    if (live) {
+        const unsigned short *const cum = ocum + g * 256, *const msk = omask + g * 256;
+        const int n_open = cum[255];
+#ifdef MAD_PROBE_STAMPS
+        if (col == 0) { atomicMax(&dbg_s[0], n_open); atomicAdd(&dbg_s[1], n_open); }
+#endif
+        for (int e = col; e < n_open; e += 256) {
+            int c = 0;      // the first column whose running count exceeds e
+#pragma unroll
+            for (int st = 128; st; st >>= 1)
+                if ((int)cum[c + st - 1] <= e) c += st;
+            unsigned m = msk[c];
+            for (int skip = e - ((int)cum[c] - __popc(m)); skip > 0; skip--) m &= m - 1;
+            settle(__builtin_ctz(m), c >> 4, c & 15);
+        }
+    }
+    DSCB_STAMP(4);
+    __syncthreads();
+    DSCB_STAMP(5);
+    DSCB_STAMP(6);
+
+    // ---- the first wave of a row: its 1 024 counts as int16 (the packed words ARE the row) and int8, its norm
+    if (live && (tid & 255) < MAD_WAVE) {
         const int l = (int)lane_id();
-        const bool dead = s_oob[rr & 3] != 0;      // Descriptor.py:142-149: a sample left the grid -> the whole descriptor is zero
-        uint4 *const H4 = (uint4 *)(hist + (rr % 3) * 512);
-        uint4 w0 = H4[2 * l], w1 = H4[2 * l + 1];
-        H4[2 * l] = make_uint4(0, 0, 0, 0);
-        H4[2 * l + 1] = make_uint4(0, 0, 0, 0);
-        if (dead) w0 = w1 = make_uint4(0, 0, 0, 0);
-        const int64_t row = recs[r].row;
+        const uint4 *const H4 = (const uint4 *)H;
+        const uint4 w0 = H4[2 * l], w1 = H4[2 * l + 1];
+        const int64_t row = rowi[g];
         uint4 *const o16 = (uint4 *)(A.dsc + row * 1024);
         o16[2 * l] = w0;
         o16[2 * l + 1] = w1;
@@ -1511,38 +1592,26 @@ __global__ __launch_bounds__(DSCB_THREADS, 8) void k_describe_ball(Batch<Describ
             ss = wave_sum_i32(ss);
             if (l == 0) A.norm[row] = sqrt((double)ss);
         }
-    };
-
-    // Row rr = r - r_begin lives in histogram rr % 3, queue rr & 1, flags rr & 3.  Between two barriers: the table tier of row rr
-    // | barrier rr | the open samples of row rr, the write-out (and zeroing) of row rr - 1, the flags of row rr + 2 reset.  A
-    // histogram is written again three barriers after its write-out, a queue two after its drain, a flag two after its last reader.
-    const int wave = tid >> 6;
-    for (int r = r_begin; r <= r_end; r++) {
-        const int rr = r - r_begin;
-        if (r < r_end) {
-            accumulate(rr, r);
-        }
-        __syncthreads();
-        if (r < r_end && tid == 0) { s_nq[(rr + 2) & 3] = 0; s_oob[(rr + 2) & 3] = 0; }
-        if (rr > 0 && wave == ((rr - 1) & 7)) write_out(rr - 1, r - 1);
-        if (r < r_end) drain(rr, r);
     }
+    DSCB_STAMP(7);
+#ifdef MAD_PROBE_STAMPS
+    if (threadIdx.x == 0 && st_slot < 16384) dscb_real[2 * st_slot + 1] = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x < 4 && st_slot < 16384) dscb_dbg[4 * st_slot + threadIdx.x] = dbg_s[threadIdx.x];
+#endif
 }
 
 static int ensure_ball(mad_ctx *ctx) {
-    if (ctx->ball_colbase) return MAD_OK;
-    int16_t h[DSCB_COL_BYTES / 2];
-    memset(h, 0, sizeof(h));
+    if (ctx->ball_colinfo) return MAD_OK;
+    unsigned h[DSCB_COLS];
     int base = 0;
     for (int c = 0; c < DSCB_COLS; c++) {
         const int hh = dscb_col_h(c / DSCB_SIDE, c % DSCB_SIDE);
-        if (hh < 0) continue;
-        h[c] = (int16_t)(base + hh);      // LDS index of the voxel dz = -hh .. hh of column (cx, cy) = h[c] + dz
-        base += 2 * hh + 1;
+        h[c] = hh < 0 ? (31u << 16) : ((unsigned)base | (unsigned)hh << 16);      // LDS index of the column's voxel dz = -hh: base; it holds 2 hh + 1 texels
+        if (hh >= 0) base += 2 * hh + 1;
     }
     if (base != DSCB_NBALL) return mad_fail(ctx, MAD_EINVAL, "k_describe_ball: the ball has %d texels, built for %d", base, DSCB_NBALL);
-    MAD_HIP(hipMalloc((void **)&ctx->ball_colbase, sizeof(h)));
-    MAD_HIP(hipMemcpy(ctx->ball_colbase, h, sizeof(h), hipMemcpyHostToDevice));
+    MAD_HIP(hipMalloc((void **)&ctx->ball_colinfo, sizeof(h)));
+    MAD_HIP(hipMemcpy(ctx->ball_colinfo, h, sizeof(h), hipMemcpyHostToDevice));
     MAD_HIP(hipFuncSetAttribute((const void *)k_describe_ball, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DSCB_LDS_BYTES));
     return MAD_OK;
 }
@@ -1584,7 +1653,7 @@ int mad_describe_device_many(mad_ctx *ctx, int n_jobs, const DescribeJob *jobs, 
             A.row_anchor = J.d_row_anchor; A.row_R = J.d_row_R; A.row_Rinv = J.d_row_Rinv; A.row_perm = J.d_row_perm; A.n_rows = J.d_n_rows; A.overflow = J.d_overflow;
             A.r = r; A.eq = ctx->eq[1]; A.dsc = J.d_dsc; A.dsc8 = J.d_dsc8; A.norm = J.d_norm; A.row_rec = J.d_row_rec;
             A.queue_cap = std::max(ctx->dsc_queue_cap, 0);
-            A.row_limit = ball ? J.d_anc_rows + 2 * (int64_t)J.n_rowwise : nullptr;      // first row position of the first base-octave anchor
+            A.row_limit = ball ? J.d_anc_rows + MAD_ANCROW_WORDS * (int64_t)J.n_rowwise : nullptr;      // first row position of the first base-octave anchor
             B.first[B.n_jobs++] = (int)blk;
             // one workgroup per possible row, a multiple of 8 per job (one share per XCD).  With the ball kernel this grid only has
             // the octave-0 rows to cover: their share of the hint by anchors, with room (a launch that falls short raises `overflow`)
@@ -1595,8 +1664,8 @@ int mad_describe_device_many(mad_ctx *ctx, int n_jobs, const DescribeJob *jobs, 
             if (ball) {
                 DescribeBallArgs &Q = BB.job[BB.n_jobs];
                 Q.f = J.f[1]; Q.row_rec = J.d_row_rec; Q.anc_rows = J.d_anc_rows; Q.row_R = J.d_row_R;
-                Q.n_base = n_base; Q.n_rowwise = J.n_rowwise; Q.queue_cap = std::max(ctx->dsc_queue_cap, 0);
-                Q.eq = ctx->eq[1]; Q.overflow = J.d_overflow; Q.colbase = ctx->ball_colbase; Q.dsc = J.d_dsc; Q.dsc8 = J.d_dsc8; Q.norm = J.d_norm;
+                Q.n_base = n_base; Q.n_rowwise = J.n_rowwise;
+                Q.eq = ctx->eq[1]; Q.overflow = J.d_overflow; Q.colinfo = ctx->ball_colinfo; Q.dsc = J.d_dsc; Q.dsc8 = J.d_dsc8; Q.norm = J.d_norm;
                 BB.first[BB.n_jobs++] = (int)bblk;
                 max_fan = std::max(max_fan, J.fan);
             }
@@ -1622,7 +1691,8 @@ int mad_describe_device_many(mad_ctx *ctx, int n_jobs, const DescribeJob *jobs, 
         if (BB.n_jobs > 0) {
             // every job's grid: `chunks` runs of DSCB_RPB rows x its base-octave anchors rounded up to 8 (an anchor has at most fan rows;
             // the workgroups of runs an anchor does not have return at once)
-            const int chunks = (max_fan + DSCB_RPB - 1) / DSCB_RPB;
+            static const int chunks_probe = getenv("MAD_BALL_CHUNKS") ? atoi(getenv("MAD_BALL_CHUNKS")) : 0;      // timing probe only: anchors with more rows lose them
+            const int chunks = chunks_probe > 0 ? chunks_probe : (max_fan + DSCB_RPB - 1) / DSCB_RPB;
             int64_t at = 0;
             for (int q = 0; q < BB.n_jobs; q++) {
                 BB.first[q] = (int)at;

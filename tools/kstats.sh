@@ -9,6 +9,6 @@ python3 - "$f" <<'PY'
 import csv, sys
 for r in csv.DictReader(open(sys.argv[1])):
     n = r["Name"].split("(")[0].replace("void ", "")
-    if n.startswith("k_pose") or n.startswith("k_prune") or n.startswith("k_topk") or n.startswith("k_corr"):
+    if n.startswith(("k_pose", "k_prune", "k_topk", "k_corr", "k_describe", "k_orient", "k_pair", "k_zero", "k_copy")):
         print("%-28s calls %4s avg %7.1f us min %7.1f max %7.1f" % (n[:28], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3))
 PY
