@@ -193,7 +193,8 @@ struct mad_ctx {
     int mask_r = -1;
     int mask_n = 0;
     unsigned *ball_colinfo = nullptr;        // k_describe_ball: LDS offset and half-length of every (x, y) column of the base-octave sample ball (device)
-    bool dsc_ball = true;                    // base-octave rows described anchor by anchor from a ball of texels in LDS (MAD_NO_BALL / "dsc_ball": per row, as octave 0)
+    bool dsc_ball = false;                   // mad_set_option "dsc_ball" / MAD_BALL=1: base-octave rows described anchor by anchor from a ball of texels in LDS
+                                             // (k_describe_ball; measured slower than k_describe on C3 / C4 / C5: DESIGN.md section 6d -- off by default)
     // named grow-only scratch buffers
     DevBuf scratch[64 * MAD_LANES];   // MAD_LANES independent copies: matches in flight do not share scratch
     int lane = 0;                    // the copy the current call works in

@@ -2943,7 +2943,7 @@ extern "C" int mad_set_build_many(mad_ctx *ctx, int n_sets, mad_set *const *sets
         const int n = n_anchors[i];
         // (r = 8, the default patch: the only size k_describe_ball is built for)
         const int bdims[3] = {oj[i].f[1].nx, oj[i].f[1].ny, oj[i].f[1].nz};
-        const bool sort_ball = r == 8 && oj[i].f[1].tex4 != nullptr && ctx->spatial_order;
+        const bool sort_ball = ctx->dsc_ball && r == 8 && oj[i].f[1].tex4 != nullptr && ctx->spatial_order;
         MAD_TRY(set_upload_anchors(ctx, s, anc_coords[i], anc_octave[i], anc_subv[i], anc_index[i], n, 0, sort_ball ? bdims : nullptr));
         s->D = 64 * ctx->eq_host[1].Z;
         MAD_TRY(set_reserve_rows(ctx, s, (int64_t)n * lim_main * lim_sec));
@@ -2960,7 +2960,7 @@ extern "C" int mad_set_build_many(mad_ctx *ctx, int n_sets, mad_set *const *sets
         out.anc_order = ctx->spatial_order ? (const int32_t *)s->anc_order.p : nullptr;
         out.row_perm = ctx->spatial_order ? (int32_t *)s->row_perm.p : nullptr;
         out.row_rec = (DscRowRec *)s->row_rec.p;
-        out.anc_rows = out.anc_order ? (int32_t *)s->anc_rows.p : nullptr;
+        out.anc_rows = out.anc_order && sort_ball ? (int32_t *)s->anc_rows.p : nullptr;
         out.counters_zeroed = true;
         DescribeJob &Q = dj[i];
         Q.f[0] = J.f[0]; Q.f[1] = J.f[1];
@@ -3405,7 +3405,7 @@ extern "C" int mad_set_option(mad_ctx *ctx, const char *name, double value) {
         (name[0] == 'o' ? ctx->ori_queue_cap : ctx->dsc_queue_cap) = (int)value;
         return MAD_OK;
     }
-    if (!strcmp(name, "dsc_ball")) {      // 1 (default): the base-octave anchors through k_describe_ball; 0: every row through k_describe
+    if (!strcmp(name, "dsc_ball")) {      // 1: the base-octave anchors through k_describe_ball; 0 (default): every row through k_describe
         ctx->dsc_ball = value != 0;
         return MAD_OK;
     }

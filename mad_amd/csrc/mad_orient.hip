@@ -435,7 +435,8 @@ __device__ __forceinline__ void put_row_rec(const RowsArgs &A, int64_t pos, int 
     q.c[0] = A.coords[3 * a]; q.c[1] = A.coords[3 * a + 1]; q.c[2] = A.coords[3 * a + 2];
     q.octave = A.anc_octave ? A.anc_octave[a] : A.uniform_octave;
     for (int i = 0; i < 9; i++) q.inv[i] = inv[i];
-    // the float32 values k_describe's threads form for themselves, once per row (k_describe_ball takes them with scalar loads)
+    if (!A.anc_rows) return;      // (only k_describe_ball reads the rest)
+    // the float32 values k_describe's threads form for themselves, once per row
     for (int i = 0; i < 9; i++) q.hf[i] = (float)inv[i];
     for (int i = 0; i < 9; i++) q.rf[i] = i < 6 ? (float)R[i] : (float)R[i] * (1.0f / 511.0f);
     for (int i = 0; i < 3; i++) q.ru[i] = (float)R[6 + i];
@@ -1625,8 +1626,7 @@ int mad_describe_device_many(mad_ctx *ctx, int n_jobs, const DescribeJob *jobs, 
         return mad_fail(ctx, MAD_EINVAL, "mad_describe: %d descriptor zones: 16 for every layout, up to 128 (the 112-zone table) for the default 64 regions and dsc_radius 16", Zd);
     if (r < 2 || r > 8 || (r % 2)) return mad_fail(ctx, MAD_EINVAL, "mad_describe: dsc radius %d must be 2, 4, 6 or 8", r);
     const bool tab = Zd == 16 && ctx->eq_host[1].tab_ok && dsc_size == 64 && 2 * r == 16;
-    static const bool no_ball = getenv("MAD_NO_BALL") != nullptr;      // diagnostic switch: every row through k_describe, as in round 3
-    const bool ball_ok = tab && ctx->dsc_ball && !no_ball;
+    const bool ball_ok = tab && ctx->dsc_ball;      // (mad_set_option "dsc_ball", MAD_BALL=1: off by default)
     if (ball_ok) MAD_TRY(ensure_ball(ctx));
     for (int j0 = 0; j0 < n_jobs; j0 += MAD_BATCH_MAX) {
         Batch<DescribeArgs> B;

@@ -990,11 +990,12 @@ def test_full_queues_of_undecided_directions_change_nothing(lib, fields, ori_cap
 @pytest.mark.gpu
 @pytest.mark.parametrize("dsc_cap", [1 << 20, 3])
 def test_base_octave_rows_from_a_ball_in_lds_equal_rows_described_one_by_one(lib, dsc_cap):
-    """k_describe_ball (round 4): the base-octave anchors whose ball of samples lies inside the grid are described anchor by anchor
-    from 11 027 4-byte texels staged in LDS, the others (octave 0, anchors near the border) row by row by k_describe.  The set is
-    bit for bit the set k_describe alone makes (mad_set_option "dsc_ball" = 0), and its descriptors are the oracle's
-    (Descriptor.py:123-202) -- anchors with 1 .. 20+ rows (several runs of rows per anchor), border anchors, rejected anchors,
-    both octaves in one set, and the full-queue path (dsc_cap = 3: every row again with the exact arithmetic)."""
+    """k_describe_ball (round 4; mad_set_option "dsc_ball" = 1, off by default): the base-octave anchors whose ball of samples lies
+    inside the grid are described anchor by anchor from 11 027 4-byte texels staged in LDS, the others (octave 0, anchors near the
+    border) row by row by k_describe.  The set is bit for bit the set k_describe alone makes, and its descriptors are the oracle's
+    (Descriptor.py:123-202) -- anchors with 1 .. 20+ rows (several runs of rows per anchor), border anchors, rejected anchors, both
+    octaves in one set, rows turned about z only (every sample next to a nearest-voxel tie), and k_describe's full-queue path
+    beside it (dsc_cap = 3)."""
     shape1, shape0 = (64, 64, 60), (60, 64, 70)
     _, gx1, gy1, gz1 = _field(shape1, 31)
     _, gx0, gy0, gz0 = _field(shape0, 32)
@@ -1011,13 +1012,14 @@ def test_base_octave_rows_from_a_ball_in_lds_equal_rows_described_one_by_one(lib
     assert inside.sum() >= 20 and (~inside).sum() >= 10, "the anchors must exercise both kernels"
     try:
         lib.set_option("dsc_queue", dsc_cap)
+        lib.set_option("dsc_ball", 1)
         ball = lib.set_build(*job)
         have = ball.download()
         lib.set_option("dsc_ball", 0)
         rowwise = lib.set_build(*job)
         want = rowwise.download()
     finally:
-        lib.set_option("dsc_ball", 1)
+        lib.set_option("dsc_ball", 0)
         lib.set_option("dsc_queue", 1 << 20)
     assert ball.size() == rowwise.size() and ball.size()[0] > 200
     for key in ("anchor", "main", "sec", "R", "dsc"):
@@ -1030,15 +1032,15 @@ def test_base_octave_rows_from_a_ball_in_lds_equal_rows_described_one_by_one(lib
         ref = O.describe(gx, gy, gz, o, coords[have["anchor"][rows]], have["R"][rows], E16.sphere_eqsp)
         np.testing.assert_array_equal(have["dsc"][rows], ref, err_msg="octave %d" % o)
     # a set rebuilt in place with the same anchors (the unchanged-anchors path keeps the sorting), then with other anchors
-    lib.set_build(*job, into=ball)
-    np.testing.assert_array_equal(ball.download()["dsc"], want["dsc"])
     job2 = ([s0, s1], coords[::-1].copy(), octave[::-1].copy(), subv[::-1].copy(), np.arange(len(coords), dtype=np.int32))
-    lib.set_build(*job2, into=ball)
-    lib.set_option("dsc_ball", 0)
+    lib.set_option("dsc_ball", 1)
     try:
-        lib.set_build(*job2, into=rowwise)
+        lib.set_build(*job, into=ball)
+        np.testing.assert_array_equal(ball.download()["dsc"], want["dsc"])
+        lib.set_build(*job2, into=ball)
     finally:
-        lib.set_option("dsc_ball", 1)
+        lib.set_option("dsc_ball", 0)
+    lib.set_build(*job2, into=rowwise)
     np.testing.assert_array_equal(ball.download()["dsc"], rowwise.download()["dsc"])
     ball.close()
     rowwise.close()
