@@ -265,6 +265,7 @@ struct GemmJob {
 struct GemmBatch {
     int n_jobs;
     int K;
+    int split_tail;                // the tiles of a last, short round as 128 x 128 halves (MAD_GEMM_NO_SPLIT: whole tiles, as in round 3)
     double cc;
     GemmJob job[MAD_BATCH_MAX];
 };
@@ -297,6 +298,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_corr_gemm2(GemmBatch G) {
     G2_STAMP(0);
     const int ld_row = lane >> 2, ld_chunk = ((lane & 3) ^ ((lane >> 4) & 3)) * 16;
     const int rd_off = (lane & 15) * 64 + ((((lane >> 4) ^ ((lane & 15) >> 2)) & 3) * 16);
+    const bool g2_split = G.split_tail != 0;
     for (int j = 0; j < G.n_jobs; j++) {
         const GemmJob &J = G.job[j];
         const int64_t hp = ((int64_t)*J.n_hi + 127) / 128 * 128, lp = ((int64_t)*J.n_lo + 127) / 128 * 128;
@@ -310,9 +312,10 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_corr_gemm2(GemmBatch G) {
         const int64_t begin = per_xcd * xcd, end = begin + per_xcd < tiles ? begin + per_xcd : tiles;
         const int64_t cnt = end > begin ? end - begin : 0;
         const int64_t ldm = lp / 32;
-        for (; t < base + cnt; t += nslot) {
-            const int64_t tile = begin + (t - base);
-            const int64_t row0 = (tile % tiles_m) * G2_BM, col0 = (tile / tiles_m) * G2_BN;
+        // One tile of MT x 16 rows per wave-row (MT = 8: the 256 x 128 tile; MT = 4: its upper or lower half, 128 x 128, a wave owning
+        // 64 x 64) -- the same stages, fragment layout and epilogue.
+        auto run_tile = [&](auto mt_tag, const int64_t row0, const int64_t col0) {
+            constexpr int MT = decltype(mt_tag)::value, NA = MT / 2;      // NA: 16-row blocks of A a wave stages per K stage
             G2_STAMP(1);
             // |h| per row, cc |l| per column (zero rows count as norm 1, MaD.py:416).  Plain loads, before any LDS-DMA is in
             // flight: the compiler drains the vector-memory counter completely at their first use.
@@ -325,60 +328,63 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_corr_gemm2(GemmBatch G) {
                     sT[G2_BM + tid] = (float)(G.cc * (u > 0 ? u : 1.0));
                 }
             }
-            // this lane's source rows: blocks w, w + 4, w + 8, w + 12 of A (rows past the last 128-row block of a set with an
+            // this lane's source rows: blocks w, w + 4, ... of A (rows past the last 128-row block of a set with an
             // odd number of them are read from its last row and never stored), blocks w, w + 4 of B
-            const int8_t *src[6];
+            const int8_t *src[NA + 2];
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
+            for (int i = 0; i < NA; i++) {
                 const int64_t r = row0 + (w + 4 * i) * 16 + ld_row;
                 src[i] = J.A + (r < hp ? r : hp - 1) * K + ld_chunk;
             }
 #pragma unroll
-            for (int i = 0; i < 2; i++) src[4 + i] = J.B + (col0 + (w + 4 * i) * 16 + ld_row) * K + ld_chunk;
+            for (int i = 0; i < 2; i++) src[NA + i] = J.B + (col0 + (w + 4 * i) * 16 + ld_row) * K + ld_chunk;
             auto issue = [&](int s) {
                 int8_t *slot = g2_smem + (s % G2_NSTAGE) * G2_STAGE;
                 const int k0 = s * G2_BK;
 #pragma unroll
-                for (int i = 0; i < 4; i++) glds16(src[i] + k0, slot + (w + 4 * i) * 1024);
+                for (int i = 0; i < NA; i++) glds16(src[i] + k0, slot + (w + 4 * i) * 1024);
 #pragma unroll
-                for (int i = 0; i < 2; i++) glds16(src[4 + i] + k0, slot + (16 + w + 4 * i) * 1024);
+                for (int i = 0; i < 2; i++) glds16(src[NA + i] + k0, slot + (16 + w + 4 * i) * 1024);
             };
-            v4i acc[8][4];
+            v4i acc[MT][4];
 #pragma unroll
-            for (int m = 0; m < 8; m++)
+            for (int m = 0; m < MT; m++)
 #pragma unroll
                 for (int n = 0; n < 4; n++) acc[m][n] = (v4i){0, 0, 0, 0};
             G2_STAMP(2);
             issue(0);
             if (n_k > 1) issue(1);
-            // One stage: wait for its bytes, barrier, the twelve fragment reads up front (48 registers), then the 32 MFMAs with the
-            // six LDS-DMA pieces of stage s + 2 spread between them.  The order is pinned with sched_group_barrier: left alone the
-            // compiler keeps two A fragments live, waits for lgkmcnt(0) five times a stage, and issues the six pieces in a burst
+            // One stage: wait for its bytes, barrier, the fragment reads up front, then the MFMAs with the LDS-DMA pieces of stage
+            // s + 2 spread between them.  The order is pinned with sched_group_barrier: left alone the
+            // compiler keeps two A fragments live, waits for lgkmcnt(0) five times a stage, and issues the pieces in a burst
             // right behind the barrier, next to the reads, where a piece costs most to issue (1 640 clocks per stage for the two
             // workgroups of a CU against 1 024 of MFMA issue, in-kernel stamps).
             auto stage = [&](int s, auto more) {
-                if (decltype(more)::value || s + 1 < n_k) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                if (decltype(more)::value || s + 1 < n_k) {      // the pieces of the stage after this one may still be in flight
+                    if (MT == 8) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");      // NA + 2 pieces per stage and wave
+                    else if (MT == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+                } else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();      // stage s has landed for everybody; everybody has read stage s - 1, whose slot is filled next
                 const int8_t *slot = g2_smem + (s % G2_NSTAGE) * G2_STAGE;
-                v4i fa[8], fb[4];
+                v4i fa[MT], fb[4];
 #pragma unroll
                 for (int n = 0; n < 4; n++) fb[n] = *(const v4i *)(slot + (16 + wn * 4 + n) * 1024 + rd_off);
 #pragma unroll
-                for (int m = 0; m < 8; m++) fa[m] = *(const v4i *)(slot + (wm * 8 + m) * 1024 + rd_off);
+                for (int m = 0; m < MT; m++) fa[m] = *(const v4i *)(slot + (wm * MT + m) * 1024 + rd_off);
                 if (decltype(more)::value) issue(s + 2);
 #pragma unroll
-                for (int m = 0; m < 8; m++)
+                for (int m = 0; m < MT; m++)
 #pragma unroll
                     for (int n = 0; n < 4; n++)
                         acc[m][n] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[m], fb[n], acc[m][n], 0, 0, 0);
                 // the B fragments and the first two of A, then per A fragment: its four MFMAs, the read of the fragment after next, a piece
                 __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
 #pragma unroll
-                for (int m = 0; m < 8; m++) {
+                for (int m = 0; m < MT; m++) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                   // MFMA
-                    if (m + 2 < 8) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                    // DS read
-                    if (decltype(more)::value && m < 6) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // one LDS-DMA piece (VMEM read)
+                    if (m + 2 < MT) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                   // DS read
+                    if (decltype(more)::value && m < NA + 2) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // one LDS-DMA piece (VMEM read); a quarter tile's third piece falls where it may
                 }
             };
             for (int s = 0; s + 2 < n_k; s++) {
@@ -390,13 +396,13 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_corr_gemm2(GemmBatch G) {
             G2_STAMP(4);
             // Epilogue, as in k_corr_gemm: a candidate bit per entry (float32 test with a margin: a superset of the reference's
             // float64 test), the int32 dot product stored for candidates only, mask words assembled on the scalar unit.
-            if (row0 + wm * 128 < hp) {
+            if (row0 + wm * (MT * 16) < hp) {
                 int32_t *Ct = J.C + row0 * lp + col0;
                 uint32_t *Mt = J.mask + row0 * ldm + col0 / 32;
                 const unsigned lp32 = (unsigned)lp, ldm32 = (unsigned)ldm;
                 // byte offsets from the tile's (uniform) base, 32-bit: a tile spans 256 rows of at most 2^20 columns
-                const unsigned voff = ((unsigned)(wm * 128 + (lane >> 4) * 4) * lp32 + (unsigned)(wn * 64 + (lane & 15))) * 4u;
-                const unsigned moff = ((unsigned)(wm * 128 + (lane & 3) * 4) * ldm32 + (unsigned)(wn * 2 + (lane >> 2))) * 4u;      // lanes 0..7: row group, word
+                const unsigned voff = ((unsigned)(wm * (MT * 16) + (lane >> 4) * 4) * lp32 + (unsigned)(wn * 64 + (lane & 15))) * 4u;
+                const unsigned moff = ((unsigned)(wm * (MT * 16) + (lane & 3) * 4) * ldm32 + (unsigned)(wn * 2 + (lane >> 2))) * 4u;      // lanes 0..7: row group, word
                 float tl[4];
 #pragma unroll
                 for (int n = 0; n < 4; n++) {      // cc |l| moved towards "candidate" by the margin (|h| > 0, so the product moves with it)
@@ -404,10 +410,10 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_corr_gemm2(GemmBatch G) {
                     tl[n] = v - fabsf(v) * 4e-6f;
                 }
 #pragma unroll
-                for (int m = 0; m < 8; m++)
+                for (int m = 0; m < MT; m++)
 #pragma unroll
                     for (int jj = 0; jj < 4; jj++) {
-                        const float th = sT[wm * 128 + m * 16 + (lane >> 4) * 4 + jj];
+                        const float th = sT[wm * (MT * 16) + m * 16 + (lane >> 4) * 4 + jj];
                         unsigned long long bal[4];
                         // the row's offsets are formed here, on the scalar unit, and not hoisted: 64 precomputed addresses spill
                         unsigned rc = (unsigned)(m * 16 + jj) * lp32 * 4u, rm = (unsigned)(m * 16 + jj) * ldm32 * 4u;
@@ -439,8 +445,29 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_corr_gemm2(GemmBatch G) {
 #ifdef MAD_PROBE_STAMPS
             first_tile = false;
 #endif
+        };
+        // Whole rounds of the XCD's workgroups take whole tiles.  What is left over -- 7 tiles for 64 workgroups on a C3 match, a
+        // second round that costs a third of the launch (tools/probe_gemm_sizes.py: 512 tiles 26.5 us, 568 tiles 39.3 us) -- is dealt
+        // in halves of a tile (128 x 128) when that spreads it over more of the XCD's workgroups: twice as many, each on a CU of its
+        // own for half as long.  int32 sums are exact under any split.
+        const int64_t full = g2_split ? cnt / nslot * nslot : cnt, rem = cnt - full;
+        // (quarters -- a third instantiation of the tile -- were built and measured: 37.0 us per C3 launch against 36.1 with halves
+        // only, 39.8 without the split: the extra spills cost what the finer deal gains)
+        const int parts = rem > 0 && 2 * rem <= nslot ? 2 : 1;
+        const int64_t units = full + rem * parts;
+        for (; t < base + units; t += nslot) {
+            const int64_t u = t - base;
+            if (parts == 1 || u < full) {
+                const int64_t tile = begin + u;
+                run_tile(std::integral_constant<int, 8>(), (tile % tiles_m) * G2_BM, (tile / tiles_m) * G2_BN);
+            } else {
+                const int64_t h = u - full, tile = begin + full + h / parts;
+                const int64_t row0 = (tile % tiles_m) * G2_BM + (h % parts) * (G2_BM / parts), col0 = (tile / tiles_m) * G2_BN;
+                if (row0 >= hp) continue;      // (below a set's last, odd block of 128 rows: nothing)
+                run_tile(std::integral_constant<int, 4>(), row0, col0);
+            }
         }
-        base += cnt;
+        base += units;
     }
 }
 
@@ -2124,6 +2151,8 @@ static int correlate_gemm(mad_ctx *ctx, int n_jobs, const GemmJob *jobs, int D, 
         }
         GemmBatch G;
         G.n_jobs = std::min(n_jobs - j0, MAD_BATCH_MAX); G.K = D; G.cc = cc;
+        static const bool no_split = getenv("MAD_GEMM_NO_SPLIT") != nullptr;      // diagnostic switch: whole tiles only, as in round 3
+        G.split_tail = no_split ? 0 : 1;
         for (int j = 0; j < G.n_jobs; j++) G.job[j] = jobs[j0 + j];
         MAD_TRY(gemm2_launch(ctx, G));
     }
