@@ -130,6 +130,16 @@ class Structure(object):
         self.index = np.arange(len(anchors), dtype=np.int32)
         self.item = 0      # position of a subunit in the workload's list
 
+    def anchor_list(self, variant=0):
+        """The structure's anchors as mad_set_build takes them.  variant 1: the same anchors listed in reverse (FRESH): a set
+        rebuilt with the other list cannot take the library's unchanged-anchors shortcut, so the step pays for the whole upload."""
+        if variant == 0:
+            return self.slots, self.coords, self.octave, self.subv, self.index
+        rev = self.__dict__.get("_rev")
+        if rev is None:
+            rev = self._rev = tuple(np.ascontiguousarray(a[::-1]) for a in (self.coords, self.octave, self.subv, self.index))
+        return (self.slots,) + rev
+
     def base_gradient(self):
         """(3, X, Y, Z) float32 gradient of the base octave on the host, for the CPU baseline sample."""
         return self.gradient(1)
@@ -165,6 +175,7 @@ def build_inputs(lib, W, rank=0, world=1, items=None):
     mass_all = np.concatenate(placed_mass)
     t0 = time.time()
     the_map = Structure(lib, np.concatenate(placed), mass_all, W["res"], W["vs"], N=W["N"], tag="map", noise=W.get("noise", 0.0))
+    the_map.placed = placed      # the copies as they sit in the map: subunit s, copy c = placed[s * copies + c]
     sub_structs = []
     for s, a, m in subs:
         st = Structure(lib, a, m, W["res"], W["vs"])
@@ -182,6 +193,10 @@ HOST_T = {}
 
 _BATCHES = {}
 BATCHED = {"on": os.environ.get("MAD_BUILD_BATCH", "0") == "1", "asked": "MAD_BUILD_BATCH" in os.environ}
+# FRESH: every rebuild of a group of sets gets the OTHER listing of the same anchors (Structure.anchor_list), so that the library's
+# upload does its whole work in every timed step -- duplicate canonicalisation, Morton sort, 90 KB of staging per step -- instead of
+# recognising the lists of the previous step (set_upload_anchors' `same` branch).  Off: the lists repeat, as in rounds 1-3.
+FRESH = {"on": False, "uses": {}}
 
 
 def enqueue_builds(lib, the_map, subs, sets):
@@ -192,12 +207,16 @@ def enqueue_builds(lib, the_map, subs, sets):
     in one `mad_set_build_many` (one launch per stage: less device time, but one long dependency chain per step)."""
     t0 = time.perf_counter()
     shared = hasattr(sets[0], "enqueue")
+    var = 0
+    if FRESH["on"]:
+        var = FRESH["uses"].get(id(sets), 0) & 1
+        FRESH["uses"][id(sets)] = var + 1
     if not BATCHED["on"]:
         if shared:
             lo = sets[0].enqueue()
         else:
-            lo = lib.set_build(the_map.slots, the_map.coords, the_map.octave, the_map.subv, the_map.index, into=sets[0])
-        his = [lib.set_build(s.slots, s.coords, s.octave, s.subv, s.index, into=d) for s, d in zip(subs, sets[1:])]
+            lo = lib.set_build(*the_map.anchor_list(var), into=sets[0])
+        his = [lib.set_build(*s.anchor_list(var), into=d) for s, d in zip(subs, sets[1:])]
     else:
         ent = _BATCHES.get(id(sets))
         if ent is None or ent[1] is not sets:
@@ -439,6 +458,8 @@ def main():
                     "taken in, so that a kernel's average duration there is the one the roofline pass measures")
     ap.add_argument("--batched", action="store_true", help="one launch per stage for all structures of a step (mad_set_build_many) and one GEMM "
                     "grid for all its matches (mad_set_batching): less device time per step, longer dependency chains")
+    ap.add_argument("--repeat-anchors", action="store_true", help="feed every step the SAME anchor lists (rounds 1-3: the library then skips the "
+                    "upload work of a set rebuilt with unchanged anchors).  Default: two listings of the same anchors alternate, every step uploads")
     ap.add_argument("--emulate-rank-of", type=int, default=0, metavar="N", help="REHEARSAL on one GPU: do the per-step work of rank 0 of an N-rank "
                     "job (its share of the map build, the import of all N shares, its subunits); the other ranks' map rows are built once, untimed.  "
                     "The line is labelled as an estimate and is not a multi-GPU measurement")
@@ -548,6 +569,9 @@ def main():
         BATCHED["on"] = True
     set_groups = [[map_set()] + [_lib.DeviceSet(lib) for _ in subs] for _ in range(args.in_flight)]
     sets = set_groups[0]
+    # fresh anchor lists: one structure per set and per lane (the default on one GPU); the sharded map build and the batched launches
+    # keep their prepared jobs
+    FRESH["on"] = not args.repeat_anchors and not sharded and not BATCHED["on"]
     if args.serial:
         lib.set_overlap(False)
     if BATCHED["on"]:
@@ -580,6 +604,19 @@ def main():
             for k_, v in grp[0].host_s.items():
                 if k_ != "calls" and grp[0].host_s["calls"]:
                     host_overlapped["map_" + k_] = host_overlapped.get("map_" + k_, 0.0) + 1e3 * v / grp[0].host_s["calls"] / len(set_groups)
+
+    # The same steps with the anchor lists REPEATED (what rounds 1-3 timed): how much of a step is the upload of fresh lists.
+    ms_repeat = None
+    if FRESH["on"]:
+        FRESH["on"] = False
+        n_rep = max(args.steps // 2, 4)
+        run_steps(lib, the_map, subs, cc, dist_thr, k, set_groups, len(set_groups) + 1)      # every group once with the list it keeps
+        barrier()
+        t1 = time.perf_counter()
+        run_steps(lib, the_map, subs, cc, dist_thr, k, set_groups, n_rep)
+        barrier()
+        ms_repeat = 1e3 * (time.perf_counter() - t1) / n_rep
+        FRESH["on"] = True
 
     # One step at a time, lanes overlapped, nothing else in flight: what a caller who docks ONE batch waits for.
     lat = []
@@ -758,6 +795,9 @@ def main():
                              how="mad_probe_peaks, untimed, same process and device: a 1 GiB -> 1 GiB streaming copy kernel (read + write bytes) and "
                                  "v_mfma_i32_16x16x64_i8 from registers, 8 independent accumulators per wave, 4 waves per SIMD; spec figures from MI355X_MICROARCH.md")
         roof["largest_share_of_device_time"] = max(groups, key=lambda g: groups[g]["ms_total"])
+        if roof.get("traffic") and roof.get("avg_launch_ms"):      # what the kernel really moved (FETCH_SIZE + WRITE_SIZE of the profiled run) over the same duration
+            roof["achieved_from_counters"] = roof["traffic"] / (roof["avg_launch_ms"] * 1e-3) / 1e9
+            roof["frac_from_counters"] = roof["achieved_from_counters"] / HBM_PEAK_GBS
         roof["note"] = ("achieved = SURVEY 8(d)'s ALGORITHMIC 51 200 B per row (4 096 samples x 12 B gathered + 2 048 B written) over the launch time. "
                         "Since round 3 the kernel gathers 4-byte texels (a quantised unit direction; 16 KB per row) and fetches the 16-byte texel "
                         "only for the 3-4 % of samples its table classifier leaves open, so the bytes it really moves are about a third of the "
@@ -793,6 +833,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * t_max / args.steps,
             "latency_ms_single_step": 1e3 * float(lat_all.item()),
+            "ms_per_step_repeated_anchor_lists": ms_repeat,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "i8 (correlation, exact int32 accumulate) / f64 (binning, pose scoring)",
             "data": "synthetic",
@@ -810,6 +851,10 @@ def main():
                                                                        "inside a group of ranks (sharded_match: OR all-reduce of the cloud flags, all-gather + merge of the per-block top-k)"),
                        "correlations_per_step_by_rank": corr_by_rank,
                        "max_over_mean_rank_correlations": (max(corr_by_rank) / (sum(corr_by_rank) / len(corr_by_rank))) if sum(corr_by_rank) > 0 else None,
+                       "anchor_lists": ("fresh every step: two listings of each structure's anchors alternate, so every mad_set_build uploads, "
+                                        "canonicalises duplicates and Morton-sorts its list inside the timed region (host_ms_per_step_timed_region.build_enqueue); "
+                                        "ms_per_step_repeated_anchor_lists = the same steps with the lists repeated, as rounds 1-3 timed them") if FRESH["on"]
+                                       else "repeated: every step feeds the same lists, the library skips the upload of unchanged anchors",
                        "pipelining": "%d steps in flight: the builds (and, with 3, the matches) of the next step are enqueued before the results of a step are awaited; every step does the full work" % args.in_flight,
                        "launches": ("batched: one launch per stage for all structures of a step, one GEMM grid for all its matches" if BATCHED["on"]
                                     else "one mad_set_build per structure and one GEMM per match, each on its own lane (batched alternative: --batched)"),
@@ -821,8 +866,10 @@ def main():
                        "setup_s": t_setup,
                        "setup_detail_s": {k_: round(v, 4) for k_, v in SETUP_T.items()}},
             "roofline": roof,
-            "cpu_baseline": cpu,
-            "cpu_baseline_all_cores": cpu_all,
+            # cpu_baseline = the oracle on the SAME work as the timed step (every anchor of both octaves, all subunits) on the host cores of
+            # this box's share; the one-core figure is a bounded sample (the base-octave anchors: the full step takes minutes on one core)
+            "cpu_baseline": cpu_all if cpu_all is not None else cpu,
+            "cpu_baseline_one_core_sample": cpu if cpu_all is not None else None,
             "refine_ccc": refine_line,
             "one_gpu_same_workload": one_gpu,
         }

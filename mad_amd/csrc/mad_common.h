@@ -132,6 +132,7 @@ enum { MAD_T_ORIENT = 0, MAD_T_DESCRIBE, MAD_T_CORRELATE, MAD_T_PAIRS, MAD_T_POS
 #define MAD_T_RING 32
 #define MAD_LANES 8
 #define MAD_BRACKETS 3      // mad_match_topk_many_begin brackets that may be open at once (steps in flight - 1)
+#define MAD_RES (2 * MAD_LANES)      // matches of one bracket that may be in flight: two per lane, the second queued behind the first on the lane's stream
 
 struct TimerGroup {
     hipEvent_t start[MAD_T_RING];
@@ -200,12 +201,12 @@ struct mad_ctx {
     int lane = 0;                    // the copy the current call works in
     // two result slots per lane: one per open mad_match_topk_many bracket, so that a second batch of matches can be enqueued
     // (and deliver into its own pinned staging) before the first one has been collected
-    hipEvent_t lane_done[MAD_BRACKETS][MAD_LANES]; // recorded behind the last operation a bracket enqueued in each lane
+    hipEvent_t lane_done[MAD_BRACKETS][MAD_RES];   // recorded behind the last operation of a bracket's match (result index: lane, or MAD_LANES + lane for a lane's second match)
     hipEvent_t lane_pre[MAD_LANES];     // mad_match_topk_many: a lane is ready for the bracket's common GEMM
     hipEvent_t gemm_done[MAD_BRACKETS];            // ... and that GEMM has been enqueued (per open bracket)
-    void *host_res[MAD_BRACKETS][MAD_LANES] = {};   // pinned staging of a match's results / indices / status
-    size_t host_res_cap[MAD_BRACKETS][MAD_LANES] = {};
-    int res_slot = 0;                    // the slot the match calls below read and write
+    void *host_res[MAD_BRACKETS][MAD_RES] = {};     // pinned staging of a match's results / indices / status
+    size_t host_res_cap[MAD_BRACKETS][MAD_RES] = {};
+    int res_slot = 0, res_idx = 0;       // the (bracket, result index) the match calls below read and write
     // host pinned staging for small read-backs
     int64_t *pinned = nullptr;     // 1024 slots: [16 * lane ..] read-backs of the lane, [64..] two per mad_set
     int next_pinned = 64;

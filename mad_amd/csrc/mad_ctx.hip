@@ -87,7 +87,7 @@ extern "C" int mad_init(int device, mad_ctx **out) {
             (void)hipEventCreate(&ctx->timers[g].stop[i]);
         }
     for (int r = 0; r < MAD_BRACKETS; r++)
-        for (int l = 0; l < MAD_LANES; l++) (void)hipEventCreateWithFlags(&ctx->lane_done[r][l], hipEventDisableTiming);
+        for (int l = 0; l < MAD_RES; l++) (void)hipEventCreateWithFlags(&ctx->lane_done[r][l], hipEventDisableTiming);
     for (int l = 0; l < MAD_LANES; l++) (void)hipEventCreateWithFlags(&ctx->lane_pre[l], hipEventDisableTiming);
     for (int r = 0; r < MAD_BRACKETS; r++) (void)hipEventCreateWithFlags(&ctx->gemm_done[r], hipEventDisableTiming);
     *out = ctx;
@@ -115,13 +115,12 @@ extern "C" void mad_destroy(mad_ctx *ctx) {
             (void)hipEventDestroy(ctx->timers[g].stop[i]);
         }
     for (int r = 0; r < MAD_BRACKETS; r++) (void)hipEventDestroy(ctx->gemm_done[r]);
-    for (int l = 0; l < MAD_LANES; l++) {
-        (void)hipEventDestroy(ctx->lane_pre[l]);
+    for (int l = 0; l < MAD_LANES; l++) (void)hipEventDestroy(ctx->lane_pre[l]);
+    for (int l = 0; l < MAD_RES; l++)
         for (int r = 0; r < MAD_BRACKETS; r++) {
             (void)hipEventDestroy(ctx->lane_done[r][l]);
             if (ctx->host_res[r][l]) (void)hipHostFree(ctx->host_res[r][l]);
         }
-    }
     for (int l = 0; l < MAD_LANES; l++)
         if (ctx->lane_stream[l]) (void)hipStreamDestroy(ctx->lane_stream[l]);
     delete ctx;

@@ -3147,7 +3147,7 @@ static int match_enqueue_tail(mad_ctx *ctx, const mad_set *hi, const mad_set *lo
     const int64_t hint = ctx->lane_sel_hint[ctx->lane];
     const ResultArgs RA = {scratch<int32_t>(ctx, S_PAIR_HI), scratch<int32_t>(ctx, S_PAIR_LO), scratch<double>(ctx, S_PAIR_SCORE),
                            scratch<int32_t>(ctx, S_COUNTS), H.p, H.R, H.meta, L.p, L.Rinv, L.meta, H.row_anchor, L.row_anchor,
-                           (double *)ctx->host_res[ctx->res_slot][ctx->lane], P.k};
+                           (double *)ctx->host_res[ctx->res_slot][ctx->res_idx], P.k};
     if (pruned && !P.no_small && hint > 0 && hint <= TKS_CAP / 2 && P.k <= TKS_CAP) {
         mad_timer_begin(ctx, MAD_T_TOPK);
         static bool attr_t = false;
@@ -3168,7 +3168,7 @@ static int match_enqueue_tail(mad_ctx *ctx, const mad_set *hi, const mad_set *lo
     MAD_HIP(hipGetLastError());
     // rows, pair ranks and status words were written by the kernel straight into the pinned staging of this (bracket, lane): no copy
     // engine, no blit kernel; the host reads them once the event has passed
-    MAD_HIP(hipEventRecord(ctx->lane_done[ctx->res_slot][ctx->lane], ctx->stream));
+    MAD_HIP(hipEventRecord(ctx->lane_done[ctx->res_slot][ctx->res_idx], ctx->stream));
     return MAD_OK;
 }
 
@@ -3190,15 +3190,15 @@ static int match_prepare(mad_ctx *ctx, const mad_set *hi, const mad_set *lo, dou
     MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_HI_CLOUD), (size_t)hi->n_anchors * 24 + 24));
     MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_SEL_OUT), (size_t)(P->k + 8) * 8));
     MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_RESULTS), tail_bytes(P->k) + 64));
-    if (ctx->host_res_cap[ctx->res_slot][ctx->lane] < tail_bytes(P->k)) {
-        if (ctx->host_res[ctx->res_slot][ctx->lane]) {
+    if (ctx->host_res_cap[ctx->res_slot][ctx->res_idx] < tail_bytes(P->k)) {
+        if (ctx->host_res[ctx->res_slot][ctx->res_idx]) {
             MAD_HIP(hipStreamSynchronize(ctx->stream));
-            (void)hipHostFree(ctx->host_res[ctx->res_slot][ctx->lane]);
-            ctx->host_res[ctx->res_slot][ctx->lane] = nullptr;
+            (void)hipHostFree(ctx->host_res[ctx->res_slot][ctx->res_idx]);
+            ctx->host_res[ctx->res_slot][ctx->res_idx] = nullptr;
         }
         const size_t want = tail_bytes(P->k) * 2;
-        if (hipHostMalloc(&ctx->host_res[ctx->res_slot][ctx->lane], want) != hipSuccess) return mad_fail(ctx, MAD_ENOMEM, "pinned result staging of %zu bytes", want);
-        ctx->host_res_cap[ctx->res_slot][ctx->lane] = want;
+        if (hipHostMalloc(&ctx->host_res[ctx->res_slot][ctx->res_idx], want) != hipSuccess) return mad_fail(ctx, MAD_ENOMEM, "pinned result staging of %zu bytes", want);
+        ctx->host_res_cap[ctx->res_slot][ctx->res_idx] = want;
     }
     // capacity hints: the score matrix for ~8 rows per anchor, pairs for 2 % of the matrix; both grow on demand
     const int64_t full_c = (mad_ceil_div(hi->cap_rows, 128) * 128) * (mad_ceil_div(lo->cap_rows, 128) * 128);
@@ -3222,9 +3222,10 @@ static int match_prepare(mad_ctx *ctx, const mad_set *hi, const mad_set *lo, dou
 
 // read the status of the match that ran in `lane` (already complete).  Returns 1 when it has to be repeated with
 // larger capacities (updated in P), 0 when it is final (outputs filled), negative on error.
-static int match_finish(mad_ctx *ctx, int lane, const mad_set *hi, const mad_set *lo, MatchPlan *P, double *results,
+static int match_finish(mad_ctx *ctx, int ri, const mad_set *hi, const mad_set *lo, MatchPlan *P, double *results,
                         int64_t *pair_index, int64_t *n_out, int64_t *stats) {
-    const char *base = (const char *)ctx->host_res[ctx->res_slot][lane];
+    const int lane = ri % MAD_LANES;      // ri: the match's result index in its bracket (its lane, or MAD_LANES + lane for the lane's second match)
+    const char *base = (const char *)ctx->host_res[ctx->res_slot][ri];
     const int64_t *h_idx = (const int64_t *)(base + (size_t)P->k * MAD_RESULT_COLS * 8);
     const int32_t *hs = (const int32_t *)(h_idx + P->k);
     if (hs[ST_NHI + 3] || hs[ST_NLO + 3]) {
@@ -3287,6 +3288,7 @@ extern "C" int mad_match_topk(mad_ctx *ctx, const mad_set *hi, const mad_set *lo
     ctx->match.n_pairs = 0;
     if (match_trivial(hi, lo)) return MAD_OK;
     mad_use_lane(ctx, 0);
+    ctx->res_idx = 0;
     MatchPlan P;
     MAD_TRY(match_prepare(ctx, hi, lo, dist, k, &P));
     for (int attempt = 0; attempt < 5; attempt++) {
@@ -3310,26 +3312,28 @@ struct ManyState {
     int64_t k = 1;
     double *results = nullptr;
     int64_t *pair_index = nullptr, *n_out = nullptr, *stats = nullptr;
-    MatchPlan plans[MAD_LANES];
-    int pending[MAD_LANES];
+    MatchPlan plans[MAD_RES];      // by result index: ri = the match's lane, or MAD_LANES + lane for the second match of a lane
+    int pending[MAD_RES];
     int slot = 0;      // result slot (pinned staging + completion events) of this bracket
 };
 
-static int many_retire(mad_ctx *ctx, ManyState &M, int lane) {
-    const int i = M.pending[lane];
+static int many_retire(mad_ctx *ctx, ManyState &M, int ri) {
+    const int i = M.pending[ri];
     if (i < 0) return MAD_OK;
-    M.pending[lane] = -1;
+    const int lane = ri % MAD_LANES;
+    M.pending[ri] = -1;
     ctx->res_slot = M.slot;
-    MAD_HIP(hipEventSynchronize(ctx->lane_done[M.slot][lane]));
+    ctx->res_idx = ri;
+    MAD_HIP(hipEventSynchronize(ctx->lane_done[M.slot][ri]));
     double *res_i = M.results ? M.results + (size_t)i * M.k * MAD_RESULT_COLS : nullptr;
     int64_t *idx_i = M.pair_index ? M.pair_index + (size_t)i * M.k : nullptr;
     int64_t *st_i = M.stats ? M.stats + 4 * i : nullptr;
-    int rc = match_finish(ctx, lane, M.hi[i], M.lo, &M.plans[lane], res_i, idx_i, &M.n_out[i], st_i);
+    int rc = match_finish(ctx, ri, M.hi[i], M.lo, &M.plans[ri], res_i, idx_i, &M.n_out[i], st_i);
     for (int attempt = 0; rc == 1 && attempt < 5; attempt++) {      // rare: repeat this one synchronously
         mad_use_lane(ctx, lane);
-        MAD_TRY(match_enqueue(ctx, M.hi[i], M.lo, M.cc, M.dist, M.plans[lane]));
+        MAD_TRY(match_enqueue(ctx, M.hi[i], M.lo, M.cc, M.dist, M.plans[ri]));
         MAD_HIP(hipStreamSynchronize(ctx->stream));
-        rc = match_finish(ctx, lane, M.hi[i], M.lo, &M.plans[lane], res_i, idx_i, &M.n_out[i], st_i);
+        rc = match_finish(ctx, ri, M.hi[i], M.lo, &M.plans[ri], res_i, idx_i, &M.n_out[i], st_i);
     }
     if (rc == 1) return mad_fail(ctx, MAD_EHIP, "mad_match_topk_many: capacity negotiation did not converge");
     return rc;
@@ -3347,7 +3351,7 @@ extern "C" int mad_match_topk_many_begin(mad_ctx *ctx, int n, const mad_set *con
     ctx->res_slot = M.slot;
     M.n = n; M.hi.assign(hi, hi + n); M.lo = lo; M.cc = cc; M.dist = dist; M.k = k;
     M.results = results; M.pair_index = pair_index; M.n_out = n_out; M.stats = stats;
-    for (int l = 0; l < MAD_LANES; l++) M.pending[l] = -1;
+    for (int l = 0; l < MAD_RES; l++) M.pending[l] = -1;
     ctx->many[M.slot] = Mp;
     int rc_all = MAD_OK;
     // The first match of every lane goes out in a batch: each lane enqueues what precedes its GEMM, ONE grid then computes the
@@ -3369,6 +3373,7 @@ extern "C" int mad_match_topk_many_begin(mad_ctx *ctx, int n, const mad_set *con
         if (taken[lane] || hi[i]->D != hi[0]->D) continue;
         taken[lane] = true;
         mad_use_lane(ctx, lane);
+        ctx->res_idx = lane;
         rc_all = match_prepare(ctx, hi[i], lo, dist, k, &M.plans[lane]);
         if (rc_all != MAD_OK) break;
         GemmJob job;
@@ -3388,6 +3393,7 @@ extern "C" int mad_match_topk_many_begin(mad_ctx *ctx, int n, const mad_set *con
         for (size_t b = 0; b < batch.size() && rc_all == MAD_OK; b++) {
             const int i = batch[b], lane = hi[i]->lane;
             mad_use_lane(ctx, lane);
+            ctx->res_idx = lane;
             if (lane != g) MAD_HIP(hipStreamWaitEvent(ctx->stream, ctx->gemm_done[M.slot], 0));
             rc_all = match_enqueue_tail(ctx, hi[i], lo, cc, dist, M.plans[lane]);
             M.pending[lane] = i;
@@ -3397,17 +3403,31 @@ extern "C" int mad_match_topk_many_begin(mad_ctx *ctx, int n, const mad_set *con
         if (!hi[i] || match_trivial(hi[i], lo)) continue;
         if (std::find(batch.begin(), batch.end(), i) != batch.end()) continue;
         const int lane = hi[i]->lane;
-        rc_all = many_retire(ctx, M, lane);
-        if (rc_all != MAD_OK) break;
+        // A lane that already carries a match of this bracket takes a second one BEHIND it on its stream, with result staging of
+        // its own (more subunits than lanes -- C5: 12 -- used to make the host wait here for the first match's results); only a
+        // third match of one lane in one bracket waits for the first to be collected.
+        int ri = lane;
+        if (M.pending[ri] >= 0) ri = MAD_LANES + lane;
+        if (M.pending[ri] >= 0) {
+            ri = lane;
+            rc_all = many_retire(ctx, M, ri);
+            if (rc_all != MAD_OK) break;
+            if (M.pending[MAD_LANES + lane] >= 0) {      // (keep the lane's matches in order: the waiting one becomes its first)
+                rc_all = many_retire(ctx, M, MAD_LANES + lane);
+                if (rc_all != MAD_OK) break;
+            }
+        }
         mad_use_lane(ctx, lane);
-        rc_all = match_prepare(ctx, hi[i], lo, dist, k, &M.plans[lane]);
+        ctx->res_slot = M.slot;
+        ctx->res_idx = ri;
+        rc_all = match_prepare(ctx, hi[i], lo, dist, k, &M.plans[ri]);
         if (rc_all != MAD_OK) break;
-        rc_all = match_enqueue(ctx, hi[i], lo, cc, dist, M.plans[lane]);
-        M.pending[lane] = i;
+        rc_all = match_enqueue(ctx, hi[i], lo, cc, dist, M.plans[ri]);
+        M.pending[ri] = i;
     }
     mad_use_lane(ctx, ctx->match.lane);
     if (rc_all != MAD_OK) {      // leave nothing in flight behind a failed call
-        for (int l = 0; l < MAD_LANES; l++)
+        for (int l = 0; l < MAD_RES; l++)
             if (M.pending[l] >= 0) { (void)hipEventSynchronize(ctx->lane_done[M.slot][l]); M.pending[l] = -1; }
         const int slot = M.slot;
         delete Mp;
@@ -3415,6 +3435,7 @@ extern "C" int mad_match_topk_many_begin(mad_ctx *ctx, int n, const mad_set *con
         ctx->many_open--;      // the newest bracket: the ring just shrinks again
     }
     ctx->res_slot = 0;
+    ctx->res_idx = 0;
     return rc_all;
 }
 
@@ -3457,7 +3478,7 @@ extern "C" int mad_match_topk_many_finish(mad_ctx *ctx) {
     const int slot = ctx->many_oldest;      // the oldest of the open brackets
     ManyState *Mp = (ManyState *)ctx->many[slot];
     int rc_all = MAD_OK;
-    for (int l = 0; l < MAD_LANES; l++) {
+    for (int l = 0; l < MAD_RES; l++) {
         const int rc = many_retire(ctx, *Mp, l);
         if (rc_all == MAD_OK) rc_all = rc;
     }
@@ -3466,6 +3487,7 @@ extern "C" int mad_match_topk_many_finish(mad_ctx *ctx) {
     ctx->many_oldest = (slot + 1) % MAD_BRACKETS;
     ctx->many_open--;
     ctx->res_slot = 0;
+    ctx->res_idx = 0;
     mad_use_lane(ctx, ctx->match.lane);
     return rc_all;
 }

@@ -133,3 +133,74 @@ def test_run_mad_on_two_ranks_writes_what_one_rank_writes(tmp_path, monkeypatch,
     for n in names:
         with open(os.path.join(dirs[1], out, n)) as fa, open(os.path.join(dirs[0], out, n)) as fb:
             assert fa.read() == fb.read(), n
+
+
+def test_run_mad_on_the_frozen_c1_workload(tmp_path, monkeypatch, lib):
+    """BASELINE configs[0] as frozen in bench/configs/c1.json -- the 64^3 map at 2.0 A per voxel of two distinct subunits (seeds 1,
+    2), 10 A -- through the run_MaD.py flow (run_MaD.py:64-76): the map from a file, both subunits docked, each one's best solution
+    on its planted copy, build_assembly's best model = the planted dimer.  (run(ori_eqsp_size=16), the survey's "coarse eqsp", is
+    accepted and ignored exactly as the reference ignores it: MaD.py:87)"""
+    import bench
+    from mad_amd import _lib, mapio
+    from mad_amd.PDB import PDB
+    monkeypatch.setattr(_lib, "_default", lib)
+    lib._eq_loaded = {}
+    monkeypatch.chdir(tmp_path)
+    W = bench.WORKLOADS["c1"]
+    the_map, subs, _ = bench.build_inputs(lib, W, 0)
+    assert the_map.shape == (64, 64, 64) and len(subs) == 2
+    mapio.write_mrc("c1map.mrc", the_map.grid, the_map.origin, W["vs"])
+    for s, seed in enumerate(W["seeds"]):
+        coords, names, elems = synth.random_globule(W["n_atoms"], W["radius"], seed=seed)
+        np.testing.assert_array_equal(coords, subs[s].atoms)
+        synth.write_pdb("sub%d.pdb" % s, coords, names, elems)
+    truth = the_map.placed
+    for st_ in [the_map] + subs:
+        st_.ms.release_device()
+
+    from mad import MaD
+    mad = MaD.MaD()
+    mad.add_map("c1map.mrc", W["res"])
+    mad.add_subunit("sub0.pdb")
+    mad.add_subunit("sub1.pdb")
+    mad.run(ori_eqsp_size=16)
+    out = mad.out_folder
+    for s in range(2):
+        with open(os.path.join(out, "Solutions_refined_sub%d.csv" % s)) as fh:
+            rows = list(csv.DictReader(fh))
+        assert list(rows[0].keys()) == ["ID", "Repeatability", "Weight", "mCC", "RWmCC"] and len(rows) >= 1
+        sol = PDB(os.path.join(out, "individual_solutions", "sol_sub%d_%s.pdb" % (s, rows[0]["ID"])))
+        rmsd = float(np.sqrt(((sol.coords - truth[s]) ** 2).sum(1).mean()))
+        print("c1 subunit %d: %d solutions, best: repeatability %s, mCC %s, RMSD to the planted copy %.2f A" % (s, len(rows), rows[0]["Repeatability"], rows[0]["mCC"], rmsd))
+        assert rmsd < 4.0 and float(rows[0]["mCC"]) > 0.7      # a voxel is 2 A, the map 10 A
+    mad.build_assembly()
+    with open(os.path.join(out, "complex_ranking.csv")) as fh:
+        models = list(csv.DictReader(fh))
+    best = max(models, key=lambda r: float(r["CC"]))
+    print("c1 assembly: %d models, best CC %s" % (len(models), best["CC"]))
+    assert float(best["CC"]) > 0.8
+
+
+def test_bench_on_two_ranks_shares_the_map_build_and_gathers_the_topk(tmp_path):
+    """`python bench.py --gpus 2 --workload c4` as the driver starts it (the parent spawns its ranks with torch.distributed.run), here
+    with the collectives over gloo because the box has one GPU (MAD_DIST_BACKEND=gloo: both ranks share it).  The N > 1 path end to
+    end in fresh child processes: the map set assembled from the two ranks' shares is bit for bit the set one GPU builds
+    (ShardedSetBuild: export -> all-gather -> import), and every subunit's top-k after the exchange equals the one-GPU run's."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MAD_DIST_BACKEND="gloo", MAD_DIST_TIMEOUT_S="240", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "c4", "--steps", "4", "--warmup", "1", "--no-cpu-baseline"],
+                       cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-4000:])
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["subunits"] == 8 and d["config"]["subunits_this_rank"] == 4
+    assert d["config"]["sharded_map_set_identical_to_unsharded"] is True
+    assert d["one_gpu_same_workload"]["topk_identical_to_sharded_run"] is True
+    assert len(d["config"]["correlations_per_step_by_rank"]) == 2 and min(d["config"]["correlations_per_step_by_rank"]) > 0
+    assert d["value"] > 0 and d["ms_per_step"] > 0
