@@ -116,8 +116,8 @@ def _pad_rows(dsc, to=128):
 class BuildBatch(object):
     """The argument tables of one `mad_set_build_many` call (several structures, one launch per stage), kept alive between steps."""
 
-    def __init__(self, lib, jobs, r, lim_main, lim_sec):
-        self.lib, self.r, self.lim_main, self.lim_sec = lib, int(r), int(lim_main), int(lim_sec)
+    def __init__(self, lib, jobs, r, lim_main, lim_sec, gw_sig=0.0):
+        self.lib, self.r, self.lim_main, self.lim_sec, self.gw_sig = lib, int(r), int(lim_main), int(lim_sec), float(gw_sig)
         n = len(jobs)
         self.sets = [job[5] if len(job) > 5 and job[5] is not None else DeviceSet(lib) for job in jobs]
         self._keep = []
@@ -141,6 +141,7 @@ class BuildBatch(object):
         self._n = (C.c_int * max(n, 1))(*counts)
 
     def run(self):
+        self.lib.set_orient_window(self.gw_sig)      # the window is state of the context: every build states its own, as set_build does
         for s, n in zip(self.sets, self.counts):
             s.n_anchors = n
         self.lib._chk(self.lib.dll.mad_set_build_many(self.lib.ctx, C.c_int(len(self.sets)), self._h, self._slots, self._coords, self._octave,
@@ -362,7 +363,9 @@ class Lib(object):
         self._chk(self.dll.mad_set_eqsp(self.ctx, C.c_int(which), C.c_int(len(bounds)), _p(bounds), _p(to_dom), _p(adj_sec)))
 
     def set_orient_window(self, gw_sig=0.0):
-        """Orientator(gw_sig): Gaussian window on the orientation histogram for the following orient / set_build calls (0 = none)."""
+        """Orientator(gw_sig): Gaussian window on the orientation histogram (0 = none) for the following `orient` calls.  The window is
+        state of the context; `set_build`, `set_build_many` and `BuildBatch.run` set it themselves for every build (their `gw_sig`,
+        default 0), so what is set here does not reach them.  A change of window waits for the device (mad_synchronize)."""
         if getattr(self, "_gw_sig", 0.0) != float(gw_sig):
             self._chk(self.dll.mad_set_orient_window(self.ctx, C.c_double(float(gw_sig))))
             self._gw_sig = float(gw_sig)
@@ -485,15 +488,14 @@ class Lib(object):
                                          C.c_int(len(anc_octave)), C.c_int(r), C.c_int(lim_main), C.c_int(lim_sec)))
         return s
 
-    def prepare_build_many(self, jobs, r=8, lim_main=6, lim_sec=6):
+    def prepare_build_many(self, jobs, r=8, lim_main=6, lim_sec=6, gw_sig=0.0):
         """jobs: [(slots, anc_coords, anc_octave, anc_subv, anc_index, into-or-None), ...] -> a BuildBatch whose `run()` enqueues
         orientation + description of all of them with one launch per stage (`mad_set_build_many`) and returns the sets.
         Prepared once, run every step: the argument arrays are converted and pinned down here."""
-        return BuildBatch(self, jobs, r, lim_main, lim_sec)
+        return BuildBatch(self, jobs, r, lim_main, lim_sec, gw_sig)
 
     def set_build_many(self, jobs, r=8, lim_main=6, lim_sec=6, gw_sig=0.0):
-        self.set_orient_window(gw_sig)
-        return self.prepare_build_many(jobs, r, lim_main, lim_sec).run()
+        return self.prepare_build_many(jobs, r, lim_main, lim_sec, gw_sig).run()
 
     def set_load(self, row_anchor, row_main, row_R, dsc, anc_subv, anc_index, anc_octave):
         s = DeviceSet(self)

@@ -2847,38 +2847,79 @@ static int set_upload_anchors(mad_ctx *ctx, mad_set *s, const int32_t *anc_coord
         // sub-voxel position.  canon[i] = the first anchor with the coordinates of anchor i; the "takes part in a pair" flags
         // are raised on the canonical anchor only, so the cloud and its size l count such a position once.
         int32_t *canon = (int32_t *)(h + o_canon);
-        std::vector<int32_t> order(n);
-        for (int i = 0; i < n; i++) order[i] = i;
-        std::sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
-            const int c = memcmp(anc_subv + 3 * a, anc_subv + 3 * b, 24);
-            return c != 0 ? c < 0 : a < b;
-        });
-        for (int i = 0; i < n; i++)
-            canon[order[i]] = (i > 0 && memcmp(anc_subv + 3 * order[i], anc_subv + 3 * order[i - 1], 24) == 0) ? canon[order[i - 1]] : order[i];
+        // (the bytes of an anchor's three coordinates hashed to 40 bits and sorted with the anchor's number in the low 24: one sort of
+        // plain 64-bit words -- the lists arrive fresh every step, this runs on the host in front of every build -- and the bytes
+        // themselves compared only inside a run of equal hashes)
+        static thread_local std::vector<uint64_t> keys;
+        keys.resize((size_t)n);
+        const bool packable = n < (1 << 24);
+        if (packable) {
+            for (int i = 0; i < n; i++) {
+                uint64_t w[3];
+                memcpy(w, anc_subv + 3 * i, 24);
+                uint64_t x = w[0] * 0x9E3779B97F4A7C15ull;
+                x = (x ^ (x >> 29) ^ w[1]) * 0xBF58476D1CE4E5B9ull;
+                x = (x ^ (x >> 32) ^ w[2]) * 0x94D049BB133111EBull;
+                x ^= x >> 31;
+                keys[i] = (x & ~(uint64_t)0xffffff) | (uint64_t)i;
+            }
+            std::sort(keys.begin(), keys.end());
+            for (int i = 0; i < n;) {
+                int e = i + 1;
+                while (e < n && (keys[e] >> 24) == (keys[i] >> 24)) e++;
+                // anchors i .. e - 1 (ascending numbers) share a hash: each takes the first of them with its very bytes (nearly always: itself)
+                for (int a = i; a < e; a++) {
+                    const int ia = (int)(keys[a] & 0xffffff);
+                    int first = ia;
+                    for (int b = i; b < a; b++) {
+                        const int ib = (int)(keys[b] & 0xffffff);
+                        if (memcmp(anc_subv + 3 * ia, anc_subv + 3 * ib, 24) == 0) { first = canon[ib]; break; }
+                    }
+                    canon[ia] = first;
+                }
+                i = e;
+            }
+        } else {
+            std::vector<int32_t> order(n);
+            for (int i = 0; i < n; i++) order[i] = i;
+            std::sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
+                const int c = memcmp(anc_subv + 3 * a, anc_subv + 3 * b, 24);
+                return c != 0 ? c < 0 : a < b;
+            });
+            for (int i = 0; i < n; i++)
+                canon[order[i]] = (i > 0 && memcmp(anc_subv + 3 * order[i], anc_subv + 3 * order[i - 1], 24) == 0) ? canon[order[i - 1]] : order[i];
+        }
         // The order the build kernels work in: by octave (one texture each), then along a Morton curve through the voxel
         // coordinates.  The reference lists anchors by detector response; workgroups that run side by side then sample balls
         // all over a 1-2 GB texture.  In Morton order they sample overlapping balls and meet in the XCD's L2.
         int32_t *work = (int32_t *)(h + o_order);
         for (int i = 0; i < n; i++) work[i] = i;
         if (anc_coords) {
-            std::vector<uint64_t> key(n);
             auto spread = [](uint64_t v) {      // 21 bits -> every third bit
                 v &= 0x1fffff;
                 v = (v | v << 32) & 0x1f00000000ffffull; v = (v | v << 16) & 0x1f0000ff0000ffull; v = (v | v << 8) & 0x100f00f00f00f00full;
                 v = (v | v << 4) & 0x10c30c30c30c30c3ull; v = (v | v << 2) & 0x1249249249249249ull;
                 return v;
             };
+            bool small = packable;      // coordinates below 2^12 (after the octave's shift): class (2 bits) | Morton (36 bits) | number (24 bits) in one word
             for (int i = 0; i < n; i++) {
                 const int sh = anc_octave[i] == 0 ? 1 : 0;      // the same physical cell size in both octaves
                 const uint64_t x = (uint64_t)std::max(anc_coords[3 * i], 0) >> sh, y = (uint64_t)std::max(anc_coords[3 * i + 1], 0) >> sh,
                                z = (uint64_t)std::max(anc_coords[3 * i + 2], 0) >> sh;
-                // (bit 62: a base-octave anchor whose ball of samples lies inside the grid -- k_describe_ball's, behind all others)
+                // (bit 63: a base-octave anchor whose ball of samples lies inside the grid -- k_describe_ball's, behind all others)
                 const bool ball = bd[0] > 0 && anc_octave[i] == 1 &&
                                   mad_ball_interior(anc_coords[3 * i], anc_coords[3 * i + 1], anc_coords[3 * i + 2], bd[0], bd[1], bd[2]);
                 if (ball) s->n_rowwise--;
-                key[i] = ((uint64_t)ball << 63) | ((uint64_t)(anc_octave[i] != 0) << 62) | ((spread(x) << 2 | spread(y) << 1 | spread(z)) & ~(3ull << 62));
+                small = small && (x | y | z) < 4096;
+                keys[i] = ((uint64_t)ball << 63) | ((uint64_t)(anc_octave[i] != 0) << 62) | ((spread(x) << 2 | spread(y) << 1 | spread(z)) & ~(3ull << 62));
             }
-            std::sort(work, work + n, [&](int32_t a, int32_t b) { return key[a] != key[b] ? key[a] < key[b] : a < b; });
+            if (small) {      // equal keys (anchors in one cell) keep their list order, as below: the number is the low end of the word
+                for (int i = 0; i < n; i++) keys[i] = (keys[i] & (3ull << 62)) | ((keys[i] & ((1ull << 36) - 1)) << 24) | (uint64_t)i;
+                std::sort(keys.begin(), keys.end());
+                for (int i = 0; i < n; i++) work[i] = (int32_t)(keys[i] & 0xffffff);
+            } else {
+                std::sort(work, work + n, [&](int32_t a, int32_t b) { return keys[a] != keys[b] ? keys[a] < keys[b] : a < b; });
+            }
         }
     }
     // a kernel reads the pinned buffer directly: in stream order, without the copy engine's start-up latency

@@ -279,12 +279,31 @@ __global__ __launch_bounds__(ORI_THREADS, GW ? 4 : ORI_WPE) void k_orient(Batch<
         if (eqsp_tier2(&fast, (double)vx[v], (double)vy[v], (double)vz[v], true, [&](int zn) { tally(0, zn, v); })) return;
         for (unsigned zs = eqsp_trig_zones(trig, (double)vx[v], (double)vy[v], (double)vz[v], 1); zs; zs >>= 8) tally(0, (int)(zs & 255u) - 1, v);
     };
-    for (int v = tid; v < nvox; v += ORI_THREADS) {
-        const int zn = eqsp_fast32<true>(&fast, vx[v], vy[v], vz[v]);
-        if (zn >= 0) { tally(0, zn, v); continue; }
-        const int slot = atomicAdd(&s_nq, 1);
-        if (slot < A.queue_cap) queue[slot] = v;
-        else exact_first(v);      // queue full (only if nearly every direction sat on a bound): in place
+    // (the voxels of a thread classified side by side, in straight-line code: each classification is a chain of three dependent LDS
+    // reads, and five of them one after the other were 4 500 of an anchor's 45 600 cycles; the tallies follow)
+    for (int v0 = tid; v0 < nvox; v0 += ORI_TRIPS * ORI_THREADS) {
+        int zn[ORI_TRIPS];
+#pragma unroll
+        for (int k = 0; k < ORI_TRIPS; k++) {
+            const int v = min(v0 + k * ORI_THREADS, nvox - 1);
+            zn[k] = eqsp_fast32<true>(&fast, vx[v], vy[v], vz[v]);
+        }
+#pragma unroll
+        for (int k = 0; k < ORI_TRIPS; k++) {
+            const int v = v0 + k * ORI_THREADS;
+            if (v >= nvox) continue;
+            if (zn[k] >= 0) { tally(0, zn[k], v); continue; }
+            const int slot = atomicAdd(&s_nq, 1);
+            if (slot < A.queue_cap) queue[slot] = v;      // (a full queue: the whole pass again below)
+        }
+    }
+    __syncthreads();
+    if (s_nq > A.queue_cap) {
+        // more undecided directions than the queue holds (only if nearly every direction sat on a bound; mad_set_option "ori_queue"
+        // drives it): the whole first pass again with the reference's arithmetic (uniform over the workgroup)
+        for (int i = tid; i < MAD_MAX_Z; i += ORI_THREADS) hist[0][i] = 0;
+        __syncthreads();
+        for (int v = tid; v < nvox; v += ORI_THREADS) exact_first(v);
     }
     __syncthreads();
     ORI_STAMP(3);
@@ -292,7 +311,7 @@ __global__ __launch_bounds__(ORI_THREADS, GW ? 4 : ORI_WPE) void k_orient(Batch<
     // (the reference's float32 arithmetic), the quantisation, the main bins and their rotations -- four barrier-separated
     // phases before, a third of the anchor's time for a handful of lanes' work.
     if (tid < MAD_WAVE) {
-        const int nq = min(s_nq, A.queue_cap);
+        const int nq = s_nq > A.queue_cap ? 0 : s_nq;
         const int lane = lane_id();
         for (int qi = lane; qi < nq; qi += MAD_WAVE) exact_first(queue[qi]);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // the wave's own LDS atomics above before its reads below
@@ -326,29 +345,48 @@ __global__ __launch_bounds__(ORI_THREADS, GW ? 4 : ORI_WPE) void k_orient(Batch<
 
     // step03 for every main-bin candidate at once: rotate by to_dom (Orientator.py:303) and re-bin
     ORI_STAMP(6);
+    // (a voxel's candidates classified side by side, three at a time in straight-line code, so that their chains of dependent LDS
+    // reads overlap instead of following each other: this pass was 12 100 of an anchor's 45 600 cycles, two thirds of its
+    // instructions -- then the tallies.  A group's last candidates may repeat the anchor's last one: classified, not tallied)
+    constexpr int ORI_SIDE = 3;
     for (int v = tid; v < nvox; v += ORI_THREADS) {
         const float g0 = vx[v], g1 = vy[v], g2 = vz[v];
-        for (int c = 0; c < nmain; c++) {
-            if (main_list[c] == 0) continue;               // Orientator.py:211: the pole keeps the first binning
-            const float *d = s_domf[c];
-            const float rx = g0 * d[0] + g1 * d[1] + g2 * d[2];
-            const float ry = g0 * d[3] + g1 * d[4] + g2 * d[5];
-            const float rz = g0 * d[6] + g1 * d[7] + g2 * d[8];
-            const int zn = eqsp_fast32<true>(&fast, rx, ry, rz);
-            if (zn >= 0) { tally(1 + c, zn, v); continue; }
-            const int slot = atomicAdd(&s_nq, 1);
-            if (slot < A.queue_cap) { queue[slot] = v | (c << 16); continue; }
-            // queue full (only if nearly every direction sat on a bound): exact test in place
-            const double *dd = s_dom[c];
-            const double e0 = g0, e1 = g1, e2 = g2;
-            classify_exact64(&fast, trig, e0 * dd[0] + e1 * dd[1] + e2 * dd[2], e0 * dd[3] + e1 * dd[4] + e2 * dd[5],
-                             e0 * dd[6] + e1 * dd[7] + e2 * dd[8], [&](int z2) { tally(1 + c, z2, v); });
+        for (int c0 = 0; c0 < nmain; c0 += ORI_SIDE) {
+            int zn[ORI_SIDE];
+#pragma unroll
+            for (int u = 0; u < ORI_SIDE; u++) {
+                const float *d = s_domf[min(c0 + u, nmain - 1)];
+                const float rx = g0 * d[0] + g1 * d[1] + g2 * d[2];
+                const float ry = g0 * d[3] + g1 * d[4] + g2 * d[5];
+                const float rz = g0 * d[6] + g1 * d[7] + g2 * d[8];
+                zn[u] = eqsp_fast32<true>(&fast, rx, ry, rz);
+            }
+#pragma unroll
+            for (int u = 0; u < ORI_SIDE; u++) {
+                const int c = c0 + u;
+                if (c >= nmain || main_list[c] == 0) continue;      // Orientator.py:211: the pole keeps the first binning
+                if (zn[u] >= 0) { tally(1 + c, zn[u], v); continue; }
+                const int slot = atomicAdd(&s_nq, 1);
+                if (slot < A.queue_cap) queue[slot] = v | (c << 16);      // (a full queue: the whole pass again below)
+            }
         }
     }
     __syncthreads();
     ORI_STAMP(7);
-    {
-        const int nq = min(s_nq, A.queue_cap);      // ~0.1 % of nvox * nmain in practice
+    if (s_nq > A.queue_cap) {
+        // the queue overflowed (see the first pass): every candidate's histogram again, every direction with the exact arithmetic
+        for (int i = tid; i < nmain * MAD_MAX_Z; i += ORI_THREADS) (&hist[1][0])[i] = 0;
+        __syncthreads();
+        for (int e = tid; e < nvox * nmain; e += ORI_THREADS) {
+            const int v = e / nmain, c = e - v * nmain;
+            if (main_list[c] == 0) continue;
+            const double *d = s_dom[c];
+            const double g0 = vx[v], g1 = vy[v], g2 = vz[v];
+            classify_exact64(&fast, trig, g0 * d[0] + g1 * d[1] + g2 * d[2], g0 * d[3] + g1 * d[4] + g2 * d[5], g0 * d[6] + g1 * d[7] + g2 * d[8],
+                             [&](int zn) { tally(1 + c, zn, v); });
+        }
+    } else {
+        const int nq = s_nq;      // ~0.1 % of nvox * nmain in practice
         for (int qi = tid; qi < nq; qi += ORI_THREADS) {
             const int v = queue[qi] & 0xffff, c = queue[qi] >> 16;
             const double *d = s_dom[c];
