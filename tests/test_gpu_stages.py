@@ -1044,3 +1044,76 @@ def test_base_octave_rows_from_a_ball_in_lds_equal_rows_described_one_by_one(lib
     np.testing.assert_array_equal(ball.download()["dsc"], rowwise.download()["dsc"])
     ball.close()
     rowwise.close()
+
+
+@pytest.mark.gpu
+def test_partitioned_match_blocks_beside_an_open_bracket_equal_the_unsharded_topk(lib):
+    """dist.PartitionedMatch on the device (12 subunits on 8 ranks: BASELINE configs[4]): every rank opens its asynchronous bracket of
+    whole subunits (mad_match_topk_many_begin) and, with that bracket OPEN, runs its block of a leftover subunit through the
+    synchronous mad_match_shard_pairs / _topk on lane 0 of the same context -- the same scratch slots, pinned words and status
+    block a lane-0 match of the bracket uses.  All eight ranks of the plan are played in turn on this GPU, the group
+    collectives replaced by stand-ins that carry the REAL flags and per-block lists from rank to rank (three rounds: flags,
+    blocks, merge).  Every leftover subunit's merged rows must be the rows of mad_match_topk on the whole map set, and every whole
+    subunit's rows must come out of the bracket untouched by the shard calls in between."""
+    from mad_amd import dist as mdist
+    from mad_amd.eqsp import EQSP_Sphere
+    from mad_amd.orient_tables import orientation_matrices
+    e112, e16 = EQSP_Sphere(112), EQSP_Sphere(16)
+    dom, adj = orientation_matrices(e112)
+    lib.set_eqsp(0, e112.sphere_eqsp, dom, adj)
+    lib.set_eqsp(1, e16.sphere_eqsp)
+    shape = (56, 60, 64)
+    slot = lib.new_slot()
+    lib.upload_field(slot, synth.gradient_field(synth.blob_volume(shape, n_blobs=60, seed=9, sigma=(1.5, 3.5))))
+    rng = np.random.default_rng(5)
+
+    def a_set(n, seed):
+        coords = synth.interior_anchors(shape, n, 12, seed)
+        return lib.set_build([-1, slot], coords, np.ones(n, np.int32), coords.astype(np.float64) * 1.5 + rng.normal(scale=0.2, size=(n, 3)), np.arange(n))
+
+    n_items, world, cc, dist_, k = 12, 8, 0.45, 4.0, 30
+    lo = a_set(150, 250)
+    his = [a_set(40 + 5 * (i % 4), 300 + i) for i in range(n_items)]      # lanes 0..7 hold the first eight, lanes 0..3 the leftover four as well
+    want = []
+    for hi in his:
+        top, idx, st = lib.match_topk(hi, lo, cc, dist_, k)
+        assert st["n_pairs"] > 50
+        want.append(top)
+    units, groups = mdist.plan_partition(n_items, world)
+    assert [len(g) for g in groups] == [2, 2, 2, 2] and all(len(u) == 2 for u in units)
+    flags, blocks = {}, {}      # what the group collectives would carry: per leftover item, per part
+
+    def play(rank, stage):
+        """One rank's step; stage 0 records its flags, 1 its block's list (under the group's true flags), 2 merges the group's lists."""
+        pm = mdist.PartitionedMatch(n_items, rank, world)
+        item, part = pm.blocks[0][1], pm.blocks[0][2]
+
+        def reduce_flags(f):
+            f = np.asarray(f, dtype=np.uint8).copy()
+            if stage == 0:
+                flags.setdefault(item, {})[part] = f
+                return f
+            return np.bitwise_or.reduce(np.stack([flags[item][p] for p in sorted(flags[item])]), axis=0)
+
+        def gather(parts):
+            if stage == 1:
+                blocks.setdefault(item, {})[part] = [np.array(x, copy=True) for x in parts]
+            if stage < 2:
+                return [parts]
+            return [blocks[item][p] for p in sorted(blocks[item])]
+
+        pm.stand_ins = (reduce_flags, gather)
+        mine = [his[i] for i in pm.items]
+        state = pm.begin(lib, mine, lo, cc, dist_, k)      # bracket open while the shard calls run
+        corr, tops, stats = pm.finish(lib, state)
+        return pm, tops
+
+    for stage in (0, 1, 2):
+        for rank in range(world):
+            pm, tops = play(rank, stage)
+            np.testing.assert_array_equal(tops[0], want[pm.items[0]], err_msg="whole subunit %d of rank %d, round %d" % (pm.items[0], rank, stage))
+            if stage == 2 and mdist.owner_of(pm.blocks[0][1], world) == rank:      # the rank that reports the leftover subunit
+                np.testing.assert_array_equal(tops[1], want[pm.blocks[0][1]], err_msg="leftover subunit %d merged on rank %d" % (pm.blocks[0][1], rank))
+    assert sorted(blocks) == [8, 9, 10, 11] and all(sorted(b) == [0, 1] for b in blocks.values())
+    for s in his + [lo]:
+        s.close()
