@@ -100,141 +100,8 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ unsigned s_pack_ll(unsigned a, unsigned b) { unsigned r; asm("s_pack_ll_b32_b16 %0, %1, %2" : "=s"(r) : "s"(a), "s"(b)); return r; }
 __device__ __forceinline__ unsigned s_pack_hh(unsigned a, unsigned b) { unsigned r; asm("s_pack_hh_b32_b16 %0, %1, %2" : "=s"(r) : "s"(a), "s"(b)); return r; }
 
-// persistent over 128 x 128 tiles; the row counts (hence the tile grid and ldc) are read on the device
-//
-// Epilogue: besides the int32 dot products, every tile leaves one bit per correlation in `mask` ([row][ldc / 32]
-// words): set when the score MAY exceed cc.  The test is a float32 product with a relative margin of 4e-6
-// (dot > cc |h| |l| (1 - margin)), i.e. a superset of the reference's float64 `dot / (|h| |l|) > cc`; the pair
-// kernels apply the exact expression to the flagged entries only (~0.1 % of the matrix) instead of dividing
-// and comparing N_hi x N_lo times, and never read the rest of C.
-__global__ __launch_bounds__(GEMM_THREADS) void k_corr_gemm(const int8_t *__restrict__ A, const int8_t *__restrict__ B,
-                                                            int K, int32_t *__restrict__ C, const int32_t *__restrict__ n_hi_ptr,
-                                                            const int32_t *__restrict__ n_lo_ptr, int64_t cap_c,
-                                                            int32_t *__restrict__ status, const double *__restrict__ hn,
-                                                            const double *__restrict__ ln, double cc, uint32_t *__restrict__ mask) {
-    __shared__ __align__(16) int8_t sA[GEMM_BM * GEMM_LDA];
-    __shared__ __align__(16) int8_t sB[GEMM_BN * GEMM_LDA];
-    __shared__ float sT[GEMM_BM + GEMM_BN];
-    const int64_t hp = ((int64_t)*n_hi_ptr + GEMM_BM - 1) / GEMM_BM * GEMM_BM;
-    const int64_t lp = ((int64_t)*n_lo_ptr + GEMM_BN - 1) / GEMM_BN * GEMM_BN;
-    if (hp * lp > cap_c) {
-        if (blockIdx.x == 0 && threadIdx.x == 0) status[ST_FLAG_C] = 1;
-        return;
-    }
-    const int64_t tiles_n = lp / GEMM_BN, tiles = (hp / GEMM_BM) * tiles_n;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, w = tid >> 6;
-    const int wm = w >> 1, wn = w & 1;
-    // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  XCD x takes a contiguous run
-    // of the tiles in column-major order, i.e. ~1/8 of the lo rows (1 MB on the C3 map) against all hi rows: both operands
-    // of its tiles then live in its L2 instead of every XCD streaming the whole lo set once per hi row block.
-    const int64_t tiles_m = hp / GEMM_BM, per_xcd = (tiles + 7) / 8;
-    const int xcd = blockIdx.x & 7;
-    const int64_t t_end = per_xcd * (xcd + 1) < tiles ? per_xcd * (xcd + 1) : tiles;
-    for (int64_t t = per_xcd * xcd + (blockIdx.x >> 3); t < t_end; t += gridDim.x >> 3) {
-        const int64_t row0 = (t % tiles_m) * GEMM_BM, col0 = (t / tiles_m) * GEMM_BN;
-        v4i acc[4][4];
-#pragma unroll
-        for (int m = 0; m < 4; m++)
-#pragma unroll
-            for (int n = 0; n < 4; n++) acc[m][n] = (v4i){0, 0, 0, 0};
-        // The norms the epilogue needs, fetched before the K loop and parked in LDS (|h| per row, cc |l| per column; zero
-        // rows count as norm 1, MaD.py:416): sixteen dependent round trips after the loop would cost more than the loop
-        // itself, and as registers they would halve the occupancy.
-        {
-            const double v = tid < GEMM_BM ? hn[row0 + tid] : ln[col0 + tid - GEMM_BM];
-            const double u = v > 0 ? v : 1.0;
-            sT[tid] = tid < GEMM_BM ? (float)u : (float)(cc * u);
-        }
-        // stage = 128 rows x 128 B of each operand: 1024 16-byte chunks per operand, 4 per thread.  The global loads of
-        // stage k + 1 are issued before the MFMAs of stage k, so their latency runs under the arithmetic.
-        v4i ra[4], rb[4];
-        auto fetch = [&](int k0) {
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const int c = tid + GEMM_THREADS * i;
-                const int r = c >> 3, q = c & 7;
-                ra[i] = *(const v4i *)(A + (row0 + r) * K + k0 + q * 16);
-                rb[i] = *(const v4i *)(B + (col0 + r) * K + k0 + q * 16);
-            }
-        };
-        fetch(0);
-        for (int k0 = 0; k0 < K; k0 += GEMM_BK) {
-            __syncthreads();      // previous stage fully consumed
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const int c = tid + GEMM_THREADS * i;
-                const int r = c >> 3, q = c & 7;
-                *(v4i *)(sA + r * GEMM_LDA + q * 16) = ra[i];
-                *(v4i *)(sB + r * GEMM_LDA + q * 16) = rb[i];
-            }
-            __syncthreads();
-            if (k0 + GEMM_BK < K) fetch(k0 + GEMM_BK);
-#pragma unroll
-            for (int kk = 0; kk < GEMM_BK / 64; kk++) {
-                v4i fa[4], fb[4];
-                const int koff = kk * 64 + (lane >> 4) * 16;
-#pragma unroll
-                for (int m = 0; m < 4; m++) fa[m] = *(const v4i *)(sA + (wm * 64 + m * 16 + (lane & 15)) * GEMM_LDA + koff);
-#pragma unroll
-                for (int n = 0; n < 4; n++) fb[n] = *(const v4i *)(sB + (wn * 64 + n * 16 + (lane & 15)) * GEMM_LDA + koff);
-#pragma unroll
-                for (int m = 0; m < 4; m++)
-#pragma unroll
-                    for (int n = 0; n < 4; n++)
-                        acc[m][n] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa[m], fb[n], acc[m][n], 0, 0, 0);
-            }
-        }
-        // C/D layout of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg
-        // Epilogue.  Per entry: int -> float, one product, one compare (the compare IS the ballot).  Everything else is per ballot
-        // and on the scalar unit: a candidate store only where a ballot is non-zero (23 % of them), and the eight mask words of a
-        // row group cut out of the four ballots with scalar shifts and handed to lanes 0..7 with v_writelane -- the earlier form,
-        // which indexed the ballots by lane, compiled into 224 v_cndmask per tile.  Offsets are 32-bit from a per-tile base.
-        const int64_t ldm = lp / 32;
-        int32_t *Ct = C + row0 * lp + col0;                                   // uniform
-        uint32_t *Mt = mask + row0 * ldm + col0 / 32;                         // uniform
-        const unsigned lp32 = (unsigned)lp, ldm32 = (unsigned)ldm;
-        const unsigned voff = mad_u24((unsigned)(wm * 64 + (lane >> 4) * 4), lp32, (unsigned)(wn * 64 + (lane & 15)));      // < 2^24: 128 rows x lp
-        const unsigned moff = mad_u24((unsigned)(wm * 64 + (lane & 3) * 4), ldm32, (unsigned)(wn * 2 + (lane >> 2)));        // lanes 0..7: row group, word
-        float tl[4];
-#pragma unroll
-        for (int n = 0; n < 4; n++) {      // cc |l| moved towards "candidate" by the margin (|h| > 0, so the product moves with it)
-            const float v = sT[GEMM_BM + wn * 64 + n * 16 + (lane & 15)];
-            tl[n] = v - fabsf(v) * 4e-6f;
-        }
-#pragma unroll
-        for (int m = 0; m < 4; m++)
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const float th = sT[wm * 64 + m * 16 + (lane >> 4) * 4 + j];
-                unsigned long long bal[4];
-#pragma unroll
-                for (int n = 0; n < 4; n++) {
-                    const int d = acc[m][n][j];
-                    const bool cand = (float)d > th * tl[n];
-                    bal[n] = __ballot(cand);
-                    if (bal[n] != 0ull) {      // wave-uniform: only candidates are ever read back (k_pair_count / k_pair_emit), ~0.4 % of the entries
-                        if (cand) Ct[voff + (unsigned)(m * 16 + j) * lp32 + (unsigned)(n * 16)] = d;
-                    }
-                }
-                // bits 16 g .. 16 g + 15 of a ballot = row group g (= lane >> 4), columns n * 16 ..: word (g, h) = columns 32 h .. 32 h + 31
-                // = the g-th 16-bit piece of ballot 2 h beside that of ballot 2 h + 1: one s_pack each
-                int w = 0;
-#define MAD_MASK_WORD(G, Hh) ((G) & 1 ? s_pack_hh((unsigned)(bal[2 * (Hh)] >> (32 * ((G) >> 1))), (unsigned)(bal[2 * (Hh) + 1] >> (32 * ((G) >> 1)))) \
-                                      : s_pack_ll((unsigned)(bal[2 * (Hh)] >> (32 * ((G) >> 1))), (unsigned)(bal[2 * (Hh) + 1] >> (32 * ((G) >> 1)))))
-#define MAD_WRITELANE(G, Hh, LANE) asm volatile("v_writelane_b32 %0, %1, " #LANE : "+v"(w) : "s"(MAD_MASK_WORD(G, Hh)))
-                MAD_WRITELANE(0, 0, 0); MAD_WRITELANE(1, 0, 1); MAD_WRITELANE(2, 0, 2); MAD_WRITELANE(3, 0, 3);
-                MAD_WRITELANE(0, 1, 4); MAD_WRITELANE(1, 1, 5); MAD_WRITELANE(2, 1, 6); MAD_WRITELANE(3, 1, 7);
-#undef MAD_WRITELANE
-#undef MAD_MASK_WORD
-                if (lane < 8) Mt[moff + (unsigned)(m * 16 + j) * ldm32] = (unsigned)w;
-            }
-        __syncthreads();
-    }
-}
-
 // ---------------------------------------------------------------------------
-// The same contraction, second form: 256 x 128 tiles (a wave owns 128 x 64: 12 fragment reads per 32 MFMAs instead of 8 per
+// The contraction of a11 (MaD.py:420) on the matrix cores: 256 x 128 tiles (a wave owns 128 x 64: 12 fragment reads per 32 MFMAs instead of 8 per
 // 16), operands staged global -> LDS by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write pass), three
 // stages of 64 bytes of K in a ring with ONE barrier per stage and the loads of two stages in flight across it, and the tiles of
 // SEVERAL matches (jobs) in one persistent grid: the matches of a step share the lo (map) rows, and the ~570 tiles of one
@@ -394,8 +261,11 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_corr_gemm2(GemmBatch G) {
             stage(n_k - 2, std::false_type());      // (K is a multiple of 128: at least two stages)
             stage(n_k - 1, std::false_type());
             G2_STAMP(4);
-            // Epilogue, as in k_corr_gemm: a candidate bit per entry (float32 test with a margin: a superset of the reference's
-            // float64 test), the int32 dot product stored for candidates only, mask words assembled on the scalar unit.
+            // Epilogue: besides the int32 dot products of the candidates, every tile leaves one bit per correlation in `mask`
+            // ([row][ldc / 32] words): set when the score MAY exceed cc.  The test is a float32 product with a relative margin of 4e-6
+            // (dot > cc |h| |l| (1 - margin)), i.e. a superset of the reference's float64 `dot / (|h| |l|) > cc` (MaD.py:423); the pair
+            // kernels apply the exact expression to the flagged entries only (~0.1 % of the matrix) instead of dividing and comparing
+            // N_hi x N_lo times, and never read the rest of C.  The mask words are assembled on the scalar unit.
             if (row0 + wm * (MT * 16) < hp) {
                 int32_t *Ct = J.C + row0 * lp + col0;
                 uint32_t *Mt = J.mask + row0 * ldm + col0 / 32;
@@ -512,52 +382,11 @@ __global__ __launch_bounds__(256) void k_pair_count(const int32_t *__restrict__ 
     }
 }
 
-__global__ __launch_bounds__(256) void k_pair_emit(const int32_t *__restrict__ C, const uint32_t *__restrict__ mask,
-                                                   const int32_t *__restrict__ n_hi_ptr, const int32_t *__restrict__ n_lo_ptr,
-                                                   const double *__restrict__ hn, const double *__restrict__ ln,
-                                                   const int32_t *__restrict__ row_off, int64_t cap_pairs,
-                                                   int32_t *__restrict__ pair_hi, int32_t *__restrict__ pair_lo,
-                                                   double *__restrict__ pair_score, const int32_t *__restrict__ hi_row_anchor,
-                                                   const int32_t *__restrict__ lo_row_anchor, const int32_t *__restrict__ hi_canon,
-                                                   const int32_t *__restrict__ lo_canon, uint8_t *__restrict__ used_hi,
-                                                   uint8_t *__restrict__ used_lo, int32_t *__restrict__ status) {
-    __shared__ int wt[5];
-    if (status[ST_FLAG_C]) return;
-    const int64_t n_hi = *n_hi_ptr, n_lo = *n_lo_ptr;
-    const int64_t ldc = (n_lo + GEMM_BN - 1) / GEMM_BN * GEMM_BN, ldm = ldc / 32;
-    if (row_off[n_hi] > cap_pairs) {
-        if (blockIdx.x == 0 && threadIdx.x == 0) status[ST_FLAG_PAIRS] = 1;
-        return;
-    }
-    for (int64_t i = blockIdx.x; i < n_hi; i += gridDim.x) {
-        const double nh = hn[i];
-        int64_t base = row_off[i];
-        if (row_off[i + 1] == base) continue;
-        for (int64_t w0 = 0; w0 < ldm; w0 += 256) {
-            const int64_t w = w0 + threadIdx.x;
-            unsigned m = w < ldm ? mask[i * ldm + w] : 0;
-            int tot;
-            int64_t o = base + block_excl_scan(__popc(m), wt, &tot);
-            while (m) {      // ascending columns: the row-major order of np.where (MaD.py:423)
-                const int b = __ffs(m) - 1;
-                m &= m - 1;
-                const int64_t j = w * 32 + b;
-                pair_hi[o] = (int32_t)i;
-                pair_lo[o] = (int32_t)j;
-                pair_score[o] = corr_score(C[i * ldc + j], nh, ln[j]);
-                if (used_lo) { const int a = lo_row_anchor ? lo_row_anchor[j] : (int)j; used_lo[lo_canon ? lo_canon[a] : a] = 1; }
-                o++;
-            }
-            base += tot;
-        }
-        if (threadIdx.x == 0 && used_hi) { const int a = hi_row_anchor ? hi_row_anchor[i] : (int)i; used_hi[hi_canon ? hi_canon[a] : a] = 1; }
-    }
-}
-
-// k_pair_emit with the scan inside (round 3: one launch fewer per match).  A workgroup takes the rows b, b + G, b + 2 G, ...; the
-// number of pairs before row b is a block reduction over row_cnt[0 .. b), and from one of its rows to the next it adds the G counts
-// in between -- a handful of cached loads per thread instead of a one-workgroup scan launch between count and emit.  Workgroup 0
-// also forms the total (status[ST_NPAIRS], the overflow flag).  Rows, order and scores are those of k_pair_emit.
+// Ordered compaction of the flagged entries into the pair list (np.where's row-major order, MaD.py:423), the prefix sum of the rows'
+// counts inside: a workgroup takes the rows b, b + G, b + 2 G, ...; the number of pairs before row b is a block reduction over
+// row_cnt[0 .. b), and from one of its rows to the next it adds the G counts in between -- a handful of cached loads per thread
+// instead of a one-workgroup scan launch between count and emit (rounds 1-2).  Workgroup 0 also forms the total
+// (status[ST_NPAIRS], the overflow flag).  It marks the anchors that take part in a pair (the clouds of MaD.py:427-428).
 // (Also tried: count + scan + emit as ONE launch, rows ticketed in order and the offsets by a decoupled look-back over 8-byte row
 // descriptors -- correct, and 75-85 us per match against 28 for the three launches: 2 200 workgroups that reach the look-back together
 // find no inclusive prefix nearby and poll each other's descriptors through the fabric.)
@@ -1606,12 +1435,22 @@ __global__ __launch_bounds__(PB_THREADS) void k_pose_bounds(const int32_t *__res
             else atomicAdd(&hist[i], lh[i]);
         }
     if (leave_t) {
-        // The workgroup that finishes last takes T_stop = the k_stop-th largest lower bound of phase 1 for phase 2.  Atomics only,
-        // no fence: a workgroup's adds have come back before its ticket goes out, the last one reads the bins with agent-scope
-        // loads.  (A __threadfence() here -- an agent-scope release -- writes the L2 back in every workgroup: +60 us per match.)
+        // The workgroup that finishes last takes T_stop = the k_stop-th largest lower bound of phase 1 for phase 2.
+        // What this hand-off relies on, and what it does not:
+        //  * ordering: every thread's adds above are RETURNING atomics (the value is back when the add has been performed at
+        //    the coherence point, the L2 of this agent), the barrier collects the workgroup's, and thread 0 then takes the ticket with
+        //    an acq_rel read-modify-write at agent scope -- a release for this workgroup's adds, an acquire for the last workgroup --
+        //    so the last one's loads of the bins (agent scope, below) see every workgroup's adds.  One ordered RMW per workgroup, no
+        //    __threadfence(): an agent-scope fence in every thread writes the L2 back in every workgroup, +60 us per match.
+        //  * and if a bin WERE read stale (a count too low), the threshold derived from it could only come out LOWER: T is the
+        //    k_stop-th largest lower bound, monotonic in every bin.  A lower T_stop abandons fewer pairs in phase 2 -- less pruning,
+        //    the same selection {U >= final T} and the same top-k ("score first, then abandon").  So the
+        //    result never depended on this ordering; the number of pairs selected, and with it the sizes of later launches, did.
+        //  * hist[nbins + 1] (T_stop) and hist[nbins + 2] (the ticket) lie inside the region the match's zero fill clears before
+        //    every attempt (zr_hist2: n_hi_anchors + 17 words; nbins = l_hi + 1 <= n_hi_anchors + 1), asserted on the host.
         asm volatile("" :: "v"(came_back));
         __syncthreads();
-        if (threadIdx.x == 0) t_sh[0] = atomicAdd(&hist[nbins + 2], 1) == (int)gridDim.x - 1;
+        if (threadIdx.x == 0) t_sh[0] = __hip_atomic_fetch_add(&hist[nbins + 2], 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
         __syncthreads();
         if (t_sh[0]) {      // (uniform)
             __syncthreads();
@@ -2140,15 +1979,8 @@ static int correlate_reserve(mad_ctx *ctx, const Side &hi, const Side &lo, int D
 }
 
 static int correlate_gemm(mad_ctx *ctx, int n_jobs, const GemmJob *jobs, int D, double cc) {
-    static const bool old_gemm = getenv("MAD_GEMM_V1") != nullptr;      // diagnostic switch: the 128 x 128 register-staged kernel
     mad_timer_begin(ctx, MAD_T_CORRELATE);
     for (int j0 = 0; j0 < n_jobs; j0 += MAD_BATCH_MAX) {
-        if (old_gemm) {
-            for (int j = j0; j < n_jobs && j < j0 + MAD_BATCH_MAX; j++)
-                hipLaunchKernelGGL(k_corr_gemm, dim3(ctx->n_cu * 4), dim3(GEMM_THREADS), 0, ctx->stream, jobs[j].A, jobs[j].B, D, jobs[j].C,
-                                   jobs[j].n_hi, jobs[j].n_lo, jobs[j].cap_c, jobs[j].status, jobs[j].hn, jobs[j].ln, cc, jobs[j].mask);
-            continue;
-        }
         GemmBatch G;
         G.n_jobs = std::min(n_jobs - j0, MAD_BATCH_MAX); G.K = D; G.cc = cc;
         static const bool no_split = getenv("MAD_GEMM_NO_SPLIT") != nullptr;      // diagnostic switch: whole tiles only, as in round 3
@@ -2165,25 +1997,11 @@ static int correlate_pairs(mad_ctx *ctx, const Side &hi, const Side &lo, double 
                            uint8_t *d_used_lo) {
     int32_t *C = scratch<int32_t>(ctx, S_CMAT);
     uint32_t *mask = scratch<uint32_t>(ctx, S_CMASK);
-    static const bool no_fuse = getenv("MAD_NO_FUSE") != nullptr;      // diagnostic switch: the launch-per-step form of round 2
-    if (!no_fuse) {
-        mad_timer_begin(ctx, MAD_T_PAIRS);
-        hipLaunchKernelGGL(k_pair_count, dim3(ctx->n_cu * 8), dim3(256), 0, ctx->stream, C, mask, hi.n_rows, lo.n_rows, hi.norm, lo.norm, cc,
-                           scratch<int32_t>(ctx, S_ROWCNT), d_status);
-        hipLaunchKernelGGL(k_pair_emit2, dim3(ctx->n_cu * 8), dim3(256), 0, ctx->stream, C, mask, hi.n_rows, lo.n_rows, hi.norm, lo.norm,
-                           scratch<int32_t>(ctx, S_ROWCNT), cap_pairs, scratch<int32_t>(ctx, S_PAIR_HI), scratch<int32_t>(ctx, S_PAIR_LO),
-                           scratch<double>(ctx, S_PAIR_SCORE), hi.row_anchor, lo.row_anchor, hi.anc_canon, lo.anc_canon, d_used_hi, d_used_lo,
-                           d_status);
-        mad_timer_end(ctx, MAD_T_PAIRS);
-        MAD_HIP(hipGetLastError());
-        return MAD_OK;
-    }
     mad_timer_begin(ctx, MAD_T_PAIRS);
     hipLaunchKernelGGL(k_pair_count, dim3(ctx->n_cu * 8), dim3(256), 0, ctx->stream, C, mask, hi.n_rows, lo.n_rows, hi.norm, lo.norm, cc,
                        scratch<int32_t>(ctx, S_ROWCNT), d_status);
-    mad_scan_small(ctx, scratch<int32_t>(ctx, S_ROWCNT), scratch<int32_t>(ctx, S_ROWOFF), hi.n_rows, d_status + ST_NPAIRS);
-    hipLaunchKernelGGL(k_pair_emit, dim3(ctx->n_cu * 8), dim3(256), 0, ctx->stream, C, mask, hi.n_rows, lo.n_rows, hi.norm, lo.norm,
-                       scratch<int32_t>(ctx, S_ROWOFF), cap_pairs, scratch<int32_t>(ctx, S_PAIR_HI), scratch<int32_t>(ctx, S_PAIR_LO),
+    hipLaunchKernelGGL(k_pair_emit2, dim3(ctx->n_cu * 8), dim3(256), 0, ctx->stream, C, mask, hi.n_rows, lo.n_rows, hi.norm, lo.norm,
+                       scratch<int32_t>(ctx, S_ROWCNT), cap_pairs, scratch<int32_t>(ctx, S_PAIR_HI), scratch<int32_t>(ctx, S_PAIR_LO),
                        scratch<double>(ctx, S_PAIR_SCORE), hi.row_anchor, lo.row_anchor, hi.anc_canon, lo.anc_canon, d_used_hi, d_used_lo,
                        d_status);
     mad_timer_end(ctx, MAD_T_PAIRS);
@@ -2376,8 +2194,7 @@ static int pose_device(mad_ctx *ctx, const Side &hi, const Side &lo, int32_t *d_
         for (int j = n_jobs; j < 4; j++) { J.B[j] = B; J.rad[j] = 0; J.plane[j] = 0; J.planes[j] = 2; J.bits[j] = nullptr; }
         MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_PG_PAIRS), (size_t)cap_pairs * sizeof(PosePair)));
         PosePair *d_rec = scratch<PosePair>(ctx, S_PG_PAIRS);
-        static const bool no_fuse = getenv("MAD_NO_FUSE") != nullptr;      // diagnostic switch: the launch-per-step form of round 2
-        if (fused && !no_fuse) {
+        if (fused) {
             PoseSetup S;
             S.pts = d_cloud; S.used = d_cloud_used; S.n = n_cloud; S.G = G;
             S.cell_start = scratch<int32_t>(ctx, S_PG_START); S.cell_start16 = d_start16; S.sorted = scratch<double>(ctx, S_PG_PTS);
@@ -2448,6 +2265,9 @@ static int pose_device(mad_ctx *ctx, const Side &hi, const Side &lo, int32_t *d_
     hipLaunchKernelGGL((k_pose_bounds<NBV, SPL>), dim3(ctx->n_cu), dim3(PB_THREADS), lds_b, ctx->stream, d_status, cap_pairs, d_rec, d_hi_cloud, B, \
                        d_bits, PC, d_bits_c, scratch<int32_t>(ctx, S_COUNTS), scratch<unsigned short>(ctx, S_TMP_C), hist2, nbins,              \
                        (const double *)scratch<double>(ctx, S_PAIR_SCORE), pb_phase, target_a, pb_stop)
+            // (T_stop and the ticket of phase 1, hist2[nbins + 1] and [nbins + 2], must lie inside the zero-filled region of the match)
+            static_assert(3 <= 17, "hist2 has l_hi_max + 17 words (zr_hist2): bins 0 .. l_hi_max, then T_stop and the ticket");
+            if (split && nbins + 3 > l_hi_max + 17) return mad_fail(ctx, MAD_EINVAL, "pose bounds: %d bins for %d hi anchors", nbins, l_hi_max);
             for (int pass = 0; pass < (split ? 2 : 1); pass++) {
                 const int pb_phase = split ? pass + 1 : 0;
                 const int64_t pb_stop = split ? prune_k : 0;      // phase 1 leaves T_stop for phase 2 (hist2[nbins + 1]; [nbins + 2]: its workgroups' tickets)
@@ -2472,7 +2292,7 @@ static int pose_device(mad_ctx *ctx, const Side &hi, const Side &lo, int32_t *d_
 #undef MAD_PB_LAUNCH
             // the selection: inside the exact search itself (k_pose_lds, own) when this lane's previous match has told how many pairs
             // to expect, else a launch of its own
-            if (fused && !no_fuse && fits64 && ctx->lane_sel_hint[ctx->lane] > 0) {
+            if (fused && fits64 && ctx->lane_sel_hint[ctx->lane] > 0) {
                 own.upper = scratch<unsigned short>(ctx, S_TMP_C); own.hist = hist2; own.nbins = nbins; own.k = prune_k;
                 own.sel_out = scratch<int32_t>(ctx, S_TMP_D); own.sel_cap = cap_pairs; own.status_w = d_status;
                 if (own_sel) *own_sel = true;

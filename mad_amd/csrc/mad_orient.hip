@@ -641,8 +641,7 @@ static int orient_batch(mad_ctx *ctx, int n_jobs, const OrientJob *jobs, int r, 
     int64_t a0 = 0, blk = 0;
     int max_n = 0;
     for (int j = 0; j < n_jobs; j++) max_n = std::max(max_n, jobs[j].n);
-    static const bool no_fuse = getenv("MAD_NO_FUSE") != nullptr;      // diagnostic switch: the launch-per-step form of round 2
-    const bool one_launch = !no_fuse && max_n <= ORI_ROWS_MAX_N && fan <= 1024;
+    const bool one_launch = max_n <= ORI_ROWS_MAX_N && fan <= 1024;      // (beyond: a scan of its own and the row expansion, two launches)
     for (int j = 0; j < n_jobs; j++) {
         const OrientJob &J = jobs[j];
         OrientArgs &A = B.job[j];

@@ -1117,3 +1117,35 @@ def test_partitioned_match_blocks_beside_an_open_bracket_equal_the_unsharded_top
     assert sorted(blocks) == [8, 9, 10, 11] and all(sorted(b) == [0, 1] for b in blocks.values())
     for s in his + [lo]:
         s.close()
+
+
+@pytest.mark.gpu
+def test_two_phase_bounds_pass_selects_the_same_pairs_run_after_run(lib, fields):
+    """k_pose_bounds in two launches (mad_set_option "pose_split" = 1): phase 2 abandons pairs against the threshold T_stop that the
+    LAST workgroup of phase 1 leaves behind (an acq_rel ticket at agent scope; mad_match.hip).  With the lanes overlapped -- other
+    matches running beside it, workgroups starting late -- the number of pairs that reach the exact search must be the same in every
+    run (it was not while phase 2 read the histogram its own workgroups were still adding to), and the top-k with it."""
+    f = fields[1]
+    rng = np.random.default_rng(3)
+    sets = []
+    for n, seed in ((160, 41), (70, 42), (64, 43), (58, 44)):
+        coords = synth.interior_anchors(f["shape"], n, 10, seed)
+        sets.append(lib.set_build([-1, f["slot"]], coords, np.ones(n, np.int32), coords * 1.5 + rng.normal(scale=0.2, size=(n, 3)), np.arange(n)))
+    lo, his = sets[0], sets[1:]
+    cc, dist_, k = 0.3, 4.0, 20
+    try:
+        lib.set_option("pose_split", 1)
+        lib.set_option("pose_split_min", 64)      # a first phase of a few pairs only: the second has something to abandon
+        seen = []
+        for it in range(20):
+            out = lib.match_topk_many(his, lo, cc, dist_, k)      # three matches side by side on their lanes
+            top, idx, st = lib.match_topk(his[0], lo, cc, dist_, k)
+            seen.append((int(lib.last_pose_selected()), st["n_pairs"], top.tobytes(), tuple(o[0].tobytes() for o in out)))
+            assert np.array_equal(out[0][0], top)
+        assert seen[0][1] > 500 and 0 < seen[0][0] < seen[0][1]
+        assert all(s == seen[0] for s in seen), sorted({s[0] for s in seen})
+    finally:
+        lib.set_option("pose_split", -1)
+        lib.set_option("pose_split_min", 4096)
+    for s in sets:
+        s.close()
