@@ -1710,6 +1710,7 @@ int mad_describe_device_many(mad_ctx *ctx, int n_jobs, const DescribeJob *jobs, 
         if (B.n_jobs == 0) continue;
         B.first[B.n_jobs] = (int)blk;
         const unsigned nblk = (unsigned)blk;
+        static const size_t dsc_pad = getenv("MAD_DSC_PAD_KB") ? (size_t)atoi(getenv("MAD_DSC_PAD_KB")) * 1024 : 0;      // probe: LDS a row's workgroup holds without using it (fewer rows per CU, room for other kernels' workgroups)
         mad_timer_begin(ctx, MAD_T_DESCRIBE);
         // the default layout takes the 4-byte texels and the table classifier when the descriptor table has them (MAD_NO_TAB: never)
         switch (dsc_size == 64 ? 2 * r : -dsc_size) {
@@ -1721,7 +1722,7 @@ int mad_describe_device_many(mad_ctx *ctx, int n_jobs, const DescribeJob *jobs, 
             case -1: hipLaunchKernelGGL((k_describe<16, 1>), dim3(nblk), dim3(DSC_THREADS), 0, ctx->stream, B); break;
             default:
                 if (Zd > 16) hipLaunchKernelGGL((k_describe<16, 64, 128>), dim3(nblk), dim3(DSC_THREADS), 0, ctx->stream, B);
-                else if (tab) hipLaunchKernelGGL((k_describe<16, 64, 16, true>), dim3(nblk), dim3(DSC_THREADS), 0, ctx->stream, B);
+                else if (tab) hipLaunchKernelGGL((k_describe<16, 64, 16, true>), dim3(nblk), dim3(DSC_THREADS), dsc_pad, ctx->stream, B);
                 else hipLaunchKernelGGL(k_describe<16>, dim3(nblk), dim3(DSC_THREADS), 0, ctx->stream, B);
                 break;
         }
