@@ -519,9 +519,9 @@ def main():
     n_ranks_part = emu if emu else world
     pm = None
     if n_ranks_part > 1 and W["n_sub"] % n_ranks_part != 0 and os.environ.get("MAD_NO_PARTITION", "0") != "1":
-        ident = (lambda f: np.asarray(f, dtype=np.uint8).copy(), lambda parts: [parts])      # a rehearsed rank has nobody to exchange with
+        # (a rehearsed rank has nobody to exchange with: "local" = the asynchronous path of a node without its collectives)
         pm = mdist.PartitionedMatch(W["n_sub"], 0 if emu else rank, n_ranks_part, make_group=None if emu else dist.new_group,
-                                    stand_ins=ident if emu else None)
+                                    stand_ins="local" if emu else None)
         PM["pm"] = pm
     the_map, subs, t_setup = build_inputs(lib, W, 0 if emu else rank, emu if emu else world, items=pm.items if pm else None)
     if world > 1:      # one anchor list for everybody: the shares of the map build are indices into it

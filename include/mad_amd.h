@@ -336,6 +336,31 @@ int mad_match_shard_topk(mad_ctx *ctx, const mad_set *hi, const mad_set *lo, con
                          const uint8_t *used_lo_all, double dist, int64_t k, double *results, int64_t *pair_rank,
                          int32_t *counts, int64_t *n_out, int64_t *l_hi);
 
+/*
+ * Stages B and C without a host round trip (MaD.py:420-451 for one block of map rows; the loop it shards is serial over subunits,
+ * MaD.py:165-190).  Everything is enqueued on the lane of `hi`; the flags and the shard's list live in DEVICE memory of the caller,
+ * who orders the two exchanges of SURVEY.md 8(e) -- the OR all-reduce of the flags, the all-gather of the lists -- on that lane's
+ * stream (mad_set_stream(hi)) between and behind the two calls.
+ *   mad_match_shard_begin: hi against the lo rows [lo_begin, lo_end) of a lo set ASSUMED to have n_lo rows (the caller cut the blocks
+ *     from that number; the device checks it).  d_flags: hi->n_anchors + lo->n_anchors bytes, hi's flags first.
+ *   mad_match_shard_score: the shard's pairs against the global clouds (d_flags_all: the OR over the shards, same layout); d_out:
+ *     mad_match_shard_record_doubles(k) float64 = [rows m, flags, |hi cloud|, pairs][k x 23 result rows][k counts][k pair ranks].
+ *     flags != 0 (1 score-matrix capacity, 2 pair capacity, 4 n_lo was wrong, 8 selection list): m = 0, repeat the shard through
+ *     mad_match_shard_pairs / mad_match_shard_topk.
+ */
+int64_t mad_match_shard_record_doubles(int64_t k);
+int mad_match_shard_begin(mad_ctx *ctx, const mad_set *hi, const mad_set *lo, int64_t lo_begin, int64_t lo_end, int64_t n_lo,
+                          double cc, uint8_t *d_flags);
+int mad_match_shard_score(mad_ctx *ctx, const mad_set *hi, const mad_set *lo, const uint8_t *d_flags_all, double dist, int64_t k,
+                          double *d_out);
+/*
+ * The records of a group's shards (n float64 in device memory: what the caller's all-gather left behind mad_match_shard_score) to
+ * the host: copied into pinned memory of the library on the lane of `hi`; *ticket names the copy.  mad_match_shard_wait blocks
+ * until it has arrived and copies it to `out` (host).  At most 8 copies of one lane may be pending.
+ */
+int mad_match_shard_collect(mad_ctx *ctx, const mad_set *hi, const double *d_all, int64_t n, int *ticket);
+int mad_match_shard_wait(mad_ctx *ctx, int ticket, double *out, int64_t n);
+
 /* ---- one structure's rows built in shares on several GPUs (stage A).  Orientation and description
  *      are independent per anchor (Orientator.py:80-108, Descriptor.py:106-116): anchor a of the structure's list goes
  *      to share a % n_shares (local position a / n_shares), every rank runs mad_set_build on its share, the shares

@@ -24,7 +24,7 @@ SYMBOLS = [
     "mad_set_orient_window", "mad_orient", "mad_describe", "mad_describe_sized", "mad_correlate", "mad_pose_score", "mad_topk",
     "mad_set_create", "mad_set_destroy", "mad_set_build", "mad_set_build_many", "mad_set_load", "mad_set_size", "mad_set_download",
     "mad_match_topk", "mad_match_topk_many", "mad_match_topk_many_begin", "mad_match_topk_many_finish", "mad_set_batching", "mad_set_option", "mad_last_pose_kernel", "mad_last_pose_selected", "mad_match_fetch", "mad_match_results", "mad_match_used",
-    "mad_match_shard_pairs", "mad_match_shard_topk",
+    "mad_match_shard_pairs", "mad_match_shard_topk", "mad_match_shard_begin", "mad_match_shard_score", "mad_match_shard_record_doubles", "mad_match_shard_collect", "mad_match_shard_wait",
     "mad_set_wire_bytes", "mad_set_export", "mad_set_import", "mad_set_lane", "mad_set_stream", "mad_set_bind_lane",
     "mad_upload_density", "mad_refine", "mad_structure_to_density", "mad_ccc", "mad_density_ccc", "mad_dock_refine_score", "mad_grid_overlap", "mad_overlap_matrix",
     "mad_space_create", "mad_space_destroy", "mad_space_build", "mad_space_info", "mad_space_download",
@@ -88,6 +88,8 @@ def load_library():
         _dll.mad_last_pose_selected.argtypes = [C.c_void_p]
         _dll.mad_set_wire_bytes.restype = C.c_int64
         _dll.mad_set_wire_bytes.argtypes = [C.c_int, C.c_int64]
+        _dll.mad_match_shard_record_doubles.restype = C.c_int64
+        _dll.mad_match_shard_record_doubles.argtypes = [C.c_int64]
         _dll.mad_destroy.restype = None
         _dll.mad_set_destroy.restype = None
         _dll.mad_space_destroy.restype = None
@@ -595,6 +597,30 @@ class Lib(object):
                                                 _p(cnt), C.byref(n), C.byref(l_hi)))
         m = n.value
         return res[:m].copy(), cnt[:m].copy(), rank[:m].copy(), l_hi.value
+
+    def match_shard_record_doubles(self, k):
+        return int(self.dll.mad_match_shard_record_doubles(C.c_int64(int(k))))
+
+    def match_shard_begin(self, hi, lo, lo_begin, lo_end, n_lo, cc, flags_ptr):
+        """Stage B, asynchronous on hi's lane: the shard's flags go to device memory at `flags_ptr` (hi.n_anchors + lo.n_anchors bytes)."""
+        self._chk(self.dll.mad_match_shard_begin(self.ctx, hi.h, lo.h, C.c_int64(int(lo_begin)), C.c_int64(int(lo_end)), C.c_int64(int(n_lo)),
+                                                 C.c_double(cc), C.c_void_p(int(flags_ptr))))
+
+    def match_shard_score(self, hi, lo, flags_all_ptr, dist, k, out_ptr):
+        """Stage C, asynchronous: the shard's record (match_shard_record_doubles(k) float64) goes to device memory at `out_ptr`."""
+        self._chk(self.dll.mad_match_shard_score(self.ctx, hi.h, lo.h, C.c_void_p(int(flags_all_ptr)), C.c_double(dist), C.c_int64(int(k)),
+                                                 C.c_void_p(int(out_ptr))))
+
+    def match_shard_collect(self, hi, all_ptr, n):
+        """The n float64 at device address `all_ptr` on their way to the host, behind everything enqueued on hi's lane -> ticket."""
+        t = C.c_int(0)
+        self._chk(self.dll.mad_match_shard_collect(self.ctx, hi.h, C.c_void_p(int(all_ptr)), C.c_int64(int(n)), C.byref(t)))
+        return t.value
+
+    def match_shard_wait(self, ticket, n):
+        out = np.zeros(int(n))
+        self._chk(self.dll.mad_match_shard_wait(self.ctx, C.c_int(int(ticket)), _p(out), C.c_int64(int(n))))
+        return out
 
     # -- a structure's rows built in shares (SURVEY.md 8(e) stage A; the all-gather itself is mad_amd/dist.py's) --------
     def set_wire_bytes(self, cap_rows, D=1024):

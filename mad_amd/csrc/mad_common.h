@@ -132,6 +132,7 @@ enum { MAD_T_ORIENT = 0, MAD_T_DESCRIBE, MAD_T_CORRELATE, MAD_T_PAIRS, MAD_T_POS
 #define MAD_T_RING 32
 #define MAD_LANES 8
 #define MAD_BRACKETS 3      // mad_match_topk_many_begin brackets that may be open at once (steps in flight - 1)
+#define MAD_SHARD_RING 8     // shard records of one lane that may be on their way to the host at once
 #define MAD_RES (2 * MAD_LANES)      // matches of one bracket that may be in flight: two per lane, the second queued behind the first on the lane's stream
 
 struct TimerGroup {
@@ -168,6 +169,12 @@ struct MatchState {            // the most recent mad_match_topk call
     // the shard left in lane 0 by mad_match_shard_pairs, consumed by mad_match_shard_topk
     const void *shard_hi = nullptr, *shard_lo = nullptr;
     int64_t shard_begin = 0, shard_end = 0, shard_pairs = 0, shard_cap_pairs = 0;
+};
+
+struct ShardAsync {            // a mad_match_shard_begin waiting for its mad_match_shard_score, per lane
+    const void *hi = nullptr, *lo = nullptr;
+    uint64_t hi_gen = 0, lo_gen = 0;
+    int64_t begin = 0, nb = 0, n_lo = 0, cap_pairs = 0;
 };
 
 struct mad_ctx {
@@ -212,6 +219,13 @@ struct mad_ctx {
     int next_pinned = 64;
     DensityDev dens;
     MatchState match;
+    ShardAsync shard_async[MAD_LANES];
+    // mad_match_shard_collect / _wait: a ring of pinned staging buffers and completion events per lane (steps in flight)
+    void *shard_host[MAD_LANES][MAD_SHARD_RING] = {};
+    size_t shard_host_cap[MAD_LANES][MAD_SHARD_RING] = {};
+    hipEvent_t shard_ev[MAD_LANES][MAD_SHARD_RING] = {};
+    bool shard_busy[MAD_LANES][MAD_SHARD_RING] = {};
+    int shard_next[MAD_LANES] = {};
     int last_pose_kernel = -1;               // 0 k_pose_lds, 1 k_pose_lds32, 2 k_pose (mad_last_pose_kernel)
     int64_t lane_sel_hint[MAD_LANES] = {};   // pairs the last pruned match of a lane sent to the exact search (sizes the next launch)
     void *many[MAD_BRACKETS] = {};           // open mad_match_topk_many_begin brackets (ManyState, mad_match.hip), by result slot: a ring

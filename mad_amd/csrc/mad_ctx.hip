@@ -116,6 +116,11 @@ extern "C" void mad_destroy(mad_ctx *ctx) {
         }
     for (int r = 0; r < MAD_BRACKETS; r++) (void)hipEventDestroy(ctx->gemm_done[r]);
     for (int l = 0; l < MAD_LANES; l++) (void)hipEventDestroy(ctx->lane_pre[l]);
+    for (int l = 0; l < MAD_LANES; l++)
+        for (int r = 0; r < MAD_SHARD_RING; r++) {
+            if (ctx->shard_ev[l][r]) (void)hipEventDestroy(ctx->shard_ev[l][r]);
+            if (ctx->shard_host[l][r]) (void)hipHostFree(ctx->shard_host[l][r]);
+        }
     for (int l = 0; l < MAD_RES; l++)
         for (int r = 0; r < MAD_BRACKETS; r++) {
             (void)hipEventDestroy(ctx->lane_done[r][l]);

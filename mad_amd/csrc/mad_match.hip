@@ -3507,6 +3507,171 @@ extern "C" int mad_match_shard_topk(mad_ctx *ctx, const mad_set *hi, const mad_s
     return MAD_OK;
 }
 
+// ---------------------------------------------------------------------------
+// The same two stages without a host round trip (round 4): everything is enqueued on the lane of the hi set, the flags and the
+// shard's list stay in DEVICE memory of the caller (torch tensors: mad_amd/dist.py orders its two collectives -- an OR all-reduce,
+// an all-gather -- on that lane's stream between and behind the two calls, the ExternalStream pattern of ShardedSetBuild), and the
+// host reads one small record per shard when the step is collected.  What a host decision settled in the synchronous form is a
+// flag in that record instead: a pair list or score matrix beyond its capacity hint, a lo set whose row count is not the one the
+// block bounds were computed from.  A flagged shard is repeated by the caller through the synchronous calls above.
+// ---------------------------------------------------------------------------
+
+#define ST_SHARD_NLO 17      // status word: the lo set has another number of rows than the caller assumed when it cut the blocks
+
+__global__ void k_shard_head(int32_t *st, int32_t nb, const int32_t *lo_n_rows, int32_t n_lo_assumed) {
+    if (threadIdx.x == 0) {
+        st[ST_NLO] = nb;
+        if (*lo_n_rows != n_lo_assumed) st[ST_SHARD_NLO] = 1;
+    }
+}
+
+// out: [0] rows m, [1] flags (1 score matrix capacity, 2 pair capacity, 4 lo row count, 8 selection list), [2] size of the global hi
+// cloud, [3] pairs of the shard, then k x 23 result rows, k match counts, k global pair ranks (hi_row * N_lo + lo_row), all float64
+__global__ void k_shard_pack(const int64_t *__restrict__ sel, const int32_t *__restrict__ st, int64_t k, const int32_t *__restrict__ ph,
+                             const int32_t *__restrict__ pl, const int32_t *__restrict__ cnt, const double *__restrict__ rows, int64_t n_lo,
+                             int64_t begin, double *__restrict__ out) {
+    const int flags = (st[ST_FLAG_C] ? 1 : 0) | (st[ST_FLAG_PAIRS] ? 2 : 0) | (st[ST_SHARD_NLO] ? 4 : 0) | (st[ST_FLAG_SEL] ? 8 : 0);
+    const int64_t m = (st[ST_NPAIRS] > 0 && !flags) ? min((int64_t)st[ST_NKEYS], k) : 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { out[0] = (double)m; out[1] = (double)flags; out[2] = (double)st[ST_LHI]; out[3] = (double)st[ST_NPAIRS]; }
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < k; t += (int64_t)gridDim.x * blockDim.x) {
+        const bool have = t < m;
+        const int64_t p = have ? sel[t] : 0;
+        for (int c = 0; c < MAD_RESULT_COLS; c++) out[4 + t * MAD_RESULT_COLS + c] = have ? rows[t * MAD_RESULT_COLS + c] : 0.0;
+        out[4 + k * MAD_RESULT_COLS + t] = have ? (double)cnt[p] : 0.0;
+        out[4 + k * (MAD_RESULT_COLS + 1) + t] = have ? (double)((int64_t)ph[p] * n_lo + begin + pl[p]) : 0.0;
+    }
+}
+
+extern "C" int64_t mad_match_shard_record_doubles(int64_t k) { return 4 + (k < 1 ? 1 : k) * (MAD_RESULT_COLS + 2); }
+
+// Stage B, asynchronous: hi against the lo rows [lo_begin, lo_end) of a lo set assumed to have n_lo rows.  d_flags (device,
+// hi->n_anchors + lo->n_anchors bytes) receives this shard's "anchor takes part in a pair" flags, hi's first.
+extern "C" int mad_match_shard_begin(mad_ctx *ctx, const mad_set *hi, const mad_set *lo, int64_t lo_begin, int64_t lo_end, int64_t n_lo,
+                                     double cc, uint8_t *d_flags) {
+    if (!ctx || !hi || !lo || !d_flags) return MAD_EINVAL;
+    if (hi->D != lo->D) return mad_fail(ctx, MAD_EINVAL, "mad_match_shard_begin: descriptor lengths %d vs %d", hi->D, lo->D);
+    if (lo_begin < 0 || lo_end < lo_begin || lo_end > n_lo || n_lo > lo->cap_rows)
+        return mad_fail(ctx, MAD_EINVAL, "mad_match_shard_begin: lo rows [%lld, %lld) of %lld (capacity %lld)", (long long)lo_begin, (long long)lo_end, (long long)n_lo, (long long)lo->cap_rows);
+    const int lane = hi->lane;
+    mad_use_lane(ctx, lane);
+    ShardAsync &S = ctx->shard_async[lane];
+    S = ShardAsync();
+    const int64_t nb = lo_end - lo_begin;
+    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_ZERO), zero_bytes(hi, lo)));
+    int32_t *st = zero_status(ctx);
+    uint8_t *d_used_hi = zr_used_hi(st, hi->n_anchors), *d_used_lo = zr_used_lo(st, hi->n_anchors);
+    MAD_HIP(hipStreamWaitEvent(ctx->stream, hi->built, 0));
+    MAD_HIP(hipStreamWaitEvent(ctx->stream, lo->built, 0));
+    const int64_t cap_pairs = std::max<int64_t>(ctx->match.cap_pairs, 1 << 16);
+    // the score matrix for the rows hi had at its previous build (a hint: the device flags a matrix that does not fit)
+    const int64_t hi_rows = std::min<int64_t>(hi->cap_rows, hi->rows_hint > 0 ? hi->rows_hint + hi->rows_hint / 8 + 64 : (int64_t)hi->n_anchors * 8 + 128);
+    const int64_t cap_c = (mad_ceil_div(std::max<int64_t>(hi_rows, 1), 128) * 128) * (mad_ceil_div(std::max<int64_t>(nb, 1), 128) * 128);
+    if (cap_c >= ((int64_t)1 << 31)) return mad_fail(ctx, MAD_EINVAL, "mad_match_shard_begin: score matrix of %lld entries", (long long)cap_c);
+    mad_zero_words(ctx, st, zero_bytes(hi, lo));
+    hipLaunchKernelGGL(k_shard_head, dim3(1), dim3(64), 0, ctx->stream, st, (int32_t)nb, (const int32_t *)lo->dev_n.p, (int32_t)n_lo);
+    const Side H = side_of(hi), L = side_block(lo, lo_begin, st + ST_NLO, nb);
+    MAD_TRY(correlate_device(ctx, H, L, hi->D, cc, st, cap_c, cap_pairs, d_used_hi, d_used_lo));
+    if (hi->n_anchors > 0) MAD_HIP(hipMemcpyAsync(d_flags, d_used_hi, (size_t)hi->n_anchors, hipMemcpyDeviceToDevice, ctx->stream));
+    if (lo->n_anchors > 0) MAD_HIP(hipMemcpyAsync(d_flags + hi->n_anchors, d_used_lo, (size_t)lo->n_anchors, hipMemcpyDeviceToDevice, ctx->stream));
+    S.hi = hi; S.lo = lo; S.hi_gen = hi->gen; S.lo_gen = lo->gen; S.begin = lo_begin; S.nb = nb; S.n_lo = n_lo; S.cap_pairs = cap_pairs;
+    return MAD_OK;
+}
+
+// Stage C, asynchronous: the shard's pairs scored against the GLOBAL clouds -- d_flags_all = the OR of all shards' flags, same
+// layout, device memory -- and its k best packed into d_out (mad_match_shard_record_doubles(k) float64, device memory).
+extern "C" int mad_match_shard_score(mad_ctx *ctx, const mad_set *hi, const mad_set *lo, const uint8_t *d_flags_all, double dist, int64_t k,
+                                     double *d_out) {
+    if (!ctx || !hi || !lo || !d_flags_all || !d_out) return MAD_EINVAL;
+    if (!(dist > 0) || k < 1) return mad_fail(ctx, MAD_EINVAL, "mad_match_shard_score: dist %g k %lld", dist, (long long)k);
+    const int lane = hi->lane;
+    mad_use_lane(ctx, lane);
+    const ShardAsync S = ctx->shard_async[lane];
+    if (S.hi != hi || S.lo != lo || S.hi_gen != hi->gen || S.lo_gen != lo->gen)
+        return mad_fail(ctx, MAD_EINVAL, "mad_match_shard_score: call mad_match_shard_begin for these sets (as they are now) first");
+    ctx->shard_async[lane] = ShardAsync();
+    int32_t *st = zero_status(ctx);
+    int32_t *hist = zr_hist(st);
+    uint8_t *d_used_hi = zr_used_hi(st, hi->n_anchors), *d_used_lo = zr_used_lo(st, hi->n_anchors);
+    // the global flags replace the shard's own; the histograms of the selection start from zero
+    if (hi->n_anchors > 0) MAD_HIP(hipMemcpyAsync(d_used_hi, d_flags_all, (size_t)hi->n_anchors, hipMemcpyDeviceToDevice, ctx->stream));
+    if (lo->n_anchors > 0) MAD_HIP(hipMemcpyAsync(d_used_lo, d_flags_all + hi->n_anchors, (size_t)lo->n_anchors, hipMemcpyDeviceToDevice, ctx->stream));
+    MAD_HIP(hipMemsetAsync(hist, 0, (size_t)(hi->n_anchors + 17) * 8, ctx->stream));      // hist and hist2
+    MAD_HIP(hipMemsetAsync(st + ST_NKEYS, 0, 4, ctx->stream));
+    MAD_HIP(hipMemsetAsync(st + ST_NSEL, 0, 4, ctx->stream));
+    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_HI_CLOUD), (size_t)hi->n_anchors * 24 + 24));
+    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_SEL_OUT), (size_t)(k + 8) * 8));
+    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_RESULTS), (size_t)(k + 1) * MAD_RESULT_COLS * 8));
+    hipLaunchKernelGGL(k_compact_cloud, dim3(1), dim3(1024), 0, ctx->stream,
+                       CloudJob{(const double *)hi->anc_subv.p, d_used_hi, hi->n_anchors, scratch<double>(ctx, S_HI_CLOUD), st + ST_LHI, nullptr, nullptr, st});
+    MAD_HIP(hipGetLastError());
+    const Side H = side_of(hi), L = side_block(lo, S.begin, st + ST_NLO, S.nb);
+    const bool fits = clouds_fit_lds(hi->n_anchors, lo->n_anchors);
+    CellGrid G;
+    if (!fits) {
+        if (!lo->cells_ready || lo->cell_size != dist) {      // (once per lo set and distance: shared by every later match)
+            MAD_TRY(mad_build_cells(ctx, const_cast<mad_set *>(lo), dist));
+            MAD_HIP(hipStreamSynchronize(ctx->stream));
+        }
+        G.start = (const int32_t *)lo->cell_start.p; G.pts = (const double *)lo->cell_pts.p; G.ids = (const int32_t *)lo->cell_ids.p;
+        for (int d = 0; d < 3; d++) { G.mn[d] = lo->cell_min[d]; G.dim[d] = lo->cell_dim[d]; }
+        G.cell = lo->cell_size;
+        G.used = d_used_lo;
+    }
+    MAD_TRY(pose_device(ctx, H, L, st, S.cap_pairs, scratch<double>(ctx, S_HI_CLOUD), hi->n_anchors, (const double *)lo->anc_subv.p,
+                        lo->n_anchors, d_used_lo, lo->bb_min, lo->bb_max, fits ? nullptr : &G, dist, k, zr_hist2(st, hi->n_anchors)));
+    MAD_TRY(topk_device(ctx, scratch<int32_t>(ctx, S_COUNTS), st, S.cap_pairs, k, hi->n_anchors, scratch<int64_t>(ctx, S_SEL_OUT), hist));
+    hipLaunchKernelGGL(k_results, dim3((unsigned)mad_ceil_div(k, 256)), dim3(256), 0, ctx->stream, scratch<int64_t>(ctx, S_SEL_OUT),
+                       st + ST_NKEYS, k, scratch<int32_t>(ctx, S_PAIR_HI), scratch<int32_t>(ctx, S_PAIR_LO),
+                       scratch<double>(ctx, S_PAIR_SCORE), scratch<int32_t>(ctx, S_COUNTS), st, H.p, H.R, H.meta, L.p, L.Rinv, L.meta,
+                       H.row_anchor, L.row_anchor, scratch<double>(ctx, S_RESULTS), 0);
+    hipLaunchKernelGGL(k_shard_pack, dim3((unsigned)mad_ceil_div(k, 256)), dim3(256), 0, ctx->stream, scratch<int64_t>(ctx, S_SEL_OUT), st, k,
+                       scratch<int32_t>(ctx, S_PAIR_HI), scratch<int32_t>(ctx, S_PAIR_LO), scratch<int32_t>(ctx, S_COUNTS),
+                       scratch<double>(ctx, S_RESULTS), S.n_lo, S.begin, d_out);
+    MAD_HIP(hipGetLastError());
+    return MAD_OK;
+}
+
+// The records of a group's shards (d_all: n float64 in device memory, e.g. what the all-gather behind mad_match_shard_score left) on
+// their way to the host: a copy into pinned memory of the library on the lane of `hi`, an event behind it.  *ticket names the
+// copy for mad_match_shard_wait, which blocks until it has arrived and hands it out.  The staging and the events are the library's
+// own: the caller's framework never records an event on, or ties memory to, a stream the library destroys.
+extern "C" int mad_match_shard_collect(mad_ctx *ctx, const mad_set *hi, const double *d_all, int64_t n, int *ticket) {
+    if (!ctx || !hi || !d_all || !ticket || n < 1) return MAD_EINVAL;
+    const int lane = hi->lane;
+    mad_use_lane(ctx, lane);
+    int slot = -1;
+    for (int t = 0; t < MAD_SHARD_RING && slot < 0; t++) {
+        const int c = (ctx->shard_next[lane] + t) % MAD_SHARD_RING;
+        if (!ctx->shard_busy[lane][c]) slot = c;
+    }
+    if (slot < 0) return mad_fail(ctx, MAD_EINVAL, "mad_match_shard_collect: %d records of lane %d have not been waited for", MAD_SHARD_RING, lane);
+    ctx->shard_next[lane] = (slot + 1) % MAD_SHARD_RING;
+    const size_t bytes = (size_t)n * 8;
+    if (ctx->shard_host_cap[lane][slot] < bytes) {
+        if (ctx->shard_host[lane][slot]) (void)hipHostFree(ctx->shard_host[lane][slot]);
+        ctx->shard_host[lane][slot] = nullptr;
+        ctx->shard_host_cap[lane][slot] = 0;
+        if (hipHostMalloc(&ctx->shard_host[lane][slot], bytes * 2) != hipSuccess) return mad_fail(ctx, MAD_ENOMEM, "pinned shard records of %zu bytes", bytes * 2);
+        ctx->shard_host_cap[lane][slot] = bytes * 2;
+    }
+    if (!ctx->shard_ev[lane][slot]) MAD_HIP(hipEventCreateWithFlags(&ctx->shard_ev[lane][slot], hipEventDisableTiming));
+    MAD_HIP(hipMemcpyAsync(ctx->shard_host[lane][slot], d_all, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    MAD_HIP(hipEventRecord(ctx->shard_ev[lane][slot], ctx->stream));
+    ctx->shard_busy[lane][slot] = true;
+    *ticket = lane * MAD_SHARD_RING + slot;
+    return MAD_OK;
+}
+
+extern "C" int mad_match_shard_wait(mad_ctx *ctx, int ticket, double *out, int64_t n) {
+    if (!ctx || !out || n < 1 || ticket < 0 || ticket >= MAD_LANES * MAD_SHARD_RING) return MAD_EINVAL;
+    const int lane = ticket / MAD_SHARD_RING, slot = ticket % MAD_SHARD_RING;
+    if (!ctx->shard_busy[lane][slot] || ctx->shard_host_cap[lane][slot] < (size_t)n * 8) return mad_fail(ctx, MAD_EINVAL, "mad_match_shard_wait: ticket %d is not pending", ticket);
+    MAD_HIP(hipEventSynchronize(ctx->shard_ev[lane][slot]));
+    memcpy(out, ctx->shard_host[lane][slot], (size_t)n * 8);
+    ctx->shard_busy[lane][slot] = false;
+    return MAD_OK;
+}
+
 // The match counts of ALL pairs of the last match: when its pose search was pruned by bounds (only the k best were asked for),
 // run the exact search over every pair now.  The pair list, the clouds' flags and the status words of that match are still in its
 // lane's scratch (the condition mad_match_fetch has always had); the two sets must still exist.

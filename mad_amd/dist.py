@@ -187,6 +187,8 @@ class PartitionedMatch(object):
 
     def __init__(self, n_items, rank, world, make_group=None, stand_ins=None):
         self.n_items, self.rank, self.world = n_items, rank, world
+        self.n_lo_seen = None      # rows of the map set at the last collected step: what the next steps cut their blocks from
+        self.async_ok = False      # RCCL groups (or the rehearsal of one rank: stand_ins == "local"): ShardedMatchAsync
         self.units, self.groups = plan_partition(n_items, world)
         self.mine = self.units[rank]
         self.items = [u[1] for u in self.mine]
@@ -200,22 +202,36 @@ class PartitionedMatch(object):
                 g = make_group(ranks) if len(ranks) < world else None      # None = the default group (all ranks)
                 if rank in ranks:
                     self.pg[j] = g
+            import torch.distributed as dist
+            self.async_ok = dist.get_backend() == "nccl"
+        if stand_ins == "local":      # the rehearsal of ONE rank on one GPU: nobody to exchange with, everything else as on a node
+            self.stand_ins, self.async_ok = None, True
+            self.local = True
+        else:
+            self.local = False
 
     def load(self):
         return partition_load(self.units)
+
+    def _block_sync(self, lib, hi, lo, cc, dist_thr, k, part, parts, j):
+        kw = {}
+        if self.stand_ins is not None:
+            kw = dict(reduce_flags=self.stand_ins[0], gather=self.stand_ins[1])
+        elif self.local:
+            kw = dict(reduce_flags=lambda f: np.asarray(f, dtype=np.uint8).copy(), gather=lambda parts_: [parts_])
+        return sharded_match(lib, hi, lo, cc, dist_thr, k, part, parts, group=self.pg.get(j), **kw)[0]
 
     def begin(self, lib, his, lo, cc, dist_thr, k):
         handle = lib.match_topk_many_begin(list(his[:self.n_whole]), lo, cc, dist_thr, k)
         done = []
         for hi, (_, item, part, parts, j) in zip(his[self.n_whole:], self.blocks):
-            kw = {}
-            if self.stand_ins is not None:
-                kw = dict(reduce_flags=self.stand_ins[0], gather=self.stand_ins[1])
-            rows, cnt, prank = sharded_match(lib, hi, lo, cc, dist_thr, k, part, parts, group=self.pg.get(j), **kw)
-            n_lo, _ = lo.size()
-            n_hi, _ = hi.size()
-            b, e = lo_row_block(n_lo, part, parts)
-            done.append(dict(item=item, part=part, parts=parts, rows=rows, n_corr=int(n_hi) * int(e - b), n_hi=int(n_hi), n_lo=int(e - b)))
+            d = dict(item=item, part=part, parts=parts, j=j, hi=hi, lo=lo, args=(cc, dist_thr, k), rows=None, pending=None)
+            if self.async_ok and self.n_lo_seen is not None and self.stand_ins is None:
+                # no host round trip: both stages and both exchanges on the lane of the subunit's set, collected in finish()
+                d["pending"] = ShardedMatchAsync(lib, hi, lo, cc, dist_thr, k, part, parts, self.n_lo_seen, group=self.pg.get(j), local=self.local)
+            else:
+                d["rows"] = self._block_sync(lib, hi, lo, cc, dist_thr, k, part, parts, j)
+            done.append(d)
         return handle, done
 
     def finish(self, lib, state):
@@ -227,6 +243,15 @@ class PartitionedMatch(object):
             tops.append(top)
             stats.append(st)
         for d in done:
+            if d["pending"] is not None:
+                res = d["pending"].finish()
+                # (None: a shard of the group raised a flag -- every rank of the group has seen it and repeats the match the slow way)
+                d["rows"] = res[0] if res is not None else self._block_sync(lib, d["hi"], d["lo"], *d["args"], d["part"], d["parts"], d["j"])
+            n_lo, _ = d["lo"].size()
+            n_hi, _ = d["hi"].size()
+            self.n_lo_seen = int(n_lo)
+            b, e = lo_row_block(n_lo, d["part"], d["parts"])
+            d.update(n_corr=int(n_hi) * int(e - b), n_hi=int(n_hi), n_lo=int(e - b))
             corr += d["n_corr"]
             if owner_of(d["item"], self.world) == self.rank:      # rank item % world reports the merged rows (identical on every rank of the group)
                 tops.append(d["rows"])
@@ -276,6 +301,73 @@ def sharded_match(lib, hi, lo, cc, dist, k, rank, world, reduce_flags=None, gath
             return all_gather_arrays(parts, k, group=group)
     shards = gather([rows, cnt, prank])
     return merge_topk([s[0] for s in shards], [s[1] for s in shards], [s[2] for s in shards], k)
+
+
+class ShardedMatchAsync(object):
+    """`sharded_match` without a host round trip (round 4): both stages are enqueued on the lane of `hi`
+    (`mad_match_shard_begin` / `mad_match_shard_score`), the flags and the shard's record stay in device tensors, and the two
+    exchanges of SURVEY.md 8(e) -- OR all-reduce, all-gather -- are issued on that lane's stream between and behind them (the
+    ExternalStream pattern of ShardedSetBuild).  `finish()` waits for ONE device-to-host copy and merges, or returns None when some
+    shard of the group raised a flag (a capacity hint too small, a map set with another row count than `n_lo`): every rank of
+    the group sees the same records, so all of them then repeat the match through the synchronous `sharded_match`.
+
+    group: the torch.distributed group of the shards (RCCL); `local=True`: no collective at all -- the rehearsal of one rank, or a
+    group of one."""
+
+    _pool = {}      # device / pinned buffers of finished handles, by size (released before the interpreter tears the runtime down)
+
+    def __init__(self, lib, hi, lo, cc, dist_thr, k, part, parts, n_lo, group=None, local=False):
+        import torch
+        if not ShardedMatchAsync._pool:
+            import atexit
+            atexit.register(ShardedMatchAsync._pool.clear)
+        self.k, self.parts, self.part = int(k), int(parts), int(part)
+        self.rec = lib.match_shard_record_doubles(self.k)
+        n_fl = max(hi.n_anchors + lo.n_anchors, 1)
+        world = 1 if local else parts
+        key = (n_fl, self.rec, world)
+        free = ShardedMatchAsync._pool.setdefault(key, [])
+        if free:
+            self.buf = free.pop()
+        else:
+            # (torch.empty: no fill kernel on torch's stream to race with the library's writes on the lane's; every byte is written.
+            # Nothing is ALLOCATED while the lane's stream is torch's current one: the allocator would tie blocks to a stream that the
+            # library destroys before torch shuts down)
+            self.buf = dict(flags=torch.empty(n_fl, dtype=torch.uint8, device="cuda"), mine=torch.empty(self.rec, dtype=torch.float64, device="cuda"),
+                            all=torch.empty(world * self.rec, dtype=torch.float64, device="cuda"))
+        self.key = key
+        B = self.buf
+        b, e = lo_row_block(n_lo, part, parts)
+        stream = torch.cuda.ExternalStream(hi.stream())
+        lib.match_shard_begin(hi, lo, b, e, n_lo, cc, B["flags"].data_ptr())
+        if not local:
+            import torch.distributed as dist
+            with torch.cuda.stream(stream):      # behind the shard's pair kernels, in front of its pose kernels
+                dist.all_reduce(B["flags"], op=dist.ReduceOp.MAX, group=group, async_op=True).wait()
+        lib.match_shard_score(hi, lo, B["flags"].data_ptr(), dist_thr, self.k, B["mine"].data_ptr())
+        src = B["mine"]
+        if not local:
+            with torch.cuda.stream(stream):
+                dist.all_gather_into_tensor(B["all"], B["mine"], group=group, async_op=True).wait()
+            src = B["all"]
+        # (the copy to the host and its event are the library's: torch records nothing on a stream it does not own)
+        self.lib, self.n_out = lib, src.numel()
+        self.ticket = lib.match_shard_collect(hi, src.data_ptr(), self.n_out)
+
+    def finish(self):
+        """-> (rows, counts, global pair ranks) merged over the shards, or None (some shard flagged: repeat synchronously)."""
+        B, k = self.buf, self.k
+        out = self.lib.match_shard_wait(self.ticket, self.n_out).reshape(-1, self.rec)
+        ShardedMatchAsync._pool[self.key].append(B)
+        if np.any(out[:, 1] != 0):
+            return None
+        rows, cnt, prank = [], [], []
+        for r in out:
+            m = int(r[0])
+            rows.append(r[4:4 + m * RESULT_COLS].reshape(m, RESULT_COLS))
+            cnt.append(r[4 + k * RESULT_COLS:4 + k * RESULT_COLS + m].astype(np.int64))
+            prank.append(r[4 + k * (RESULT_COLS + 1):4 + k * (RESULT_COLS + 1) + m].astype(np.int64))
+        return merge_topk(rows, cnt, prank, k)
 
 
 def all_gather_arrays(parts, k, group=None, device=None):

@@ -1149,3 +1149,75 @@ def test_two_phase_bounds_pass_selects_the_same_pairs_run_after_run(lib, fields)
         lib.set_option("pose_split_min", 4096)
     for s in sets:
         s.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("parts", [1, 3])
+def test_sharded_match_without_host_round_trips_equals_unsharded(lib, parts):
+    """mad_match_shard_begin / mad_match_shard_score (round 4): the two stages of a sharded match enqueued on the subunit's lane, the
+    flags and the shard's record in device tensors (here torch's: what dist.ShardedMatchAsync hands over), the OR of the flags taken
+    on the device between the two calls.  Merged over the shards the k best are those of mad_match_topk on the whole map set --
+    rows, counts, order; a wrong row count of the map set and a pair capacity that is too small come back as flags, not as rows."""
+    import torch
+    from mad_amd import dist as mdist
+    from mad_amd.eqsp import EQSP_Sphere
+    from mad_amd.orient_tables import orientation_matrices
+    e112, e16 = EQSP_Sphere(112), EQSP_Sphere(16)
+    dom, adj = orientation_matrices(e112)
+    lib.set_eqsp(0, e112.sphere_eqsp, dom, adj)
+    lib.set_eqsp(1, e16.sphere_eqsp)
+    shape = (56, 60, 64)
+    slot = lib.new_slot()
+    lib.upload_field(slot, synth.gradient_field(synth.blob_volume(shape, n_blobs=60, seed=9, sigma=(1.5, 3.5))))
+    rng = np.random.default_rng(parts)
+    sets = []
+    for n in (150, 60):
+        coords = synth.interior_anchors(shape, n, 12, 100 + n)
+        sets.append(lib.set_build([-1, slot], coords, np.ones(n, np.int32), coords.astype(np.float64) * 1.5 + rng.normal(scale=0.2, size=(n, 3)), np.arange(n)))
+    lo, hi = sets
+    cc, dist_, k = 0.45, 4.0, 40
+    top, idx, st = lib.match_topk(hi, lo, cc, dist_, k)
+    assert st["n_pairs"] > 200 and len(top) == k
+    ph, pl, _, cnt = lib.match_fetch(st["n_pairs"])
+    n_lo = lo.size()[0]
+    ref_rank = ph[idx].astype(np.int64) * n_lo + pl[idx]
+    rec = lib.match_shard_record_doubles(k)
+    # (every tensor is allocated up front, on torch's own stream, and the device is idle before the library writes into them)
+    flags = [torch.zeros(hi.n_anchors + lo.n_anchors, dtype=torch.uint8, device="cuda") for _ in range(parts)]
+    flags_all, own = torch.zeros_like(flags[0]), torch.zeros_like(flags[0])
+    records = torch.zeros(parts, rec, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    for p in range(parts):      # Exchange 1 needs every shard's flags ...
+        b, e = mdist.lo_row_block(n_lo, p, parts)
+        lib.match_shard_begin(hi, lo, b, e, n_lo, cc, flags[p].data_ptr())
+    lib.synchronize()
+    for f in flags:
+        torch.maximum(flags_all, f, out=flags_all)
+    torch.cuda.synchronize()
+    for p in range(parts):      # ... then every shard again (one lane: the next shard's pairs replace this one's), scored under the OR
+        b, e = mdist.lo_row_block(n_lo, p, parts)
+        lib.match_shard_begin(hi, lo, b, e, n_lo, cc, own.data_ptr())
+        lib.match_shard_score(hi, lo, flags_all.data_ptr(), dist_, k, records[p].data_ptr())
+        lib.synchronize()
+        assert torch.equal(own, flags[p])
+    out = records.cpu().numpy()
+    assert np.all(out[:, 1] == 0) and int(out[:, 3].sum()) == st["n_pairs"] and np.all(out[:, 2] == st["l_hi"])
+    rows, cn, pr = [], [], []
+    for r in out:
+        m = int(r[0])
+        rows.append(r[4:4 + m * 23].reshape(m, 23)); cn.append(r[4 + k * 23:4 + k * 23 + m].astype(np.int64)); pr.append(r[4 + k * 24:4 + k * 24 + m].astype(np.int64))
+    mrows, mcnt, mrank = mdist.merge_topk(rows, cn, pr, k)
+    np.testing.assert_array_equal(mrank, ref_rank)
+    np.testing.assert_array_equal(mcnt, cnt[idx])
+    np.testing.assert_allclose(mrows, top, rtol=0, atol=1e-12)
+    # the object mad_amd.dist uses, alone on its GPU (no collective): one shard = the whole pair grid
+    if parts == 1:
+        h = mdist.ShardedMatchAsync(lib, hi, lo, cc, dist_, k, 0, 1, n_lo, local=True)
+        r2, c2, p2 = h.finish()
+        np.testing.assert_array_equal(p2, ref_rank)
+        np.testing.assert_allclose(r2, top, rtol=0, atol=1e-12)
+        # a map set with another row count than the blocks were cut from: refused by the device, reported, nothing returned
+        bad = mdist.ShardedMatchAsync(lib, hi, lo, cc, dist_, k, 0, 1, n_lo - 1, local=True)
+        assert bad.finish() is None
+    for s in sets:
+        s.close()
