@@ -129,10 +129,29 @@ class MaD(object):
             return 0, 1, None
         import torch.distributed as dist
         if not dist.is_initialized():
+            import datetime
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29544")
-            dist.init_process_group(os.environ.get("MAD_CONTROL_BACKEND", "gloo"))
+            os.environ.setdefault("MASTER_PORT", "29544")      # (a launcher sets its own; this is the fallback of a hand-started job)
+            # a rank that died must not hold the others for the backend's default half hour
+            dist.init_process_group(os.environ.get("MAD_CONTROL_BACKEND", "gloo"),
+                                    timeout=datetime.timedelta(seconds=int(os.environ.get("MAD_DIST_TIMEOUT_S", "600"))))
         return dist.get_rank(), dist.get_world_size(), dist
+
+    def _all_ranks(self, dist, work):
+        """Runs `work()` on this rank and agrees with the others on the outcome BEFORE the exchange that follows: the helpers of the
+        reference print and sys.exit(1) on bad input (Dmap.py:45-49, PDB.py:13-15), and a rank that leaves alone would hold the
+        others in the next barrier until the group's timeout.  Every rank raises when any rank failed."""
+        err, out = None, None
+        try:
+            out = work()
+        except BaseException as e:      # SystemExit included
+            err = "%s: %s" % (type(e).__name__, e)
+        seen = [None] * dist.get_world_size()
+        dist.all_gather_object(seen, err)
+        bad = [(r, e) for r, e in enumerate(seen) if e is not None]
+        if bad:
+            raise RuntimeError("MaD> rank %d failed (%s); stopping all %d ranks" % (bad[0][0], bad[0][1], len(seen)))
+        return out
 
     # ------------------------------------------------------------------ driver
     def run(self, transform_subunits=False, detect_sigma=2.0, presmooth_sigma=1, ori_eqsp_size=112, dsc_eqsp_size=16,
@@ -159,8 +178,10 @@ class MaD(object):
         # one results folder for the job: rank 0 prepares it, everybody learns its name and the processed inputs
         state = [None]
         if rank == 0:
-            self._prep_files_folders()
+            self._all_ranks(dist, self._prep_files_folders)
             state = [(self.out_folder, self.processed_map, getattr(self, "voxsp", None), self.processed_subunits, self.processed_ensembles)]
+        else:
+            self._all_ranks(dist, lambda: None)
         dist.broadcast_object_list(state, src=0)
         self.out_folder, self.processed_map, self.voxsp, self.processed_subunits, self.processed_ensembles = state[0]
         return True
@@ -190,10 +211,9 @@ class MaD(object):
             for ek in self.processed_ensembles:
                 jobs += [(fk, v[0], "frame") for fk, v in self.processed_ensembles[ek].items()]
             names = {}
-            for i, (key, struct, what) in enumerate(jobs):
+            for key, struct, what in jobs:
                 names[key] = self._cache_name(key, detect_sigma, presmooth_sigma, patch_size, ori_eqsp_size, dsc_eqsp_size)
-                if i % world == rank:
-                    described(key, struct, what)
+            self._all_ranks(dist, lambda: [described(key, struct, what) for i, (key, struct, what) in enumerate(jobs) if i % world == rank])
             dist.barrier()
             self.map_dsc = self._load_descriptors(names[self.map_name])
             for k in self.processed_subunits:
@@ -223,9 +243,13 @@ class MaD(object):
             for ek in self.processed_ensembles:
                 jobs += [("frame", ek, fk) for fk in self.processed_ensembles[ek]]
             mine = {}
-            for kind, owner_key, key in shard_round_robin(jobs, rank, world):
-                pdbfile, n_copies = self.processed_subunits[key] if kind == "sub" else self.processed_ensembles[owner_key][key]
-                mine[(kind, owner_key, key)] = self._match_filter_refine(pdbfile, n_copies, key, cc_threshold, weight_threshold, n_samples)
+
+            def dock_mine():
+                for kind, owner_key, key in shard_round_robin(jobs, rank, world):
+                    pdbfile, n_copies = self.processed_subunits[key] if kind == "sub" else self.processed_ensembles[owner_key][key]
+                    mine[(kind, owner_key, key)] = self._match_filter_refine(pdbfile, n_copies, key, cc_threshold, weight_threshold, n_samples)
+
+            self._all_ranks(dist, dock_mine)
             everyone = [None] * world
             dist.all_gather_object(everyone, mine)
             files_of = {}
@@ -260,7 +284,7 @@ class MaD(object):
         from . import assembly
         rank, world, dist = self._ranks()
         if world > 1:      # one rank builds the models (the combinatorics are sequential); the others wait for its files
-            out = assembly.build_assembly(self, max_models=max_models, max_overlap_complex=max_overlap_complex) if rank == 0 else None
+            out = self._all_ranks(dist, lambda: assembly.build_assembly(self, max_models=max_models, max_overlap_complex=max_overlap_complex) if rank == 0 else None)
             dist.barrier()
             return out
         return assembly.build_assembly(self, max_models=max_models, max_overlap_complex=max_overlap_complex)

@@ -119,3 +119,49 @@ def test_run_on_two_ranks_equals_one_rank(tmp_path):
         assert t2[name] == t1[name], name
     # every structure was described exactly once, by somebody: the cache holds the map, three subunits and two frames
     assert len(os.listdir(os.path.join(two, "dsc_db"))) == len(os.listdir(os.path.join(one, "dsc_db"))) == 6
+
+
+def _failing_worker(rank, world, port, folder, inputs):
+    import time
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK=str(rank), MAD_DIST_TIMEOUT_S="120")
+    Fake = _fake_mad()
+
+    class Failing(Fake):
+        def _match_filter_refine(self, pdbfile, n_copies, k, *a):
+            if k == "subA":      # rank 0's first docking dies the way the reference's helpers do (print + sys.exit(1), PDB.py:13-15)
+                raise SystemExit(1)
+            return super()._match_filter_refine(pdbfile, n_copies, k, *a)
+
+    cwd = os.getcwd()
+    os.chdir(folder)
+    t0 = time.time()
+    try:
+        mad = Failing()
+        mad.add_map(os.path.join(inputs, "map.sit"), 8.0)
+        mad.add_subunit(os.path.join(inputs, "subA.pdb"), n_copies=2)
+        mad.add_subunit(os.path.join(inputs, "subB.pdb"))
+        try:
+            mad.run()
+            outcome = "finished"
+        except RuntimeError as e:
+            outcome = "raised: %s" % e
+    finally:
+        os.chdir(cwd)
+    with open(os.path.join(folder, "outcome%d.txt" % rank), "w") as fh:
+        fh.write("%s\n%.1f\n" % (outcome, time.time() - t0))
+
+
+def test_a_rank_that_fails_stops_every_rank(tmp_path):
+    """A rank that raises (or sys.exits, as the reference's helpers do on bad input) inside its share of MaD.run() must not leave
+    the others in a barrier until the group's timeout: the ranks agree on the outcome before every exchange, and all of them raise."""
+    import torch.multiprocessing as mp
+    inputs = str(tmp_path / "inputs")
+    _make_inputs(inputs)
+    two = str(tmp_path / "two")
+    os.makedirs(two)
+    mp.spawn(_failing_worker, args=(2, _free_port(), two, inputs), nprocs=2, join=True)
+    for r in range(2):
+        with open(os.path.join(two, "outcome%d.txt" % r)) as fh:
+            outcome, secs = fh.read().splitlines()
+        assert outcome.startswith("raised: MaD> rank 0 failed (SystemExit"), (r, outcome)
+        assert float(secs) < 60.0
