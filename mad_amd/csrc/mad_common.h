@@ -304,7 +304,7 @@ enum {
     S_PAIR_HI, S_PAIR_LO, S_PAIR_SCORE, S_COUNTS, S_USED_HI, S_USED_LO, S_HI_CLOUD, S_MISC,
     S_HIST, S_SEL, S_RESULTS, S_TMP_A, S_TMP_B, S_TMP_C, S_TMP_D, S_TMP_E, S_TMP_F, S_TMP_G,
     S_TIE_FLAG, S_TIE_OFF, S_SEL_OUT, S_TMP_H, S_TMP_I, S_TMP_J,
-    S_CELL_START, S_CELL_PTS, S_CELL_IDS, S_PG_START, S_PG_PTS, S_PG_PTSF, S_ZERO, S_CMASK, S_PG_BITS, S_PG_PAIRS, S_PERM_OFF, S_N_SLOTS
+    S_CELL_START, S_CELL_PTS, S_CELL_IDS, S_PG_START, S_PG_PTS, S_PG_PTSF, S_ZERO, S_CMASK, S_PG_BITS, S_PG_PAIRS, S_PERM_OFF, S_CFLAG, S_N_SLOTS
 };
 static_assert(S_N_SLOTS <= 64, "grow mad_ctx::scratch");
 

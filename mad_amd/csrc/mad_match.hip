@@ -120,6 +120,9 @@ __device__ __forceinline__ unsigned s_pack_hh(unsigned a, unsigned b) { unsigned
 #define G2_STAGE ((G2_BM + G2_BN) * G2_BK)
 #define G2_LDS (G2_NSTAGE * G2_STAGE + (G2_BM + G2_BN) * 4)
 
+// row pitch (bytes) of the candidate flags: one byte per mask word (32 columns) of the padded matrix, rows aligned for 4-byte reads
+__host__ __device__ __forceinline__ int64_t mad_cflag_pitch(int64_t ldc) { return (ldc / 32 + 3) & ~(int64_t)3; }
+
 struct GemmJob {
     const int8_t *A, *B;           // hi rows, lo rows (int8, K bytes each, zero-padded to multiples of 128 rows)
     int32_t *C;
@@ -128,6 +131,7 @@ struct GemmJob {
     int32_t *status;
     const double *hn, *ln;
     uint32_t *mask;
+    uint8_t *cflag;                // zeroed by the caller: one byte per mask word, set where the word has a bit (the pair kernels look nowhere else)
 };
 struct GemmBatch {
     int n_jobs;
@@ -178,7 +182,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_corr_gemm2(GemmBatch G) {
         const int64_t tiles_m = (hp + G2_BM - 1) / G2_BM, tiles = tiles_m * (lp / G2_BN), per_xcd = (tiles + 7) / 8;
         const int64_t begin = per_xcd * xcd, end = begin + per_xcd < tiles ? begin + per_xcd : tiles;
         const int64_t cnt = end > begin ? end - begin : 0;
-        const int64_t ldm = lp / 32;
+        const int64_t ldm = lp / 32, ldf = mad_cflag_pitch(lp);
         // One tile of MT x 16 rows per wave-row (MT = 8: the 256 x 128 tile; MT = 4: its upper or lower half, 128 x 128, a wave owning
         // 64 x 64) -- the same stages, fragment layout and epilogue.
         auto run_tile = [&](auto mt_tag, const int64_t row0, const int64_t col0) {
@@ -269,10 +273,12 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_corr_gemm2(GemmBatch G) {
             if (row0 + wm * (MT * 16) < hp) {
                 int32_t *Ct = J.C + row0 * lp + col0;
                 uint32_t *Mt = J.mask + row0 * ldm + col0 / 32;
+                uint8_t *Ft = J.cflag + row0 * ldf + col0 / 32;
                 const unsigned lp32 = (unsigned)lp, ldm32 = (unsigned)ldm;
                 // byte offsets from the tile's (uniform) base, 32-bit: a tile spans 256 rows of at most 2^20 columns
                 const unsigned voff = ((unsigned)(wm * (MT * 16) + (lane >> 4) * 4) * lp32 + (unsigned)(wn * 64 + (lane & 15))) * 4u;
                 const unsigned moff = ((unsigned)(wm * (MT * 16) + (lane & 3) * 4) * ldm32 + (unsigned)(wn * 2 + (lane >> 2))) * 4u;      // lanes 0..7: row group, word
+                const unsigned ldf32 = (unsigned)ldf, foff = (unsigned)(wm * (MT * 16) + (lane & 3) * 4) * ldf32 + (unsigned)(wn * 2 + (lane >> 2));      // lanes 0..7, as moff
                 float tl[4];
 #pragma unroll
                 for (int n = 0; n < 4; n++) {      // cc |l| moved towards "candidate" by the margin (|h| > 0, so the product moves with it)
@@ -285,6 +291,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_corr_gemm2(GemmBatch G) {
                     for (int jj = 0; jj < 4; jj++) {
                         const float th = sT[wm * (MT * 16) + m * 16 + (lane >> 4) * 4 + jj];
                         unsigned long long bal[4];
+                        bool some = false;      // (uniform: set inside the rare branches below, nothing to compute where there is no candidate)
                         // the row's offsets are formed here, on the scalar unit, and not hoisted: 64 precomputed addresses spill
                         unsigned rc = (unsigned)(m * 16 + jj) * lp32 * 4u, rm = (unsigned)(m * 16 + jj) * ldm32 * 4u;
                         asm volatile("" : "+s"(rc), "+s"(rm));
@@ -295,6 +302,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_corr_gemm2(GemmBatch G) {
                             const bool cand = (float)d > th * tl[n];
                             bal[n] = __ballot(cand);
                             if (bal[n] != 0ull) {
+                                some = true;
                                 if (cand) *(int32_t *)(crow + n * 64) = d;
                             }
                         }
@@ -307,6 +315,13 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_corr_gemm2(GemmBatch G) {
 #undef MAD_WRITELANE
 #undef MAD_MASK_WORD
                         if (lane < 8) *(uint32_t *)((char *)Mt + (moff + rm)) = (unsigned)wd;
+                        // where the pair kernels have to look at all: a byte per mask word, written only where the word has a bit
+                        // (0.2 % of the entries are candidates; the array arrives zeroed) -- by the lanes that hold the eight words
+                        if (some) {      // (uniform, and rare: the arithmetic stays inside)
+                            unsigned rf = (unsigned)(m * 16 + jj) * ldf32;
+                            asm volatile("" : "+s"(rf));
+                            if (lane < 8 && wd != 0) Ft[foff + rf] = 1;
+                        }
                     }
             }
             G2_STAMP(5);
@@ -350,47 +365,101 @@ __device__ __forceinline__ double corr_score(int dot, double nh, double nl) {
     return (double)dot / ((nh > 0 ? nh : 1.0) * (nl > 0 ? nl : 1.0));
 }
 
-// Exact test of the entries the GEMM flagged; the mask word is rewritten with the exact bits, so that the
-// emit pass only has to place them.  One workgroup per hi row (persistent), one thread per 32 columns.
-__global__ __launch_bounds__(256) void k_pair_count(const int32_t *__restrict__ C, uint32_t *__restrict__ mask,
-                                                    const int32_t *__restrict__ n_hi_ptr, const int32_t *__restrict__ n_lo_ptr,
-                                                    const double *__restrict__ hn, const double *__restrict__ ln, double cc,
-                                                    int32_t *__restrict__ row_cnt, const int32_t *__restrict__ status) {
-    __shared__ int wt[4];
-    if (status[ST_FLAG_C]) return;
-    const int64_t n_hi = *n_hi_ptr, n_lo = *n_lo_ptr;
-    const int64_t ldc = (n_lo + GEMM_BN - 1) / GEMM_BN * GEMM_BN, ldm = ldc / 32;
-    for (int64_t i = blockIdx.x; i < n_hi; i += gridDim.x) {
-        const double nh = hn[i];
-        int c = 0;
-        for (int64_t w = threadIdx.x; w < ldm; w += 256) {
-            unsigned m = mask[i * ldm + w], exact = 0;
+// The flagged entries of row i behind the candidate flags f .. f + 3 of this lane (a byte per mask word, set by the GEMM where the
+// word has a bit: 0.2 % of the entries are candidates), gathered IN COLUMN ORDER into the wave's list in LDS: the four mask words of a lane
+// are requested together (a word behind a clear flag is 0 without a load), a wave scan of the bit counts places every lane's
+// columns.  Returns how many; beyond PAIR_LIST entries per pass the caller walks the words itself.  -- Rounds 1-3 read every word of
+// the mask in both pair kernels, a workgroup and several barriers per row, and each thread chased its own word's bits one after the
+// other; a list lets the dependent loads behind every candidate (dot product, norm) go out side by side, one candidate per lane.
+#define PAIR_LIST 1024
+#define PAIR_WORDS 4      // mask words (= candidate flags) of a lane per pass: a wave covers 64 x 4 x 32 = 8 192 columns
+__device__ __forceinline__ int pair_list_row(const uint32_t *__restrict__ mask_row, const uint8_t *__restrict__ flag_row, int64_t f0, int64_t ldf,
+                                             unsigned *__restrict__ list, unsigned mw[PAIR_WORDS]) {
+    const int lane = (int)lane_id();
+    const int64_t f = f0 + PAIR_WORDS * lane;
+    const unsigned fl = f < ldf ? *(const unsigned *)(flag_row + f) : 0u;
+    int pc = 0;
+#pragma unroll
+    for (int q = 0; q < PAIR_WORDS; q++) {
+        mw[q] = ((fl >> (8 * q)) & 0xffu) ? mask_row[f + q] : 0u;
+        pc += __popc(mw[q]);
+    }
+    const int inc = wave_incl_scan_i32(pc);
+    const int total = __builtin_amdgcn_readlane(inc, MAD_WAVE - 1);
+    if (total <= PAIR_LIST) {
+        int o = inc - pc;
+#pragma unroll
+        for (int q = 0; q < PAIR_WORDS; q++) {
+            unsigned m = mw[q];
             while (m) {
                 const int b = __ffs(m) - 1;
                 m &= m - 1;
-                const int64_t j = w * 32 + b;
-                if (j < n_lo && corr_score(C[i * ldc + j], nh, ln[j]) > cc) exact |= 1u << b;
+                list[o++] = (unsigned)((f + q) * 32 + b);
             }
-            mask[i * ldm + w] = exact;
-            c += __popc(exact);
+        }
+    }
+    return total;
+}
+
+// Exact test of the entries the GEMM flagged (its float32 test with a margin is a superset of MaD.py:423's float64 one): a bit that
+// fails is cleared in the mask, the row's count goes to row_cnt.  One WAVE per hi row, four rows per workgroup, persistent.
+__global__ __launch_bounds__(256) void k_pair_count(const int32_t *__restrict__ C, uint32_t *__restrict__ mask, const uint8_t *__restrict__ cflag,
+                                                    const int32_t *__restrict__ n_hi_ptr, const int32_t *__restrict__ n_lo_ptr,
+                                                    const double *__restrict__ hn, const double *__restrict__ ln, double cc,
+                                                    int32_t *__restrict__ row_cnt, const int32_t *__restrict__ status) {
+    __shared__ unsigned s_list[4][PAIR_LIST];
+    if (status[ST_FLAG_C]) return;
+    const int64_t n_hi = *n_hi_ptr, n_lo = *n_lo_ptr;
+    const int64_t ldc = (n_lo + GEMM_BN - 1) / GEMM_BN * GEMM_BN, ldm = ldc / 32, ldf = mad_cflag_pitch(ldc);
+    const int lane = (int)lane_id();
+    unsigned *const list = s_list[threadIdx.x >> 6];
+    for (int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); i < n_hi; i += (int64_t)gridDim.x * 4) {
+        const double nh = hn[i];
+        uint32_t *const mrow = mask + i * ldm;
+        int c = 0;
+        for (int64_t f0 = 0; f0 < ldf; f0 += PAIR_WORDS * MAD_WAVE) {
+            unsigned mw[PAIR_WORDS];
+            const int total = pair_list_row(mrow, cflag + i * ldf, f0, ldf, list, mw);
+            if (total > PAIR_LIST) {      // a pass with more candidates than the list holds: every lane walks its own words
+#pragma unroll
+                for (int q = 0; q < PAIR_WORDS; q++) {
+                    unsigned m = mw[q], exact = 0;
+                    if (!m) continue;
+                    const int64_t w = f0 + PAIR_WORDS * lane + q;
+                    while (m) {
+                        const int b = __ffs(m) - 1;
+                        m &= m - 1;
+                        const int64_t j = w * 32 + b;
+                        if (j < n_lo && corr_score(C[i * ldc + j], nh, ln[j]) > cc) exact |= 1u << b;
+                    }
+                    mrow[w] = exact;
+                    c += __popc(exact);
+                }
+                continue;
+            }
+            for (int k = lane; k < total; k += MAD_WAVE) {      // (the wave's own LDS writes above are visible to it: LDS operations of a wave execute in order)
+                const int64_t j = list[k];
+                const bool ok = j < n_lo && corr_score(C[i * ldc + j], nh, ln[j]) > cc;
+                if (!ok) atomicAnd(&mrow[j >> 5], ~(1u << (j & 31)));
+                c += ok ? 1 : 0;
+            }
         }
         c = wave_sum_i32(c);
-        __syncthreads();
-        if (lane_id() == 0) wt[threadIdx.x >> 6] = c;
-        __syncthreads();
-        if (threadIdx.x == 0) row_cnt[i] = wt[0] + wt[1] + wt[2] + wt[3];
+        if (lane == 0) row_cnt[i] = c;
     }
 }
 
 // Ordered compaction of the flagged entries into the pair list (np.where's row-major order, MaD.py:423), the prefix sum of the rows'
-// counts inside: a workgroup takes the rows b, b + G, b + 2 G, ...; the number of pairs before row b is a block reduction over
-// row_cnt[0 .. b), and from one of its rows to the next it adds the G counts in between -- a handful of cached loads per thread
-// instead of a one-workgroup scan launch between count and emit (rounds 1-2).  Workgroup 0 also forms the total
-// (status[ST_NPAIRS], the overflow flag).  It marks the anchors that take part in a pair (the clouds of MaD.py:427-428).
-// (Also tried: count + scan + emit as ONE launch, rows ticketed in order and the offsets by a decoupled look-back over 8-byte row
+// counts inside: a workgroup takes the rows 4 b .. 4 b + 3, 4 (b + G) .., one wave each; the number of pairs before its first row is
+// a block reduction over the counts of the rows in between (a handful of cached loads per thread instead of a one-workgroup scan
+// launch between count and emit: rounds 1-2), a wave's own offset adds the counts of the workgroup's earlier rows.  Inside a row the
+// candidates stand in the wave's list in column order (pair_list_row): the k-th goes to position base + k, one candidate per lane.
+// Workgroup 0 also forms the total (status[ST_NPAIRS], the overflow flag).  Marks the anchors that take part in a pair (the clouds
+// of MaD.py:427-428).
+// (Also tried, round 3: count + scan + emit as ONE launch, rows ticketed in order and the offsets by a decoupled look-back over 8-byte row
 // descriptors -- correct, and 75-85 us per match against 28 for the three launches: 2 200 workgroups that reach the look-back together
 // find no inclusive prefix nearby and poll each other's descriptors through the fabric.)
-__global__ __launch_bounds__(256) void k_pair_emit2(const int32_t *__restrict__ C, const uint32_t *__restrict__ mask,
+__global__ __launch_bounds__(256) void k_pair_emit2(const int32_t *__restrict__ C, const uint32_t *__restrict__ mask, const uint8_t *__restrict__ cflag,
                                                     const int32_t *__restrict__ n_hi_ptr, const int32_t *__restrict__ n_lo_ptr,
                                                     const double *__restrict__ hn, const double *__restrict__ ln,
                                                     const int32_t *__restrict__ row_cnt, int64_t cap_pairs,
@@ -399,11 +468,14 @@ __global__ __launch_bounds__(256) void k_pair_emit2(const int32_t *__restrict__ 
                                                     const int32_t *__restrict__ lo_row_anchor, const int32_t *__restrict__ hi_canon,
                                                     const int32_t *__restrict__ lo_canon, uint8_t *__restrict__ used_hi,
                                                     uint8_t *__restrict__ used_lo, int32_t *__restrict__ status) {
-    __shared__ int wt[5];
+    __shared__ unsigned s_list[4][PAIR_LIST];
     __shared__ long long s_sum[4];
+    __shared__ int s_cnt[4];
     if (status[ST_FLAG_C]) return;
     const int64_t n_hi = *n_hi_ptr, n_lo = *n_lo_ptr;
-    const int64_t ldc = (n_lo + GEMM_BN - 1) / GEMM_BN * GEMM_BN, ldm = ldc / 32;
+    const int64_t ldc = (n_lo + GEMM_BN - 1) / GEMM_BN * GEMM_BN, ldm = ldc / 32, ldf = mad_cflag_pitch(ldc);
+    const int lane = (int)lane_id(), wv = threadIdx.x >> 6;
+    unsigned *const list = s_list[wv];
     // sum of row_cnt[a .. b) over the workgroup
     auto block_sum = [&](int64_t a, int64_t b) -> long long {
         long long v = 0;
@@ -411,7 +483,7 @@ __global__ __launch_bounds__(256) void k_pair_emit2(const int32_t *__restrict__ 
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, MAD_WAVE);
         __syncthreads();
-        if (lane_id() == 0) s_sum[threadIdx.x >> 6] = v;
+        if (lane == 0) s_sum[wv] = v;
         __syncthreads();
         return s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
     };
@@ -424,31 +496,48 @@ __global__ __launch_bounds__(256) void k_pair_emit2(const int32_t *__restrict__ 
     }
     int64_t done = 0;      // rows whose counts are in `before`
     long long before = 0;
-    for (int64_t i = blockIdx.x; i < n_hi; i += gridDim.x) {
-        before += block_sum(done, i);
-        done = i;
-        const int count = row_cnt[i];
-        if (count == 0 || before + count > cap_pairs) continue;      // (a list that overflows is never read: the match is repeated)
+    for (int64_t i0 = (int64_t)blockIdx.x * 4; i0 < n_hi; i0 += (int64_t)gridDim.x * 4) {      // (uniform over the workgroup)
+        before += block_sum(done, i0);
+        const int64_t i = i0 + wv;
+        const int count = i < n_hi ? row_cnt[i] : 0;
+        if (lane == 0) s_cnt[wv] = count;
+        __syncthreads();
+        long long mine = before;
+        for (int q = 0; q < wv; q++) mine += s_cnt[q];
+        before += s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        done = min(i0 + 4, n_hi);
+        if (count == 0 || mine + count > cap_pairs) continue;      // (a list that overflows is never read: the match is repeated)
         const double nh = hn[i];
-        int64_t base = before;
-        for (int64_t w0 = 0; w0 < ldm; w0 += 256) {
-            const int64_t w = w0 + threadIdx.x;
-            unsigned m = w < ldm ? mask[i * ldm + w] : 0;
-            int tot;
-            int64_t o = base + block_excl_scan(__popc(m), wt, &tot);
-            while (m) {      // ascending columns: the row-major order of np.where (MaD.py:423)
-                const int b = __ffs(m) - 1;
-                m &= m - 1;
-                const int64_t j = w * 32 + b;
-                pair_hi[o] = (int32_t)i;
-                pair_lo[o] = (int32_t)j;
-                pair_score[o] = corr_score(C[i * ldc + j], nh, ln[j]);
-                if (used_lo) { const int a = lo_row_anchor ? lo_row_anchor[j] : (int)j; used_lo[lo_canon ? lo_canon[a] : a] = 1; }
-                o++;
+        int64_t base = mine;
+        auto put = [&](int64_t o, int64_t j) {
+            pair_hi[o] = (int32_t)i;
+            pair_lo[o] = (int32_t)j;
+            pair_score[o] = corr_score(C[i * ldc + j], nh, ln[j]);
+            if (used_lo) { const int a = lo_row_anchor ? lo_row_anchor[j] : (int)j; used_lo[lo_canon ? lo_canon[a] : a] = 1; }
+        };
+        for (int64_t f0 = 0; f0 < ldf; f0 += PAIR_WORDS * MAD_WAVE) {
+            unsigned mw[PAIR_WORDS];
+            const int total = pair_list_row(mask + i * ldm, cflag + i * ldf, f0, ldf, list, mw);
+            if (total > PAIR_LIST) {      // more candidates in this pass than the list holds: every lane places its own, in order
+                int pc = 0;
+#pragma unroll
+                for (int q = 0; q < PAIR_WORDS; q++) pc += __popc(mw[q]);
+                int64_t o = base + wave_incl_scan_i32(pc) - pc;
+#pragma unroll
+                for (int q = 0; q < PAIR_WORDS; q++) {
+                    unsigned m = mw[q];
+                    while (m) {      // ascending columns: the row-major order of np.where (MaD.py:423)
+                        const int b = __ffs(m) - 1;
+                        m &= m - 1;
+                        put(o++, (f0 + PAIR_WORDS * lane + q) * 32 + b);
+                    }
+                }
+            } else {
+                for (int k = lane; k < total; k += MAD_WAVE) put(base + k, (int64_t)list[k]);
             }
-            base += tot;
+            base += total;
         }
-        if (threadIdx.x == 0 && used_hi) { const int a = hi_row_anchor ? hi_row_anchor[i] : (int)i; used_hi[hi_canon ? hi_canon[a] : a] = 1; }
+        if (lane == 0 && used_hi) { const int a = hi_row_anchor ? hi_row_anchor[i] : (int)i; used_hi[hi_canon ? hi_canon[a] : a] = 1; }
     }
 }
 
@@ -1960,6 +2049,9 @@ static int gemm2_launch(mad_ctx *ctx, const GemmBatch &G) {
     return MAD_OK;
 }
 
+// bytes of the candidate flags of a score matrix of cap_c entries (rows x pitch <= cap_c / 32 + 3 rows' worth: twice the entries / 32 covers it)
+static size_t cflag_bytes(int64_t cap_c) { return (size_t)cap_c / 16 + 64; }
+
 // The correlation stage in three pieces, so that the GEMMs of several matches can go out as ONE launch (mad_match_topk_many):
 // the scratch of this lane sized and the GEMM's arguments filled in; the GEMM; threshold + ordered compaction of the pairs.
 static int correlate_reserve(mad_ctx *ctx, const Side &hi, const Side &lo, int D, double cc, int32_t *d_status, int64_t cap_c,
@@ -1973,8 +2065,9 @@ static int correlate_reserve(mad_ctx *ctx, const Side &hi, const Side &lo, int D
     MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_PAIR_LO), (size_t)cap_pairs * 4));
     MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_PAIR_SCORE), (size_t)cap_pairs * 8));
     MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_CMASK), (size_t)cap_c / 8 + 64));
+    MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_CFLAG), cflag_bytes(cap_c)));
     *job = GemmJob{hi.dsc8, lo.dsc8, scratch<int32_t>(ctx, S_CMAT), hi.n_rows, lo.n_rows, cap_c, d_status, hi.norm, lo.norm,
-                   scratch<uint32_t>(ctx, S_CMASK)};
+                   scratch<uint32_t>(ctx, S_CMASK), scratch<uint8_t>(ctx, S_CFLAG)};
     return MAD_OK;
 }
 
@@ -1998,9 +2091,10 @@ static int correlate_pairs(mad_ctx *ctx, const Side &hi, const Side &lo, double 
     int32_t *C = scratch<int32_t>(ctx, S_CMAT);
     uint32_t *mask = scratch<uint32_t>(ctx, S_CMASK);
     mad_timer_begin(ctx, MAD_T_PAIRS);
-    hipLaunchKernelGGL(k_pair_count, dim3(ctx->n_cu * 8), dim3(256), 0, ctx->stream, C, mask, hi.n_rows, lo.n_rows, hi.norm, lo.norm, cc,
+    const uint8_t *cflag = scratch<uint8_t>(ctx, S_CFLAG);
+    hipLaunchKernelGGL(k_pair_count, dim3(ctx->n_cu * 4), dim3(256), 0, ctx->stream, C, mask, cflag, hi.n_rows, lo.n_rows, hi.norm, lo.norm, cc,
                        scratch<int32_t>(ctx, S_ROWCNT), d_status);
-    hipLaunchKernelGGL(k_pair_emit2, dim3(ctx->n_cu * 8), dim3(256), 0, ctx->stream, C, mask, hi.n_rows, lo.n_rows, hi.norm, lo.norm,
+    hipLaunchKernelGGL(k_pair_emit2, dim3(ctx->n_cu * 4), dim3(256), 0, ctx->stream, C, mask, cflag, hi.n_rows, lo.n_rows, hi.norm, lo.norm,
                        scratch<int32_t>(ctx, S_ROWCNT), cap_pairs, scratch<int32_t>(ctx, S_PAIR_HI), scratch<int32_t>(ctx, S_PAIR_LO),
                        scratch<double>(ctx, S_PAIR_SCORE), hi.row_anchor, lo.row_anchor, hi.anc_canon, lo.anc_canon, d_used_hi, d_used_lo,
                        d_status);
@@ -2013,6 +2107,7 @@ static int correlate_device(mad_ctx *ctx, const Side &hi, const Side &lo, int D,
                             int64_t cap_pairs, uint8_t *d_used_hi, uint8_t *d_used_lo) {
     GemmJob job;
     MAD_TRY(correlate_reserve(ctx, hi, lo, D, cc, d_status, cap_c, cap_pairs, &job));
+    mad_zero_words(ctx, job.cflag, cflag_bytes(cap_c));
     MAD_TRY(correlate_gemm(ctx, 1, &job, D, cc));
     return correlate_pairs(ctx, hi, lo, cc, d_status, cap_pairs, d_used_hi, d_used_lo);
 }
@@ -2982,8 +3077,9 @@ static int match_enqueue_head(mad_ctx *ctx, const mad_set *hi, const mad_set *lo
     pose_plan(ctx, hi->n_anchors, lo->n_anchors, lo->bb_min, lo->bb_max, !P.fits, P.dist, P.k, true, &P.pose);
     const size_t bits_bytes = P.pose.fine_bytes + P.pose.coarse_bytes;
     MAD_TRY(mad_reserve(ctx, mad_sb(ctx, S_PG_BITS), bits_bytes + 16));
-    mad_zero_words3(ctx, st, zero_bytes(hi, lo), mad_sb(ctx, S_PG_BITS).p, bits_bytes, nullptr, 0);
-    return correlate_reserve(ctx, H, L, hi->D, cc, st, P.cap_c, P.cap_pairs, job);
+    MAD_TRY(correlate_reserve(ctx, H, L, hi->D, cc, st, P.cap_c, P.cap_pairs, job));
+    mad_zero_words3(ctx, st, zero_bytes(hi, lo), mad_sb(ctx, S_PG_BITS).p, bits_bytes, job->cflag, cflag_bytes(P.cap_c));
+    return MAD_OK;
 }
 
 static int match_enqueue_tail(mad_ctx *ctx, const mad_set *hi, const mad_set *lo, double cc, double dist, MatchPlan &P) {
