@@ -397,6 +397,7 @@ __device__ __forceinline__ int pair_list_row(const uint32_t *__restrict__ mask_r
                 list[o++] = (unsigned)((f + q) * 32 + b);
             }
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // the lanes' writes above before the wave's reads of the list (LDS operations of a wave execute in order)
     }
     return total;
 }
