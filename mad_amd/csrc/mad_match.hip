@@ -343,8 +343,10 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_corr_gemm2(GemmBatch G) {
         for (; t < base + units; t += nslot) {
             const int64_t u = t - base;
             if (parts == 1 || u < full) {
-                const int64_t tile = begin + u;
-                run_tile(std::integral_constant<int, 8>(), (tile % tiles_m) * G2_BM, (tile / tiles_m) * G2_BN);
+                const int64_t tile = begin + u, row0 = (tile % tiles_m) * G2_BM, col0 = (tile / tiles_m) * G2_BN;
+                // (a set's last, odd block of 128 rows: the upper half of a tile is all there is)
+                if (row0 + G2_BM / 2 >= hp) run_tile(std::integral_constant<int, 4>(), row0, col0);
+                else run_tile(std::integral_constant<int, 8>(), row0, col0);
             } else {
                 const int64_t h = u - full, tile = begin + full + h / parts;
                 const int64_t row0 = (tile % tiles_m) * G2_BM + (h % parts) * (G2_BM / parts), col0 = (tile / tiles_m) * G2_BN;
