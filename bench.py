@@ -243,22 +243,52 @@ def enqueue_builds(lib, the_map, subs, sets):
 PM = {"pm": None}      # dist.PartitionedMatch when some subunits' pair grids are split over groups of ranks (n_sub % ranks != 0)
 
 
+# A map set built in shares travels in wire images of a fixed capacity (dist.ShardedSetBuild).  A build that outgrows it makes the
+# import report MAD_ENOSPC at the first use of the set -- on every rank that uses it, the images being the same everywhere.  The rank
+# notes it here, hands its word to the others with the step's top-k exchange (a rank without a match in that step learns it there),
+# and all ranks then size the images again at the same step (main: ResizeMapImages).
+OVERFLOW = {"seen": 0, "resizes": 0, "watch": False}
+
+
+class ResizeMapImages(Exception):
+    pass
+
+
+def _overflowed(err):
+    if OVERFLOW["watch"] and "ENOSPC" in str(err) and "mad_set_import" in str(err):
+        OVERFLOW["seen"] = 1
+        return True
+    return False
+
+
 def begin_matches(lib, his, lo, cc, dist, k):
-    if PM["pm"] is not None:
-        return PM["pm"].begin(lib, his, lo, cc, dist, k)
-    return lib.match_topk_many_begin(his, lo, cc, dist, k)
+    try:
+        if PM["pm"] is not None:
+            return PM["pm"].begin(lib, his, lo, cc, dist, k)
+        return lib.match_topk_many_begin(his, lo, cc, dist, k)
+    except RuntimeError as e:      # _lib.MadBackendError
+        if not _overflowed(e):
+            raise
+        return None
 
 
 def collect(lib, handle, his):
     t0 = time.perf_counter()
-    if PM["pm"] is not None:
-        corr, tops, stats = PM["pm"].finish(lib, handle)
-    else:
+    try:
+        if handle is None:      # the step's matches were not begun (begin_matches)
+            corr, tops, stats = 0, [], []
+        elif PM["pm"] is not None:
+            corr, tops, stats = PM["pm"].finish(lib, handle)
+        else:
+            corr, tops, stats = 0, [], []
+            for top, idx, st in lib.match_topk_many_finish(handle):
+                corr += st["n_corr"]
+                tops.append(top)
+                stats.append(st)
+    except RuntimeError as e:      # _lib.MadBackendError
+        if not _overflowed(e):
+            raise
         corr, tops, stats = 0, [], []
-        for top, idx, st in lib.match_topk_many_finish(handle):
-            corr += st["n_corr"]
-            tops.append(top)
-            stats.append(st)
     HOST_T["match_wait"] = HOST_T.get("match_wait", 0.0) + time.perf_counter() - t0
     for hi, st in zip(his, stats):
         if "n_hi" not in st:
@@ -292,28 +322,31 @@ def run_steps(lib, the_map, subs, cc, dist, k, set_groups, n_steps, after_step=N
             after_step(res[1])
         return res
 
-    for i in range(n_steps):
-        lo, his = built
-        t0 = time.perf_counter()
-        open_steps.append((begin_matches(lib, his, lo, cc, dist, k), his))
-        HOST_T["match_enqueue"] = HOST_T.get("match_enqueue", 0.0) + time.perf_counter() - t0
-        if i + 1 < n_steps:      # its group was last read by step i + 1 - depth, collected by now
-            built = enqueue_builds(lib, the_map, subs, set_groups[(i + 1) % depth])
-        if len(open_steps) > lag:
+    try:
+        for i in range(n_steps):
+            lo, his = built
+            t0 = time.perf_counter()
+            open_steps.append((begin_matches(lib, his, lo, cc, dist, k), his))
+            HOST_T["match_enqueue"] = HOST_T.get("match_enqueue", 0.0) + time.perf_counter() - t0
+            if i + 1 < n_steps:      # its group was last read by step i + 1 - depth, collected by now
+                built = enqueue_builds(lib, the_map, subs, set_groups[(i + 1) % depth])
+            if len(open_steps) > lag:
+                out = finish_oldest()
+        while open_steps:
             out = finish_oldest()
-    while open_steps:
-        out = finish_oldest()
+    except ResizeMapImages:      # raised by after_step on every rank at the same step: what is in flight is collected and dropped
+        while open_steps:
+            handle, his = open_steps.pop(0)
+            collect(lib, handle, his)
+        raise
     return out
 
 
-def refine_ccc_leg(lib, the_map, subs, tops, W, n_cand=8):
+def refine_ccc_leg(lib, the_map, subs, tops, W, n_cand=8, reps=3):
     """refinement + CCC reported as their own line (candidates/s).  The n_cand best poses of
     every subunit are refined against the map (a13, all candidates in one launch), then each refined copy is turned
     into a simulated density (a14-a15) and scored by CCC against the map (a16) without leaving the device."""
     lib.upload_density(the_map.grid, the_map.origin, W["vs"])
-    lib.timing_reset()
-    lib.synchronize()
-    t0 = time.perf_counter()
     n_done, n_conv, best, steps_total, vox = 0, 0, [], 0, 0
     # ONE device call for all subunits (mad_dock_refine_score): the poses of the n_cand best rows of each go in (MaD.py:451: hi point,
     # lo point, rotation), the atoms are placed, refined, turned into densities and scored on the device; the coordinates stay there
@@ -326,14 +359,20 @@ def refine_ccc_leg(lib, the_map, subs, tops, W, n_cand=8):
         rot.append(np.swapaxes(top[:m, 14:23].reshape(m, 3, 3), 1, 2).reshape(m, 9))      # rows hold x' = R (x - hi) + lo: rotate_atoms takes R^T
         owner += [si] * m
         vox += m * int(np.prod(sub.shape))
-    if owner:
+    dts = []
+    for _ in range(reps if owner else 0):      # the same call `reps` times, the median reported: the first one also sizes the library's buffers
+        lib.timing_reset()
+        lib.synchronize()
+        t0 = time.perf_counter()
         _, conv, last, ccc = lib.dock_refine_score([s_.atoms for s_ in subs], [s_.mass for s_ in subs], np.concatenate(hi_p), np.concatenate(lo_p),
                                                    np.concatenate(rot), W["res"], want_coords=False, cand_struct=np.array(owner, np.int32))
+        lib.synchronize()
+        dts.append(time.perf_counter() - t0)
+    if owner:
         n_done, n_conv = len(owner), int(np.sum(conv))
         steps_total = int(np.sum(np.asarray(last) + 1))
         best = [float(np.max(ccc[np.array(owner) == si])) for si in sorted(set(owner))]
-    lib.synchronize()
-    dt = time.perf_counter() - t0
+    dt = float(np.median(dts)) if dts else 1.0
     ms = {g: lib.timing_get(g)[0] for g in ("refine", "density", "ccc")}
     n_atoms = int(len(subs[0].atoms)) if subs else 0
     roofs = {}
@@ -347,7 +386,7 @@ def refine_ccc_leg(lib, the_map, subs, tops, W, n_cand=8):
     if ms["density"] > 0 and vox:      # splat + three separable blur passes (float64 read + write each) + float32 conversion
         a = (3 * 16 + 12) * vox / (ms["density"] * 1e-3) / 1e9
         roofs["density"] = dict(kernel="k_splat_b + k_blur_b x3 + k_to_f32_b + k_norm_b (all candidates per launch)", bound="hbm", achieved=a, peak=HBM_PEAK_GBS, unit="GB/s", frac=a / HBM_PEAK_GBS)
-    return dict(value=n_done / dt, unit="candidates/s", candidates=n_done, converged=n_conv, seconds=dt, atoms_per_candidate=n_atoms,
+    return dict(value=n_done / dt, unit="candidates/s", candidates=n_done, converged=n_conv, seconds=dt, seconds_each=[round(x, 5) for x in dts], atoms_per_candidate=n_atoms,
                 best_ccc_per_subunit=[round(float(b), 4) for b in best], kernel_ms=ms, roofline=roofs,
                 note="mad_dock_refine_score, one call for the candidates of all subunits: placement, refinement, density simulation and CCC on the "
                      "device, poses in and scores out (the refined coordinates are not fetched); not part of the headline metric")
@@ -460,6 +499,9 @@ def main():
                     "grid for all its matches (mad_set_batching): less device time per step, longer dependency chains")
     ap.add_argument("--repeat-anchors", action="store_true", help="feed every step the SAME anchor lists (rounds 1-3: the library then skips the "
                     "upload work of a set rebuilt with unchanged anchors).  Default: two listings of the same anchors alternate, every step uploads")
+    ap.add_argument("--rehearse-resize", type=int, default=0, metavar="ROWS", help="REHEARSAL (N > 1): after the set-up the wire images of one group's "
+                    "map build are cut to ROWS rows, so that the next import overflows (MAD_ENOSPC) and the ranks have to agree on sizing them again; the "
+                    "line reports map_image_resizes")
     ap.add_argument("--emulate-rank-of", type=int, default=0, metavar="N", help="REHEARSAL on one GPU: do the per-step work of rank 0 of an N-rank "
                     "job (its share of the map build, the import of all N shares, its subunits); the other ranks' map rows are built once, untimed.  "
                     "The line is labelled as an estimate and is not a multi-GPU measurement")
@@ -543,8 +585,14 @@ def main():
     def exchange(tops):
         """The step's second exchange: every rank receives every subunit's top-k poses (one fused all-gather of
         n_sub x k x 23 float64, mad_amd/dist.py).  It is started asynchronously and collected one step later, so it
-        overlaps the next step's kernels."""
-        return mdist.TopkExchange(tops, k, W["n_sub"], rank, world)
+        overlaps the next step's kernels.  This rank's overflow word (OVERFLOW) travels with it."""
+        return mdist.TopkExchange(tops, k, W["n_sub"], rank, world, status=OVERFLOW["seen"])
+
+    def finish_exchange(x):
+        got = x.finish()
+        if any(x.status):      # the same words on every rank, so every rank stops at this step
+            raise ResizeMapImages()
+        return got
 
     sharded = world > 1 or emu or use_dist      # use_dist at world 1 (MAD_DIST_FORCE): export -> RCCL all-gather -> import of the one share
 
@@ -580,24 +628,49 @@ def main():
     # its describe grid and a match its pair capacity from what the previous use of the same objects needed; the wire images
     # of a sharded map build are sized by a blocking first build), the way an allocator is warmed before a run.  The W
     # warm-up steps and the K timed steps that follow all do the full work.
-    for grp in set_groups:
-        for _ in range(2):
-            hot_path_step(lib, the_map, subs, cc, dist_thr, k, grp)
-    run_steps(lib, the_map, subs, cc, dist_thr, k, set_groups, args.warmup, after_step=lambda tops: exchange(tops).finish())
-    HOST_T.clear()
-    barrier()
-    t0 = time.perf_counter()
+    OVERFLOW["watch"] = world > 1
     pending = [None]
 
     def after_step(tops):      # the exchange of step i completes while step i + 1 runs
         if pending[0] is not None:
-            pending[0].finish()
+            last, pending[0] = pending[0], None
+            finish_exchange(last)
         pending[0] = exchange(tops)
 
-    corr, tops, stats = run_steps(lib, the_map, subs, cc, dist_thr, k, set_groups, args.steps, after_step=after_step)
-    gathered = pending[0].finish() if pending[0] is not None else []      # every step's exchange completes inside the timed region
-    barrier()
-    dt = time.perf_counter() - t0
+    def resize_map_images():
+        """Every rank, at the same point: nothing in flight, then the blocking sizing of every group's map images (a MAX
+        all-reduce each, dist.ShardedSetBuild.resize)."""
+        if pending[0] is not None:
+            pending[0].finish()
+            pending[0] = None
+        barrier()
+        for grp in set_groups:
+            grp[0].resize()
+        OVERFLOW["seen"] = 0
+        OVERFLOW["resizes"] += 1
+
+    for attempt in range(4):
+        try:
+            for grp in set_groups:
+                for _ in range(2):
+                    finish_exchange(exchange(hot_path_step(lib, the_map, subs, cc, dist_thr, k, grp)[1]))
+            if args.rehearse_resize and attempt == 0 and world > 1:      # see the option's help
+                barrier()
+                set_groups[1 % len(set_groups)][0].shrink_for_rehearsal(args.rehearse_resize)
+            run_steps(lib, the_map, subs, cc, dist_thr, k, set_groups, args.warmup, after_step=lambda tops: finish_exchange(exchange(tops)))
+            HOST_T.clear()
+            barrier()
+            t0 = time.perf_counter()
+            corr, tops, stats = run_steps(lib, the_map, subs, cc, dist_thr, k, set_groups, args.steps, after_step=after_step)
+            last, pending[0] = pending[0], None
+            gathered = finish_exchange(last) if last is not None else []      # every step's exchange completes inside the timed region
+            barrier()
+            dt = time.perf_counter() - t0
+            break
+        except ResizeMapImages:
+            resize_map_images()
+    else:
+        sys.exit("bench.py: the map's wire images overflowed again after %d re-sizings" % OVERFLOW["resizes"])
     host_overlapped = {k_: 1e3 * v / max(args.steps, 1) for k_, v in HOST_T.items()}
     if sharded:      # the pieces of build_enqueue that belong to the sharded map build, per call, over the whole run so far
         for grp in set_groups:
@@ -863,6 +936,7 @@ def main():
                        "topk_agrees_with_cpu_oracle_on": None if agree is None else ("every anchor of both octaves, all subunits (the full step) and the base-octave sample" if agree_whole is not None else "the base-octave sample"),
                        "topk_agrees_on_sample": agree,
                        "sharded_map_set_identical_to_unsharded": shard_check,
+                       "map_image_resizes": OVERFLOW["resizes"],      # times the ranks agreed to size the map's wire images again (0 unless rehearsed)
                        "setup_s": t_setup,
                        "setup_detail_s": {k_: round(v, 4) for k_, v in SETUP_T.items()}},
             "roofline": roof,

@@ -569,8 +569,8 @@ class Lib(object):
         pending = getattr(self, "_open_brackets", [])
         if not pending or pending[0] is not h:
             raise MadBackendError("MaD> match_topk_many_finish: brackets finish in the order they were begun")
+        self._open_brackets = pending[1:]      # the library closes the bracket whether or not one of its matches failed
         self._chk(self.dll.mad_match_topk_many_finish(self.ctx))
-        self._open_brackets = pending[1:]
         out = []
         for i in range(h["n"]):
             g = int(h["n_out"][i])

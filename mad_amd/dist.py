@@ -73,7 +73,10 @@ class TopkExchange(object):
         sets.append(st)
         return st
 
-    def __init__(self, tops, k, n_items_total, rank, world, group=None, device=None):
+    def __init__(self, tops, k, n_items_total, rank, world, group=None, device=None, status=0):
+        """`status`: one word of this rank's own (0 = its step went through) that travels with the rows; after `finish()`
+        `self.status` holds every rank's word -- how the ranks learn, without a collective of its own, that one of them has
+        to stop or re-size (bench.py: a map image that outgrew its wire buffer)."""
         import torch
         import torch.distributed as dist
         self.k, self.n_items, self.world = k, n_items_total, world
@@ -81,15 +84,17 @@ class TopkExchange(object):
         mine = list(tops) + [np.zeros((0, RESULT_COLS))] * (self.per_rank - len(tops))
         block, valid = pack_topk(mine, k)
         self.work = None
+        self.status = [int(status)]
         if world == 1 and not (dist.is_available() and dist.is_initialized()):
             self.local = (block, valid)
             return
         dev = device if device is not None else ("cuda" if dist.get_backend(group) == "nccl" else "cpu")
-        n = block.size + valid.size
+        n = block.size + valid.size + 1
         st = self.st = self._staging(n, world, dev)
         h = st["h_in"].numpy()
         h[:block.size] = block.reshape(-1)
-        h[block.size:] = valid
+        h[block.size:n - 1] = valid
+        h[n - 1] = float(int(status))
         self.n = n
         if dev == "cpu":      # gloo: flat tensors in host memory
             self.work = dist.all_gather_into_tensor(st["h_out"], st["h_in"], group=group, async_op=True)
@@ -112,6 +117,7 @@ class TopkExchange(object):
         else:
             self.work.wait()
         out = self.st["h_out"].numpy().reshape(self.world, self.n)
+        self.status = [int(x) for x in out[:, self.n - 1]]
         res = []
         for item in range(self.n_items):
             r, slot = owner_of(item, self.world), item // self.world
@@ -487,17 +493,29 @@ class ShardedSetBuild(object):
             t = torch.tensor([rows], dtype=torch.int64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
             rows_max = int(t.item())
-        self.cap_rows = rows_max + rows_max // 8 + 64
-        nbytes = self.lib.set_wire_bytes(self.cap_rows)
-        dev = "cpu" if self.backend == "gloo" else "cuda"
-        self.wire = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
-        self.gathered = torch.zeros(self.world * nbytes, dtype=torch.uint8, device=dev)
+        self._allocate(rows_max + rows_max // 8 + 64)
+        nbytes = self.wire.numel()
         if self.backend == "emulate":      # the other ranks' images, once
             for rr in range(self.world):
                 self._build_share(rr, into=tmp)
                 self.lib.set_export(tmp, self.cap_rows, device_ptr=self.gathered.data_ptr() + rr * nbytes)
             self.lib.synchronize()
             tmp.close()
+
+    def _allocate(self, cap_rows):
+        import torch
+        self.cap_rows = int(cap_rows)
+        nbytes = self.lib.set_wire_bytes(self.cap_rows)
+        dev = "cpu" if self.backend == "gloo" else "cuda"
+        self.wire = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+        self.gathered = torch.zeros(self.world * nbytes, dtype=torch.uint8, device=dev)
+
+    def shrink_for_rehearsal(self, cap_rows):
+        """Rehearsal of an overflow (bench.py --rehearse-resize, tests): wire images of `cap_rows` rows, as if an earlier, smaller
+        build had sized them.  The next import then reports MAD_ENOSPC at the first use of the full set and the ranks have to
+        agree on `resize()`.  Every rank calls it with the same value, nothing may be in flight."""
+        if self.sharded and self.backend != "emulate":
+            self._allocate(cap_rows)
 
     def build_job(self):
         """The (slots, coords, octave, subv, index, into) of this rank's part, for `lib.prepare_build_many`: the caller builds

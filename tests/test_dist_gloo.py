@@ -36,7 +36,11 @@ def _worker(rank, world, port, n_items, k, out_dir):
     flags = np.zeros(37, np.uint8)
     flags[rank::5] = 1
     red = mdist.or_reduce_flags(flags)
-    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), red=red, **{"item%d" % i: g for i, g in enumerate(got)})
+    # the status word that travels with the rows: rank 1 reports 7, every rank reads [0, 7] and the rows are what they were
+    x = mdist.TopkExchange(tops, k, n_items, rank, world, status=7 * rank)
+    again = x.finish()
+    assert all(np.array_equal(a, b) for a, b in zip(again, got))
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), red=red, status=np.array(x.status), **{"item%d" % i: g for i, g in enumerate(got)})
     dist.barrier()
     dist.destroy_process_group()
 
@@ -56,6 +60,7 @@ def test_all_gather_topk_two_ranks(tmp_path, n_items):
     want[1::5] = 1
     for o in outs:
         np.testing.assert_array_equal(o["red"], want)
+        np.testing.assert_array_equal(o["status"], [0, 7])
 
 
 def test_shard_round_robin_covers_everything():

@@ -181,11 +181,15 @@ def test_run_mad_on_the_frozen_c1_workload(tmp_path, monkeypatch, lib):
     assert float(best["CC"]) > 0.8
 
 
-def test_bench_on_two_ranks_shares_the_map_build_and_gathers_the_topk(tmp_path):
+@pytest.mark.parametrize("overflow", [False, True], ids=["sized", "image_overflows"])
+def test_bench_on_two_ranks_shares_the_map_build_and_gathers_the_topk(tmp_path, overflow):
     """`python bench.py --gpus 2 --workload c4` as the driver starts it (the parent spawns its ranks with torch.distributed.run), here
     with the collectives over gloo because the box has one GPU (MAD_DIST_BACKEND=gloo: both ranks share it).  The N > 1 path end to
     end in fresh child processes: the map set assembled from the two ranks' shares is bit for bit the set one GPU builds
-    (ShardedSetBuild: export -> all-gather -> import), and every subunit's top-k after the exchange equals the one-GPU run's."""
+    (ShardedSetBuild: export -> all-gather -> import), and every subunit's top-k after the exchange equals the one-GPU run's.
+    image_overflows: one group's wire images are cut to 64 rows after the set-up (--rehearse-resize), so an import inside the pipelined
+    steps reports MAD_ENOSPC; the ranks learn of it through the top-k exchange, drop what is in flight, size the images again
+    together and start over -- same checks, one re-sizing on the line."""
     import json
     import subprocess
     import sys
@@ -193,8 +197,8 @@ def test_bench_on_two_ranks_shares_the_map_build_and_gathers_the_topk(tmp_path):
     env = dict(os.environ, MAD_DIST_BACKEND="gloo", MAD_DIST_TIMEOUT_S="240", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
         env.pop(k, None)
-    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "c4", "--steps", "4", "--warmup", "1", "--no-cpu-baseline"],
-                       cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=600)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "c4", "--steps", "4", "--warmup", "1", "--no-cpu-baseline"] +
+                       (["--rehearse-resize", "64"] if overflow else []), cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-4000:])
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, p.stdout[-2000:]
@@ -204,3 +208,4 @@ def test_bench_on_two_ranks_shares_the_map_build_and_gathers_the_topk(tmp_path):
     assert d["one_gpu_same_workload"]["topk_identical_to_sharded_run"] is True
     assert len(d["config"]["correlations_per_step_by_rank"]) == 2 and min(d["config"]["correlations_per_step_by_rank"]) > 0
     assert d["value"] > 0 and d["ms_per_step"] > 0
+    assert d["config"]["map_image_resizes"] == (1 if overflow else 0)
