@@ -119,6 +119,7 @@ __device__ __forceinline__ unsigned s_pack_hh(unsigned a, unsigned b) { unsigned
 #define G2_NSTAGE 3
 #define G2_STAGE ((G2_BM + G2_BN) * G2_BK)
 #define G2_LDS (G2_NSTAGE * G2_STAGE + (G2_BM + G2_BN) * 4)
+static_assert(G2_BM == 256 && G2_BN == 128, "the tile arithmetic of k_corr_gemm2 shifts by these");
 
 // row pitch (bytes) of the candidate flags: one byte per mask word (32 columns) of the padded matrix, rows aligned for 4-byte reads
 __host__ __device__ __forceinline__ int64_t mad_cflag_pitch(int64_t ldc) { return (ldc / 32 + 3) & ~(int64_t)3; }
@@ -172,14 +173,14 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_corr_gemm2(GemmBatch G) {
     const bool g2_split = G.split_tail != 0;
     for (int j = 0; j < G.n_jobs; j++) {
         const GemmJob &J = G.job[j];
-        const int64_t hp = ((int64_t)*J.n_hi + 127) / 128 * 128, lp = ((int64_t)*J.n_lo + 127) / 128 * 128;
+        const int64_t hp = (((int64_t)*J.n_hi + 127) >> 7) << 7, lp = (((int64_t)*J.n_lo + 127) >> 7) << 7;
         if (hp * lp > J.cap_c) {
             if (blockIdx.x == 0 && tid == 0) J.status[ST_FLAG_C] = 1;
             continue;
         }
         // XCD x takes a contiguous run of the job's tiles in column-major order: ~1/8 of the lo rows against all hi rows, for
         // every job of the batch in turn -- the lo slice stays in its L2 from one match to the next
-        const int64_t tiles_m = (hp + G2_BM - 1) / G2_BM, tiles = tiles_m * (lp / G2_BN), per_xcd = (tiles + 7) / 8;
+        const int64_t tiles_m = (hp + G2_BM - 1) >> 8, tiles = tiles_m * (lp >> 7), per_xcd = (tiles + 7) >> 3;      // (G2_BM 256, G2_BN 128)
         const int64_t begin = per_xcd * xcd, end = begin + per_xcd < tiles ? begin + per_xcd : tiles;
         const int64_t cnt = end > begin ? end - begin : 0;
         const int64_t ldm = lp / 32, ldf = mad_cflag_pitch(lp);
@@ -268,17 +269,20 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_corr_gemm2(GemmBatch G) {
             // Epilogue: besides the int32 dot products of the candidates, every tile leaves one bit per correlation in `mask`
             // ([row][ldc / 32] words): set when the score MAY exceed cc.  The test is a float32 product with a relative margin of 4e-6
             // (dot > cc |h| |l| (1 - margin)), i.e. a superset of the reference's float64 `dot / (|h| |l|) > cc` (MaD.py:423); the pair
-            // kernels apply the exact expression to the flagged entries only (~0.1 % of the matrix) instead of dividing and comparing
-            // N_hi x N_lo times, and never read the rest of C.  The mask words are assembled on the scalar unit.
+            // kernels apply the exact expression to the flagged entries only (~0.2 % of the matrix) instead of dividing and comparing
+            // N_hi x N_lo times, and never read the rest of C.
+            // Round 4: a mask word is WRITTEN only where it has a bit, next to its candidate flag (`cflag`, zeroed by the caller; the pair
+            // kernels read a mask word only behind a set flag, so the rest of `mask` is never looked at and need not be initialised).  Per
+            // group of 4 rows x 64 columns the wave spends 12 vector instructions (convert, multiply, compare per entry; the compares land
+            // in scalar registers), three scalar ORs and ONE branch; two groups in three have no candidate and end there.  Before, every
+            // group paid four branches, eight scalar packs, eight v_writelane and a store: the epilogue was 36 % of a tile.
             if (row0 + wm * (MT * 16) < hp) {
-                int32_t *Ct = J.C + row0 * lp + col0;
-                uint32_t *Mt = J.mask + row0 * ldm + col0 / 32;
-                uint8_t *Ft = J.cflag + row0 * ldf + col0 / 32;
-                const unsigned lp32 = (unsigned)lp, ldm32 = (unsigned)ldm;
-                // byte offsets from the tile's (uniform) base, 32-bit: a tile spans 256 rows of at most 2^20 columns
-                const unsigned voff = ((unsigned)(wm * (MT * 16) + (lane >> 4) * 4) * lp32 + (unsigned)(wn * 64 + (lane & 15))) * 4u;
-                const unsigned moff = ((unsigned)(wm * (MT * 16) + (lane & 3) * 4) * ldm32 + (unsigned)(wn * 2 + (lane >> 2))) * 4u;      // lanes 0..7: row group, word
-                const unsigned ldf32 = (unsigned)ldf, foff = (unsigned)(wm * (MT * 16) + (lane & 3) * 4) * ldf32 + (unsigned)(wn * 2 + (lane >> 2));      // lanes 0..7, as moff
+                const unsigned lp32 = (unsigned)lp, ldm32 = (unsigned)ldm, ldf32 = (unsigned)ldf;
+                // the tile's bases, formed once and held in scalar registers (left to itself the compiler re-reads the job from the kernel
+                // arguments and repeats the 64-bit products in every rare branch)
+                unsigned long long ctb = (unsigned long long)(J.C + row0 * lp + col0), mtb = (unsigned long long)(J.mask + row0 * ldm + col0 / 32),
+                                   ftb = (unsigned long long)(J.cflag + row0 * ldf + col0 / 32);
+                asm volatile("" : "+s"(ctb), "+s"(mtb), "+s"(ftb));
                 float tl[4];
 #pragma unroll
                 for (int n = 0; n < 4; n++) {      // cc |l| moved towards "candidate" by the margin (|h| > 0, so the product moves with it)
@@ -286,26 +290,31 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_corr_gemm2(GemmBatch G) {
                     tl[n] = v - fabsf(v) * 4e-6f;
                 }
 #pragma unroll
-                for (int m = 0; m < MT; m++)
+                for (int m = 0; m < MT; m++) {
+                    const float4 th4 = *(const float4 *)&sT[wm * (MT * 16) + m * 16 + (lane >> 4) * 4];
+                    const float thv[4] = {th4.x, th4.y, th4.z, th4.w};
 #pragma unroll
                     for (int jj = 0; jj < 4; jj++) {
-                        const float th = sT[wm * (MT * 16) + m * 16 + (lane >> 4) * 4 + jj];
                         unsigned long long bal[4];
-                        bool some = false;      // (uniform: set inside the rare branches below, nothing to compute where there is no candidate)
-                        // the row's offsets are formed here, on the scalar unit, and not hoisted: 64 precomputed addresses spill
-                        unsigned rc = (unsigned)(m * 16 + jj) * lp32 * 4u, rm = (unsigned)(m * 16 + jj) * ldm32 * 4u;
-                        asm volatile("" : "+s"(rc), "+s"(rm));
-                        char *crow = (char *)Ct + (voff + rc);
+                        bool cand[4];
 #pragma unroll
                         for (int n = 0; n < 4; n++) {
-                            const int d = acc[m][n][jj];
-                            const bool cand = (float)d > th * tl[n];
-                            bal[n] = __ballot(cand);
-                            if (bal[n] != 0ull) {
-                                some = true;
-                                if (cand) *(int32_t *)(crow + n * 64) = d;
-                            }
+                            cand[n] = (float)acc[m][n][jj] > thv[jj] * tl[n];
+                            bal[n] = __ballot(cand[n]);
                         }
+                        if ((bal[0] | bal[1] | bal[2] | bal[3]) == 0ull) continue;      // (uniform)
+                        // the rest is the rare part: every address is formed here, from the tile's (uniform) bases and 32-bit offsets -- a tile
+                        // spans 256 rows of at most 2^20 columns
+                        unsigned rowt = (unsigned)(m * 16 + jj);      // (+ 4 x row group: the row within the wave's part of the tile)
+                        asm volatile("" : "+s"(rowt));      // formed here, on the scalar unit, and not hoisted: 32 x 3 precomputed offsets spill
+                        rowt += (unsigned)(wm * (MT * 16));
+                        typedef __attribute__((address_space(1))) char gchar;      // (global, not flat, stores)
+                        gchar *const crow = (gchar *)ctb + ((rowt + (unsigned)(lane >> 4) * 4u) * lp32 + (unsigned)(wn * 64 + (lane & 15))) * 4u;
+#pragma unroll
+                        for (int n = 0; n < 4; n++)
+                            if (cand[n]) *(__attribute__((address_space(1))) int32_t *)(crow + n * 64) = acc[m][n][jj];
+                        // the eight mask words of the group (4 row groups x 2 words of 32 columns) are cut from the four ballots on the
+                        // scalar unit and handed to lanes 0..7
                         int wd = 0;
 #define MAD_MASK_WORD(Gg, Hh) ((Gg) & 1 ? s_pack_hh((unsigned)(bal[2 * (Hh)] >> (32 * ((Gg) >> 1))), (unsigned)(bal[2 * (Hh) + 1] >> (32 * ((Gg) >> 1)))) \
                                         : s_pack_ll((unsigned)(bal[2 * (Hh)] >> (32 * ((Gg) >> 1))), (unsigned)(bal[2 * (Hh) + 1] >> (32 * ((Gg) >> 1)))))
@@ -314,15 +323,13 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_corr_gemm2(GemmBatch G) {
                         MAD_WRITELANE(0, 1, 4); MAD_WRITELANE(1, 1, 5); MAD_WRITELANE(2, 1, 6); MAD_WRITELANE(3, 1, 7);
 #undef MAD_WRITELANE
 #undef MAD_MASK_WORD
-                        if (lane < 8) *(uint32_t *)((char *)Mt + (moff + rm)) = (unsigned)wd;
-                        // where the pair kernels have to look at all: a byte per mask word, written only where the word has a bit
-                        // (0.2 % of the entries are candidates; the array arrives zeroed) -- by the lanes that hold the eight words
-                        if (some) {      // (uniform, and rare: the arithmetic stays inside)
-                            unsigned rf = (unsigned)(m * 16 + jj) * ldf32;
-                            asm volatile("" : "+s"(rf));
-                            if (lane < 8 && wd != 0) Ft[foff + rf] = 1;
+                        if (lane < 8 && wd != 0) {      // lane: row group lane & 3, word lane >> 2
+                            const unsigned r = rowt + (unsigned)(lane & 3) * 4u, wcol = (unsigned)(wn * 2 + (lane >> 2));
+                            *(__attribute__((address_space(1))) uint32_t *)((gchar *)mtb + (r * ldm32 + wcol) * 4u) = (unsigned)wd;
+                            ((__attribute__((address_space(1))) uint8_t *)ftb)[r * ldf32 + wcol] = 1;
                         }
                     }
+                }
             }
             G2_STAMP(5);
             __syncthreads();      // the norms and the last stages have been read: the next tile may overwrite them
@@ -335,7 +342,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_corr_gemm2(GemmBatch G) {
         // second round that costs a third of the launch (tools/probe_gemm_sizes.py: 512 tiles 26.5 us, 568 tiles 39.3 us) -- is dealt
         // in halves of a tile (128 x 128) when that spreads it over more of the XCD's workgroups: twice as many, each on a CU of its
         // own for half as long.  int32 sums are exact under any split.
-        const int64_t full = g2_split ? cnt / nslot * nslot : cnt, rem = cnt - full;
+        // (tile numbers fit 32 bits -- the matrix has fewer than 2^31 entries -- and a 32-bit division is a tenth of a 64-bit one)
+        const int64_t full = g2_split ? (int64_t)((unsigned)cnt / (unsigned)nslot * (unsigned)nslot) : cnt, rem = cnt - full;
         // (quarters -- a third instantiation of the tile -- were built and measured: 37.0 us per C3 launch against 36.1 with halves
         // only, 39.8 without the split: the extra spills cost what the finer deal gains)
         const int parts = rem > 0 && 2 * rem <= nslot ? 2 : 1;
@@ -343,13 +351,14 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_corr_gemm2(GemmBatch G) {
         for (; t < base + units; t += nslot) {
             const int64_t u = t - base;
             if (parts == 1 || u < full) {
-                const int64_t tile = begin + u, row0 = (tile % tiles_m) * G2_BM, col0 = (tile / tiles_m) * G2_BN;
+                const unsigned tile = (unsigned)(begin + u), tcol = tile / (unsigned)tiles_m;
+                const int64_t row0 = (int64_t)(tile - tcol * (unsigned)tiles_m) * G2_BM, col0 = (int64_t)tcol * G2_BN;
                 // (a set's last, odd block of 128 rows: the upper half of a tile is all there is)
                 if (row0 + G2_BM / 2 >= hp) run_tile(std::integral_constant<int, 4>(), row0, col0);
                 else run_tile(std::integral_constant<int, 8>(), row0, col0);
             } else {
-                const int64_t h = u - full, tile = begin + full + h / parts;
-                const int64_t row0 = (tile % tiles_m) * G2_BM + (h % parts) * (G2_BM / parts), col0 = (tile / tiles_m) * G2_BN;
+                const unsigned h = (unsigned)(u - full), tile = (unsigned)(begin + full) + h / 2u, tcol = tile / (unsigned)tiles_m;      // (parts == 2)
+                const int64_t row0 = (int64_t)(tile - tcol * (unsigned)tiles_m) * G2_BM + (h & 1u) * (G2_BM / 2), col0 = (int64_t)tcol * G2_BN;
                 if (row0 >= hp) continue;      // (below a set's last, odd block of 128 rows: nothing)
                 run_tile(std::integral_constant<int, 4>(), row0, col0);
             }

@@ -1016,6 +1016,12 @@ __global__ __launch_bounds__(DSC_THREADS, TAB ? DSC_OCC_TAB : DSC_OCC) void k_de
     FieldDev F;
     F.tex = oct == 1 ? F1.tex : F0.tex; F.nx = oct == 1 ? F1.nx : F0.nx; F.ny = oct == 1 ? F1.ny : F0.ny; F.nz = oct == 1 ? F1.nz : F0.nz;
     F.tex4 = oct == 1 ? F1.tex4 : F0.tex4;
+#ifdef DSC_TEX_AUX      // probe builds (tools/build_variant.sh -DDSC_TEX_AUX=n): the texel gathers as buffer loads with cache-policy bits n (1 sc0, 2 nt, 16 sc1)
+    const __amdgpu_buffer_rsrc_t tex_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)F.tex4, 0, F.nx * F.ny * F.nz * 4, 0x00020000);
+#define DSC_TEX4(at) ((unsigned)__builtin_amdgcn_raw_buffer_load_b32(tex_rsrc, (int)((at) * 4u), 0, DSC_TEX_AUX))
+#else
+#define DSC_TEX4(at) (F.tex4[at])
+#endif
     const double *Rrow = A.row_R + 9 * row;
     DSC_STAMP(1);
 
@@ -1077,7 +1083,7 @@ __global__ __launch_bounds__(DSC_THREADS, TAB ? DSC_OCC_TAB : DSC_OCC) void k_de
                         n0 = min(max(n0, 0), F.nx - 1); n1 = min(max(n1, 0), F.ny - 1); n2 = min(max(n2, 0), F.nz - 1);
                     }
                     const unsigned at = mad_u24(mad_u24((unsigned)n0, (unsigned)F.ny, (unsigned)n1), (unsigned)F.nz, (unsigned)n2);      // nx ny < 2^24 (checked at allocation)
-                    if (TAB) { qi[i] = at; q4[i] = F.tex4[at]; }
+                    if (TAB) { qi[i] = at; q4[i] = DSC_TEX4(at); }
                     else t[i] = F.tex[at];
                     unsure |= safe ? 0u : (1u << i);
                 }
@@ -1089,7 +1095,7 @@ __global__ __launch_bounds__(DSC_THREADS, TAB ? DSC_OCC_TAB : DSC_OCC) void k_de
                 for (int i = 0; i < PS; i++)
                     if (unsure & (1u << i)) {
                         const unsigned at = exact_index(pass * PS + i, &oob);
-                        if (TAB) { qi[i] = at; q4[i] = F.tex4[at]; }
+                        if (TAB) { qi[i] = at; q4[i] = DSC_TEX4(at); }
                         else t[i] = F.tex[at];
                     }
             }
