@@ -249,7 +249,8 @@ int mad_set_batching(mad_ctx *ctx, int on);
 /* Tuning values that change speed, never results.  "pose_split" (-1 auto: subunits of more than 512 anchors; 0 off; 1 on): the
  * pose search of mad_match_topk* brackets the best-scoring pairs first and, in a second launch, abandons every other pair as
  * soon as its running upper bound falls below the k-th lower bound of the first batch.  "pose_split_min": that first batch
- * holds at least this many pairs (default 4096) and at least 64 k. "ori_queue" / "dsc_queue": entries in use of the queues through which k_orient / k_describe hand the
+ * holds at least this many pairs (default 4096) and at least 64 k.  "pose_mx" (0 default, 1): the bracket of hi clouds of up to 512
+ * points with its coarse map on the matrix cores, four pairs per wave (k_pose_bounds_mx; measured slower, kept for comparison).  "ori_queue" / "dsc_queue": entries in use of the queues through which k_orient / k_describe hand the
  * directions their fast classifiers cannot decide to the exact one (defaults: all 512 / 768); a small value drives the kernels'
  * full-queue paths for every anchor / row -- a test hook, the results are the same. */
 int mad_set_option(mad_ctx *ctx, const char *name, double value);

@@ -63,6 +63,7 @@ extern "C" int mad_init(int device, mad_ctx **out) {
     ctx->batch_gemm = getenv("MAD_GEMM_BATCH") != nullptr;
     if (getenv("MAD_POSE_SPLIT_MIN")) ctx->pose_split_min = atoll(getenv("MAD_POSE_SPLIT_MIN"));
     if (getenv("MAD_POSE_SPLIT")) ctx->pose_split = atoi(getenv("MAD_POSE_SPLIT"));
+    if (getenv("MAD_POSE_MX")) ctx->pose_mx = atoi(getenv("MAD_POSE_MX")) != 0;
     if (getenv("MAD_BALL")) ctx->dsc_ball = atoi(getenv("MAD_BALL")) != 0;      // k_describe_ball for the base-octave anchors (off by default: DESIGN.md section 6d)
     ctx->device = device;
     ctx->n_cu = prop.multiProcessorCount;

@@ -118,7 +118,7 @@ __device__ __forceinline__ unsigned s_pack_hh(unsigned a, unsigned b) { unsigned
 #define G2_BK 64
 #define G2_NSTAGE 3
 #define G2_STAGE ((G2_BM + G2_BN) * G2_BK)
-#define G2_LDS (G2_NSTAGE * G2_STAGE + (G2_BM + G2_BN) * 4)
+#define G2_LDS (G2_NSTAGE * G2_STAGE + 2 * (G2_BM + G2_BN) * 4)      // three stages + two norm buffers (the tile in its K loop, the next one)
 static_assert(G2_BM == 256 && G2_BN == 128, "the tile arithmetic of k_corr_gemm2 shifts by these");
 
 // row pitch (bytes) of the candidate flags: one byte per mask word (32 columns) of the padded matrix, rows aligned for 4-byte reads
@@ -171,6 +171,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_corr_gemm2(GemmBatch G) {
     const int ld_row = lane >> 2, ld_chunk = ((lane & 3) ^ ((lane >> 4) & 3)) * 16;
     const int rd_off = (lane & 15) * 64 + ((((lane >> 4) ^ ((lane & 15) >> 2)) & 3) * 16);
     const bool g2_split = G.split_tail != 0;
+    int nbuf = 0;      // which of the two norm buffers the tile in its K loop uses
     for (int j = 0; j < G.n_jobs; j++) {
         const GemmJob &J = G.job[j];
         const int64_t hp = (((int64_t)*J.n_hi + 127) >> 7) << 7, lp = (((int64_t)*J.n_lo + 127) >> 7) << 7;
@@ -185,38 +186,62 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_corr_gemm2(GemmBatch G) {
         const int64_t cnt = end > begin ? end - begin : 0;
         const int64_t ldm = lp / 32, ldf = mad_cflag_pitch(lp);
         // One tile of MT x 16 rows per wave-row (MT = 8: the 256 x 128 tile; MT = 4: its upper or lower half, 128 x 128, a wave owning
-        // 64 x 64) -- the same stages, fragment layout and epilogue.
-        auto run_tile = [&](auto mt_tag, const int64_t row0, const int64_t col0) {
-            constexpr int MT = decltype(mt_tag)::value, NA = MT / 2;      // NA: 16-row blocks of A a wave stages per K stage
-            G2_STAMP(1);
-            // |h| per row, cc |l| per column (zero rows count as norm 1, MaD.py:416).  Plain loads, before any LDS-DMA is in
-            // flight: the compiler drains the vector-memory counter completely at their first use.
-            {
+        // 64 x 64) -- the same stages, fragment layout and epilogue.  A tile goes through three phases:
+        //   start(tile)    its norms into one of two norm buffers, this lane's source rows, the LDS-DMA pieces of its first two K stages
+        //   the K loop     (its first barrier is where the norms and stage 0 become visible to everybody)
+        //   the epilogue   registers and the norm buffer only -- no stage of LDS
+        // and the workgroup's NEXT tile is started between the K loop and the epilogue of the current one, so that its first stages
+        // (3 700 clocks of L2 / HBM latency, in-kernel stamps) fly under the epilogue (6 500 clocks) instead of in front of its K loop.
+        const int8_t *srcA[4], *srcB[2];      // this lane's source rows of the tile in its K loop (rewritten by start(next) once that loop is over)
+        auto start = [&](const int na, const int64_t row0, const int64_t col0, const int buf, auto norms_last) {      // na = MT / 2: 16-row blocks of A a wave stages per K stage
+            float *const sN = sT + buf * (G2_BM + G2_BN);
+            // |h| per row, cc |l| per column (zero rows count as norm 1, MaD.py:416).  Plain loads: the compiler drains the
+            // vector-memory counter completely at their first use, so they come BEFORE the LDS-DMA pieces when an epilogue follows (it
+            // must not wait for the pieces), and AFTER them for a workgroup's first tile of a job (nothing to do but wait: one round trip
+            // instead of two).
+            auto norms = [&]() {
                 const int64_t r = row0 + tid < hp ? row0 + tid : hp - 1;
                 const double v = J.hn[r];
-                sT[tid] = (float)(v > 0 ? v : 1.0);
+                sN[tid] = (float)(v > 0 ? v : 1.0);
                 if (tid < G2_BN) {
                     const double u = J.ln[col0 + tid];
-                    sT[G2_BM + tid] = (float)(G.cc * (u > 0 ? u : 1.0));
+                    sN[G2_BM + tid] = (float)(G.cc * (u > 0 ? u : 1.0));
                 }
-            }
-            // this lane's source rows: blocks w, w + 4, ... of A (rows past the last 128-row block of a set with an
-            // odd number of them are read from its last row and never stored), blocks w, w + 4 of B
-            const int8_t *src[NA + 2];
+            };
+            if (!decltype(norms_last)::value) norms();
+            // blocks w, w + 4, ... of A (rows past the last 128-row block of a set with an odd number of them are read from its
+            // last row and never stored), blocks w, w + 4 of B
 #pragma unroll
-            for (int i = 0; i < NA; i++) {
+            for (int i = 0; i < 4; i++) {
                 const int64_t r = row0 + (w + 4 * i) * 16 + ld_row;
-                src[i] = J.A + (r < hp ? r : hp - 1) * K + ld_chunk;
+                srcA[i] = J.A + (r < hp ? r : hp - 1) * K + ld_chunk;
             }
 #pragma unroll
-            for (int i = 0; i < 2; i++) src[NA + i] = J.B + (col0 + (w + 4 * i) * 16 + ld_row) * K + ld_chunk;
+            for (int i = 0; i < 2; i++) srcB[i] = J.B + (col0 + (w + 4 * i) * 16 + ld_row) * K + ld_chunk;
+#pragma unroll
+            for (int s = 0; s < 2; s++) {
+                if (s >= n_k) break;
+                int8_t *slot = g2_smem + s * G2_STAGE;
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    if (i < na) glds16(srcA[i] + s * G2_BK, slot + (w + 4 * i) * 1024);
+#pragma unroll
+                for (int i = 0; i < 2; i++) glds16(srcB[i] + s * G2_BK, slot + (16 + w + 4 * i) * 1024);
+            }
+            if (decltype(norms_last)::value) norms();
+        };
+        // K loop + start of the next tile (next_na == 0: none) + epilogue
+        auto run_tile = [&](auto mt_tag, const int64_t row0, const int64_t col0, const int buf, const int next_na, const int64_t next_row0, const int64_t next_col0) {
+            constexpr int MT = decltype(mt_tag)::value, NA = MT / 2;
+            const float *const sN = sT + buf * (G2_BM + G2_BN);
+            G2_STAMP(1);
             auto issue = [&](int s) {
                 int8_t *slot = g2_smem + (s % G2_NSTAGE) * G2_STAGE;
                 const int k0 = s * G2_BK;
 #pragma unroll
-                for (int i = 0; i < NA; i++) glds16(src[i] + k0, slot + (w + 4 * i) * 1024);
+                for (int i = 0; i < NA; i++) glds16(srcA[i] + k0, slot + (w + 4 * i) * 1024);
 #pragma unroll
-                for (int i = 0; i < 2; i++) glds16(src[NA + i] + k0, slot + (16 + w + 4 * i) * 1024);
+                for (int i = 0; i < 2; i++) glds16(srcB[i] + k0, slot + (16 + w + 4 * i) * 1024);
             };
             v4i acc[MT][4];
 #pragma unroll
@@ -224,18 +249,17 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_corr_gemm2(GemmBatch G) {
 #pragma unroll
                 for (int n = 0; n < 4; n++) acc[m][n] = (v4i){0, 0, 0, 0};
             G2_STAMP(2);
-            issue(0);
-            if (n_k > 1) issue(1);
             // One stage: wait for its bytes, barrier, the fragment reads up front, then the MFMAs with the LDS-DMA pieces of stage
             // s + 2 spread between them.  The order is pinned with sched_group_barrier: left alone the
             // compiler keeps two A fragments live, waits for lgkmcnt(0) five times a stage, and issues the pieces in a burst
             // right behind the barrier, next to the reads, where a piece costs most to issue (1 640 clocks per stage for the two
             // workgroups of a CU against 1 024 of MFMA issue, in-kernel stamps).
+            // (the counted waits: the pieces of the stage after this one may still be in flight -- NA + 2 per wave; stores of the
+            // previous tile's epilogue that are still on their way only make a wait longer, the loads return in order)
             auto stage = [&](int s, auto more) {
-                if (decltype(more)::value || s + 1 < n_k) {      // the pieces of the stage after this one may still be in flight
-                    if (MT == 8) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");      // NA + 2 pieces per stage and wave
-                    else if (MT == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+                if (decltype(more)::value || s + 1 < n_k) {
+                    if (MT == 8) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
                 } else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();      // stage s has landed for everybody; everybody has read stage s - 1, whose slot is filled next
                 const int8_t *slot = g2_smem + (s % G2_NSTAGE) * G2_STAGE;
@@ -256,7 +280,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_corr_gemm2(GemmBatch G) {
                 for (int m = 0; m < MT; m++) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                   // MFMA
                     if (m + 2 < MT) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                   // DS read
-                    if (decltype(more)::value && m < NA + 2) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // one LDS-DMA piece (VMEM read); a quarter tile's third piece falls where it may
+                    if (decltype(more)::value && m < NA + 2) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // one LDS-DMA piece (VMEM read)
                 }
             };
             for (int s = 0; s + 2 < n_k; s++) {
@@ -266,6 +290,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_corr_gemm2(GemmBatch G) {
             stage(n_k - 2, std::false_type());      // (K is a multiple of 128: at least two stages)
             stage(n_k - 1, std::false_type());
             G2_STAMP(4);
+            __syncthreads();      // the last stages have been read by everybody: the next tile's first stages may land on them
+            if (next_na) start(next_na, next_row0, next_col0, buf ^ 1, std::false_type());
+            G2_STAMP(5);
             // Epilogue: besides the int32 dot products of the candidates, every tile leaves one bit per correlation in `mask`
             // ([row][ldc / 32] words): set when the score MAY exceed cc.  The test is a float32 product with a relative margin of 4e-6
             // (dot > cc |h| |l| (1 - margin)), i.e. a superset of the reference's float64 `dot / (|h| |l|) > cc` (MaD.py:423); the pair
@@ -286,12 +313,12 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_corr_gemm2(GemmBatch G) {
                 float tl[4];
 #pragma unroll
                 for (int n = 0; n < 4; n++) {      // cc |l| moved towards "candidate" by the margin (|h| > 0, so the product moves with it)
-                    const float v = sT[G2_BM + wn * 64 + n * 16 + (lane & 15)];
+                    const float v = sN[G2_BM + wn * 64 + n * 16 + (lane & 15)];
                     tl[n] = v - fabsf(v) * 4e-6f;
                 }
 #pragma unroll
                 for (int m = 0; m < MT; m++) {
-                    const float4 th4 = *(const float4 *)&sT[wm * (MT * 16) + m * 16 + (lane >> 4) * 4];
+                    const float4 th4 = *(const float4 *)&sN[wm * (MT * 16) + m * 16 + (lane >> 4) * 4];
                     const float thv[4] = {th4.x, th4.y, th4.z, th4.w};
 #pragma unroll
                     for (int jj = 0; jj < 4; jj++) {
@@ -331,8 +358,6 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_corr_gemm2(GemmBatch G) {
                     }
                 }
             }
-            G2_STAMP(5);
-            __syncthreads();      // the norms and the last stages have been read: the next tile may overwrite them
             G2_STAMP(6);
 #ifdef MAD_PROBE_STAMPS
             first_tile = false;
@@ -348,20 +373,30 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_corr_gemm2(GemmBatch G) {
         // only, 39.8 without the split: the extra spills cost what the finer deal gains)
         const int parts = rem > 0 && 2 * rem <= nslot ? 2 : 1;
         const int64_t units = full + rem * parts;
-        for (; t < base + units; t += nslot) {
-            const int64_t u = t - base;
-            if (parts == 1 || u < full) {
-                const unsigned tile = (unsigned)(begin + u), tcol = tile / (unsigned)tiles_m;
-                const int64_t row0 = (int64_t)(tile - tcol * (unsigned)tiles_m) * G2_BM, col0 = (int64_t)tcol * G2_BN;
-                // (a set's last, odd block of 128 rows: the upper half of a tile is all there is)
-                if (row0 + G2_BM / 2 >= hp) run_tile(std::integral_constant<int, 4>(), row0, col0);
-                else run_tile(std::integral_constant<int, 8>(), row0, col0);
-            } else {
+        // this workgroup's tiles of the job, one after the other: unit t -> (rows, columns, MT / 2), na == 0 when the job has no more
+        auto tile_of = [&](int64_t &tt, int64_t &row0, int64_t &col0) -> int {
+            for (; tt < base + units; tt += nslot) {
+                const int64_t u = tt - base;
+                if (parts == 1 || u < full) {
+                    const unsigned tile = (unsigned)(begin + u), tcol = tile / (unsigned)tiles_m;
+                    row0 = (int64_t)(tile - tcol * (unsigned)tiles_m) * G2_BM; col0 = (int64_t)tcol * G2_BN;
+                    return row0 + G2_BM / 2 >= hp ? 2 : 4;      // (a set's last, odd block of 128 rows: the upper half of a tile is all there is)
+                }
                 const unsigned h = (unsigned)(u - full), tile = (unsigned)(begin + full) + h / 2u, tcol = tile / (unsigned)tiles_m;      // (parts == 2)
-                const int64_t row0 = (int64_t)(tile - tcol * (unsigned)tiles_m) * G2_BM + (h & 1u) * (G2_BM / 2), col0 = (int64_t)tcol * G2_BN;
-                if (row0 >= hp) continue;      // (below a set's last, odd block of 128 rows: nothing)
-                run_tile(std::integral_constant<int, 4>(), row0, col0);
+                row0 = (int64_t)(tile - tcol * (unsigned)tiles_m) * G2_BM + (h & 1u) * (G2_BM / 2); col0 = (int64_t)tcol * G2_BN;
+                if (row0 < hp) return 2;      // (else: below a set's last, odd block of 128 rows -- nothing)
             }
+            return 0;
+        };
+        int64_t row0 = 0, col0 = 0, nrow0 = 0, ncol0 = 0;
+        int na = tile_of(t, row0, col0);
+        if (na) start(na, row0, col0, nbuf, std::false_type());      // (std::true_type() measured: 33.4 us per C3 launch against 32.8 -- two registers spill)
+        while (na) {
+            int64_t tn = t + nslot;
+            const int nna = tile_of(tn, nrow0, ncol0);
+            if (na == 4) run_tile(std::integral_constant<int, 8>(), row0, col0, nbuf, nna, nrow0, ncol0);
+            else run_tile(std::integral_constant<int, 4>(), row0, col0, nbuf, nna, nrow0, ncol0);
+            t = tn; na = nna; row0 = nrow0; col0 = ncol0; nbuf ^= 1;
         }
         base += units;
     }
@@ -1564,6 +1599,215 @@ __global__ __launch_bounds__(PB_THREADS) void k_pose_bounds(const int32_t *__res
     }
 }
 
+// ---- the same bracket with the coarse map on the matrix cores ---------------------------------------------------------------
+//
+// The coarse phase of k_pose_bounds spends 9 of its ~26 vector instructions per 64 points on v = M c + t.  That map is a small
+// matrix product, and v_mfma_f32_16x16x4_f32 does 16 x 16 of them per instruction if the operands are laid out for it:
+//   A (16 x 4), row 4 q + i = row i of [M | t] of pair q of FOUR pairs (i = 3: zeros);  B (4 x 16), column n = (x, y, z, 1) of point n
+//   D (16 x 16): lane l holds D[4 (l / 16) + i][l % 16], i = 0..3 = the voxel coordinates of point l % 16 under pair l / 16
+// so a wave works on four pairs at once, one pair per group of 16 lanes, 16 points per instruction, and every lane ends up with one
+// whole mapped point -- the rest of the phase (voxel, LDS bitmap, ballot compaction) runs on full lanes as before, minus the nine
+// fused multiply-adds.  float32 with another summation order than the fmaf chain: the bitmaps' slack (0.02 A against < 1e-3 A,
+// PoseBits) covers any of them, and the bracket L <= count <= U is all the selection needs (a voxel of difference moves a bound by
+// one, never the top-k).  The wave's queue holds (point | pair << 10) of all four pairs; the fine phase reads each entry's map from
+// the four records in LDS.  A group of four pairs is worked in two halves of the point blocks, so that the queue (one half, all
+// passing: 2 NB sets) stays small and the lookups of one half fly under the coarse phase of the next.  SPLIT = false only (nothing
+// is abandoned); NB <= 8.
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+template <int NB>
+__global__ __launch_bounds__(PB_THREADS) void k_pose_bounds_mx(const int32_t *__restrict__ status, int64_t cap_pairs, const PosePair *__restrict__ rec,
+                                                               const double *__restrict__ hi_cloud, PoseBits B, const unsigned *__restrict__ bits,
+                                                               PoseCoarse C, const unsigned *__restrict__ bits_c, int32_t *__restrict__ lower,
+                                                               unsigned short *__restrict__ upper, int32_t *__restrict__ hist, int nbins) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    if (status[ST_FLAG_C] || status[ST_FLAG_PAIRS]) return;
+    constexpr int NBLK = NB * 4, HALF = NBLK / 2;      // blocks of 16 points; a half of them per coarse / fine turn
+    constexpr int QSETS = 2 * NB;                      // the queue: one half with every point passing
+    constexpr int NF = NB / 2;                         // sets of 64 queued entries whose lookups are in flight (more: looked up on the spot)
+    constexpr int NWV = PB_THREADS / MAD_WAVE;
+    unsigned *lb = (unsigned *)smem;                                           // coarse bitmap
+    float4 *clf = (float4 *)(smem + pad16((size_t)C.n_words * 4));             // hi cloud, float32
+    const int64_t n_pairs = min((int64_t)status[ST_NPAIRS], cap_pairs);
+    const int l_hi = status[ST_LHI];
+    unsigned char *after = smem + pad16((size_t)C.n_words * 4) + pad16((size_t)(l_hi + 4) * 16);
+    const int wv = threadIdx.x >> 6;
+    unsigned short *queue = (unsigned short *)after + wv * ((QSETS + 1) * MAD_WAVE);
+    unsigned short *dump = queue + QSETS * MAD_WAVE;      // 64 entries behind the wave's queue, never read
+    float *wrec = (float *)(after + (size_t)NWV * (QSETS + 1) * MAD_WAVE * 2) + wv * 48;      // the fine maps of the wave's four pairs
+    int *lh = (int *)(after + (size_t)NWV * (QSETS + 1) * MAD_WAVE * 2 + (size_t)NWV * 192);
+    for (int i = threadIdx.x; i < nbins; i += PB_THREADS) lh[i] = 0;
+    stage_lds(lb, bits_c, (size_t)C.n_words * 4);
+    for (int i = threadIdx.x; i < l_hi; i += PB_THREADS)
+        clf[i] = make_float4((float)hi_cloud[3 * i], (float)hi_cloud[3 * i + 1], (float)hi_cloud[3 * i + 2], 0.f);
+    __syncthreads();
+    const int lane = lane_id(), g = lane >> 4, c16 = lane & 15;
+    const int64_t wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * NWV + wv));
+    const int64_t nwaves = (int64_t)gridDim.x * NWV;
+
+    // B operands: component g of point 16 j + c16 (g = 3: the 1 that takes the translation); a lane beyond the cloud holds a NaN,
+    // which maps to NaN and converts to voxel 0 -- on the bitmap's outermost layer, never marked
+    float bp[NBLK];
+#pragma unroll
+    for (int j = 0; j < NBLK; j++) {
+        const int a = 16 * j + c16;
+        const float4 c = clf[min(a, max(l_hi - 1, 0))];
+        const float v = g == 0 ? c.x : (g == 1 ? c.y : (g == 2 ? c.z : 1.0f));
+        bp[j] = a < l_hi ? v : __int_as_float(0x7fc00000);
+    }
+    // A operand of this lane: entry (i, k = g) of [M | t] of pair q_a, i = c16 % 4, q_a = c16 / 4 -- one float of PoseVox per lane
+    const int q_a = c16 >> 2, i_a = c16 & 3;
+    const int a_off = g < 3 ? i_a * 3 + g : 9 + i_a;      // PoseVox: m[9] (row-major), t[3]
+    auto pair_of = [&](int64_t grp, int q) -> int64_t { return wave + (4 * grp + q) * nwaves; };
+    // (both loads are unconditional, at a clamped pair: a load inside a branch makes the compiler lose count of what is in flight and
+    // wait for everything -- the lookups of the previous half included -- at the next use of any loaded value)
+    auto load_a = [&](int64_t grp) -> float {
+        const int64_t p = min(pair_of(grp, q_a), n_pairs - 1);
+        return ((const float *)&rec[p].vc)[i_a < 3 ? a_off : 0];
+    };
+    auto valid_a = [&](int64_t grp) -> bool { return pair_of(grp, q_a) < n_pairs && i_a < 3; };      // else 0: a pair past the end maps every point to voxel 0
+    auto load_f = [&](int64_t grp) -> float {      // lanes 0..47: float lane % 12 of the fine map of pair lane / 12
+        const int64_t p = min(pair_of(grp, min(lane / 12, 3)), n_pairs - 1);
+        return ((const float *)&rec[p].vf)[lane % 12];
+    };
+    const int dx1 = C.B.dim[0] - 1, dy1 = C.B.dim[1] - 1, dz1 = C.B.dim[2] - 1;
+    const int fx1 = B.dim[0] - 1, fy1 = B.dim[1] - 1, fz1 = B.dim[2] - 1;
+    const unsigned ent0 = (unsigned)c16 | ((unsigned)g << 10);
+    const v4f zero4 = {0.f, 0.f, 0.f, 0.f};
+
+    // coarse phase of one half of a group -> number of queued entries (wave-uniform)
+    auto coarse = [&](const float a_op, auto half_tag) -> int {
+        constexpr int half = decltype(half_tag)::value;      // (a constant: bp[] must be indexed with constants to stay in registers)
+        int nq = 0;
+        // four blocks (64 points x 4 pairs) at a time in straight-line code: the four matrix instructions first, then the four chains
+        // voxel -> LDS word -> bit side by side, then the queue writes
+#pragma unroll
+        for (int jb = 0; jb < HALF / 4; jb++) {
+            const int j0 = half * HALF + 4 * jb;
+            if (16 * j0 >= l_hi) break;           // wave-uniform; a block past the cloud inside a batch holds NaNs (voxel 0, never marked)
+            v4f d[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++) d[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_op, bp[half * HALF + 4 * jb + t], zero4, 0, 0, 0);
+            asm volatile("" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]));      // four results in four register quads: issued back to back (left alone the compiler reuses one quad and waits four times)
+            unsigned cw[4];
+            int jz[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const int jx = clamp0(cvt_floor(d[t][0]), dx1), jy = clamp0(cvt_floor(d[t][1]), dy1);
+                jz[t] = clamp0(cvt_floor(d[t][2]), dz1);
+                cw[t] = lb[mad_u24s(mad_u24s((unsigned)jx, (unsigned)C.B.dim[1], (unsigned)jy), (unsigned)C.B.wz, (unsigned)(jz[t] >> 5))];
+            }
+            asm volatile("" : "+v"(cw[0]), "+v"(cw[1]), "+v"(cw[2]), "+v"(cw[3]));      // (likewise: the four LDS reads go out together)
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const bool pass = __builtin_amdgcn_ubfe(cw[t], (unsigned)jz[t], 1u) != 0u;
+                const unsigned long long bal = __ballot(pass);
+                const int below = __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+                const int idx = pass ? nq + below : QSETS * MAD_WAVE + lane;      // a lane that does not pass writes to its dump slot
+                queue[idx] = (unsigned short)(ent0 + 16u * (unsigned)(j0 + t));
+                nq += __popcll(bal);
+            }
+        }
+        return nq;
+    };
+    // fine phase of the queue entries [64 s0, min(64 (s0 + NF), n)): the lookups go out ...
+    auto lookup = [&](const int s0, const int n, uint2 (&w)[NF], int (&bit)[NF]) {
+        __builtin_amdgcn_wave_barrier();      // the queue and the records were written by this wave's own lanes
+        // straight-line over all NF sets, no branch: a lane without an entry reads the queue's entry 0 (whatever it holds: a point id
+        // below 1 024, a pair below 4 -- LDS reads past the cloud return what lies there), looks up word 0 of the bitmap and tests its
+        // bit 0 -- voxel (0, 0, 0), on the outermost layer, never marked -- so it counts nothing.  (With a branch per set the compiler
+        // waits for ALL lookups in flight at the top of every set.)
+#pragma unroll
+        for (int u = 0; u < NF; u++) {
+            const int e = (s0 + u) * MAD_WAVE + lane;
+            const bool have = e < n;
+            const unsigned ent = queue[have ? e : 0];
+            const unsigned q = (ent >> 10) & 3u;
+            const float4 c = clf[ent & 1023u];
+            const float4 *mv = (const float4 *)(wrec + q * 12);
+            const float4 r0 = mv[0], r1 = mv[1], r2 = mv[2];      // m0..m3 | m4..m7 | m8 t0 t1 t2
+            const float vx = fmaf(c.z, r0.z, fmaf(c.y, r0.y, fmaf(c.x, r0.x, r2.y)));
+            const float vy = fmaf(c.z, r1.y, fmaf(c.y, r1.x, fmaf(c.x, r0.w, r2.z)));
+            const float vz = fmaf(c.z, r2.x, fmaf(c.y, r1.w, fmaf(c.x, r1.z, r2.w)));
+            const int ix = clamp0(cvt_floor(vx), fx1), iy = clamp0(cvt_floor(vy), fy1), iz = clamp0(cvt_floor(vz), fz1);
+            const unsigned fi = mad_u24s(mad_u24s((unsigned)ix, (unsigned)B.dim[1], (unsigned)iy), (unsigned)B.wz, (unsigned)(iz >> 5));
+            bit[u] = have ? (iz & 31) | (int)(q << 5) : 0;
+            w[u] = ((const uint2 *)bits)[have ? fi : 0u];
+        }
+    };
+    // ... and are counted: per lane, the inner / outer hits of pair q in bits 8 q .. 8 q + 7 of two words (a lane sees one entry per
+    // set, at most 2 x 2 NB sets per group: the fields cannot overflow)
+    unsigned acc_in = 0u, acc_out = 0u;
+    auto tally = [&](const uint2 (&w)[NF], const int (&bit)[NF]) {
+#pragma unroll
+        for (int u = 0; u < NF; u++) {
+            const unsigned in = __builtin_amdgcn_ubfe(w[u].y, (unsigned)bit[u], 1u), out = __builtin_amdgcn_ubfe(w[u].x | w[u].y, (unsigned)bit[u], 1u);
+            const unsigned sh = ((unsigned)bit[u] >> 2) & 0x18u;
+            acc_in += in << sh;
+            acc_out += out << sh;
+        }
+    };
+    auto put = [&](const int64_t grp) {      // the group's four brackets: lane q writes pair q
+        // 8-bit fields widened to 16 before the sum over the lanes: pairs 0 and 2 in one word, 1 and 3 in the other
+        const unsigned i_02 = (unsigned)wave_sum_i32((int)(acc_in & 0x00ff00ffu)), i_13 = (unsigned)wave_sum_i32((int)((acc_in >> 8) & 0x00ff00ffu));
+        const unsigned o_02 = (unsigned)wave_sum_i32((int)(acc_out & 0x00ff00ffu)), o_13 = (unsigned)wave_sum_i32((int)((acc_out >> 8) & 0x00ff00ffu));
+        acc_in = 0u; acc_out = 0u;
+        if (lane < 4) {
+            const int64_t p = pair_of(grp, lane);
+            const unsigned iw = (lane & 1) ? i_13 : i_02, ow = (lane & 1) ? o_13 : o_02;
+            const int L = (int)((iw >> (16 * (lane >> 1))) & 0xffffu), U = (int)((ow >> (16 * (lane >> 1))) & 0xffffu);
+            if (p < n_pairs) { lower[p] = L; upper[p] = (unsigned short)U; atomicAdd(&lh[min(L, nbins - 1)], 1); }
+        }
+    };
+
+    uint2 wA[NF], wB[NF];
+    int bitA[NF], bitB[NF];
+    // entries beyond the NF sets in flight (a half where more than ~3 points in 8 pass): looked up and counted on the spot, in the
+    // buffer that has just been counted
+    auto overflow = [&](const int n, uint2 (&w)[NF], int (&bit)[NF]) {
+        for (int s0 = NF; s0 * MAD_WAVE < n; s0 += NF) {
+            lookup(s0, n, w, bit);
+            tally(w, bit);
+        }
+    };
+    // Turns: (group, half) = (0, 0), (0, 1), (1, 0), ...  Per turn: the coarse phase of this half, the count of the previous turn's
+    // lookups, this half's lookups into the other buffer -- two turns per trip so that the buffers swap without copies.
+    if (wave < n_pairs) {
+#pragma unroll
+        for (int u = 0; u < NF; u++) { wB[u] = make_uint2(0u, 0u); bitB[u] = 0; }      // "the lookups of the group before the first": nothing
+        float a_op = valid_a(0) ? load_a(0) : 0.f, f_op = load_f(0);
+        for (int64_t grp = 0;; grp++) {
+            float a_next = load_a(grp + 1), f_next = load_f(grp + 1);      // (clamped: harmless past the end)
+            // half 0 of the group -> buffer A (the previous turn's lookups, half 1 of the group before, sit in buffer B)
+            const int n0 = coarse(a_op, std::integral_constant<int, 0>());
+            tally(wB, bitB);
+            if (grp > 0) put(grp - 1);
+            else { acc_in = 0u; acc_out = 0u; }
+            // the next group's operands have arrived by now (a coarse phase ago) and nothing else is in flight: taken here, before
+            // the overflow loop, whose loads the compiler cannot count
+            asm volatile("" : "+v"(a_next), "+v"(f_next));
+            if (lane < 48) wrec[lane] = f_op;      // this group's fine maps (the lookups of the group before are out)
+            overflow(n0, wB, bitB);
+            lookup(0, n0, wA, bitA);
+            // half 1 -> buffer B
+            const int n1 = coarse(a_op, std::integral_constant<int, 1>());
+            tally(wA, bitA);
+            overflow(n1, wA, bitA);
+            lookup(0, n1, wB, bitB);
+            if (pair_of(grp + 1, 0) >= n_pairs) {      // wave-uniform
+                tally(wB, bitB);
+                put(grp);
+                break;
+            }
+            a_op = valid_a(grp + 1) ? a_next : 0.f;
+            f_op = f_next;
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nbins; i += PB_THREADS)
+        if (lh[i]) atomicAdd(&hist[i], lh[i]);
+}
+
 // T = the k-th largest lower bound (from its histogram; 0 when there are fewer than k pairs), then the pairs whose upper bound
 // reaches it, in no particular order.  Every workgroup derives T for itself, as k_tie_chunks does.
 __global__ __launch_bounds__(256) void k_prune_select(const int32_t *__restrict__ status_in, int64_t cap_pairs, const int32_t *__restrict__ hist,
@@ -2057,7 +2301,8 @@ static int gemm2_launch(mad_ctx *ctx, const GemmBatch &G) {
         MAD_HIP(hipFuncSetAttribute((const void *)k_corr_gemm2, hipFuncAttributeMaxDynamicSharedMemorySize, G2_LDS));
         attr = true;
     }
-    hipLaunchKernelGGL(k_corr_gemm2, dim3(ctx->n_cu * 2), dim3(GEMM_THREADS), G2_LDS, ctx->stream, G);      // persistent: two per CU
+    static const int per_cu = getenv("MAD_GEMM_WG_PER_CU") ? std::max(1, std::min(2, atoi(getenv("MAD_GEMM_WG_PER_CU")))) : 2;      // probe: 1 leaves half of every CU to the kernels of other lanes
+    hipLaunchKernelGGL(k_corr_gemm2, dim3(ctx->n_cu * per_cu), dim3(GEMM_THREADS), G2_LDS, ctx->stream, G);      // persistent: two per CU
     return MAD_OK;
 }
 
@@ -2202,7 +2447,9 @@ static void pose_plan(const mad_ctx *ctx, int l_hi_max, int n_cloud, const doubl
         PoseBits &Bc = P.PC.B;
         // beside the bitmap: the float32 hi cloud and one queue of 2-byte point ids per wave
         const int nb_sets = (l_hi_max + MAD_WAVE - 1) / MAD_WAVE;
-        const size_t budget = (size_t)150 * 1024 - pad16((size_t)(l_hi_max + 4) * 16) - (size_t)(PB_THREADS / MAD_WAVE) * (((nb_sets + 1) & ~1) + 5) * MAD_WAVE * 2 - pad16((size_t)(l_hi_max + 1) * 4) - 64;      // queue: up to 4 sets of rounding (nbv) + the dump slots
+        // (clouds of up to 8 sets go through k_pose_bounds_mx: a queue of 2 nbv sets + the dump slots and four fine maps per wave)
+        const size_t q_sets = nb_sets <= 8 ? (size_t)2 * ((nb_sets + 1) & ~1) + 1 : (size_t)((nb_sets + 1) & ~1) + 5;      // else: up to 4 sets of rounding (nbv) + the dump slots
+        const size_t budget = (size_t)150 * 1024 - pad16((size_t)(l_hi_max + 4) * 16) - (size_t)(PB_THREADS / MAD_WAVE) * (q_sets * MAD_WAVE * 2 + 192) - pad16((size_t)(l_hi_max + 1) * 4) - 64;
         size_t n_words_c = 0;
         for (Bc.h = std::max(1.2, B.h);; Bc.h *= 1.05) {
             const double guard = dist + Bc.h * 0.8660254037844387 + slack + Bc.h;
@@ -2353,6 +2600,10 @@ static int pose_device(mad_ctx *ctx, const Side &hi, const Side &lo, int32_t *d_
                 MAD_HIP(hipFuncSetAttribute((const void *)k_pose_bounds<12, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
                 MAD_HIP(hipFuncSetAttribute((const void *)k_pose_bounds<16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
                 MAD_HIP(hipFuncSetAttribute((const void *)k_pose_bounds<16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+                MAD_HIP(hipFuncSetAttribute((const void *)k_pose_bounds_mx<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+                MAD_HIP(hipFuncSetAttribute((const void *)k_pose_bounds_mx<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+                MAD_HIP(hipFuncSetAttribute((const void *)k_pose_bounds_mx<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+                MAD_HIP(hipFuncSetAttribute((const void *)k_pose_bounds_mx<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
                 attr_b = true;
             }
             // two launches of the bounds kernel, best-scoring pairs first: the second abandons pairs early (k_pose_bounds)
@@ -2375,7 +2626,25 @@ static int pose_device(mad_ctx *ctx, const Side &hi, const Side &lo, int32_t *d_
             // (T_stop and the ticket of phase 1, hist2[nbins + 1] and [nbins + 2], must lie inside the zero-filled region of the match)
             static_assert(3 <= 17, "hist2 has l_hi_max + 17 words (zr_hist2): bins 0 .. l_hi_max, then T_stop and the ticket");
             if (split && nbins + 3 > l_hi_max + 17) return mad_fail(ctx, MAD_EINVAL, "pose bounds: %d bins for %d hi anchors", nbins, l_hi_max);
-            for (int pass = 0; pass < (split ? 2 : 1); pass++) {
+            // one phase, at most 8 sets: the coarse map on the matrix cores (k_pose_bounds_mx; MAD_POSE_MX=0: the vector form)
+            // Built for the round-3 review and measured slower on C3 (32.4 against 29.2 us per launch for clouds of 7-8 sets, 25.5 against 26.2
+            // for 6; DESIGN.md section 6d: the coarse phase loses 7 of its 26 vector instructions per 64 points, the fine phase -- whose map
+            // now is a per-lane operand read from LDS -- gains as many per 64 points again): OFF unless mad_set_option "pose_mx" (MAD_POSE_MX=1).
+            const bool mx = ctx->pose_mx != 0 && !split && nbv <= 8;
+            if (mx) {
+                const size_t lds_mx = pad16((size_t)PC.n_words * 4) + pad16((size_t)(l_hi_max + 4) * 16) +
+                                      (size_t)(PB_THREADS / MAD_WAVE) * ((size_t)(2 * nbv + 1) * MAD_WAVE * 2 + 192) + pad16((size_t)nbins * 4) + 16;
+                if (lds_mx > (size_t)155 * 1024) return mad_fail(ctx, MAD_EINVAL, "pose bounds: %zu bytes of LDS", lds_mx);
+#define MAD_PBX_LAUNCH(NBV)                                                                                                                        \
+    hipLaunchKernelGGL((k_pose_bounds_mx<NBV>), dim3(ctx->n_cu), dim3(PB_THREADS), lds_mx, ctx->stream, d_status, cap_pairs, d_rec, d_hi_cloud, B, \
+                       d_bits, PC, d_bits_c, scratch<int32_t>(ctx, S_COUNTS), scratch<unsigned short>(ctx, S_TMP_C), hist2, nbins)
+                if (nbv == 2) MAD_PBX_LAUNCH(2);
+                else if (nbv == 4) MAD_PBX_LAUNCH(4);
+                else if (nbv == 6) MAD_PBX_LAUNCH(6);
+                else MAD_PBX_LAUNCH(8);
+#undef MAD_PBX_LAUNCH
+            }
+            for (int pass = 0; pass < (mx ? 0 : (split ? 2 : 1)); pass++) {
                 const int pb_phase = split ? pass + 1 : 0;
                 const int64_t pb_stop = split ? prune_k : 0;      // phase 1 leaves T_stop for phase 2 (hist2[nbins + 1]; [nbins + 2]: its workgroups' tickets)
                 if (split) {
@@ -3413,6 +3682,10 @@ extern "C" int mad_set_option(mad_ctx *ctx, const char *name, double value) {
     if (!strcmp(name, "pose_split_min")) {      // (MAD_POSE_SPLIT_MIN in the environment sets the initial value)
         if (!(value >= 0) || !(value < 1e12)) return mad_fail(ctx, MAD_EINVAL, "mad_set_option: pose_split_min = %g", value);
         ctx->pose_split_min = (int64_t)value;
+        return MAD_OK;
+    }
+    if (!strcmp(name, "pose_mx")) {      // 1: the bounds pass of clouds of up to 512 points with its coarse map on the matrix cores (k_pose_bounds_mx)
+        ctx->pose_mx = value != 0 ? 1 : 0;
         return MAD_OK;
     }
     if (!strcmp(name, "pose_split")) {      // -1: on for hi clouds of more than 512 points (default), 0: off, 1: on

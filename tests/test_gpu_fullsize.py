@@ -176,6 +176,16 @@ def test_whole_workload_equals_the_oracle(lib, workload):
         assert np.array_equal(gcnt, cnt)
         np.testing.assert_array_equal(idx, order)
         np.testing.assert_allclose(top, res[order], rtol=1e-10, atol=1e-10)
+        if workload in ("c1", "c3", "c4"):      # the same match bracketed on the matrix cores (k_pose_bounds_mx: clouds of up to 512 points, one phase)
+            lib.set_option("pose_mx", 1)
+            try:
+                top_x, idx_x, st_x = lib.match_topk(hi_d, lo_d, cc, dist, k)
+            finally:
+                lib.set_option("pose_mx", 0)
+            assert 0 < lib.last_pose_selected() <= st["n_pairs"]
+            np.testing.assert_array_equal(idx_x, idx)
+            np.testing.assert_array_equal(top_x, top)
+            assert np.array_equal(lib.match_fetch(st["n_pairs"])[3], cnt)
         hi_d.close()
     lo_d.close()
     lib.set_option("pose_split", -1)

@@ -34,7 +34,8 @@ def main():
     assert rc == 0
     st = out.reshape(n, 8).astype(np.float64)
     t0 = st[:, 0].min()
-    names = ["start->tile", "norms", "issue+first stage", "K loop (15 stages)", "epilogue", "end barrier"]
+    names = ["kernel start -> first tile started (norms, pieces of two stages issued)", "accumulators", "first stage", "K loop (15 stages)",
+             "barrier + start of the NEXT tile", "epilogue"]
     d = np.diff(st[:, :7], axis=1)
     print("s_memtime ticks (100 MHz constant clock on gfx9: 1 tick = 10 ns); median / p10 / p90 over %d workgroups" % n)
     for k, name in enumerate(names):
