@@ -369,8 +369,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_corr_gemm2(GemmBatch G) {
         // own for half as long.  int32 sums are exact under any split.
         // (tile numbers fit 32 bits -- the matrix has fewer than 2^31 entries -- and a 32-bit division is a tenth of a 64-bit one)
         const int64_t full = g2_split ? (int64_t)((unsigned)cnt / (unsigned)nslot * (unsigned)nslot) : cnt, rem = cnt - full;
-        // (quarters -- a third instantiation of the tile -- were built and measured: 37.0 us per C3 launch against 36.1 with halves
-        // only, 39.8 without the split: the extra spills cost what the finer deal gains)
+        // (quarters -- a third instantiation of the tile -- were built and measured twice: 37.0 us per C3 launch against 36.1 with halves
+        // only in the first form of this kernel, 32.7 against 32.8 in this one: the third instantiation brings 8 spilled registers back,
+        // which cost what the finer deal gains)
         const int parts = rem > 0 && 2 * rem <= nslot ? 2 : 1;
         const int64_t units = full + rem * parts;
         // this workgroup's tiles of the job, one after the other: unit t -> (rows, columns, MT / 2), na == 0 when the job has no more
