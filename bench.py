@@ -898,6 +898,29 @@ def main():
             lib.timing_enable(False)
             roof["others"].update(refine_line.pop("roofline"))
 
+        # The workload rounds 1-2 timed (C3 WITHOUT its noise: more than twice the pairs per match), a few steps of it beside the headline so
+        # that this round's line can be held against theirs; not part of `value`.
+        side_clean = None
+        if world == 1 and not emu and wl == "c3" and not args.no_cpu_baseline and "c3clean" in WORKLOADS:
+            Wc = WORKLOADS["c3clean"]
+            map_c, subs_c, _ = build_inputs(lib, Wc)
+            groups_c = [[_lib.DeviceSet(lib) for _ in range(1 + len(subs_c))] for _ in range(args.in_flight)]
+            kc = Wc["n_samples"] * Wc["copies"]
+            for grp in groups_c:
+                for _ in range(2):
+                    hot_path_step(lib, map_c, subs_c, Wc["cc_threshold"], Wc["anchor_dist"], kc, grp)
+            n_c = max(args.steps // 2, 4)
+            run_steps(lib, map_c, subs_c, Wc["cc_threshold"], Wc["anchor_dist"], kc, groups_c, len(groups_c))
+            barrier()
+            t1 = time.perf_counter()
+            corr_c, _, _ = run_steps(lib, map_c, subs_c, Wc["cc_threshold"], Wc["anchor_dist"], kc, groups_c, n_c)
+            barrier()
+            dt_c = time.perf_counter() - t1
+            side_clean = dict(workload="c3clean: C3 without its Gaussian noise, what BENCH_r01 / r02 timed", steps=n_c, ms_per_step=1e3 * dt_c / n_c,
+                              value=corr_c * n_c / dt_c, unit="correlations/s")
+            for st_ in [map_c] + subs_c:
+                st_.ms.release_device()
+
         n_ranks = emu if emu else world
         line = {
             "metric": "anchor-pair x rotation correlations/sec on 256^3 map; top-k pose agreement",
@@ -945,6 +968,7 @@ def main():
             "cpu_baseline": cpu_all if cpu_all is not None else cpu,
             "cpu_baseline_one_core_sample": cpu if cpu_all is not None else None,
             "refine_ccc": refine_line,
+            "c3_without_noise": side_clean,
             "one_gpu_same_workload": one_gpu,
         }
         if emu:
