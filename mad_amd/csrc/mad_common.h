@@ -91,8 +91,16 @@ struct EqspDev {
     int tab_ok;
 };
 
+// How far inside a zone a direction must lie for the float32 classifier to decide it (radians of theta and of phi).  What the guard has
+// to cover: (1) the slivers of the 4-decimal tables -- a belt's last zone ends at its tabulated theta_max while the first one, reached
+// through theta + 2 pi, begins 1.47e-5 rad below it (6.2832 against 2 pi; the same in every belt of both tables, and the only
+// overlap there is: tests/test_eqsp.py::test_zone_bounds_overlap_only_at_the_seam pins it) -- inside the guard a direction must match this zone and no other;
+// (2) the float32 noise of the inputs, <= 1e-6 rad of direction = up to 5e-6 rad of theta in the collar next to a polar cap (sin phi
+// 0.19); (3) the float32 evaluation of the cross products and of z against the inward-rounded bounds, ~3e-7.  Together 2.0e-5; the
+// guard is twice that.  (1e-4 until round 4: with 4e-5 a third fewer samples fall through to the float64 queue that ends every row of
+// k_describe -- 79.5 -> 77.2 us per launch on C3, k_orient unchanged.)
 #ifndef MAD_EQSP_GUARD
-#define MAD_EQSP_GUARD 1e-4
+#define MAD_EQSP_GUARD 4e-5
 #endif
 
 // One octave's gradient field: a texel is {gx, gy, gz, |g|} (|g| in float32 exactly
@@ -639,8 +647,8 @@ __device__ __forceinline__ float approx_angle(float x, float y) {
 // Returns the one zone that contains it with a margin of MAD_EQSP_GUARD on every side, or -1 when
 // it is closer than that to a bound, near a pole, or not finite; the caller then runs the exact
 // test.  Inputs may carry float32 rounding noise (<= ~1e-6 rad): inside the margin the exact
-// float64 test on the un-noised direction gives this same zone and no other, because the noise
-// is 100x smaller than the guard and neighbouring zones overlap by < 2e-5 rad at most.
+// float64 test on the un-noised direction gives this same zone and no other, because noise and
+// the overlap of neighbouring zones (1.47e-5 rad at a belt's seam) together are half the guard (see MAD_EQSP_GUARD).
 // Branch-free on purpose (three dependent LDS reads, everything else selects): callers classify several
 // points in a row, and straight-line code lets the scheduler overlap their table reads.
 // FLAT: the final test written without short-circuit operators, so that no control flow appears and the table reads of
