@@ -554,32 +554,35 @@ __global__ __launch_bounds__(256) void k_orient_rows(Batch<RowsArgs> B, int fan,
     if (A.row_rec) put_row_rec(A, A.order ? A.perm_off[p] + s : row, (int)row, a, inv9, R9);
 }
 
-// k_orient_scan + k_orient_rows in ONE launch (round 3): every 1024-thread workgroup forms the exclusive scan of its job's
+// k_orient_scan + k_orient_rows in ONE launch (round 3): every workgroup forms the exclusive scan of its job's
 // per-anchor row counts for itself, in LDS (n ints: a thread sums a run of consecutive anchors, one block scan over the runs), the
-// working-order offset of its first anchor by a block reduction, and then expands its 1024 / fan anchors.  A few microseconds of
+// working-order offset of its first anchor by a block reduction, and then expands its ORS_THREADS / fan anchors.  A few microseconds of
 // redundant work per workgroup, all of them side by side, instead of a one-workgroup launch on the build's critical path.
 // Dynamic LDS: (max n + 1) ints.  The rows come out exactly as from the two-launch form.
 #define ORI_ROWS_MAX_N 30000      // anchors per job the one-launch form takes (LDS); beyond: k_orient_scan + k_orient_rows
-__global__ __launch_bounds__(1024) void k_orient_rows_scan(Batch<RowsArgs> B, int fan, int lim_main, const EqspDev *eq) {
+// (256 threads since round 4: a 1 024-thread workgroup needs half a CU's wave slots at once, and beside the k_describe workgroups of
+// other lanes -- 24 of a CU's 32 waves -- it waited for them: 42 us per launch in the overlapped run against 10 alone)
+#define ORS_THREADS 256
+__global__ __launch_bounds__(ORS_THREADS) void k_orient_rows_scan(Batch<RowsArgs> B, int fan, int lim_main, const EqspDev *eq) {
     extern __shared__ __align__(16) int s_off[];
-    __shared__ int wt[1024 / MAD_WAVE + 1];
-    __shared__ int s_perm[1024];
+    __shared__ int wt[ORS_THREADS / MAD_WAVE + 1];
+    __shared__ int s_perm[ORS_THREADS];
     const int job = batch_job(B, (int)blockIdx.x);
     const RowsArgs &A = B.job[job];
     const int n = A.n, tid = (int)threadIdx.x;
-    const int per = (n + 1023) / 1024;
+    const int per = (n + ORS_THREADS - 1) / ORS_THREADS;
     const int i0 = min(tid * per, n), i1 = min(i0 + per, n);
     int sum = 0;
     for (int i = i0; i < i1; i++) sum += A.slot_cnt[i];
     int total;
     int run = block_excl_scan(sum, wt, &total);
     for (int i = i0; i < i1; i++) { s_off[i] = run; run += A.slot_cnt[i]; }
-    const int ppb = 1024 / fan;                                   // anchors per workgroup
+    const int ppb = ORS_THREADS / fan;                            // anchors per workgroup
     const int p0 = ((int)blockIdx.x - B.first[job]) * ppb;        // its first position in working order
     if (p0 == 0 && tid == 0) *A.n_rows = total;
     // rows of the anchors that precede position p0 in working order, then of this workgroup's own anchors
     int before = 0;
-    for (int q = tid; q < p0; q += 1024) before += A.slot_cnt[A.order ? A.order[q] : q];
+    for (int q = tid; q < p0; q += ORS_THREADS) before += A.slot_cnt[A.order ? A.order[q] : q];
     int base;
     (void)block_excl_scan(before, wt, &base);
     const int mine = (tid < ppb && p0 + tid < n) ? A.slot_cnt[A.order ? A.order[p0 + tid] : p0 + tid] : 0;
@@ -641,7 +644,7 @@ static int orient_batch(mad_ctx *ctx, int n_jobs, const OrientJob *jobs, int r, 
     int64_t a0 = 0, blk = 0;
     int max_n = 0;
     for (int j = 0; j < n_jobs; j++) max_n = std::max(max_n, jobs[j].n);
-    const bool one_launch = max_n <= ORI_ROWS_MAX_N && fan <= 1024;      // (beyond: a scan of its own and the row expansion, two launches)
+    const bool one_launch = max_n <= ORI_ROWS_MAX_N && fan <= ORS_THREADS;      // (beyond: a scan of its own and the row expansion, two launches)
     for (int j = 0; j < n_jobs; j++) {
         const OrientJob &J = jobs[j];
         OrientArgs &A = B.job[j];
@@ -673,7 +676,7 @@ static int orient_batch(mad_ctx *ctx, int n_jobs, const OrientJob *jobs, int r, 
         if (!Q.anc_octave) Q.anc_octave = J.d_octave;
         R.first[j] = (int)blk;
         a0 += J.n;
-        blk += one_launch ? mad_ceil_div((int64_t)J.n, 1024 / fan) : mad_ceil_div((int64_t)J.n * fan, 256);
+        blk += one_launch ? mad_ceil_div((int64_t)J.n, ORS_THREADS / fan) : mad_ceil_div((int64_t)J.n * fan, 256);
         if (J.out.d_n_reject && !J.out.counters_zeroed) MAD_HIP(hipMemsetAsync(J.out.d_n_reject, 0, 4, ctx->stream));
     }
     B.first[n_jobs] = (int)a0;
@@ -701,7 +704,7 @@ static int orient_batch(mad_ctx *ctx, int n_jobs, const OrientJob *jobs, int r, 
             static bool attr_r = false;
             if (!attr_r) { MAD_HIP(hipFuncSetAttribute((const void *)k_orient_rows_scan, hipFuncAttributeMaxDynamicSharedMemorySize, (ORI_ROWS_MAX_N + 4) * 4)); attr_r = true; }
         }
-        hipLaunchKernelGGL(k_orient_rows_scan, dim3((unsigned)blk), dim3(1024), lds_r, ctx->stream, R, fan, lim_main, ctx->eq[0]);
+        hipLaunchKernelGGL(k_orient_rows_scan, dim3((unsigned)blk), dim3(ORS_THREADS), lds_r, ctx->stream, R, fan, lim_main, ctx->eq[0]);
     } else {
         hipLaunchKernelGGL(k_orient_scan, dim3(n_jobs), dim3(1024), 0, ctx->stream, R);
         hipLaunchKernelGGL(k_orient_rows, dim3((unsigned)blk), dim3(256), 0, ctx->stream, R, fan, lim_main, ctx->eq[0]);
