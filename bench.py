@@ -660,12 +660,14 @@ def main():
             run_steps(lib, the_map, subs, cc, dist_thr, k, set_groups, args.warmup, after_step=lambda tops: finish_exchange(exchange(tops)))
             HOST_T.clear()
             barrier()
+            allocs0 = lib.device_allocations()
             t0 = time.perf_counter()
             corr, tops, stats = run_steps(lib, the_map, subs, cc, dist_thr, k, set_groups, args.steps, after_step=after_step)
             last, pending[0] = pending[0], None
             gathered = finish_exchange(last) if last is not None else []      # every step's exchange completes inside the timed region
             barrier()
             dt = time.perf_counter() - t0
+            allocs_timed = lib.device_allocations() - allocs0
             break
         except ResizeMapImages:
             resize_map_images()
@@ -911,16 +913,18 @@ def main():
                     hot_path_step(lib, map_c, subs_c, Wc["cc_threshold"], Wc["anchor_dist"], kc, grp)
             n_c = max(args.steps, 4)      # (as many as the headline: the pipeline's fill and drain weigh the same)
             run_steps(lib, map_c, subs_c, Wc["cc_threshold"], Wc["anchor_dist"], kc, groups_c, len(groups_c) + args.warmup)
-            passes = []      # two passes, the faster one reported (one run in four showed a 60 ms stall in the first: scratch buffers of a lane growing)
+            passes, allocs_c = [], []      # two passes, the faster one reported (one run of eight showed a 60 ms stall in the single pass there was then; no device allocation in either pass since)
             for _ in range(2):
                 barrier()
+                a1 = lib.device_allocations()
                 t1 = time.perf_counter()
                 corr_c, _, _ = run_steps(lib, map_c, subs_c, Wc["cc_threshold"], Wc["anchor_dist"], kc, groups_c, n_c)
                 barrier()
                 passes.append(time.perf_counter() - t1)
+                allocs_c.append(lib.device_allocations() - a1)
             dt_c = min(passes)
             side_clean = dict(workload="c3clean: C3 without its Gaussian noise, what BENCH_r01 / r02 timed", steps=n_c, ms_per_step=1e3 * dt_c / n_c,
-                              ms_per_step_each_pass=[1e3 * x / n_c for x in passes], value=corr_c * n_c / dt_c, unit="correlations/s")
+                              ms_per_step_each_pass=[1e3 * x / n_c for x in passes], device_allocations_each_pass=allocs_c, value=corr_c * n_c / dt_c, unit="correlations/s")
             for st_ in [map_c] + subs_c:
                 st_.ms.release_device()
 
@@ -962,6 +966,7 @@ def main():
                        "topk_agrees_with_cpu_oracle_on": None if agree is None else ("every anchor of both octaves, all subunits (the full step) and the base-octave sample" if agree_whole is not None else "the base-octave sample"),
                        "topk_agrees_on_sample": agree,
                        "sharded_map_set_identical_to_unsharded": shard_check,
+                       "device_allocations_in_timed_region": allocs_timed,      # buffers the library (re)allocated inside the timed steps: a steady state has none
                        "map_image_resizes": OVERFLOW["resizes"],      # times the ranks agreed to size the map's wire images again (0 unless rehearsed)
                        "setup_s": t_setup,
                        "setup_detail_s": {k_: round(v, 4) for k_, v in SETUP_T.items()}},

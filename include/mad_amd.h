@@ -269,6 +269,10 @@ int mad_last_pose_kernel(mad_ctx *ctx);
  * n_pairs when nothing could be pruned.  mad_match_fetch(counts) / mad_match_results complete the other pairs on demand.
  */
 int64_t mad_last_pose_selected(mad_ctx *ctx);
+/* Device buffers the context has (re)allocated since mad_init (scratch and set storage grow on demand and never shrink).  Each is a
+ * hipMalloc -- and, when it replaces a smaller buffer, a hipFree that waits for every stream.  A caller that pipelines steps can
+ * check that its steady state shows none (bench.py: config.device_allocations_in_timed_region). */
+int64_t mad_device_allocations(mad_ctx *ctx);
 /* After mad_match_topk: all pairs of that call (for MaD._match_dsc's full return value). */
 int mad_match_fetch(mad_ctx *ctx, int32_t *pair_hi, int32_t *pair_lo, double *pair_score,
                     int32_t *counts, int64_t cap);

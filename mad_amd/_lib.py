@@ -23,7 +23,7 @@ SYMBOLS = [
     "mad_set_eqsp", "mad_upload_field", "mad_upload_field_device", "mad_free_field",
     "mad_set_orient_window", "mad_orient", "mad_describe", "mad_describe_sized", "mad_correlate", "mad_pose_score", "mad_topk",
     "mad_set_create", "mad_set_destroy", "mad_set_build", "mad_set_build_many", "mad_set_load", "mad_set_size", "mad_set_download",
-    "mad_match_topk", "mad_match_topk_many", "mad_match_topk_many_begin", "mad_match_topk_many_finish", "mad_set_batching", "mad_set_option", "mad_last_pose_kernel", "mad_last_pose_selected", "mad_match_fetch", "mad_match_results", "mad_match_used",
+    "mad_match_topk", "mad_match_topk_many", "mad_match_topk_many_begin", "mad_match_topk_many_finish", "mad_set_batching", "mad_set_option", "mad_last_pose_kernel", "mad_last_pose_selected", "mad_device_allocations", "mad_match_fetch", "mad_match_results", "mad_match_used",
     "mad_match_shard_pairs", "mad_match_shard_topk", "mad_match_shard_begin", "mad_match_shard_score", "mad_match_shard_record_doubles", "mad_match_shard_collect", "mad_match_shard_wait",
     "mad_set_wire_bytes", "mad_set_export", "mad_set_import", "mad_set_lane", "mad_set_stream", "mad_set_bind_lane",
     "mad_upload_density", "mad_refine", "mad_structure_to_density", "mad_ccc", "mad_density_ccc", "mad_dock_refine_score", "mad_grid_overlap", "mad_overlap_matrix",
@@ -86,6 +86,8 @@ def load_library():
         _dll.mad_set_stream.argtypes = [C.c_void_p, C.c_void_p]
         _dll.mad_last_pose_selected.restype = C.c_int64
         _dll.mad_last_pose_selected.argtypes = [C.c_void_p]
+        _dll.mad_device_allocations.restype = C.c_int64
+        _dll.mad_device_allocations.argtypes = [C.c_void_p]
         _dll.mad_set_wire_bytes.restype = C.c_int64
         _dll.mad_set_wire_bytes.argtypes = [C.c_int, C.c_int64]
         _dll.mad_match_shard_record_doubles.restype = C.c_int64
@@ -551,6 +553,10 @@ class Lib(object):
     def last_pose_selected(self):
         """Pairs of the last completed match that went through the exact pose search (the rest were excluded by their bounds)."""
         return int(self.dll.mad_last_pose_selected(self.ctx))
+
+    def device_allocations(self):
+        """Device buffers (re)allocated by this context so far (mad_device_allocations): 0 new ones across a steady-state region."""
+        return int(self.dll.mad_device_allocations(self.ctx))
 
     def match_topk_many_begin(self, his, lo, cc, dist, k):
         """Enqueue every match and return a handle; `match_topk_many_finish(handle)` waits and unpacks.  In between

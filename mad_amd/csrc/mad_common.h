@@ -194,6 +194,7 @@ struct mad_ctx {
     int ori_queue_cap = 1 << 20, dsc_queue_cap = 1 << 20;      // test hooks (mad_set_option "ori_queue" / "dsc_queue"): caps of the kernels' undecided queues
     int pose_mx = 0;                          // 1: k_pose_bounds_mx for hi clouds of up to 512 points (mad_set_option "pose_mx"; slower on C3, section 6d)
     int pose_split = -1;                      // pose search in two launches, best-scoring pairs first: -1 = for hi clouds of more than 512 points
+    int64_t n_device_allocs = 0;              // device buffers (re)allocated so far (mad_reserve; mad_device_allocations): a steady state has none
     int64_t pose_split_min = 4096;            // pose search: pairs in the list bracketed first (at least; mad_set_option "pose_split_min")
     bool batch_gemm = false;                  // mad_match_topk_many: the GEMMs of a bracket's matches in one launch (mad_set_batching)
     bool spatial_order = true;                // the build kernels take anchors / rows in Morton order (MAD_NO_SPATIAL_ORDER: list order)

@@ -33,8 +33,13 @@ int mad_reserve(mad_ctx *ctx, DevBuf &b, size_t bytes) {
         return mad_fail(ctx, MAD_ENOMEM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
     }
     b.cap = want;
+    ctx->n_device_allocs++;
     return MAD_OK;
 }
+
+// how many device buffers the context has (re)allocated so far: every one of them is a hipMalloc, and a hipFree that waits for all
+// streams when it replaces a smaller buffer -- a pipeline in its steady state must show none (bench.py checks its timed region)
+extern "C" int64_t mad_device_allocations(mad_ctx *ctx) { return ctx ? ctx->n_device_allocs : -1; }
 
 void mad_release(DevBuf &b) {
     if (b.p) (void)hipFree(b.p);
