@@ -62,6 +62,11 @@ def test_full_size_properties(lib, workload):
                 for grp in groups[1:depth]:
                     for s, r in zip(grp, ref_dsc):
                         np.testing.assert_array_equal(s.download()["dsc"], r)
+            # a steady state allocates nothing: the same pipelined steps again, with every buffer of the library sized by the runs above
+            # (a re-allocation frees with a device-wide wait -- mad_device_allocations, what bench.py reports for its timed region)
+            before = lib.device_allocations()
+            corr4, _, _ = bench.run_steps(lib, the_map, subs, cc, dist, k, groups, 5)
+            assert corr4 == corr and lib.device_allocations() == before
         finally:
             for grp in groups[1:]:
                 for s in grp:
