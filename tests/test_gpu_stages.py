@@ -147,6 +147,27 @@ def test_correlate_matches_oracle(lib):
         np.testing.assert_allclose(gs, rs, rtol=1e-12, atol=0)
 
 
+@pytest.mark.parametrize("n_hi, n_lo", [(1, 1), (129, 513), (257, 1300), (384, 2049), (1100, 16001)])
+def test_correlate_on_ragged_sizes(lib, n_hi, n_lo):
+    """Row counts around the GEMM's tile edges: one row; one row past a 128-row block (a tile row that is mostly padding); a hi set
+    whose last block of 128 rows is odd (its tile row is a half tile); one column past a tile; and a matrix of 625 tiles on 512
+    workgroups -- whole rounds of 256 x 128 tiles, the leftover dealt as halves, every workgroup starting its next tile under the
+    epilogue of the current one.  Pair list and scores are the oracle's.
+    (cc is not the round 0.6: among the 17.6 M scores of the largest case one IS 0.6 -- dot 4 593 over norms whose product is 7 655 --
+    and a score that equals the threshold is where dot / (|h| |l|) and the reference's sum over normalised rows may fall on either
+    side of it; tools/debug_pairs.py shows the pair.)"""
+    cc = 0.60000013
+    lo = _random_descriptors(n_lo, 31)
+    hi = _random_descriptors(n_hi, 32, base=lo[n_lo // 3:])
+    rh, rl, rs, _ = O.correlate(hi, lo, cc)
+    gh, gl, gs = lib.correlate(hi, lo, cc)
+    assert len(rs) == 0 or np.min(np.abs(rs - cc)) > 1e-12      # no score on the threshold
+    assert len(rh) >= min(n_hi, n_lo - n_lo // 3) // 2      # the planted copies
+    np.testing.assert_array_equal(gh, rh)
+    np.testing.assert_array_equal(gl, rl)
+    np.testing.assert_allclose(gs, rs, rtol=1e-12, atol=0)
+
+
 def test_correlate_threshold_on_a_score(lib):
     """cc within 1e-12 ... 1e-6 (relative) of the score of existing pairs, on either side: the GEMM's float32 candidate test
     in front of the exact float64 comparison must not lose a pair that sits just above the threshold, nor the exact test admit
