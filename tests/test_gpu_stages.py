@@ -168,6 +168,21 @@ def test_correlate_on_ragged_sizes(lib, n_hi, n_lo):
     np.testing.assert_allclose(gs, rs, rtol=1e-12, atol=0)
 
 
+@pytest.mark.parametrize("cc", [-1.0, 0.2])
+def test_correlate_rows_with_more_candidates_than_the_pair_list_holds(lib, cc):
+    """The pair kernels gather a row's flagged columns into a list of 1 024 per pass of 8 192 columns (pair_list_row) and settle one
+    candidate per lane; a pass with more candidates than that falls back to every lane walking its own mask words.  cc = -1: every
+    entry of 64 x 9 000 is a pair, in row-major order; cc = 0.2: most are."""
+    lo = _random_descriptors(9000, 41)
+    hi = _random_descriptors(64, 42, base=lo[100:])
+    rh, rl, rs, _ = O.correlate(hi, lo, cc)
+    assert len(rh) > 64 * 2000 and (len(rs) == 0 or np.min(np.abs(rs - cc)) > 1e-12)
+    gh, gl, gs = lib.correlate(hi, lo, cc)
+    np.testing.assert_array_equal(gh, rh)
+    np.testing.assert_array_equal(gl, rl)
+    np.testing.assert_allclose(gs, rs, rtol=1e-12, atol=0)
+
+
 def test_correlate_threshold_on_a_score(lib):
     """cc within 1e-12 ... 1e-6 (relative) of the score of existing pairs, on either side: the GEMM's float32 candidate test
     in front of the exact float64 comparison must not lose a pair that sits just above the threshold, nor the exact test admit
